@@ -1,0 +1,724 @@
+"""CPU oracle for the dgpsi stochastic-imputation hot path.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+and bench.py's `cpu_baseline` leg may import this module; dgp_amd/ never does.
+
+A vectorised numpy/scipy restatement of the algorithm of mingdeyu/DGP (dgpsi
+2.6.0).  Each function cites the reference file:line it follows.  It is pinned
+against golden vectors recorded from the reference itself (run in the build
+container under identity stubs of numba/pathos, see oracle/gen_golden.py and
+tests/golden/*.npz; tests/test_oracle_golden.py).
+
+Conventions: every array is float64 C-order; index arrays are int64; a GP node
+sees X = [input | global_input] (kernel_class.py:318-322); `length` has either
+one entry (shared) or one per column of X; kernel names are the reference's
+strings 'sexp' / 'matern2.5'.
+"""
+import numpy as np
+from scipy.linalg import cholesky, cho_solve, solve_triangular
+from scipy.special import erf
+
+SQ5 = np.sqrt(5.0)
+
+
+# --------------------------------------------------------------------------
+# a1/a2  kernel matrices (kernel_class.py:304-359, functions.py:16-93)
+# --------------------------------------------------------------------------
+def _absdiff(Xl, d):
+    c = Xl[:, d]
+    return np.abs(c[:, None] - c[None, :])
+
+
+def corr_matrix(X, length, name):
+    """Correlation matrix WITHOUT the nugget diagonal (unit diagonal).
+
+    sexp:      exp(-sum_d ((x_id-x_jd)/g_d)^2)            kernel_class.py:324-327
+    matern2.5: prod_d(1+sqrt5 r+5/3 r^2) exp(-sqrt5 sum r) kernel_class.py:343-345,
+               functions.py:28-34 (separable product form)
+    """
+    X = np.asarray(X, dtype=float)
+    Xl = X / np.asarray(length, dtype=float)
+    n, D = Xl.shape
+    if name == 'sexp':
+        s = np.zeros((n, n))
+        for d in range(D):
+            df = Xl[:, d][:, None] - Xl[:, d][None, :]
+            s += df * df
+        return np.exp(-s)
+    elif name == 'matern2.5':
+        prod = np.ones((n, n))
+        s = np.zeros((n, n))
+        for d in range(D):
+            r = _absdiff(Xl, d)
+            prod *= 1.0 + SQ5 * r + (5.0 / 3.0) * r * r
+            s += r
+        return prod * np.exp(-SQ5 * s)
+    raise ValueError(name)
+
+
+def k_matrix(X, length, nugget, name, W_diag=None):
+    """kernel.k_matrix(fod_eval=False): diagonal overwritten with 1+nugget (or
+    1+nugget*W_diag with replicates).  kernel_class.py:352-355."""
+    K = corr_matrix(X, length, name)
+    n = K.shape[0]
+    w = np.ones(n) if W_diag is None else np.asarray(W_diag, dtype=float)
+    K[np.arange(n), np.arange(n)] = 1.0 + float(nugget) * w
+    return K
+
+
+def k_matrix_fod(X, length, nugget, name, nugget_est, W_diag=None):
+    """kernel.k_matrix(fod_eval=True) -> (K, fod[p,n,n]); p = len(length)(+1).
+
+    dK/dlog g: sexp 2 r_d^2 K (shared: 2 sum_d r_d^2 K)  kernel_class.py:328-332,
+    functions.py:36-45; matern c_d K, c_d=(5/3) r^2 (1+sqrt5 r)/(1+sqrt5 r+5/3 r^2)
+    functions.py:71-93.  dK/dlog eta = eta*I (eta*diag(W)) kernel_class.py:346-351.
+    """
+    X = np.asarray(X, dtype=float)
+    length = np.asarray(length, dtype=float)
+    Xl = X / length
+    n, D = Xl.shape
+    K = corr_matrix(X, length, name)
+    shared = (len(length) == 1)
+    P = 1 if shared else D
+    fod = np.zeros((P, n, n))
+    for d in range(D):
+        r = _absdiff(Xl, d)
+        if name == 'sexp':
+            c = 2.0 * r * r
+        else:
+            e1 = 1.0 + SQ5 * r
+            e2 = (5.0 / 3.0) * r * r
+            c = e2 * e1 / (e1 + e2)
+        fod[0 if shared else d] += c * K
+    w = np.ones(n) if W_diag is None else np.asarray(W_diag, dtype=float)
+    if nugget_est:
+        fod = np.concatenate((fod, (float(nugget) * np.diag(w))[None]), axis=0)
+    K[np.arange(n), np.arange(n)] = 1.0 + float(nugget) * w
+    return K, fod
+
+
+# --------------------------------------------------------------------------
+# priors (kernel_class.py:93-110,361-401, functions.py:95-100)
+# --------------------------------------------------------------------------
+def log_prior(length, nugget, prior_name, prior_coef, nugget_est, cl=None):
+    """prior_coef is the STORED coefficient (ga: shape-1; inv_ga: shape+1)."""
+    length = np.asarray(length, dtype=float)
+    nugget = float(np.ravel(nugget)[0])
+    if prior_name is None:
+        return 0.0
+    if prior_name == 'ref':
+        a, b = prior_coef[0], prior_coef[1]
+        t = np.sum(cl / length) + nugget
+        return a * np.log(t) - b * t
+    a, b = prior_coef[0], prior_coef[1]
+    xs = length if not nugget_est else np.concatenate((length, [nugget]))
+    if prior_name == 'ga':
+        return float(np.sum(a * np.log(xs) - b * xs))
+    return float(np.sum(-a * np.log(xs) - b / xs))
+
+
+def log_prior_fod(length, nugget, prior_name, prior_coef, nugget_est, cl=None):
+    length = np.asarray(length, dtype=float)
+    nugget = float(np.ravel(nugget)[0])
+    if prior_name == 'ref':
+        a, b = prior_coef[0], prior_coef[1]
+        t = np.sum(cl / length) + nugget
+        fod = (b - a / t) * cl / length
+        if nugget_est:
+            fod = np.concatenate((np.atleast_1d(fod), [(a / t - b) * nugget]))
+        return np.atleast_1d(fod)
+    a, b = prior_coef[0], prior_coef[1]
+    xs = length if not nugget_est else np.concatenate((length, [nugget]))
+    if prior_name == 'ga':
+        return a - b * xs
+    return -a + b / xs
+
+
+def compute_cl(X, length_len, n_out, vecch=False):
+    """kernel.compute_cl, kernel_class.py:207-225 (X = [input|global_input])."""
+    X = np.asarray(X, dtype=float)
+    if length_len == 1:
+        if vecch:
+            rg = X.max(0) - X.min(0)
+            return np.sqrt(rg @ rg) / n_out
+        from scipy.spatial.distance import pdist
+        return np.max(pdist(X, metric='euclidean')) / n_out
+    rg = X.max(0) - X.min(0)
+    return rg / n_out ** (1.0 / length_len)
+
+
+# --------------------------------------------------------------------------
+# a5  ESS target log-likelihood (kernel_class.py:481-492)
+# --------------------------------------------------------------------------
+def log_likelihood(X, y, length, scale, nugget, name, W_diag=None):
+    """-0.5 (logdet(s2 K) + y^T (s2 K)^-1 y); no 2pi term, no prior."""
+    cov = float(np.ravel(scale)[0]) * k_matrix(X, length, nugget, name, W_diag)
+    L = cholesky(cov, lower=True, check_finite=False)
+    logdet = 2.0 * np.sum(np.log(np.abs(np.diag(L))))
+    y = np.asarray(y, dtype=float).reshape(-1, 1)
+    quad = float((y.T @ cho_solve((L, True), y, check_finite=False))[0, 0])
+    return -0.5 * (logdet + quad)
+
+
+# --------------------------------------------------------------------------
+# a8  M-step objective and gradient (kernel_class.py:403-449)
+# --------------------------------------------------------------------------
+def nll_grad(x, X, y, name, scale, nugget, nugget_est, scale_est,
+             prior_name='ga', prior_coef=None, cl=None,
+             W_diag=None, n_rep=None, sum_residual=None):
+    """Reference formulation (cho_solve with each dK as right-hand side).
+
+    x = log(length) [+ log(nugget) iff nugget_est].  Returns (nll, grad, scale)
+    where `scale` is the closed-form update when scale_est (side effect of
+    kernel.llik, kernel_class.py:428-431).  n_rep = len(rep) with replicates.
+    """
+    theta = np.exp(np.asarray(x, dtype=float))
+    if nugget_est:
+        length, nugget = theta[:-1], theta[-1]
+    else:
+        length = theta
+    nugget = float(np.ravel(nugget)[0])
+    scale = float(np.ravel(scale)[0])
+    y = np.asarray(y, dtype=float).reshape(-1, 1)
+    n = y.shape[0]
+    K, Kt = k_matrix_fod(X, length, nugget, name, nugget_est, W_diag)
+    L = cholesky(K, lower=True, check_finite=False)
+    KinvKt = np.array([cho_solve((L, True), Kt_i, check_finite=False) for Kt_i in Kt])
+    tr = np.trace(KinvKt, axis1=1, axis2=2)
+    logdet = 2.0 * np.sum(np.log(np.abs(np.diag(L))))
+    KinvY = cho_solve((L, True), y, check_finite=False)
+    YKKY = (y.T @ KinvKt @ KinvY).flatten()
+    YKinvY = float((y.T @ KinvY)[0, 0])
+    P1 = -0.5 * tr
+    P2 = 0.5 * YKKY
+    rep = n_rep is not None
+    if scale_est:
+        if not rep:
+            scale = YKinvY / n
+            nll = 0.5 * (logdet + n * np.log(scale))
+        else:
+            scale = (YKinvY + sum_residual / nugget) / n_rep
+            nll = 0.5 * (logdet + n_rep * np.log(scale))
+        g = -P1 - P2 / scale
+        if rep and nugget_est:
+            nll += 0.5 * (n_rep - n) * np.log(nugget)
+            g[-1] += 0.5 * (-sum_residual / (scale * nugget) + (n_rep - n))
+    else:
+        nll = 0.5 * (logdet + YKinvY / scale)
+        g = -P1 - P2 / scale
+        if rep and nugget_est:
+            nll += 0.5 * (sum_residual / (scale * nugget) + (n_rep - n) * np.log(nugget))
+            g[-1] += 0.5 * (-sum_residual / (scale * nugget) + (n_rep - n))
+    if prior_name is not None:
+        nll = nll - log_prior(length, nugget, prior_name, prior_coef, nugget_est, cl)
+        g = g - log_prior_fod(length, nugget, prior_name, prior_coef, nugget_est, cl)
+    return float(nll), np.asarray(g, dtype=float), scale
+
+
+# --------------------------------------------------------------------------
+# a3/a4  sampler pieces (functions.py:103-121,203-208)
+# --------------------------------------------------------------------------
+def fmvn(cov, z):
+    """L z with L = chol(cov); z is the injected N(0,I) draw (functions.py:113-121)."""
+    L = np.linalg.cholesky(cov)
+    return (L @ np.asarray(z, dtype=float).reshape(-1, 1)).flatten()
+
+
+def update_f(f, nu, theta):
+    return f * np.cos(theta) + nu * np.sin(theta)
+
+
+def ess_angles(u_theta):
+    """The proposal-angle sequence of imputation.py:81-82,115-119 assuming every
+    proposal so far was rejected.  u_theta[0] draws theta0 = 2pi u; later entries
+    are the U(0,1) draws that place theta inside the shrinking bracket
+    (numpy uniform(lo,hi) = lo + (hi-lo) u).  It is a function of the uniforms
+    alone, so a batch of B speculative proposals + 'first accepted' reproduces
+    the sequential loop exactly."""
+    u_theta = np.asarray(u_theta, dtype=float)
+    out = np.empty_like(u_theta)
+    theta = 2.0 * np.pi * u_theta[0]
+    lo, hi = theta - 2.0 * np.pi, theta
+    out[0] = theta
+    for i in range(1, len(u_theta)):
+        if theta < 0.0:
+            lo = theta
+        else:
+            hi = theta
+        theta = lo + (hi - lo) * u_theta[i]
+        out[i] = theta
+    return out
+
+
+def ess_block_sweep(f, nu, upper_loglik, log_u0, u_theta):
+    """One layer-wise ESS update (imputer.one_sample_block, imputation.py:44-119)
+    with injected randomness.
+
+    f, nu        : (n, M) current latent block and the prior draw (ellipse)
+    upper_loglik : callable(fp (n,M)) -> sum of upper-layer log-likelihoods
+    log_u0       : log of the threshold uniform (imputation.py:79)
+    u_theta      : U(0,1) draws for the angle sequence (enough of them)
+    Returns (f_new, n_proposals, thetas_tried, logliks_tried, log_y).
+    """
+    log_y = upper_loglik(f) + log_u0
+    thetas = ess_angles(u_theta)
+    lls = []
+    for i, th in enumerate(thetas):
+        fp = update_f(f, nu, th)
+        ll = upper_loglik(fp)
+        lls.append(ll)
+        if ll > log_y:
+            return fp, i + 1, thetas[:i + 1], np.array(lls), log_y
+    raise RuntimeError('ess_block_sweep: ran out of injected uniforms')
+
+
+# --------------------------------------------------------------------------
+# a10  prediction statistics (kernel_class.py:735-764, functions.py:259-272)
+# --------------------------------------------------------------------------
+def compute_stats(X, y, length, nugget, name, n_local, W_diag=None):
+    """-> dict(Rinv, Rinv_y, R2sexp, Psexp).  n_local = number of local (input)
+    columns; R2sexp/Psexp are built on the local columns only (sexp only)."""
+    R = k_matrix(X, length, nugget, name, W_diag)
+    L = np.linalg.cholesky(R)
+    n = len(R)
+    Rinv = cho_solve((L, True), np.eye(n), check_finite=False)
+    Rinv_y = cho_solve((L, True), np.asarray(y, float).reshape(-1, 1), check_finite=False).flatten()
+    out = dict(Rinv=Rinv, Rinv_y=Rinv_y, R2sexp=None, Psexp=None)
+    if name == 'sexp':
+        length = np.asarray(length, dtype=float)
+        ll = length if len(length) == 1 else length[:n_local]
+        Xl = np.asarray(X, float)[:, :n_local] / ll
+        s = np.zeros((n, n))
+        for d in range(n_local):
+            df = Xl[:, d][:, None] - Xl[:, d][None, :]
+            s += df * df
+        R2 = np.exp(-s / 2.0)
+        R2[np.arange(n), np.arange(n)] = 1.0
+        out['R2sexp'] = R2
+        out['Psexp'] = np.stack([Xl[:, d][:, None] + Xl[:, d][None, :] for d in range(n_local)])
+    return out
+
+
+# --------------------------------------------------------------------------
+# a11  GP prediction (functions.py:379-394, vecchia.py:244-265)
+# --------------------------------------------------------------------------
+def cross_corr(W, x, length, name):
+    """r[i, t] = k(W_i, x_t): (n, M).  K_vec_nb, vecchia.py:244-265."""
+    Wl = np.asarray(W, float) / np.asarray(length, float)
+    xl = np.asarray(x, float) / np.asarray(length, float)
+    n, D = Wl.shape
+    M = xl.shape[0]
+    if name == 'sexp':
+        s = np.zeros((n, M))
+        for d in range(D):
+            df = Wl[:, d][:, None] - xl[:, d][None, :]
+            s += df * df
+        return np.exp(-s)
+    prod = np.ones((n, M))
+    s = np.zeros((n, M))
+    for d in range(D):
+        r = np.abs(Wl[:, d][:, None] - xl[:, d][None, :])
+        prod *= 1.0 + SQ5 * r + (5.0 / 3.0) * r * r
+        s += r
+    return prod * np.exp(-SQ5 * s)
+
+
+def gp_predict(x, W, Rinv, Rinv_y, scale, length, nugget, name):
+    """m = Rinv_y . r ; v = |scale (1 + nugget - r^T Rinv r)|  (x, W already
+    concatenated with the global columns).  functions.py:379-394."""
+    r = cross_corr(W, x, length, name)
+    Rr = Rinv @ r
+    quad = np.sum(r * Rr, axis=0)
+    m = Rinv_y @ r
+    v = np.abs(float(np.ravel(scale)[0]) * (1.0 + float(np.ravel(nugget)[0]) - quad))
+    return m, v
+
+
+# --------------------------------------------------------------------------
+# a12-a14  linked-GP prediction (functions.py:396-506, vecchia.py:838-1000)
+# --------------------------------------------------------------------------
+def _matern_point(d, ell):
+    a = np.abs(d)
+    return (1.0 + SQ5 * a / ell + 5.0 * d * d / (3.0 * ell * ell)) * np.exp(-SQ5 * a / ell)
+
+
+def matern_I_dim(xk, zm, zv, ell):
+    """E[k(x, Z)], Z~N(zm, zv), one dimension (functions.py:463-471)."""
+    zX = zm - xk
+    if zv == 0:
+        return _matern_point(zX, ell)
+    muA = zX - SQ5 * zv / ell
+    muB = zX + SQ5 * zv / ell
+    t1 = np.exp((5 * zv - 2 * SQ5 * ell * zX) / (2 * ell ** 2)) * (
+        (1 + SQ5 * muA / ell + 5 * (muA ** 2 + zv) / (3 * ell ** 2)) * 0.5 * (1 + erf(muA / np.sqrt(2 * zv)))
+        + (SQ5 + (5 * muA) / (3 * ell)) * np.sqrt(0.5 * zv / np.pi) / ell * np.exp(-0.5 * muA ** 2 / zv))
+    t2 = np.exp((5 * zv + 2 * SQ5 * ell * zX) / (2 * ell ** 2)) * (
+        (1 - SQ5 * muB / ell + 5 * (muB ** 2 + zv) / (3 * ell ** 2)) * 0.5 * (1 + erf(-muB / np.sqrt(2 * zv)))
+        + (SQ5 - (5 * muB) / (3 * ell)) * np.sqrt(0.5 * zv / np.pi) / ell * np.exp(-0.5 * muB ** 2 / zv))
+    return t1 + t2
+
+
+def Jd(X1, X2, z_m, z_v, ell):
+    """Off-diagonal Matern-2.5 J factor, vectorised over X1, X2 (vecchia.py:915-959)."""
+    X1 = np.asarray(X1, float)
+    X2 = np.asarray(X2, float)
+    x1 = np.minimum(X1, X2)
+    x2 = np.maximum(X1, X2)
+    l = ell
+    l4 = 9 * l ** 4
+    pi = np.pi
+    E30 = 1 + (25 * x1**2 * x2**2 - 3 * SQ5 * (3 * l**3 + 5 * l * x1 * x2) * (x1 + x2) + 15 * l**2 * (x1**2 + x2**2 + 3 * x1 * x2)) / l4
+    E31 = (18 * SQ5 * l**3 + 15 * SQ5 * l * (x1**2 + x2**2) - (75 * l**2 + 50 * x1 * x2) * (x1 + x2) + 60 * SQ5 * l * x1 * x2) / l4
+    E32 = 5 * (5 * x1**2 + 5 * x2**2 + 15 * l**2 - 9 * SQ5 * l * (x1 + x2) + 20 * x1 * x2) / l4
+    E33 = 10 * (3 * SQ5 * l - 5 * x1 - 5 * x2) / l4
+    E34 = 25 / l4
+    muC = z_m - 2 * SQ5 * z_v / l
+    E3A31 = E30 + muC * E31 + (muC**2 + z_v) * E32 + (muC**3 + 3 * z_v * muC) * E33 + (muC**4 + 6 * z_v * muC**2 + 3 * z_v**2) * E34
+    E3A32 = E31 + (muC + x2) * E32 + (muC**2 + 2 * z_v + x2**2 + muC * x2) * E33 + (muC**3 + x2**3 + x2 * muC**2 + muC * x2**2 + 3 * z_v * x2 + 5 * z_v * muC) * E34
+    P1 = np.exp((10 * z_v + SQ5 * l * (x1 + x2 - 2 * z_m)) / l**2) * (
+        0.5 * E3A31 * (1 + erf((muC - x2) / np.sqrt(2 * z_v)))
+        + E3A32 * np.sqrt(0.5 * z_v / pi) * np.exp(-0.5 * (x2 - muC)**2 / z_v))
+
+    E40 = 1 + (25 * x1**2 * x2**2 + 3 * SQ5 * (3 * l**3 - 5 * l * x1 * x2) * (x2 - x1) + 15 * l**2 * (x1**2 + x2**2 - 3 * x1 * x2)) / l4
+    E41 = 5 * (3 * SQ5 * l * (x2**2 - x1**2) + 3 * l**2 * (x1 + x2) - 10 * x1 * x2 * (x1 + x2)) / l4
+    E42 = 5 * (5 * x1**2 + 5 * x2**2 - 3 * l**2 - 3 * SQ5 * l * (x2 - x1) + 20 * x1 * x2) / l4
+    E43 = -50 * (X1 + X2) / l4
+    E44 = 25 / l4
+    E4A41 = E40 + z_m * E41 + (z_m**2 + z_v) * E42 + (z_m**3 + 3 * z_v * z_m) * E43 + (z_m**4 + 6 * z_v * z_m**2 + 3 * z_v**2) * E44
+    E4A42 = E41 + (z_m + x1) * E42 + (z_m**2 + 2 * z_v + x1**2 + z_m * x1) * E43 + (z_m**3 + x1**3 + x1 * z_m**2 + z_m * x1**2 + 3 * z_v * x1 + 5 * z_v * z_m) * E44
+    E4A43 = E41 + (z_m + x2) * E42 + (z_m**2 + 2 * z_v + x2**2 + z_m * x2) * E43 + (z_m**3 + x2**3 + x2 * z_m**2 + z_m * x2**2 + 3 * z_v * x2 + 5 * z_v * z_m) * E44
+    P2 = np.exp(-SQ5 * (x2 - x1) / l) * (
+        0.5 * E4A41 * (erf((x2 - z_m) / np.sqrt(2 * z_v)) - erf((x1 - z_m) / np.sqrt(2 * z_v)))
+        + E4A42 * np.sqrt(0.5 * z_v / pi) * np.exp(-0.5 * (x1 - z_m)**2 / z_v)
+        - E4A43 * np.sqrt(0.5 * z_v / pi) * np.exp(-0.5 * (x2 - z_m)**2 / z_v))
+
+    E50 = 1 + (25 * x1**2 * x2**2 + 3 * SQ5 * (3 * l**3 + 5 * l * x1 * x2) * (x1 + x2) + 15 * l**2 * (x1**2 + x2**2 + 3 * x1 * x2)) / l4
+    E51 = (18 * SQ5 * l**3 + 15 * SQ5 * l * (x1**2 + x2**2) + (75 * l**2 + 50 * x1 * x2) * (x1 + x2) + 60 * SQ5 * l * x1 * x2) / l4
+    E52 = 5 * (5 * x1**2 + 5 * x2**2 + 15 * l**2 + 9 * SQ5 * l * (x1 + x2) + 20 * x1 * x2) / l4
+    E53 = 10 * (3 * SQ5 * l + 5 * x1 + 5 * x2) / l4
+    E54 = 25 / l4
+    muD = z_m + 2 * SQ5 * z_v / l
+    E5A51 = E50 - muD * E51 + (muD**2 + z_v) * E52 - (muD**3 + 3 * z_v * muD) * E53 + (muD**4 + 6 * z_v * muD**2 + 3 * z_v**2) * E54
+    E5A52 = E51 - (muD + x1) * E52 + (muD**2 + 2 * z_v + x1**2 + muD * x1) * E53 - (muD**3 + x1**3 + x1 * muD**2 + muD * x1**2 + 3 * z_v * x1 + 5 * z_v * muD) * E54
+    P3 = np.exp((10 * z_v - SQ5 * l * (x1 + x2 - 2 * z_m)) / l**2) * (
+        0.5 * E5A51 * (1 + erf((x1 - muD) / np.sqrt(2 * z_v)))
+        + E5A52 * np.sqrt(0.5 * z_v / pi) * np.exp(-0.5 * (x1 - muD)**2 / z_v))
+    return P1 + P2 + P3
+
+
+def Jd0(x1, z_m, z_v, ell):
+    """Diagonal Matern-2.5 J factor (vecchia.py:961-988)."""
+    x1 = np.asarray(x1, float)
+    l = ell
+    l4 = 9 * l ** 4
+    pi = np.pi
+    E30 = 1 + (25 * x1**4 - 6 * SQ5 * (3 * l**3 + 5 * l * x1**2) * x1 + 75 * l**2 * (x1**2)) / l4
+    E31 = (18 * SQ5 * l**3 + 90 * SQ5 * l * x1**2 - (150 * l**2 + 100 * x1**2) * x1) / l4
+    E32 = 5 * (30 * x1**2 + 15 * l**2 - 18 * SQ5 * l * x1) / l4
+    E33 = 10 * (3 * SQ5 * l - 10 * x1) / l4
+    E34 = 25 / l4
+    muC = z_m - 2 * SQ5 * z_v / l
+    E3A31 = E30 + muC * E31 + (muC**2 + z_v) * E32 + (muC**3 + 3 * z_v * muC) * E33 + (muC**4 + 6 * z_v * muC**2 + 3 * z_v**2) * E34
+    E3A32 = E31 + (muC + x1) * E32 + (muC**2 + 2 * z_v + x1**2 + muC * x1) * E33 + (muC**3 + x1**3 + x1 * muC**2 + muC * x1**2 + 3 * z_v * x1 + 5 * z_v * muC) * E34
+    P1 = np.exp((10 * z_v + SQ5 * l * (2 * x1 - 2 * z_m)) / l**2) * (
+        0.5 * E3A31 * (1 + erf((muC - x1) / np.sqrt(2 * z_v)))
+        + E3A32 * np.sqrt(0.5 * z_v / pi) * np.exp(-0.5 * (x1 - muC)**2 / z_v))
+    E50 = 1 + (25 * x1**4 + 6 * SQ5 * (3 * l**3 + 5 * l * x1**2) * x1 + 75 * l**2 * (x1**2)) / l4
+    E51 = (18 * SQ5 * l**3 + 90 * SQ5 * l * x1**2 + (150 * l**2 + 100 * x1**2) * x1) / l4
+    E52 = 5 * (30 * x1**2 + 15 * l**2 + 18 * SQ5 * l * x1) / l4
+    E53 = 10 * (3 * SQ5 * l + 10 * x1) / l4
+    E54 = 25 / l4
+    muD = z_m + 2 * SQ5 * z_v / l
+    E5A51 = E50 - muD * E51 + (muD**2 + z_v) * E52 - (muD**3 + 3 * z_v * muD) * E53 + (muD**4 + 6 * z_v * muD**2 + 3 * z_v**2) * E54
+    E5A52 = E51 - (muD + x1) * E52 + (muD**2 + 2 * z_v + x1**2 + muD * x1) * E53 - (muD**3 + x1**3 + x1 * muD**2 + muD * x1**2 + 3 * z_v * x1 + 5 * z_v * muD) * E54
+    P3 = np.exp((10 * z_v - SQ5 * l * (2 * x1 - 2 * z_m)) / l**2) * (
+        0.5 * E5A51 * (1 + erf((x1 - muD) / np.sqrt(2 * z_v)))
+        + E5A52 * np.sqrt(0.5 * z_v / pi) * np.exp(-0.5 * (x1 - muD)**2 / z_v))
+    return P1 + P3
+
+
+def IJ(X, z_m, z_v, length, name):
+    """I (n,), J (n,n) for one test point with input N(z_m, diag z_v).
+
+    sexp: direct form of IJ_nb (vecchia.py:845-869) == IJ_sexp (functions.py:432-451);
+    matern2.5: IJ_matern (functions.py:453-494) with the v_k = 0 branches."""
+    X = np.asarray(X, float)
+    n, d = X.shape
+    length = np.asarray(length, float)
+    if len(length) == 1:
+        length = np.full(d, length[0])
+    if name == 'sexp':
+        Xz = X - z_m
+        I1 = 1.0 / np.sqrt(np.prod(1 + 2 * z_v / length**2))
+        J1 = 1.0 / np.sqrt(np.prod(1 + 4 * z_v / length**2))
+        I = I1 * np.exp(-np.sum(Xz**2 / (2 * z_v + length**2), axis=1))
+        e = np.zeros((n, n))
+        for k in range(d):
+            a = Xz[:, k]
+            e += (a[:, None] + a[None, :])**2 / (8 * z_v[k] + 2 * length[k]**2) + (a[:, None] - a[None, :])**2 / (2 * length[k]**2)
+        J = J1 * np.exp(-e)
+        return I, J
+    I = np.ones(n)
+    J = np.ones((n, n))
+    eye = np.eye(n, dtype=bool)
+    for k in range(d):
+        xk = X[:, k]
+        Ik = matern_I_dim(xk, z_m[k], z_v[k], length[k])
+        I *= Ik
+        if z_v[k] != 0:
+            with np.errstate(all='ignore'):
+                Jk = Jd(xk[None, :], xk[:, None], z_m[k], z_v[k], length[k])
+            Jk[eye] = Jd0(xk, z_m[k], z_v[k], length[k])
+        else:
+            p = _matern_point(z_m[k] - xk, length[k])
+            Jk = p[:, None] * p[None, :]
+        J *= Jk
+    return I, J
+
+
+def link_gp_predict(m, v, z, W, Wg, Rinv, Rinv_y, scale, length, nugget, name):
+    """functions.link_gp (functions.py:396-430): per test point
+    mean = I.Rinv_y ; var = |Rinv_y^T J Rinv_y - mean^2 + scale(1+nugget-tr(Rinv J))|.
+    m, v: (M, Dw) moments of the local inputs; z: (M, Dz) or None deterministic
+    global inputs; W (n,Dw), Wg (n,Dz) training inputs."""
+    m = np.asarray(m, float)
+    v = np.asarray(v, float)
+    M = m.shape[0]
+    Dw = W.shape[1]
+    length = np.asarray(length, float)
+    Dz = 0 if z is None else z.shape[1]
+    if len(length) == 1:
+        length = np.full(Dw + Dz, length[0])
+    scale = float(np.ravel(scale)[0])
+    nugget = float(np.ravel(nugget)[0])
+    mo = np.zeros(M)
+    vo = np.zeros(M)
+    for t in range(M):
+        I, J = IJ(W, m[t], v[t], length[:Dw], name)
+        if z is not None:
+            Iz = cross_corr(Wg, z[t:t + 1], length[Dw:], name)[:, 0]
+            I = I * Iz
+            J = J * np.outer(Iz, Iz)
+        tr = np.sum(Rinv * J)
+        mu = I @ Rinv_y
+        mo[t] = mu
+        vo[t] = np.abs(Rinv_y @ J @ Rinv_y - mu**2 + scale * (1 + nugget - tr))
+    return mo, vo
+
+
+def aggregate_moments(mu_list, var_list):
+    """emulation.py:846-847: mu = mean_s mu_s ; s2 = mean_s(mu_s^2+v_s) - mu^2."""
+    mu_s = np.asarray(mu_list)
+    v_s = np.asarray(var_list)
+    mu = np.mean(mu_s, axis=0)
+    return mu, np.mean(mu_s**2 + v_s, axis=0) - mu**2
+
+
+# --------------------------------------------------------------------------
+# a17  Vecchia neighbour search (vecchia.py:20-109) -- exact brute force
+# --------------------------------------------------------------------------
+def nn_ordered(x, m):
+    """NNarray (n, m+1) int64 of vecchia.nn: row i = i and its <=m nearest
+    EARLIER points (index <= i, squared-euclidean, exact), sorted by index
+    descending, -1 padded (vecchia.py:108)."""
+    x = np.asarray(x, float)
+    n = x.shape[0]
+    m = min(m, n - 1)
+    out = np.full((n, m + 1), -1, dtype=np.int64)
+    for i in range(n):
+        d = np.sum((x[:i + 1] - x[i])**2, axis=1)
+        k = min(m + 1, i + 1)
+        idx = np.argsort(d, kind='stable')[:k]
+        out[i, :k] = idx
+    return np.fliplr(np.sort(out, axis=1))
+
+
+def pred_nn(query, x, m):
+    """get_pred_nn (vecchia.py:20-40): m nearest training points, nearest first."""
+    query = np.asarray(query, float)
+    x = np.asarray(x, float)
+    n = x.shape[0]
+    m = min(m, n)
+    if m == n:
+        k = query.shape[0]
+        return (np.arange(m)[None, :] + np.arange(k)[:, None]) % m
+    d = ((query[:, None, :] - x[None, :, :])**2).sum(-1)
+    return np.argsort(d, axis=1, kind='stable')[:, :m].astype(np.int64)
+
+
+# --------------------------------------------------------------------------
+# a18-a21  Vecchia likelihoods and sampler (vecchia.py:111-242,292-424)
+# --------------------------------------------------------------------------
+def _row_idx(NNarray, i):
+    idx = NNarray[i]
+    return idx[idx >= 0][::-1]
+
+
+def vecchia_llik(X, y, NNarray, scale, length, nugget, nugget_diag, name):
+    """vecchia.py:164-180: -0.5 (sum_i 2 log L_i[last,last] + sum_i (L_i^-1 y_i)_last^2 / scale)."""
+    X = np.asarray(X, float)
+    y = np.asarray(y, float).reshape(-1)
+    n = X.shape[0]
+    quad = 0.0
+    logdet = 0.0
+    for i in range(n):
+        idx = _row_idx(NNarray, i)
+        Ki = corr_matrix(X[idx], length, name)
+        b = len(idx)
+        Ki[np.arange(b), np.arange(b)] = 1.0 + nugget * nugget_diag[idx]
+        Li = np.linalg.cholesky(Ki)
+        w = solve_triangular(Li, y[idx], lower=True)
+        quad += w[-1]**2
+        logdet += 2 * np.log(np.abs(Li[-1, -1]))
+    return -0.5 * (logdet + quad / scale)
+
+
+def vecchia_nllik(X, y, NNarray, scale, length, nugget, nugget_diag, name,
+                  scale_est, nugget_est, origin_n, rr):
+    """vecchia.py:182-242 -> (nll, grad(p), scale)."""
+    X = np.asarray(X, float)
+    y = np.asarray(y, float).reshape(-1)
+    length = np.asarray(length, float)
+    n = X.shape[0]
+    p = len(length) + (1 if nugget_est else 0)
+    dquad = np.zeros(p)
+    dlogdet = np.zeros(p)
+    quad = 0.0
+    logdet = 0.0
+    for i in range(n):
+        idx = _row_idx(NNarray, i)
+        b = len(idx)
+        Ki, dKi = k_matrix_fod(X[idx], length, 0.0, name, False)
+        nug = nugget * nugget_diag[idx]
+        Ki[np.arange(b), np.arange(b)] = 1.0 + nug
+        if nugget_est:
+            dKi = np.concatenate((dKi, np.diag(nug)[None]), axis=0)
+        Li = np.linalg.cholesky(Ki)
+        w = solve_triangular(Li, y[idx], lower=True)
+        e = np.zeros(b)
+        e[-1] = 1.0
+        u = solve_triangular(Li.T, e, lower=False)
+        for k in range(p):
+            t = solve_triangular(Li, dKi[k] @ u, lower=True)
+            s = w @ t
+            dquad[k] += 2 * s * w[-1] - t[-1] * w[-1]**2
+            dlogdet[k] += t[-1]
+        quad += w[-1]**2
+        logdet += 2 * np.log(np.abs(Li[-1, -1]))
+    if scale_est:
+        if n == origin_n:
+            scale = quad / n
+            nll = 0.5 * (logdet + n * np.log(scale))
+            g = 0.5 * (dlogdet - dquad / scale)
+        else:
+            scale = (quad + rr / nugget) / origin_n
+            nll = 0.5 * (logdet + origin_n * np.log(scale))
+            g = 0.5 * (dlogdet - dquad / scale)
+            if nugget_est:
+                nll += 0.5 * (origin_n - n) * np.log(nugget)
+                g[-1] += 0.5 * (-rr / (scale * nugget) + (origin_n - n))
+    else:
+        nll = 0.5 * (logdet + quad / scale)
+        g = 0.5 * (dlogdet - dquad / scale)
+        if n != origin_n and nugget_est:
+            nll += 0.5 * (rr / (nugget * scale) + (origin_n - n) * np.log(nugget))
+            g[-1] += 0.5 * (-rr / (scale * nugget) + (origin_n - n))
+    return float(nll), g, float(scale)
+
+
+def L_matrix(X, NNarray, length, nugget, name):
+    """vecchia.py:409-424: row i = (e_last^T L_i^-1) reversed (self first), zero padded."""
+    X = np.asarray(X, float)
+    n, mp1 = NNarray.shape
+    out = np.zeros((n, mp1))
+    for i in range(n):
+        idx = _row_idx(NNarray, i)
+        b = len(idx)
+        Ki = corr_matrix(X[idx], length, name)
+        Ki[np.arange(b), np.arange(b)] = 1.0 + nugget
+        Li = np.linalg.cholesky(Ki)
+        e = np.zeros(b)
+        e[-1] = 1.0
+        u = solve_triangular(Li.T, e, lower=False)
+        out[i, :b] = u[::-1]
+    return out
+
+
+def forward_solve_sp(L, NNarray, b):
+    """vecchia.py:111-120 sequential sparse lower solve."""
+    n, m = L.shape
+    x = np.zeros(n)
+    for i in range(n):
+        s = 0.0
+        for j in range(1, min(i + 1, m)):
+            s += L[i, j] * x[NNarray[i, j]]
+        x[i] = (b[i] - s) / L[i, 0]
+    return x
+
+
+def fmvn_sp(X, NNarray, scale, length, nugget, name, z):
+    """vecchia.py:133-140 with injected z."""
+    L = L_matrix(X, NNarray, length, nugget, name) / np.sqrt(scale)
+    return forward_solve_sp(L, NNarray, z)
+
+
+# --------------------------------------------------------------------------
+# a22/a23  Vecchia prediction (vecchia.py:635-654,758-796)
+# --------------------------------------------------------------------------
+def gp_vecch(x, w, NNarray, y, scale, length, nugget, nugget_diag, name):
+    x = np.asarray(x, float)
+    w = np.asarray(w, float)
+    y = np.asarray(y, float).reshape(-1)
+    M = x.shape[0]
+    mo = np.zeros(M)
+    vo = np.zeros(M)
+    for i in range(M):
+        idx = NNarray[i]
+        idx = idx[idx >= 0]
+        Xi = np.vstack((w[idx], x[i:i + 1]))
+        b = len(idx) + 1
+        Ki = corr_matrix(Xi, length, name)
+        nug = np.empty(b)
+        nug[:-1] = nugget * nugget_diag[idx]
+        nug[-1] = nugget
+        Ki[np.arange(b), np.arange(b)] = 1.0 + nug
+        Li = np.linalg.cholesky(Ki)
+        mo[i] = Li[-1, :-1] @ solve_triangular(Li[:-1, :-1], y[idx], lower=True)
+        vo[i] = scale * Li[-1, -1]**2
+    return mo, vo
+
+
+def link_gp_vecch(m, v, z, w1, global_w1, NNarray, y, scale, length, nugget, nugget_diag, name):
+    m = np.asarray(m, float)
+    v = np.asarray(v, float)
+    y = np.asarray(y, float).reshape(-1)
+    M = m.shape[0]
+    Dw = w1.shape[1]
+    Dz = 0 if z is None else z.shape[1]
+    length = np.asarray(length, float)
+    if len(length) == 1:
+        length = np.full(Dw + Dz, length[0])
+    mo = np.zeros(M)
+    vo = np.zeros(M)
+    for i in range(M):
+        idx = NNarray[i]
+        idx = idx[idx >= 0]
+        b = len(idx)
+        wi = w1[idx]
+        I, J = IJ(wi, m[i], v[i], length[:Dw], name)
+        if z is not None:
+            gi = global_w1[idx]
+            Iz = cross_corr(gi, z[i:i + 1], length[Dw:], name)[:, 0]
+            I = I * Iz
+            J = J * np.outer(Iz, Iz)
+            Ki = corr_matrix(np.concatenate((wi, gi), 1), length, name)
+        else:
+            Ki = corr_matrix(wi, length, name)
+        Ki[np.arange(b), np.arange(b)] = 1.0 + nugget * nugget_diag[idx]
+        tr = np.trace(np.linalg.solve(Ki, J))
+        Li = np.linalg.cholesky(Ki)
+        Ry = cho_solve((Li, True), y[idx])
+        mu = I @ Ry
+        mo[i] = mu
+        vo[i] = np.abs(Ry @ J @ Ry - mu**2 + scale * (1 + nugget - tr))
+    return mo, vo

@@ -1,0 +1,385 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE itself (build container only).
+
+TEST INFRASTRUCTURE.  Imports /root/reference/dgpsi with the identity stubs in
+oracle/refstub/ ahead of it on sys.path (numba/pathos are not installed here;
+every @njit body is plain numpy-Python so the stubs change speed, not results)
+and records inputs + outputs of every hot-path function as small .npz fixtures
+under tests/golden/.  The fixtures are data; no reference source is copied.
+
+Usage:  python oracle/gen_golden.py            (rewrites tests/golden/*.npz)
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get('DGP_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, 'refstub'))
+
+import numpy as np  # noqa: E402
+
+import dgpsi  # noqa: E402
+from dgpsi import kernel, combine, dgp, emulator  # noqa: E402
+import dgpsi.functions as RF  # noqa: E402
+import dgpsi.vecchia as RV  # noqa: E402
+import dgpsi.imputation as RI  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('wrote', path, sum(np.asarray(a).nbytes for a in arrs.values()), 'bytes')
+
+
+def make_node(rng, n, d_loc, d_glob, name, per_dim, nugget_est, scale_est, prior, rep):
+    D = d_loc + d_glob
+    length = rng.uniform(0.4, 1.6, size=D if per_dim else 1)
+    k = kernel(length=length.copy(), scale=float(rng.uniform(0.5, 2.0)), nugget=float(rng.uniform(1e-4, 1e-2)),
+               name=name, prior_name=prior, nugget_est=nugget_est, scale_est=scale_est)
+    k.input = rng.uniform(0, 1, size=(n, d_loc))
+    k.global_input = rng.uniform(0, 1, size=(n, d_glob)) if d_glob > 0 else None
+    k.connect = np.arange(d_glob) if d_glob > 0 else None
+    k.output = rng.normal(size=(n, 1))
+    k.D = D
+    if rep:
+        counts = rng.integers(1, 4, size=n)
+        k.rep = np.repeat(np.arange(n), counts)
+        k.W_diag = 1.0 / counts
+        k.sum_residual = np.array([float(rng.uniform(0.5, 2.0))])
+    if prior == 'ref':
+        p = D
+        b = 1 / n ** (1 / p) * (k.prior_coef + p)
+        k.prior_coef = np.concatenate((k.prior_coef, b))
+        k.compute_cl()
+    return k
+
+
+def node_X(k):
+    return k.input if k.global_input is None else np.concatenate((k.input, k.global_input), 1)
+
+
+# ---------------------------------------------------------------- G1/G2/G3
+def gen_kernel_cases():
+    rng = np.random.default_rng(101)
+    out = {}
+    c = 0
+    for name in ('sexp', 'matern2.5'):
+        for per_dim in (False, True):
+            for d_glob in (0, 2):
+                for nugget_est in (False, True):
+                    for rep in (False, True):
+                        for scale_est, prior in ((True, 'ga'), (False, 'inv_ga'), (True, 'ref'), (False, None)):
+                            if rep and prior in ('inv_ga', None):
+                                continue
+                            n = int(rng.integers(12, 22))
+                            k = make_node(rng, n, 3, d_glob, name, per_dim, nugget_est, scale_est, prior, rep)
+                            pre = 'c%d_' % c
+                            out[pre + 'X'] = node_X(k)
+                            out[pre + 'y'] = k.output.copy()
+                            out[pre + 'length'] = k.length.copy()
+                            out[pre + 'scale'] = k.scale.copy()
+                            out[pre + 'nugget'] = k.nugget.copy()
+                            out[pre + 'name'] = np.array(name)
+                            out[pre + 'flags'] = np.array([per_dim, d_glob, nugget_est, rep, scale_est], dtype=np.int64)
+                            out[pre + 'prior'] = np.array('none' if prior is None else prior)
+                            if prior is not None:
+                                out[pre + 'prior_coef'] = np.asarray(k.prior_coef, float).copy()
+                            if prior == 'ref':
+                                out[pre + 'cl'] = np.atleast_1d(np.asarray(k.cl, float)).copy()
+                            if rep:
+                                out[pre + 'W_diag'] = k.W_diag.copy()
+                                out[pre + 'n_rep'] = np.array(len(k.rep))
+                                out[pre + 'sum_residual'] = k.sum_residual.copy()
+                            K = k.k_matrix()
+                            K2, fod = k.k_matrix(fod_eval=True)
+                            assert np.array_equal(K, K2) or np.allclose(K, K2, rtol=0, atol=1e-15)
+                            out[pre + 'K'] = K
+                            out[pre + 'fod'] = fod
+                            if prior != 'ref':
+                                out[pre + 'loglik'] = np.atleast_1d(k.log_likelihood_func()).flatten()
+                            x = k.log_t() + rng.normal(scale=0.1, size=len(k.log_t()))
+                            nll, g = k.llik(x.copy())
+                            out[pre + 'x'] = x
+                            out[pre + 'nll'] = np.atleast_1d(nll).flatten()
+                            out[pre + 'grad'] = np.asarray(g, float).flatten()
+                            out[pre + 'scale_after'] = np.atleast_1d(k.scale).flatten()
+                            c += 1
+    out['n_cases'] = np.array(c)
+    save('g1_kernel_llik', **out)
+
+
+# ---------------------------------------------------------------- G4/G5
+class DrawLog:
+    """Replaces numpy draws inside the reference by logged, replayable draws."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.z = []
+        self.u = []
+
+    def randn(self, *shape):
+        z = self.rng.standard_normal(shape)
+        self.z.append(z.flatten().copy())
+        return z
+
+    def uniform(self, lo=0.0, hi=1.0):
+        u = self.rng.random()
+        self.u.append(u)
+        return lo + (hi - lo) * u
+
+
+def gen_fmvn():
+    rng = np.random.default_rng(7)
+    n = 24
+    X = rng.uniform(size=(n, 3))
+    k = kernel(length=np.array([0.7]), scale=1.3, nugget=1e-5, name='matern2.5')
+    k.input = X
+    cov = k.scale * k.k_matrix()
+    log = DrawLog(3)
+    old = RF.randn
+    RF.randn = log.randn
+    try:
+        s = RF.fmvn(cov)
+        mu = rng.normal(size=n)
+        s_mu = RF.fmvn_mu(mu, cov)
+    finally:
+        RF.randn = old
+    f = rng.normal(size=(n, 2))
+    nu = rng.normal(size=(n, 2))
+    save('g4_fmvn', cov=cov, z=log.z[0], sample=s, mu=mu, z_mu=log.z[1], sample_mu=s_mu,
+         f=f, nu=nu, theta=np.array(1.234), fp=RF.update_f(f, nu, 1.234))
+
+
+def build_small_dgp(seed, n, d, names, n_out=1, three_layer=False):
+    np.random.seed(seed)
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(size=(n, d))
+    Y = np.stack([np.sin(3 * X[:, 0] * (j + 1)) + X[:, 1 % d] ** 2 for j in range(n_out)], 1)
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    l1 = [kernel(length=np.array([1.0]), name=names[0]) for _ in range(d)]
+    layers = [l1]
+    if three_layer:
+        layers.append([kernel(length=np.array([1.0]), name=names[0], connect=np.arange(d)) for _ in range(d)])
+    layers.append([kernel(length=np.array([1.0]), name=names[1], scale_est=True, connect=np.arange(d)) for _ in range(n_out)])
+    return X, Y, combine(*layers)
+
+
+def dump_structure(all_layer, pre=''):
+    out = {}
+    out[pre + 'n_layer'] = np.array(len(all_layer))
+    for l, layer in enumerate(all_layer):
+        out[pre + 'l%d_n' % l] = np.array(len(layer))
+        for k, nd in enumerate(layer):
+            p = pre + 'l%d_k%d_' % (l, k)
+            out[p + 'name'] = np.array(nd.name)
+            out[p + 'length'] = np.asarray(nd.length, float).copy()
+            out[p + 'scale'] = np.asarray(nd.scale, float).copy()
+            out[p + 'nugget'] = np.asarray(nd.nugget, float).copy()
+            out[p + 'input'] = nd.input.copy()
+            out[p + 'output'] = nd.output.copy()
+            out[p + 'input_dim'] = np.asarray(nd.input_dim, np.int64).copy()
+            out[p + 'has_global'] = np.array(nd.global_input is not None)
+            if nd.global_input is not None:
+                out[p + 'global_input'] = nd.global_input.copy()
+                out[p + 'connect'] = np.asarray(nd.connect, np.int64).copy()
+            out[p + 'scale_est'] = np.array(bool(nd.scale_est))
+            out[p + 'nugget_est'] = np.array(bool(nd.nugget_est))
+    return out
+
+
+def gen_ess():
+    """One imputer.sample(burnin=2) trajectory with logged draws (G5)."""
+    for tag, names, three in (('sexp', ('sexp', 'sexp'), False), ('matern', ('matern2.5', 'matern2.5'), False),
+                              ('deep', ('sexp', 'matern2.5'), True)):
+        X, Y, layers = build_small_dgp(11, 18, 2, names, three_layer=three)
+        model = dgp(X, Y, layers)
+        log = DrawLog(5)
+        oldr, oldu = RF.randn, RI.uniform
+        RI.fmvn.__globals__['randn'] = log.randn
+        RI.uniform = log.uniform
+        try:
+            before = dump_structure(model.all_layer, 'pre_')
+            model.imp.sample(burnin=2)
+            after = dump_structure(model.all_layer, 'post_')
+        finally:
+            RI.fmvn.__globals__['randn'] = oldr
+            RI.uniform = oldu
+        nz = len(log.z)
+        out = dict(before)
+        out.update(after)
+        out['z'] = np.stack(log.z)
+        out['u'] = np.array(log.u)
+        out['X'] = X
+        out['Y'] = Y
+        save('g5_ess_' + tag, **out)
+        print('   ess', tag, 'z draws', nz, 'u draws', len(log.u))
+
+
+# ---------------------------------------------------------------- G6/G7
+def gen_predict_pieces():
+    rng = np.random.default_rng(21)
+    out = {}
+    c = 0
+    for name in ('sexp', 'matern2.5'):
+        for per_dim in (False, True):
+            for d_glob in (0, 2):
+                n, d_loc, M = 16, 2, 7
+                k = make_node(rng, n, d_loc, d_glob, name, per_dim, False, False, 'ga', False)
+                k.compute_stats()
+                pre = 'c%d_' % c
+                out[pre + 'name'] = np.array(name)
+                out[pre + 'X'] = node_X(k)
+                out[pre + 'n_local'] = np.array(d_loc)
+                out[pre + 'y'] = k.output.copy()
+                out[pre + 'length'] = k.length.copy()
+                out[pre + 'scale'] = k.scale.copy()
+                out[pre + 'nugget'] = k.nugget.copy()
+                out[pre + 'Rinv'] = k.Rinv.copy()
+                out[pre + 'Rinv_y'] = k.Rinv_y.copy()
+                if name == 'sexp':
+                    out[pre + 'R2sexp'] = k.R2sexp.copy()
+                    out[pre + 'Psexp'] = k.Psexp.copy()
+                x = rng.uniform(size=(M, d_loc))
+                z = rng.uniform(size=(M, d_glob)) if d_glob else None
+                m_gp, v_gp = RF.gp(x, z, k.input, k.global_input, k.Rinv, k.Rinv_y, k.scale, k.length, k.nugget, k.name)
+                out[pre + 'x'] = x
+                if z is not None:
+                    out[pre + 'z'] = z
+                out[pre + 'gp_m'] = m_gp
+                out[pre + 'gp_v'] = v_gp
+                mm = rng.uniform(size=(M, d_loc))
+                vv = rng.uniform(0.001, 0.3, size=(M, d_loc))
+                vv[0, 0] = 0.0  # exercise the v_k == 0 branch (functions.py:470-471,479-481,488-491)
+                vv[1, :] = 0.0
+                lm, lv = RF.link_gp(mm, vv, z, k.input, k.global_input, k.Rinv, k.Rinv_y, k.R2sexp, k.Psexp,
+                                    k.scale[0], k.length, k.nugget[0], k.name)
+                out[pre + 'lm_in'] = mm
+                out[pre + 'lv_in'] = vv
+                out[pre + 'link_m'] = lm
+                out[pre + 'link_v'] = lv
+                c += 1
+    out['n_cases'] = np.array(c)
+    # raw I/J factors
+    X = rng.uniform(size=(9, 3))
+    zm = rng.uniform(size=3)
+    zv = np.array([0.05, 0.0, 0.4])
+    ln = np.array([0.6, 1.1, 0.8])
+    Im, Jm = RF.IJ_matern(X, zm, zv, ln)
+    Is, Js = RV.IJ_nb(X, zm, zv, ln, 'sexp')
+    Im2, Jm2 = RV.IJ_nb(X, zm, zv, ln, 'matern2.5')
+    assert np.array_equal(Im, Im2) and np.array_equal(Jm, Jm2)
+    x1 = rng.uniform(-1, 2, size=40)
+    x2 = rng.uniform(-1, 2, size=40)
+    zmm = rng.uniform(-0.5, 1.5, size=40)
+    zvv = rng.uniform(1e-3, 1.5, size=40)
+    ll = rng.uniform(0.3, 2.5, size=40)
+    jd = np.array([RV.Jd(a, b, c_, d_, e_) for a, b, c_, d_, e_ in zip(x1, x2, zmm, zvv, ll)])
+    jd0 = np.array([RV.Jd0(a, c_, d_, e_) for a, c_, d_, e_ in zip(x1, zmm, zvv, ll)])
+    out.update(ij_X=X, ij_zm=zm, ij_zv=zv, ij_len=ln, ij_I_matern=Im, ij_J_matern=Jm, ij_I_sexp=Is, ij_J_sexp=Js,
+               jd_x1=x1, jd_x2=x2, jd_zm=zmm, jd_zv=zvv, jd_len=ll, jd=jd, jd0=jd0)
+    save('g7_predict', **out)
+
+
+# ---------------------------------------------------------------- G8
+def gen_vecchia():
+    rng = np.random.default_rng(33)
+    out = {}
+    n, d, m = 200, 3, 10
+    x = rng.uniform(size=(n, d))
+    NN = RV.nn(x, m)
+    out.update(nn_x=x, nn_m=np.array(m), NNarray=NN.astype(np.int64))
+    q = rng.uniform(size=(25, d))
+    out.update(pq=q, pred_nn=RV.get_pred_nn(q, x, 12).astype(np.int64))
+    c = 0
+    for name in ('sexp', 'matern2.5'):
+        for per_dim in (False, True):
+            for nugget_est, scale_est in ((False, False), (True, True)):
+                n2, m2 = 60, 6
+                X = rng.uniform(size=(n2, d))
+                y = rng.normal(size=(n2, 1))
+                length = rng.uniform(0.4, 1.5, size=d if per_dim else 1)
+                scale, nugget = float(rng.uniform(0.5, 2)), float(rng.uniform(1e-4, 1e-2))
+                NN2 = RV.nn(X / length, m2)
+                ndg = np.ones(n2)
+                pre = 'v%d_' % c
+                out[pre + 'name'] = np.array(name)
+                out[pre + 'X'] = X
+                out[pre + 'y'] = y
+                out[pre + 'length'] = length
+                out[pre + 'scale'] = np.array(scale)
+                out[pre + 'nugget'] = np.array(nugget)
+                out[pre + 'NN'] = NN2.astype(np.int64)
+                out[pre + 'flags'] = np.array([nugget_est, scale_est], np.int64)
+                out[pre + 'llik'] = np.atleast_1d(RV.vecchia_llik(X, y, NN2, scale, length, nugget, ndg, name)).flatten()
+                nll, g, sc = RV.vecchia_nllik(X, y, NN2, scale, length, nugget, ndg, name, scale_est, nugget_est, n2, -1.0)
+                out[pre + 'nll'] = np.atleast_1d(nll).flatten()
+                out[pre + 'grad'] = np.asarray(g, float)
+                out[pre + 'scale_out'] = np.atleast_1d(sc).flatten()
+                Lm = RV.L_matrix(X, NN2, length, nugget, name)
+                out[pre + 'Lmat'] = Lm
+                b = rng.normal(size=n2)
+                out[pre + 'b'] = b
+                out[pre + 'spsolve'] = RV.forward_solve_sp(Lm / np.sqrt(scale), NN2, b)
+                xq = rng.uniform(size=(9, d))
+                pNN = RV.get_pred_nn(xq / length, X / length, 8)
+                gm, gv = RV.gp_vecch(xq, X, pNN, y, scale, length, nugget, ndg, name)
+                out[pre + 'xq'] = xq
+                out[pre + 'pNN'] = pNN.astype(np.int64)
+                out[pre + 'gpv_m'] = gm
+                out[pre + 'gpv_v'] = gv
+                mm = rng.uniform(size=(9, 2))
+                vv = rng.uniform(0.01, 0.2, size=(9, 2))
+                zz = rng.uniform(size=(9, 1))
+                lm, lv = RV.link_gp_vecch(mm, vv, zz, X[:, :2], X[:, 2:], pNN, y, scale, length, nugget, ndg, name)
+                out[pre + 'lm_in'] = mm
+                out[pre + 'lv_in'] = vv
+                out[pre + 'lz_in'] = zz
+                out[pre + 'lgv_m'] = lm
+                out[pre + 'lgv_v'] = lv
+                c += 1
+    out['n_cases'] = np.array(c)
+    save('g8_vecchia', **out)
+
+
+# ---------------------------------------------------------------- G9/G11
+def gen_emulator():
+    for tag, names in (('sexp', ('sexp', 'sexp')), ('matern', ('matern2.5', 'matern2.5'))):
+        X, Y, layers = build_small_dgp(5, 16, 2, names, n_out=2)
+        model = dgp(X, Y, layers)
+        model.train(N=6, ess_burn=2, disable=True)
+        est = model.estimate()
+        out = {}
+        for l, layer in enumerate(model.all_layer):
+            for k, nd in enumerate(layer):
+                out['path_l%d_k%d' % (l, k)] = nd.para_path.copy()
+        out.update(dump_structure(est, 'est_'))
+        emu = emulator(est, N=3)
+        out['n_imp'] = np.array(len(emu.all_layer_set))
+        for s, al in enumerate(emu.all_layer_set):
+            out.update(dump_structure(al, 's%d_' % s))
+        xt = np.random.default_rng(9).uniform(size=(11, 2))
+        mu, var = emu.predict(xt)
+        mus, vars_ = emu.predict(xt, aggregation=False)
+        out.update(xt=xt, mu=mu, var=var, mu_s=np.stack(mus), var_s=np.stack(vars_), X=X, Y=Y)
+        save('g9_emulator_' + tag, **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator']
+    if 'kernel' in which:
+        gen_kernel_cases()
+    if 'fmvn' in which:
+        gen_fmvn()
+    if 'ess' in which:
+        gen_ess()
+    if 'predict' in which:
+        gen_predict_pieces()
+    if 'vecchia' in which:
+        gen_vecchia()
+    if 'emulator' in which:
+        gen_emulator()

@@ -1,0 +1,240 @@
+"""Pin oracle/dgp_oracle.py against golden vectors recorded from the reference
+(oracle/gen_golden.py).  Tolerance: 1e-10 relative on f64 (1e-8 on the Jd-based
+Matern J factors), integers exact -- SURVEY.md section 8(c)."""
+import numpy as np
+import pytest
+
+from oracle import dgp_oracle as O
+from conftest import case
+
+RTOL = 1e-10
+
+
+def close(a, b, rtol=RTOL, atol=1e-13):
+    np.testing.assert_allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol)
+
+
+def kernel_cases(golden):
+    g = golden('g1_kernel_llik')
+    for c in range(int(g['n_cases'])):
+        yield c, case(g, 'c%d_' % c)
+
+
+def test_k_matrix_and_fod(golden):
+    for c, d in kernel_cases(golden):
+        name = str(d['name'])
+        W = d.get('W_diag')
+        nugget_est = bool(d['flags'][2])
+        K = O.k_matrix(d['X'], d['length'], d['nugget'][0], name, W)
+        close(K, d['K'])
+        K2, fod = O.k_matrix_fod(d['X'], d['length'], d['nugget'][0], name, nugget_est, W)
+        close(K2, d['K'])
+        assert fod.shape == d['fod'].shape
+        close(fod, d['fod'])
+
+
+def test_loglik(golden):
+    n = 0
+    for c, d in kernel_cases(golden):
+        if 'loglik' not in d:
+            continue
+        ll = O.log_likelihood(d['X'], d['y'], d['length'], d['scale'], d['nugget'][0], str(d['name']), d.get('W_diag'))
+        close(ll, d['loglik'][0], rtol=1e-9)
+        n += 1
+    assert n > 20
+
+
+def test_nll_grad(golden):
+    for c, d in kernel_cases(golden):
+        prior = str(d['prior'])
+        prior = None if prior == 'none' else prior
+        rep = bool(d['flags'][3])
+        nll, g, sc = O.nll_grad(d['x'], d['X'], d['y'], str(d['name']), d['scale'], d['nugget'][0],
+                                bool(d['flags'][2]), bool(d['flags'][4]), prior, d.get('prior_coef'), d.get('cl'),
+                                d.get('W_diag'), int(d['n_rep']) if rep else None,
+                                float(d['sum_residual'][0]) if rep else None)
+        close(nll, d['nll'][0], rtol=1e-9)
+        close(g, d['grad'], rtol=1e-8, atol=1e-9)
+        close(sc, d['scale_after'][0], rtol=1e-9)
+
+
+def test_fmvn_update_f(golden):
+    g = golden('g4_fmvn')
+    close(O.fmvn(g['cov'], g['z']), g['sample'])
+    close(O.fmvn(g['cov'], g['z_mu']) + g['mu'], g['sample_mu'])
+    close(O.update_f(g['f'], g['nu'], float(g['theta'])), g['fp'], rtol=1e-15)
+
+
+def load_structure(d, pre):
+    layers = []
+    for l in range(int(d[pre + 'n_layer'])):
+        layer = []
+        for k in range(int(d[pre + 'l%d_n' % l])):
+            nd = case(d, pre + 'l%d_k%d_' % (l, k))
+            nd['name'] = str(nd['name'])
+            nd['X'] = (np.concatenate((nd['input'], nd['global_input']), 1) if bool(nd['has_global']) else nd['input'])
+            layer.append(nd)
+        layers.append(layer)
+    return layers
+
+
+def replay_ess(d):
+    """Replay imputer.sample(burnin=2) (imputation.py:22-119) with the logged draws."""
+    layers = load_structure(d, 'pre_')
+    z, u = list(d['z']), list(d['u'])
+    for _ in range(3):
+        for l in range(len(layers) - 1):
+            tgt, upp = layers[l], layers[l + 1]
+            n, M = tgt[0]['output'].shape[0], len(tgt)
+            f = np.stack([nd['output'][:, 0] for nd in tgt], 1)
+            nu = np.zeros((n, M))
+            for k, nd in enumerate(tgt):
+                cov = nd['scale'][0] * O.k_matrix(nd['X'], nd['length'], nd['nugget'][0], nd['name'])
+                nu[:, k] = O.fmvn(cov, z.pop(0))
+
+            def upper(fp):
+                s = 0.0
+                for nd in upp:
+                    Xi = fp[:, nd['input_dim']]
+                    if bool(nd['has_global']):
+                        Xi = np.concatenate((Xi, nd['global_input']), 1)
+                    s += O.log_likelihood(Xi, nd['output'], nd['length'], nd['scale'], nd['nugget'][0], nd['name'])
+                return s
+            log_u0 = np.log(u.pop(0))
+            fnew, nprop, _, _, _ = O.ess_block_sweep(f, nu, upper, log_u0, u[:64])
+            del u[:nprop]
+            for k, nd in enumerate(tgt):
+                nd['output'] = fnew[:, [k]]
+            for nd in upp:
+                nd['input'] = fnew[:, nd['input_dim']]
+                nd['X'] = np.concatenate((nd['input'], nd['global_input']), 1) if bool(nd['has_global']) else nd['input']
+    assert len(z) == 0 and len(u) == 0, 'draw streams must be consumed exactly'
+    return layers
+
+
+@pytest.mark.parametrize('tag', ['sexp', 'matern', 'deep'])
+def test_ess_trajectory(golden, tag):
+    d = golden('g5_ess_' + tag)
+    layers = replay_ess(d)
+    post = load_structure(d, 'post_')
+    for la, lb in zip(layers, post):
+        for a, b in zip(la, lb):
+            close(a['output'], b['output'], rtol=1e-9)
+            close(a['input'], b['input'], rtol=1e-9)
+
+
+def test_compute_stats_gp_linkgp(golden):
+    g = golden('g7_predict')
+    for c in range(int(g['n_cases'])):
+        d = case(g, 'c%d_' % c)
+        name = str(d['name'])
+        nl = int(d['n_local'])
+        st = O.compute_stats(d['X'], d['y'], d['length'], d['nugget'][0], name, nl)
+        close(st['Rinv'], d['Rinv'], rtol=1e-7, atol=1e-7 * np.abs(d['Rinv']).max())
+        close(st['Rinv_y'], d['Rinv_y'], rtol=1e-7, atol=1e-7 * np.abs(d['Rinv_y']).max())
+        if name == 'sexp':
+            close(st['R2sexp'], d['R2sexp'])
+            close(st['Psexp'], d['Psexp'])
+        x = d['x'] if 'z' not in d else np.concatenate((d['x'], d['z']), 1)
+        m, v = O.gp_predict(x, d['X'], d['Rinv'], d['Rinv_y'], d['scale'], d['length'], d['nugget'], name)
+        close(m, d['gp_m'], rtol=1e-9, atol=1e-11)
+        close(v, d['gp_v'], rtol=1e-7, atol=1e-11)
+        W, Wg = d['X'][:, :nl], d['X'][:, nl:]
+        lm, lv = O.link_gp_predict(d['lm_in'], d['lv_in'], d.get('z'), W, Wg if 'z' in d else None, d['Rinv'], d['Rinv_y'],
+                                   d['scale'], d['length'], d['nugget'], name)
+        close(lm, d['link_m'], rtol=1e-8, atol=1e-10)
+        close(lv, d['link_v'], rtol=1e-6, atol=1e-9)
+
+
+def test_IJ_and_Jd(golden):
+    g = golden('g7_predict')
+    I, J = O.IJ(g['ij_X'], g['ij_zm'], g['ij_zv'], g['ij_len'], 'matern2.5')
+    close(I, g['ij_I_matern'], rtol=1e-10)
+    close(J, g['ij_J_matern'], rtol=1e-8)
+    I, J = O.IJ(g['ij_X'], g['ij_zm'], g['ij_zv'], g['ij_len'], 'sexp')
+    close(I, g['ij_I_sexp'])
+    close(J, g['ij_J_sexp'])
+    jd = O.Jd(g['jd_x1'], g['jd_x2'], g['jd_zm'], g['jd_zv'], g['jd_len'])
+    close(jd, g['jd'], rtol=1e-8, atol=1e-12)
+    jd0 = O.Jd0(g['jd_x1'], g['jd_zm'], g['jd_zv'], g['jd_len'])
+    close(jd0, g['jd0'], rtol=1e-8, atol=1e-12)
+
+
+def test_vecchia_nn_bit_exact(golden):
+    g = golden('g8_vecchia')
+    NN = O.nn_ordered(g['nn_x'], int(g['nn_m']))
+    assert NN.dtype == np.int64
+    np.testing.assert_array_equal(NN, g['NNarray'])
+    np.testing.assert_array_equal(O.pred_nn(g['pq'], g['nn_x'], 12), g['pred_nn'])
+
+
+def test_vecchia_kernels(golden):
+    g = golden('g8_vecchia')
+    for c in range(int(g['n_cases'])):
+        d = case(g, 'v%d_' % c)
+        name = str(d['name'])
+        X, y, NN = d['X'], d['y'], d['NN']
+        n = len(X)
+        sc, ng, ln = float(d['scale']), float(d['nugget']), d['length']
+        ndg = np.ones(n)
+        np.testing.assert_array_equal(O.nn_ordered(X / ln, 6), NN)
+        close(O.vecchia_llik(X, y, NN, sc, ln, ng, ndg, name), d['llik'][0], rtol=1e-9)
+        nll, gr, so = O.vecchia_nllik(X, y, NN, sc, ln, ng, ndg, name, bool(d['flags'][1]), bool(d['flags'][0]), n, -1.0)
+        close(nll, d['nll'][0], rtol=1e-9)
+        close(gr, d['grad'], rtol=1e-7, atol=1e-8)
+        close(so, d['scale_out'][0], rtol=1e-9)
+        Lm = O.L_matrix(X, NN, ln, ng, name)
+        close(Lm, d['Lmat'], rtol=1e-8, atol=1e-8 * np.abs(d['Lmat']).max())
+        close(O.forward_solve_sp(d['Lmat'] / np.sqrt(sc), NN, d['b']), d['spsolve'], rtol=1e-9)
+        gm, gv = O.gp_vecch(d['xq'], X, d['pNN'], y, sc, ln, ng, ndg, name)
+        close(gm, d['gpv_m'], rtol=1e-8, atol=1e-10)
+        close(gv, d['gpv_v'], rtol=1e-7, atol=1e-11)
+        lm, lv = O.link_gp_vecch(d['lm_in'], d['lv_in'], d['lz_in'], X[:, :2], X[:, 2:], d['pNN'], y, sc, ln, ng, ndg, name)
+        close(lm, d['lgv_m'], rtol=1e-7, atol=1e-9)
+        close(lv, d['lgv_v'], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('tag', ['sexp', 'matern'])
+def test_emulator_predict(golden, tag):
+    """emulator.predict (emulation.py:631-854) from the dumped imputed structures."""
+    d = golden('g9_emulator_' + tag)
+    xt = d['xt']
+    mus, vs = [], []
+    for s in range(int(d['n_imp'])):
+        layers = load_structure(d, 's%d_' % s)
+        m_in = v_in = None
+        for l, layer in enumerate(layers):
+            mo = np.zeros((len(xt), len(layer)))
+            vo = np.zeros_like(mo)
+            for k, nd in enumerate(layer):
+                nl = nd['input'].shape[1]
+                st = O.compute_stats(nd['X'], nd['output'], nd['length'], nd['nugget'][0], nd['name'], nl)
+                z = xt[:, nd['connect']] if bool(nd['has_global']) else None
+                if l == 0:
+                    x = xt[:, nd['input_dim']]
+                    if z is not None:
+                        x = np.concatenate((x, z), 1)
+                    mo[:, k], vo[:, k] = O.gp_predict(x, nd['X'], st['Rinv'], st['Rinv_y'], nd['scale'], nd['length'],
+                                                      nd['nugget'], nd['name'])
+                else:
+                    mo[:, k], vo[:, k] = O.link_gp_predict(m_in[:, nd['input_dim']], v_in[:, nd['input_dim']], z,
+                                                           nd['input'], nd.get('global_input'), st['Rinv'], st['Rinv_y'],
+                                                           nd['scale'], nd['length'], nd['nugget'], nd['name'])
+            m_in, v_in = mo, vo
+        mus.append(m_in)
+        vs.append(v_in)
+        close(m_in, d['mu_s'][s], rtol=1e-6, atol=1e-8)
+        # variance = difference of O(scale) terms through Rinv (cond ~1e6 at eta=1e-6): absolute tolerance
+        close(v_in, d['var_s'][s], rtol=1e-5, atol=2e-7)
+    mu, var = O.aggregate_moments(mus, vs)
+    close(mu, d['mu'], rtol=1e-6, atol=1e-8)
+    close(var, d['var'], rtol=1e-5, atol=2e-7)
+    # dgp.estimate (dgp.py:1529-1540): mean of para_path[int(0.75 N):]
+    est = load_structure(d, 'est_')
+    for l, layer in enumerate(est):
+        for k, nd in enumerate(layer):
+            path = d['path_l%d_k%d' % (l, k)]
+            pe = path[int(6 * 0.75):].mean(0)
+            close(nd['scale'], pe[0])
+            close(nd['length'], pe[1:-1])
+            close(nd['nugget'], pe[-1])
