@@ -1,0 +1,78 @@
+"""ctypes binding of libdgp_amd.so (include/dgp_amd.h).
+
+The HIP library IS the product: there is no CPU fallback.  If the shared
+library is missing or fails to load, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdgp_amd.so')
+
+OK, NOT_PD, BAD_ARG, HIP_ERROR = 0, 1, 2, 3
+SEXP, MATERN25 = 0, 1
+MAXD, MAXB = 64, 64
+KIND = {'sexp': SEXP, 'matern2.5': MATERN25}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'dgp_amd: %s not found -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+        '(or `make -C dgp_amd/csrc`).  dgp_amd has no CPU fallback.' % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_d = C.c_double
+_z = C.c_size_t
+
+SIGNATURES = {
+    'dgpamd_create': (_i, [_i, _p, C.POINTER(_p)]),
+    'dgpamd_destroy': (_i, [_p]),
+    'dgpamd_last_error': (C.c_char_p, [_p]),
+    'dgpamd_sync': (_i, [_p]),
+    'dgpamd_version': (C.c_char_p, []),
+    'dgpamd_padded_dim': (_l, [_l]),
+    'dgpamd_event_create': (_i, [_p, C.POINTER(_p)]),
+    'dgpamd_event_record': (_i, [_p, _p]),
+    'dgpamd_event_elapsed_ms': (_i, [_p, _p, _p, C.POINTER(C.c_float)]),
+    'dgpamd_event_destroy': (_i, [_p, _p]),
+    'dgpamd_kmatrix': (_i, [_p, _i, _l, _p, _l, _l, _p, _i, _p, _i, _p, _i, _d, _p, _p, _l, _l, _i, _p, _l, _l, _i, _i]),
+    'dgpamd_potrf_workspace': (_z, [_l, _i]),
+    'dgpamd_potrf': (_i, [_p, _l, _p, _l, _i, _p, _p, _p]),
+    'dgpamd_aug_quad': (_i, [_p, _l, _p, _l, _i, _i, _p]),
+    'dgpamd_loglik': (_i, [_p, _i, _l, _p, _l, _l, _p, _i, _p, _i, _p, _i, _d, _p, _d, _p, _p, _l, _i, _p, _p, _p]),
+    'dgpamd_trmv_lower': (_i, [_p, _l, _p, _l, _p, _p, _p, _i]),
+    'dgpamd_ess_propose': (_i, [_p, _l, _i, _p, _p, _p, _i, _p]),
+    'dgpamd_potri': (_i, [_p, _l, _p, _p, _i, _p]),
+    'dgpamd_grad_workspace': (_z, [_l, _i]),
+    'dgpamd_grad_reduce': (_i, [_p, _i, _l, _p, _l, _p, _i, _p, _i, _p, _i, _d, _p, _i, _p, _p, _p]),
+    'dgpamd_gp_workspace': (_z, [_l, _l]),
+    'dgpamd_gp_predict': (_i, [_p, _i, _l, _l, _i, _p, _p, _p, _i, _p, _l, _p, _d, _d, _p, _p, _p]),
+    'dgpamd_linkgp_workspace': (_z, [_l, _l]),
+    'dgpamd_linkgp_predict': (_i, [_p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p, _d, _d, _p, _p, _p]),
+    'dgpamd_moments_accumulate': (_i, [_p, _l, _p, _p, _p, _p]),
+    'dgpamd_moments_finalize': (_i, [_p, _l, _d, _p, _p]),
+    'dgpamd_nn_ordered': (_i, [_p, _l, _i, _p, _i, _p]),
+    'dgpamd_nn_query': (_i, [_p, _l, _l, _i, _p, _p, _i, _p]),
+    'dgpamd_vecchia_llik': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _i, _d, _p, _p]),
+    'dgpamd_vecchia_nllik': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _i, _d, _p, _i, _p]),
+    'dgpamd_vecchia_lmatrix': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _i, _d, _p]),
+    'dgpamd_vecchia_spsolve': (_i, [_p, _l, _i, _p, _p, _d, _p, _p]),
+    'dgpamd_vecchia_gp': (_i, [_p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _d, _p, _i, _d, _p, _p, _p]),
+    'dgpamd_vecchia_linkgp': (_i, [_p, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _d, _p, _i, _d, _p, _p, _p]),
+}
+
+MISSING = []
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _f = getattr(lib, _name)
+    except AttributeError:
+        MISSING.append(_name)
+        continue
+    _f.restype = _res
+    _f.argtypes = _args
+
+if MISSING:
+    raise ImportError('dgp_amd: libdgp_amd.so lacks symbols declared in include/dgp_amd.h: %s' % ', '.join(MISSING))

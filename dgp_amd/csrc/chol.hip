@@ -1,0 +1,360 @@
+// Blocked Cholesky / triangular inverse on augmented buffers (SURVEY 8 a3,a5,a8,a10).
+// Replaces the LAPACK potrf/potrs call sites of the reference
+// (kernel_class.py:417-423,483-487,746-748; functions.py:109,119).
+//
+// Right-looking, 64-wide block columns.  Per block column k:
+//   potrf_diag   one workgroup per matrix: the 64x64 diagonal block is held in
+//                registers (4x4 strided micro-tiles), each pivot column is
+//                broadcast through LDS with ONE barrier per pivot, and the same
+//                loop applies the eliminations to an identity -> the block's
+//                inverse comes out for free (used instead of a triangular solve);
+//   tile_gemm    TRSM as  P_i = A_ik * Linv_kk^T   (f64 MFMA 16x16x4),
+//                SYRK as  A_ij -= P_i P_j^T        (lower tiles only).
+// The same tile_gemm engine runs the blocked triangular inverse (recursive
+// doubling over block pairs) and K^-1 = L^-T L^-1.
+#include "common.hpp"
+#include "tile.hpp"
+
+// ----------------------------------------------------------------------------
+// diagonal block: Cholesky + inverse of the factor, in registers
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, int64_t stride_a, int k, int64_t n,
+                                                         double *ws, int64_t stride_ws, double *logdet,
+                                                         int32_t *info) {
+    __shared__ double colbuf[2][64];
+    __shared__ double rowbuf[2][64];
+    __shared__ double piv[64];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    double *Ab = A + (int64_t)b * stride_a + ((int64_t)k * 64) * ld + (int64_t)k * 64;
+    double *Wb = ws + (int64_t)b * stride_ws + (int64_t)k * 4096;
+    int64_t rem = n - (int64_t)k * 64;
+    const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+
+    double a[4][4], y[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int r = ty + 16 * p, c = tx + 16 * q;
+            a[p][q] = Ab[(int64_t)r * ld + c];
+            y[p][q] = (r == c) ? 1.0 : 0.0;
+        }
+    if (tid < 64) piv[tid] = 1.0;
+    int bad = 0;
+
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        for (int jx = 0; jx < 16; ++jx) {
+            const int j = jb * 16 + jx;
+            if (j >= ncol) break;
+            const int cur = j & 1;
+            if (tx == jx) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) colbuf[cur][ty + 16 * p] = a[p][jb];
+            }
+            if (ty == jx) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rowbuf[cur][tx + 16 * q] = y[jb][q];
+            }
+            __syncthreads();
+            double d = colbuf[cur][j];
+            if (!(d > 0.0)) {
+                if (!bad) bad = j + 1;
+                d = 1.0;
+            }
+            const double sd = sqrt(d);
+            const double inv = 1.0 / sd;
+            double lr[4], lc[4], yj[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                lr[p] = colbuf[cur][ty + 16 * p] * inv;
+                lc[p] = colbuf[cur][tx + 16 * p] * inv;
+                yj[p] = rowbuf[cur][tx + 16 * p] * inv;
+            }
+            if (tid == 0) piv[j] = d;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = ty + 16 * p;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = tx + 16 * q;
+                    if (r > j) {
+                        if (c > j) a[p][q] = fma(-lr[p], lc[q], a[p][q]);
+                        y[p][q] = fma(-lr[p], yj[q], y[p][q]);
+                    } else if (r == j) {
+                        y[p][q] = yj[q];
+                    }
+                }
+                if (tx == jx) {
+                    if (r > j)
+                        a[p][jb] = lr[p];
+                    else if (r == j)
+                        a[p][jb] = sd;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int r = ty + 16 * p, c = tx + 16 * q;
+            Ab[(int64_t)r * ld + c] = a[p][q];
+            Wb[r * 64 + c] = y[p][q];
+        }
+    __syncthreads();
+    if (tid < 64) {
+        double v = (tid < ncol) ? log(piv[tid]) : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (tid == 0) {
+            logdet[b] = (k == 0 ? 0.0 : logdet[b]) + v;
+            if (k == 0) info[b] = 0;
+            if (bad && info[b] == 0) info[b] = k * 64 + bad;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// 64x64x64 tile GEMM engine on f64 MFMA
+// ----------------------------------------------------------------------------
+enum { G_TRSM = 0, G_SYRK = 1, G_TRTRI1 = 2, G_TRTRI2 = 3, G_LAUUM = 4 };
+
+struct GemmArgs {
+    double *A;        // Np x Np buffers
+    double *B;        // second buffer (temp / inverse)
+    const double *ws; // diagonal-block inverses
+    int64_t ld, stride_a, stride_ws;
+    int64_t n;
+    int nbk;   // blocks per dimension
+    int k;     // block column (TRSM / SYRK)
+    int s;     // half-size of the pair in blocks (TRTRI)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
+    constexpr int OPA = (MODE == G_LAUUM) ? OP_KM : OP_MK;
+    constexpr int OPB = (MODE == G_TRSM || MODE == G_SYRK) ? OP_MK : OP_KM;
+    __shared__ double As[(OPA == OP_MK) ? 64 * LDM : KC * LDK];
+    __shared__ double Bs[(OPB == OP_MK) ? 64 * LDM : KC * LDK];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t ld = g.ld;
+    double *A = g.A + (int64_t)blockIdx.z * g.stride_a;
+    double *B = g.B ? g.B + (int64_t)blockIdx.z * g.stride_a : nullptr;
+
+    int bi, bj, kb0, kb1;          // output tile, k-block range [kb0, kb1)
+    double *C;                     // output buffer
+    double sign = 1.0;
+    bool accumulate = false;
+    if (MODE == G_TRSM) {
+        bi = g.k + 1 + blockIdx.x; bj = g.k; kb0 = g.k; kb1 = g.k + 1; C = A;
+    } else if (MODE == G_SYRK) {
+        int ti, tj;
+        tri_decode(blockIdx.x, ti, tj);
+        bi = g.k + 1 + ti; bj = g.k + 1 + tj; kb0 = g.k; kb1 = g.k + 1; C = A;
+        sign = -1.0; accumulate = true;
+    } else if (MODE == G_TRTRI1 || MODE == G_TRTRI2) {
+        const int s = g.s, per = s * s;
+        const int p = blockIdx.x / per, rem = blockIdx.x - p * per;
+        const int base = 2 * p * s;
+        bi = base + s + rem / s; bj = base + rem % s;
+        if (bi >= g.nbk) return;
+        if (MODE == G_TRTRI1) {           // T = L21 * Linv11   (Linv11 lower: kb >= bj)
+            kb0 = bj; kb1 = base + s; C = B;
+        } else {                          // X21 = -Linv22 * T  (Linv22 lower: kb <= bi)
+            kb0 = base + s; kb1 = bi + 1; C = A; sign = -1.0;
+        }
+    } else {                              // LAUUM: Kinv_ij = sum_{kb >= bi} Linv[kb][bi]^T Linv[kb][bj]
+        tri_decode(blockIdx.x, bi, bj);
+        kb0 = bi; kb1 = (int)((g.n + 63) / 64); C = B;
+    }
+
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
+    if (accumulate) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[t][r] = C[((int64_t)bi * 64 + crow + 4 * r) * ld + (int64_t)bj * 64 + 16 * t + ccol];
+    }
+
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const double *Ag, *Bg;
+        int64_t lda = ld, ldb = ld;
+        int limA = 64, limB = 64;
+        if (MODE == G_TRSM) {
+            Ag = A + ((int64_t)bi * 64) * ld + (int64_t)kb * 64;
+            Bg = g.ws + (int64_t)blockIdx.z * g.stride_ws + (int64_t)kb * 4096; ldb = 64;
+        } else if (MODE == G_SYRK) {
+            Ag = A + ((int64_t)bi * 64) * ld + (int64_t)kb * 64;
+            Bg = A + ((int64_t)bj * 64) * ld + (int64_t)kb * 64;
+        } else if (MODE == G_TRTRI1) {
+            Ag = A + ((int64_t)bi * 64) * ld + (int64_t)kb * 64;
+            Bg = A + ((int64_t)kb * 64) * ld + (int64_t)bj * 64;
+        } else if (MODE == G_TRTRI2) {
+            Ag = A + ((int64_t)bi * 64) * ld + (int64_t)kb * 64;
+            Bg = B + ((int64_t)kb * 64) * ld + (int64_t)bj * 64;
+        } else {
+            Ag = A + ((int64_t)kb * 64) * ld + (int64_t)bi * 64;
+            Bg = A + ((int64_t)kb * 64) * ld + (int64_t)bj * 64;
+            int64_t lim = g.n - (int64_t)kb * 64;   // rows >= n (right-hand sides) do not belong to L^-1
+            limA = limB = lim >= 64 ? 64 : (int)lim;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (OPA == OP_MK) load_mk(Ag, lda, As, tid, h); else load_km(Ag, lda, As, tid, h, limA);
+            if (OPB == OP_MK) load_mk(Bg, ldb, Bs, tid, h); else load_km(Bg, ldb, Bs, tid, h, limB);
+            __syncthreads();
+            mfma_tile<OPA, OPB>(As, Bs, acc, wave, lane, sign);
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gr = (int64_t)bi * 64 + crow + 4 * r, gc = (int64_t)bj * 64 + 16 * t + ccol;
+            C[gr * ld + gc] = acc[t][r];
+            if (MODE == G_LAUUM && bi != bj) C[gc * ld + gr] = acc[t][r];
+        }
+}
+
+// place the diagonal-block inverses on the diagonal of the (to be inverted) factor
+__global__ __launch_bounds__(256) void put_diag_inverse_kernel(double *A, int64_t ld, const double *ws) {
+    const int kb = blockIdx.x, tid = threadIdx.x;
+    double *Ab = A + ((int64_t)kb * 64) * ld + (int64_t)kb * 64;
+    const double *W = ws + (int64_t)kb * 4096;
+    for (int idx = tid; idx < 4096; idx += 256) Ab[(int64_t)(idx >> 6) * ld + (idx & 63)] = W[idx];
+}
+
+// rows [n, n+r) of L^-1 (columns < n) are -alpha^T: copy them beside K^-1
+__global__ void copy_aug_rows_kernel(const double *A, double *B, int64_t ld, int64_t n, int r) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    for (int q = 0; q < r; ++q) B[(n + q) * ld + j] = A[(n + q) * ld + j];
+}
+
+__global__ void aug_quad_kernel(const double *A, int64_t ld, int64_t stride_a, int64_t n, int r, double *quad) {
+    int b = blockIdx.x, t = threadIdx.x;
+    if (t < r * r) {
+        int q = t / r, q2 = t % r;
+        quad[(int64_t)b * r * r + t] = -A[(int64_t)b * stride_a + (n + q) * ld + n + q2];
+    }
+}
+
+// out[b][i] = sqrt(scale_b) * sum_{j<=i} L[i][j] z[b][j]; one wave per row
+struct TrmvArgs {
+    const double *L;
+    int64_t ld, stride_a, n;
+    const double *z;
+    double *out;
+    double sscale[DGPAMD_MAXB];
+};
+__global__ __launch_bounds__(256) void trmv_lower_kernel(TrmvArgs a) {
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= a.n) return;
+    const double *row = a.L + (int64_t)b * a.stride_a + i * a.ld;
+    const double *z = a.z + (int64_t)b * a.n;
+    double s = 0.0;
+    for (int64_t j = lane; j <= i; j += 64) s = fma(row[j], z[j], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) a.out[(int64_t)b * a.n + i] = a.sscale[b] * s;
+}
+
+// ----------------------------------------------------------------------------
+// host drivers
+// ----------------------------------------------------------------------------
+size_t potrf_ws_doubles(int64_t n, int batch) {
+    int64_t nbk = padded_dim(n) / 64;
+    return (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB;   // diagonal inverses + {logdet, quad} scratch
+}
+
+extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
+    return potrf_ws_doubles(n, batch) * sizeof(double) + DGPAMD_MAXB * sizeof(int32_t);
+}
+
+int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
+              double *ws) {
+    const int64_t Np = padded_dim(n);
+    const int nbk = (int)(Np / 64);
+    const int64_t stride_ws = (int64_t)nbk * 4096;
+    GemmArgs g;
+    g.A = A; g.B = nullptr; g.ws = ws; g.ld = Np; g.stride_a = stride_a; g.stride_ws = stride_ws;
+    g.n = n; g.nbk = nbk; g.k = 0; g.s = 0;
+    for (int k = 0; k < nbk; ++k) {
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, ctx->stream, A, Np, stride_a, k, n, ws,
+                           stride_ws, logdet, info);
+        const int m = nbk - k - 1;
+        if (m > 0 && (int64_t)k * 64 < n) {
+            g.k = k;
+            hipLaunchKernelGGL(tile_gemm_kernel<G_TRSM>, dim3(m, 1, batch), dim3(256), 0, ctx->stream, g);
+            hipLaunchKernelGGL(tile_gemm_kernel<G_SYRK>, dim3(m * (m + 1) / 2, 1, batch), dim3(256), 0, ctx->stream, g);
+        }
+    }
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet,
+                            int32_t *info, void *work) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || !A || !logdet || !info || !work) BAD_ARG(ctx, "null pointer or n <= 0");
+    if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
+    const int64_t Np = padded_dim(n);
+    if (batch > 1 && stride_a < Np * Np) BAD_ARG(ctx, "stride_a < Np*Np");
+    return run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work);
+}
+
+extern "C" int dgpamd_aug_quad(dgpamd_ctx *ctx, int64_t n, const double *A, int64_t stride_a, int batch, int r,
+                               double *quad) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (!A || !quad || r <= 0 || r * r > 256 || n + r > padded_dim(n)) BAD_ARG(ctx, "bad arguments");
+    hipLaunchKernelGGL(aug_quad_kernel, dim3(batch), dim3(256), 0, ctx->stream, A, padded_dim(n), stride_a, n, r, quad);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_trmv_lower(dgpamd_ctx *ctx, int64_t n, const double *L, int64_t stride_a, const double *scale_h,
+                                 const double *z, double *out, int batch) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || !L || !z || !out || !scale_h) BAD_ARG(ctx, "null pointer or n <= 0");
+    if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
+    TrmvArgs a;
+    a.L = L; a.ld = padded_dim(n); a.stride_a = stride_a; a.n = n; a.z = z; a.out = out;
+    for (int b = 0; b < batch; ++b) a.sscale[b] = sqrt(scale_h[b]);
+    hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((n + 3) / 4), batch), dim3(256), 0, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_potri(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || !A || !Ainv || !work || r < 0) BAD_ARG(ctx, "null pointer or n <= 0");
+    const int64_t Np = padded_dim(n);
+    if (n + r > Np) BAD_ARG(ctx, "too many right-hand sides");
+    const int nbk = (int)(Np / 64);
+    GemmArgs g;
+    g.A = A; g.B = Ainv; g.ws = (const double *)work; g.ld = Np; g.stride_a = 0; g.stride_ws = 0;
+    g.n = n; g.nbk = nbk; g.k = 0; g.s = 0;
+    hipLaunchKernelGGL(put_diag_inverse_kernel, dim3(nbk), dim3(256), 0, ctx->stream, A, Np, (const double *)work);
+    for (int s = 1; s < nbk; s *= 2) {
+        const int np = (nbk + 2 * s - 1) / (2 * s);
+        g.s = s;
+        hipLaunchKernelGGL(tile_gemm_kernel<G_TRTRI1>, dim3(np * s * s), dim3(256), 0, ctx->stream, g);
+        hipLaunchKernelGGL(tile_gemm_kernel<G_TRTRI2>, dim3(np * s * s), dim3(256), 0, ctx->stream, g);
+    }
+    const int nbn = (int)((n + 63) / 64);
+    hipLaunchKernelGGL(tile_gemm_kernel<G_LAUUM>, dim3(nbn * (nbn + 1) / 2), dim3(256), 0, ctx->stream, g);
+    if (r > 0)
+        hipLaunchKernelGGL(copy_aug_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, Ainv,
+                           Np, n, r);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}

@@ -1,0 +1,110 @@
+// Shared host/device helpers of libdgp_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dgp_amd.h"
+
+#define NB 64          // factorisation block / tile edge
+#define LDT 66         // LDS leading dimension of a 64-wide f64 tile (conflict-free ds_read_b64 fragments)
+
+struct dgpamd_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    char err[512];
+};
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,  \
+                     hipGetErrorString(e__));                                                      \
+            return DGPAMD_HIP_ERROR;                                                               \
+        }                                                                                          \
+    } while (0)
+
+#define LAUNCH_CHECK(ctx) HIP_TRY(ctx, hipGetLastError())
+
+#define BAD_ARG(ctx, msg)                                                     \
+    do {                                                                      \
+        snprintf((ctx)->err, sizeof((ctx)->err), "%s: %s", __func__, msg);    \
+        return DGPAMD_BAD_ARG;                                                \
+    } while (0)
+
+static inline int64_t padded_dim(int64_t n) { return ((n + 1 + NB - 1) / NB) * NB; }
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Kernel parameters of one GP node's correlation function, passed by value.
+struct KernParams {
+    int kind;                  // DGPAMD_SEXP / DGPAMD_MATERN25
+    int Dl, Dg;                // local (gathered) and global columns
+    int colmap[DGPAMD_MAXD];   // gathered column of Xloc for d < Dl
+    double inv_len[DGPAMD_MAXD];
+    double nugget;
+};
+
+static inline int fill_kern_params(dgpamd_ctx *ctx, KernParams &kp, int kind, const int32_t *colmap_h, int Dl, int Dg,
+                                   const double *length_h, int nlen, double nugget) {
+    int D = Dl + Dg;
+    if (kind != DGPAMD_SEXP && kind != DGPAMD_MATERN25) BAD_ARG(ctx, "kind must be 0 (sexp) or 1 (matern2.5)");
+    if (D <= 0 || D > DGPAMD_MAXD) BAD_ARG(ctx, "need 1 <= Dl+Dg <= DGPAMD_MAXD");
+    if (nlen != 1 && nlen != D) BAD_ARG(ctx, "nlen must be 1 or Dl+Dg");
+    kp.kind = kind;
+    kp.Dl = Dl;
+    kp.Dg = Dg;
+    for (int d = 0; d < D; ++d) {
+        kp.colmap[d] = (d < Dl) ? (colmap_h ? colmap_h[d] : d) : 0;
+        kp.inv_len[d] = 1.0 / length_h[nlen == 1 ? 0 : d];
+    }
+    kp.nugget = nugget;
+    return DGPAMD_OK;
+}
+
+#define SQRT5 2.23606797749978969641
+
+// one-dimensional factors of the correlation functions on SCALED differences
+__device__ __forceinline__ void corr_accum_sexp(double d, double &s) { s = fma(d, d, s); }
+__device__ __forceinline__ void corr_accum_matern(double d, double &prod, double &s) {
+    double r = fabs(d);
+    prod *= fma(r, fma(r, 5.0 / 3.0, SQRT5), 1.0);
+    s += r;
+}
+
+// lower-triangle tile index t -> (bi, bj), bi >= bj, t = bi(bi+1)/2 + bj
+__device__ __forceinline__ void tri_decode(int t, int &bi, int &bj) {
+    int b = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((b + 1) * (b + 2) / 2 <= t) ++b;
+    while (b * (b + 1) / 2 > t) --b;
+    bi = b;
+    bj = t - b * (b + 1) / 2;
+}
+
+// ---- cross-file internals -------------------------------------------------
+struct KmatArgs {
+    KernParams kp;
+    int64_t n;
+    const double *Xloc;
+    int64_t ldloc, stride_loc;
+    const double *Xglob;
+    const double *W;
+    double *K;
+    int64_t ldk, stride_k;
+    int full;
+    const double *Y;
+    int64_t ldy, stride_y;
+    int r;
+};
+int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch);
+int build_kmat_args(dgpamd_ctx *ctx, KmatArgs &a, int kind, int64_t n, const double *Xloc, int64_t ldloc,
+                    int64_t stride_loc, const int32_t *colmap_h, int Dl, const double *Xglob, int Dg,
+                    const double *length_h, int nlen, double nugget, const double *W, double *K, int64_t ldk,
+                    int64_t stride_k, int full, const double *Y, int64_t ldy, int64_t stride_y, int r, int batch);
+int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
+              double *ws);
+size_t potrf_ws_doubles(int64_t n, int batch);
+

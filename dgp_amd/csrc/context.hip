@@ -1,0 +1,75 @@
+// Context, stream and timing entry points of libdgp_amd.
+#include "common.hpp"
+
+#include <new>
+
+extern "C" const char *dgpamd_version(void) { return "dgp_amd 0.1 (gfx950)"; }
+
+extern "C" int64_t dgpamd_padded_dim(int64_t n) { return padded_dim(n); }
+
+extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
+    if (!out) return DGPAMD_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return DGPAMD_HIP_ERROR;
+    if (device < 0 || device >= count) return DGPAMD_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess) return DGPAMD_HIP_ERROR;
+    dgpamd_ctx *ctx = new (std::nothrow) dgpamd_ctx;
+    if (!ctx) return DGPAMD_HIP_ERROR;
+    ctx->device = device;
+    ctx->err[0] = 0;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return DGPAMD_HIP_ERROR;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_destroy(dgpamd_ctx *ctx) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DGPAMD_OK;
+}
+
+extern "C" const char *dgpamd_last_error(const dgpamd_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int dgpamd_sync(dgpamd_ctx *ctx) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_event_create(dgpamd_ctx *ctx, void **ev) {
+    if (!ctx || !ev) return DGPAMD_BAD_ARG;
+    hipEvent_t e;
+    HIP_TRY(ctx, hipEventCreate(&e));
+    *ev = (void *)e;
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_event_record(dgpamd_ctx *ctx, void *ev) {
+    if (!ctx || !ev) return DGPAMD_BAD_ARG;
+    HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, ctx->stream));
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_event_elapsed_ms(dgpamd_ctx *ctx, void *start, void *stop, float *ms_h) {
+    if (!ctx || !start || !stop || !ms_h) return DGPAMD_BAD_ARG;
+    HIP_TRY(ctx, hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(ctx, hipEventElapsedTime(ms_h, (hipEvent_t)start, (hipEvent_t)stop));
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_event_destroy(dgpamd_ctx *ctx, void *ev) {
+    if (!ctx || !ev) return DGPAMD_BAD_ARG;
+    HIP_TRY(ctx, hipEventDestroy((hipEvent_t)ev));
+    return DGPAMD_OK;
+}

@@ -1,0 +1,166 @@
+// Kernel-matrix assembly: K_ij = c(x_i, x_j), diag = 1 + nugget*W_i.
+// Replaces kernel.k_matrix (kernel_class.py:304-359): scipy pdist/squareform for
+// 'sexp', numba pdist_matern_coef (functions.py:16-34) for 'matern2.5'.
+//
+// One 256-thread workgroup per 64x64 LOWER tile (bi >= bj); the two 64-row slabs
+// of X are gathered ([Xloc[:,colmap] | Xglob]), scaled by 1/lengthscale and
+// staged transposed in LDS; each thread owns a 4x4 strided micro-tile
+// (rows ty+16a, cols tx+16b) so that every store instruction of a wave writes
+// four full 128-byte lines.  The kernel is f64-VALU + HBM-write bound.
+#include "common.hpp"
+
+
+template <int KIND>
+__global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
+    extern __shared__ double lds[];
+    const int D = a.kp.Dl + a.kp.Dg;
+    double *XiT = lds;            // [D][64]
+    double *XjT = lds + D * 64;   // [D][64]
+    int bi, bj;
+    tri_decode(blockIdx.x, bi, bj);
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64;
+    const double *Xl = a.Xloc + (int64_t)b * a.stride_loc;
+
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+        int row = idx / D, d = idx - row * D;
+        int64_t gi = i0 + row, gj = j0 + row;
+        double vi = 0.0, vj = 0.0;
+        if (d < a.kp.Dl) {
+            int c = a.kp.colmap[d];
+            if (gi < a.n) vi = Xl[gi * a.ldloc + c];
+            if (gj < a.n) vj = Xl[gj * a.ldloc + c];
+        } else {
+            int c = d - a.kp.Dl;
+            if (gi < a.n) vi = a.Xglob[gi * a.kp.Dg + c];
+            if (gj < a.n) vj = a.Xglob[gj * a.kp.Dg + c];
+        }
+        double il = a.kp.inv_len[d];
+        XiT[d * 64 + row] = vi * il;
+        XjT[d * 64 + row] = vj * il;
+    }
+    __syncthreads();
+
+    double s[4][4], pr[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s[p][q] = 0.0;
+            pr[p][q] = 1.0;
+        }
+    for (int d = 0; d < D; ++d) {
+        double xi[4], xj[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            xi[p] = XiT[d * 64 + ty + 16 * p];
+            xj[p] = XjT[d * 64 + tx + 16 * p];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double df = xi[p] - xj[q];
+                if (KIND == DGPAMD_SEXP)
+                    corr_accum_sexp(df, s[p][q]);
+                else
+                    corr_accum_matern(df, pr[p][q], s[p][q]);
+            }
+    }
+
+    double *Kb = a.K + (int64_t)b * a.stride_k;
+    const double *Yb = a.Y ? a.Y + (int64_t)b * a.stride_y : nullptr;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t gi = i0 + ty + 16 * p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t gj = j0 + tx + 16 * q;
+            double v;
+            if (KIND == DGPAMD_SEXP)
+                v = exp(-s[p][q]);
+            else
+                v = pr[p][q] * exp(-SQRT5 * s[p][q]);
+            if (gi == gj) v = 1.0 + a.kp.nugget * (a.W ? a.W[gi < a.n ? gi : 0] : 1.0);
+            if (a.full) {
+                if (gi < a.n && gj < a.n) {
+                    Kb[gi * a.ldk + gj] = v;
+                    if (bi != bj) Kb[gj * a.ldk + gi] = v;
+                }
+            } else {
+                // augmented factorisation buffer: rows >= n carry right-hand sides, corner zero
+                if (gi >= a.n) {
+                    int64_t qy = gi - a.n;
+                    v = (gj < a.n && qy < a.r) ? Yb[qy * a.ldy + gj] : 0.0;
+                } else if (gj >= a.n) {
+                    v = 0.0;
+                }
+                Kb[gi * a.ldk + gj] = v;
+            }
+        }
+    }
+}
+
+int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch) {
+    const int D = a.kp.Dl + a.kp.Dg;
+    int64_t rows = a.full ? a.n : padded_dim(a.n);
+    int nbk = (int)((rows + 63) / 64);
+    int ntiles = nbk * (nbk + 1) / 2;
+    size_t shm = (size_t)2 * D * 64 * sizeof(double);
+    dim3 grid(ntiles, 1, batch);
+    if (a.kp.kind == DGPAMD_SEXP)
+        hipLaunchKernelGGL(kmatrix_kernel<DGPAMD_SEXP>, grid, dim3(256), shm, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(kmatrix_kernel<DGPAMD_MATERN25>, grid, dim3(256), shm, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+int build_kmat_args(dgpamd_ctx *ctx, KmatArgs &a, int kind, int64_t n, const double *Xloc, int64_t ldloc,
+                    int64_t stride_loc, const int32_t *colmap_h, int Dl, const double *Xglob, int Dg,
+                    const double *length_h, int nlen, double nugget, const double *W, double *K, int64_t ldk,
+                    int64_t stride_k, int full, const double *Y, int64_t ldy, int64_t stride_y, int r, int batch) {
+    if (n <= 0) BAD_ARG(ctx, "n must be positive");
+    if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
+    if (Dl < 0 || Dg < 0) BAD_ARG(ctx, "negative dimension");
+    if ((Dl > 0 && !Xloc) || (Dg > 0 && !Xglob) || !K || !length_h) BAD_ARG(ctx, "null pointer");
+    if (r < 0 || (r > 0 && !Y)) BAD_ARG(ctx, "r > 0 needs Y");
+    if (!full) {
+        if (ldk != padded_dim(n)) BAD_ARG(ctx, "augmented buffer needs ldk == dgpamd_padded_dim(n)");
+        if (n + r > ldk) BAD_ARG(ctx, "too many right-hand sides for the padded buffer");
+    } else if (ldk < n) {
+        BAD_ARG(ctx, "ldk < n");
+    }
+    int rc = fill_kern_params(ctx, a.kp, kind, colmap_h, Dl, Dg, length_h, nlen, nugget);
+    if (rc) return rc;
+    a.n = n;
+    a.Xloc = Xloc;
+    a.ldloc = ldloc;
+    a.stride_loc = stride_loc;
+    a.Xglob = Xglob;
+    a.W = W;
+    a.K = K;
+    a.ldk = ldk;
+    a.stride_k = stride_k;
+    a.full = full;
+    a.Y = Y;
+    a.ldy = ldy;
+    a.stride_y = stride_y;
+    a.r = r;
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_kmatrix(dgpamd_ctx *ctx, int kind, int64_t n, const double *Xloc, int64_t ldloc,
+                              int64_t stride_loc, const int32_t *colmap_h, int Dl, const double *Xglob, int Dg,
+                              const double *length_h, int nlen, double nugget, const double *W, double *K,
+                              int64_t ldk, int64_t stride_k, int full, const double *Y, int64_t ldy,
+                              int64_t stride_y, int r, int batch) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    KmatArgs a;
+    int rc = build_kmat_args(ctx, a, kind, n, Xloc, ldloc, stride_loc, colmap_h, Dl, Xglob, Dg, length_h, nlen, nugget,
+                             W, K, ldk, stride_k, full, Y, ldy, stride_y, r, batch);
+    if (rc) return rc;
+    return launch_kmatrix(ctx, a, batch);
+}

@@ -1,0 +1,301 @@
+// Training-path pipelines (SURVEY 8 a4,a5,a8): ESS proposals, the batched ESS
+// target log-likelihood, and the in-flight derivative reductions of the M-step.
+#include "common.hpp"
+
+#include <math.h>
+
+// ---------------------------------------------------------------------------
+// a4  update_f (functions.py:203-208), batched over speculative angles
+// ---------------------------------------------------------------------------
+struct ProposeArgs {
+    const double *F, *NU;
+    double *FP;
+    int64_t count;   // n*M
+    double c[DGPAMD_MAXB], s[DGPAMD_MAXB];
+};
+__global__ __launch_bounds__(256) void ess_propose_kernel(ProposeArgs a) {
+    const int b = blockIdx.y;
+    const double c = a.c[b], s = a.s[b];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * 256)
+        a.FP[(int64_t)b * a.count + i] = a.F[i] * c + a.NU[i] * s;
+}
+
+extern "C" int dgpamd_ess_propose(dgpamd_ctx *ctx, int64_t n, int M, const double *F, const double *NU,
+                                  const double *theta_h, int batch, double *FP) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || M <= 0 || !F || !NU || !theta_h || !FP) BAD_ARG(ctx, "null pointer or empty block");
+    if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
+    ProposeArgs a;
+    a.F = F; a.NU = NU; a.FP = FP; a.count = n * M;
+    for (int b = 0; b < batch; ++b) {
+        a.c[b] = cos(theta_h[b]);
+        a.s[b] = sin(theta_h[b]);
+    }
+    int64_t blocks = (a.count + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ess_propose_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a5  log_likelihood_func (kernel_class.py:481-492), batched
+// ---------------------------------------------------------------------------
+__global__ void loglik_finish_kernel(const double *A, int64_t ld, int64_t stride_a, int64_t n, const double *logdet,
+                                     double scale, double *ll, int batch) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double quad = -A[(int64_t)b * stride_a + n * ld + n];
+    ll[b] = -0.5 * ((double)n * log(scale) + logdet[b] + quad / scale);
+}
+
+extern "C" int dgpamd_loglik(dgpamd_ctx *ctx, int kind, int64_t n, const double *Xloc, int64_t ldloc,
+                             int64_t stride_loc, const int32_t *colmap_h, int Dl, const double *Xglob, int Dg,
+                             const double *length_h, int nlen, double nugget, const double *W, double scale,
+                             const double *y, double *A, int64_t stride_a, int batch, double *ll, int32_t *info,
+                             void *work) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (!y || !A || !ll || !info || !work) BAD_ARG(ctx, "null pointer");
+    if (!(scale > 0.0)) BAD_ARG(ctx, "scale must be positive");
+    const int64_t Np = padded_dim(n);
+    if (batch > 1 && stride_a < Np * Np) BAD_ARG(ctx, "stride_a < Np*Np");
+    KmatArgs a;
+    int rc = build_kmat_args(ctx, a, kind, n, Xloc, ldloc, stride_loc, colmap_h, Dl, Xglob, Dg, length_h, nlen, nugget,
+                             W, A, Np, stride_a, 0, y, n, 0, 1, batch);
+    if (rc) return rc;
+    rc = launch_kmatrix(ctx, a, batch);
+    if (rc) return rc;
+    double *ws = (double *)work;
+    double *logdet = ws + (size_t)batch * (Np / 64) * 4096;
+    rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, ws);
+    if (rc) return rc;
+    hipLaunchKernelGGL(loglik_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, A, Np, stride_a, n, logdet, scale, ll,
+                       batch);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a8  derivative reductions of kernel.llik (kernel_class.py:414-427) without
+//     ever storing dK:  tr_p = sum Kinv o dK_p ,  quad_p = alpha^T dK_p alpha.
+//     dK/dlog g_d = c_d K: sexp c_d = 2 r_d^2 (functions.py:36-45);
+//     matern c_d = (5/3) r^2 (1+sqrt5 r)/(1+sqrt5 r+5/3 r^2) (functions.py:71-93);
+//     shared lengthscale: sum over d.  dK/dlog eta = eta diag(W) (kernel_class.py:346-351).
+// ---------------------------------------------------------------------------
+struct GradArgs {
+    KernParams kp;
+    int64_t n;
+    const double *Xloc;
+    int64_t ldloc;
+    const double *Xglob;
+    const double *W;
+    const double *Ainv;
+    int64_t ld;
+    int shared_len, nugget_est, P;
+    double *partial;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <int KIND>
+__device__ __forceinline__ double dcoef(double df) {
+    if (KIND == DGPAMD_SEXP) return 2.0 * df * df;
+    double r = fabs(df);
+    double e1 = fma(r, SQRT5, 1.0), e2 = (5.0 / 3.0) * r * r;
+    return e2 * e1 / (e1 + e2);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs a) {
+    extern __shared__ double lds[];
+    const int D = a.kp.Dl + a.kp.Dg;
+    double *XiT = lds, *XjT = lds + D * 64;
+    double *red = lds + 2 * D * 64;   // [4 waves][2P]
+    int bi, bj;
+    tri_decode(blockIdx.x, bi, bj);
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, wave = tid >> 6, lane = tid & 63;
+    const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
+    const int P2 = 2 * a.P;
+
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+        int row = idx / D, d = idx - row * D;
+        int64_t gi = i0 + row, gj = j0 + row;
+        double vi = 0.0, vj = 0.0;
+        if (d < a.kp.Dl) {
+            int c = a.kp.colmap[d];
+            if (gi < n) vi = a.Xloc[gi * a.ldloc + c];
+            if (gj < n) vj = a.Xloc[gj * a.ldloc + c];
+        } else {
+            int c = d - a.kp.Dl;
+            if (gi < n) vi = a.Xglob[gi * a.kp.Dg + c];
+            if (gj < n) vj = a.Xglob[gj * a.kp.Dg + c];
+        }
+        XiT[d * 64 + row] = vi * a.kp.inv_len[d];
+        XjT[d * 64 + row] = vj * a.kp.inv_len[d];
+    }
+    __syncthreads();
+
+    double s[4][4], pr[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s[p][q] = 0.0;
+            pr[p][q] = 1.0;
+        }
+    for (int d = 0; d < D; ++d) {
+        double xi[4], xj[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            xi[p] = XiT[d * 64 + ty + 16 * p];
+            xj[p] = XjT[d * 64 + tx + 16 * p];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double df = xi[p] - xj[q];
+                if (KIND == DGPAMD_SEXP)
+                    corr_accum_sexp(df, s[p][q]);
+                else
+                    corr_accum_matern(df, pr[p][q], s[p][q]);
+            }
+    }
+    // weights w1 = wt K_ij Kinv_ij , w2 = wt K_ij alpha_i alpha_j  (off-diagonal, in range)
+    const double wt = (bi == bj) ? 1.0 : 2.0;
+    double w1[4][4], w2[4][4], ai[4], aj[4];
+    const double *arow = a.Ainv + n * a.ld;   // row n = -alpha^T
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int64_t gi = i0 + ty + 16 * p, gj = j0 + tx + 16 * p;
+        ai[p] = gi < n ? -arow[gi] : 0.0;
+        aj[p] = gj < n ? -arow[gj] : 0.0;
+    }
+    double trn = 0.0, qn = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t gi = i0 + ty + 16 * p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t gj = j0 + tx + 16 * q;
+            double kv = (KIND == DGPAMD_SEXP) ? exp(-s[p][q]) : pr[p][q] * exp(-SQRT5 * s[p][q]);
+            const bool in = gi < n && gj < n;
+            double kinv = in ? a.Ainv[gi * a.ld + gj] : 0.0;
+            if (!in || gi == gj) kv = 0.0;
+            w1[p][q] = wt * kv * kinv;
+            w2[p][q] = wt * kv * ai[p] * aj[q];
+            if (a.nugget_est && in && gi == gj) {
+                double w = a.W ? a.W[gi] : 1.0;
+                trn += a.kp.nugget * w * kinv;
+                qn += a.kp.nugget * w * ai[p] * ai[p];
+            }
+        }
+    }
+    const int npl = a.shared_len ? 1 : D;
+    if (a.shared_len) {
+        double tr = 0.0, qd = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double xi[4], xj[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                xi[p] = XiT[d * 64 + ty + 16 * p];
+                xj[p] = XjT[d * 64 + tx + 16 * p];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double c = dcoef<KIND>(xi[p] - xj[q]);
+                    tr = fma(c, w1[p][q], tr);
+                    qd = fma(c, w2[p][q], qd);
+                }
+        }
+        tr = wave_sum(tr);
+        qd = wave_sum(qd);
+        if (lane == 0) {
+            red[wave * P2 + 0] = tr;
+            red[wave * P2 + a.P] = qd;
+        }
+    } else {
+        for (int d = 0; d < D; ++d) {
+            double xi[4], xj[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                xi[p] = XiT[d * 64 + ty + 16 * p];
+                xj[p] = XjT[d * 64 + tx + 16 * p];
+            }
+            double tr = 0.0, qd = 0.0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double c = dcoef<KIND>(xi[p] - xj[q]);
+                    tr = fma(c, w1[p][q], tr);
+                    qd = fma(c, w2[p][q], qd);
+                }
+            tr = wave_sum(tr);
+            qd = wave_sum(qd);
+            if (lane == 0) {
+                red[wave * P2 + d] = tr;
+                red[wave * P2 + a.P + d] = qd;
+            }
+        }
+    }
+    if (a.nugget_est) {
+        trn = wave_sum(trn);
+        qn = wave_sum(qn);
+        if (lane == 0) {
+            red[wave * P2 + npl] = trn;
+            red[wave * P2 + a.P + npl] = qn;
+        }
+    }
+    __syncthreads();
+    if (tid < P2) a.partial[(int64_t)blockIdx.x * P2 + tid] = red[tid] + red[P2 + tid] + red[2 * P2 + tid] + red[3 * P2 + tid];
+}
+
+__global__ __launch_bounds__(256) void grad_final_kernel(const double *partial, int ntiles, int P2, double *out) {
+    __shared__ double sm[4];
+    const int idx = blockIdx.x, tid = threadIdx.x;
+    double v = 0.0;
+    for (int t = tid; t < ntiles; t += 256) v += partial[(int64_t)t * P2 + idx];
+    v = wave_sum(v);
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) out[idx] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+extern "C" size_t dgpamd_grad_workspace(int64_t n, int nparam) {
+    int64_t nb = (n + 63) / 64;
+    return (size_t)(nb * (nb + 1) / 2) * 2 * (size_t)nparam * sizeof(double);
+}
+
+extern "C" int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n, const double *Xloc, int64_t ldloc,
+                                  const int32_t *colmap_h, int Dl, const double *Xglob, int Dg, const double *length_h,
+                                  int nlen, double nugget, const double *W, int nugget_est, const double *Ainv,
+                                  double *out, void *work) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || !Ainv || !out || !work || !length_h) BAD_ARG(ctx, "null pointer or n <= 0");
+    if ((Dl > 0 && !Xloc) || (Dg > 0 && !Xglob)) BAD_ARG(ctx, "null input pointer");
+    GradArgs a;
+    int rc = fill_kern_params(ctx, a.kp, kind, colmap_h, Dl, Dg, length_h, nlen, nugget);
+    if (rc) return rc;
+    const int D = Dl + Dg;
+    a.n = n; a.Xloc = Xloc; a.ldloc = ldloc; a.Xglob = Xglob; a.W = W; a.Ainv = Ainv; a.ld = padded_dim(n);
+    a.shared_len = (nlen == 1); a.nugget_est = nugget_est ? 1 : 0;
+    a.P = (nlen == 1 ? 1 : D) + a.nugget_est;
+    a.partial = (double *)work;
+    const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
+    size_t shm = ((size_t)2 * D * 64 + 4 * 2 * a.P) * sizeof(double);
+    if (kind == DGPAMD_SEXP)
+        hipLaunchKernelGGL(grad_reduce_kernel<DGPAMD_SEXP>, dim3(ntiles), dim3(256), shm, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(grad_reduce_kernel<DGPAMD_MATERN25>, dim3(ntiles), dim3(256), shm, ctx->stream, a);
+    hipLaunchKernelGGL(grad_final_kernel, dim3(2 * a.P), dim3(256), 0, ctx->stream, (const double *)work, ntiles,
+                       2 * a.P, out);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}

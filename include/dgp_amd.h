@@ -1,0 +1,221 @@
+/*
+ * dgp_amd.h -- C-ABI of the MI355X-native stochastic-imputation engine.
+ *
+ * This is the drop-in boundary for dgpsi's SI training / imputed-GP prediction
+ * hot path (mingdeyu/DGP).  Each entry point replaces one njit/LAPACK operator
+ * of the reference; the reference interface is cited as file:line relative to
+ * the reference repository.  A dgpsi maintainer binds these with ctypes (see
+ * INTEGRATION.md); dgp_amd/ is the Python host that does exactly that.
+ *
+ * Conventions
+ *   - every array argument is a DEVICE pointer unless its name ends in `_h`
+ *     (host) ; f64 row-major (C order) and int64 indices, like numpy's;
+ *   - all launches go to the HIP stream given to dgpamd_create(); nothing
+ *     synchronises unless documented; workspaces are caller-allocated with the
+ *     size returned by the matching *_workspace() query (bytes);
+ *   - kernel kind: 0 = 'sexp', 1 = 'matern2.5' (reference passes these strings);
+ *   - every function returns 0 on success, DGPAMD_BAD_ARG, or DGPAMD_HIP_ERROR
+ *     (message via dgpamd_last_error).  Loss of positive-definiteness is
+ *     reported through device-side `info` words (LAPACK convention: 0 = ok,
+ *     j>0 = leading minor j not positive) which the host shim turns into
+ *     numpy.linalg.LinAlgError (reference: scipy/numpy cholesky raising,
+ *     dgp.py:1402, kernel_class.py:749).
+ *
+ * "Augmented" matrices.  A factorisation buffer is an Np x Np row-major array,
+ * Np = dgpamd_padded_dim(n) (a multiple of 64, > n).  Rows/cols [0,n) hold the
+ * SPD matrix (lower triangle is referenced), rows [n, n+r) hold r right-hand
+ * sides y_q^T in columns [0,n) and the bottom-right corner starts at zero.
+ * dgpamd_potrf factors the leading n columns only, so on exit row n+q holds
+ * w_q = L^-1 y_q and the corner entry (n+q, n+q') holds -w_q . w_q'
+ * (the quadratic forms y^T K^-1 y come out of the trailing update for free).
+ */
+#ifndef DGP_AMD_H
+#define DGP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGPAMD_OK 0
+#define DGPAMD_NOT_PD 1
+#define DGPAMD_BAD_ARG 2
+#define DGPAMD_HIP_ERROR 3
+
+#define DGPAMD_SEXP 0
+#define DGPAMD_MATERN25 1
+
+#define DGPAMD_MAXD 64   /* max columns of [input | global_input] of one GP node */
+#define DGPAMD_MAXB 64   /* max matrices in one batched call */
+
+typedef struct dgpamd_ctx dgpamd_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+/* stream: a hipStream_t created by the caller (e.g. torch's current stream),
+ * or NULL to let the library create (and own) one.                           */
+int dgpamd_create(int device, void *stream, dgpamd_ctx **out);
+int dgpamd_destroy(dgpamd_ctx *ctx);
+const char *dgpamd_last_error(const dgpamd_ctx *ctx);
+int dgpamd_sync(dgpamd_ctx *ctx);
+const char *dgpamd_version(void);
+int64_t dgpamd_padded_dim(int64_t n); /* Np for an n x n problem (>= n+1, multiple of 64) */
+
+/* Timing on the library's stream (bench.py: HIP events around the timed region). */
+int dgpamd_event_create(dgpamd_ctx *ctx, void **ev);
+int dgpamd_event_record(dgpamd_ctx *ctx, void *ev);
+int dgpamd_event_elapsed_ms(dgpamd_ctx *ctx, void *start, void *stop, float *ms_h); /* syncs on stop */
+int dgpamd_event_destroy(dgpamd_ctx *ctx, void *ev);
+
+/* ---- a1/a2  kernel-matrix assembly ---------------------------------------
+ * kernel.k_matrix()  kernel_class.py:304-359 (pdist/squareform + functions.py:16-34).
+ * X = [Xloc[:, colmap] | Xglob]: Xloc is (n x ldloc) with batch stride
+ * `stride_loc` (elements) and Dl gathered columns colmap_h[0..Dl); Xglob is
+ * (n x Dg), shared by the batch (may be NULL iff Dg == 0).
+ * length_h: 1 (shared) or Dl+Dg lengthscales.  Diagonal = 1 + nugget*W[i]
+ * (W = NULL -> 1)  kernel_class.py:352-355.
+ * Output, per batch b: K + b*stride_k, ld = ldk.
+ *   full != 0 : the n x n matrix, both triangles (ldk >= n)            [k_matrix()]
+ *   full == 0 : augmented factorisation buffer (ldk = Np): lower tiles of K,
+ *               rows [n, n+r) <- Y (r x n, ld = ldy, batch stride stride_y; may
+ *               be NULL iff r == 0), zero corner.                                */
+int dgpamd_kmatrix(dgpamd_ctx *ctx, int kind, int64_t n,
+                   const double *Xloc, int64_t ldloc, int64_t stride_loc, const int32_t *colmap_h, int Dl,
+                   const double *Xglob, int Dg,
+                   const double *length_h, int nlen, double nugget, const double *W,
+                   double *K, int64_t ldk, int64_t stride_k, int full,
+                   const double *Y, int64_t ldy, int64_t stride_y, int r,
+                   int batch);
+
+/* ---- LAPACK potrf (+ the forward solves and log-determinant it feeds) -----
+ * scipy.linalg.cholesky / np.linalg.cholesky call sites kernel_class.py:417,483,746,
+ * functions.py:109,119 ; logdet_nb functions.py:220-222 ; cho_solve with y
+ * kernel_class.py:423,487.
+ * In place on `batch` augmented buffers (see top).  logdet[b] = 2 sum log L_ii;
+ * info[b] as LAPACK.  work: dgpamd_potrf_workspace(n,batch) bytes; it keeps the
+ * inverses of the 64x64 diagonal blocks for dgpamd_potri.                      */
+size_t dgpamd_potrf_workspace(int64_t n, int batch);
+int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch,
+                 double *logdet, int32_t *info, void *work);
+
+/* Read the quadratic forms out of factored buffers: quad[b*r*r + q*r + q'] =
+ * y_q^T K^-1 y_q'  (= -corner).                                               */
+int dgpamd_aug_quad(dgpamd_ctx *ctx, int64_t n, const double *A, int64_t stride_a, int batch, int r, double *quad);
+
+/* ---- a5  ESS target log-likelihood, batched over speculative proposals -----
+ * kernel.log_likelihood_func  kernel_class.py:481-492:
+ *   ll[b] = -0.5 ( n log(scale) + logdet(K_b) + y^T K_b^-1 y / scale )
+ * Fused pipeline: kmatrix (augmented with y) -> potrf -> read-out.  A is scratch
+ * for `batch` augmented buffers.  y: (n) shared by the batch.                  */
+int dgpamd_loglik(dgpamd_ctx *ctx, int kind, int64_t n,
+                  const double *Xloc, int64_t ldloc, int64_t stride_loc, const int32_t *colmap_h, int Dl,
+                  const double *Xglob, int Dg,
+                  const double *length_h, int nlen, double nugget, const double *W, double scale,
+                  const double *y, double *A, int64_t stride_a, int batch,
+                  double *ll, int32_t *info, void *work);
+
+/* ---- a3  fmvn: nu = sqrt(scale) * L z  -------------------------------------
+ * functions.fmvn  functions.py:113-121 (chol(scale*K) z = sqrt(scale) chol(K) z).
+ * L: factored augmented buffers (batch stride stride_a); z, out: (batch x n).   */
+int dgpamd_trmv_lower(dgpamd_ctx *ctx, int64_t n, const double *L, int64_t stride_a, const double *scale_h,
+                      const double *z, double *out, int batch);
+
+/* ---- a4  ESS proposals: FP[b] = F cos(theta_b) + NU sin(theta_b) -----------
+ * functions.update_f  functions.py:203-208.  F, NU: (n x M); FP: (batch x n x M). */
+int dgpamd_ess_propose(dgpamd_ctx *ctx, int64_t n, int M, const double *F, const double *NU,
+                       const double *theta_h, int batch, double *FP);
+
+/* ---- inverse from the factor (cho_solve(L, I))  kernel_class.py:418,747 -----
+ * On entry A holds dgpamd_potrf output (and `work` its workspace).  On exit
+ * Ainv (Np x Np buffer) holds K^-1 in BOTH triangles of [0,n)x[0,n) and row n+q
+ * of columns [0,n) holds -alpha_q^T = -(K^-1 y_q)^T.  A is overwritten with L^-1. */
+int dgpamd_potri(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work);
+
+/* ---- a8  M-step objective pieces -------------------------------------------
+ * kernel.llik  kernel_class.py:403-449 restructured:
+ *   tr_p   = sum_ij Kinv_ij dK_p,ij          (= trace(K^-1 dK_p))
+ *   quad_p = sum_ij alpha_i alpha_j dK_p,ij  (= y^T K^-1 dK_p K^-1 y)
+ * with dK_p recomputed in flight (never stored).  p runs over the lengthscales
+ * (nlen == 1: the summed derivative) and, iff nugget_est, the nugget last.
+ * out (host-visible after sync): out[0..P) = tr_p, out[P..2P) = quad_p.
+ * Ainv: from dgpamd_potri (alpha is read from its row n, negated).             */
+int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n,
+                       const double *Xloc, int64_t ldloc, const int32_t *colmap_h, int Dl,
+                       const double *Xglob, int Dg,
+                       const double *length_h, int nlen, double nugget, const double *W, int nugget_est,
+                       const double *Ainv, double *out, void *work);
+size_t dgpamd_grad_workspace(int64_t n, int nparam);
+
+/* ---- a11  GP prediction ------------------------------------------------------
+ * functions.gp  functions.py:379-394 (+ K_vec_nb vecchia.py:244-265):
+ *   m_t = Rinv_y . r_t ,  v_t = | scale (1 + nugget - r_t^T Rinv r_t) |
+ * x: (M x D) test inputs already concatenated [local | global]; Wtr: (n x D)
+ * training inputs; Rinv: n x n symmetric with leading dimension ldr; ry: (n).
+ * mean/var: (M).  work: dgpamd_gp_workspace(n, M) bytes.                      */
+size_t dgpamd_gp_workspace(int64_t n, int64_t M);
+int dgpamd_gp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int D,
+                      const double *x, const double *Wtr, const double *length_h, int nlen,
+                      const double *Rinv, int64_t ldr, const double *ry, double scale, double nugget,
+                      double *mean, double *var, void *work);
+
+/* ---- a12-a14  linked-GP prediction ------------------------------------------
+ * functions.link_gp  functions.py:396-430 with IJ_sexp :432-451 / IJ_matern
+ * :453-494 (Jd, Jd0 vecchia.py:915-988), trace_sum :496-506, quad vecchia.py:990:
+ *   mean_t = I_t . ry ,  var_t = | ry^T J_t ry - mean_t^2 + scale (1 + nugget - tr(Rinv J_t)) |
+ * m, v: (M x Dw) input moments; z: (M x Dz) deterministic global inputs (NULL iff
+ * Dz == 0); Wtr: (n x Dw), Wg: (n x Dz).  Psexp/R2sexp are never materialised. */
+size_t dgpamd_linkgp_workspace(int64_t n, int64_t M);
+int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz,
+                          const double *m, const double *v, const double *z,
+                          const double *Wtr, const double *Wg, const double *length_h, int nlen,
+                          const double *Rinv, int64_t ldr, const double *ry, double scale, double nugget,
+                          double *mean, double *var, void *work);
+
+/* ---- a15  imputation-moment accumulation (emulation.py:846-847) --------------
+ * sum_mu += mu ; sum_m2 += mu^2 + var   (count elements).  finalize:
+ * mu = sum_mu / S ; var = sum_m2 / S - mu^2.                                   */
+int dgpamd_moments_accumulate(dgpamd_ctx *ctx, int64_t count, const double *mu, const double *var,
+                              double *sum_mu, double *sum_m2);
+int dgpamd_moments_finalize(dgpamd_ctx *ctx, int64_t count, double S, double *sum_mu_to_mu, double *sum_m2_to_var);
+
+/* ---- a17  Vecchia neighbour search --------------------------------------------
+ * vecchia.nn  vecchia.py:61-109: NNarray (n x (m+1)) int64, row i = i and its <= m
+ * nearest EARLIER points (exact, squared-euclidean on x), sorted by index
+ * descending, -1 padded.  vecchia.get_pred_nn  vecchia.py:20-40: (M x m) nearest
+ * training points, nearest first.  x, q are already divided by the lengthscales. */
+int dgpamd_nn_ordered(dgpamd_ctx *ctx, int64_t n, int D, const double *x, int m, int64_t *NNarray);
+int dgpamd_nn_query(dgpamd_ctx *ctx, int64_t M, int64_t n, int D, const double *q, const double *x, int m, int64_t *NN);
+
+/* ---- a19-a21  Vecchia likelihoods and sampler ---------------------------------
+ * vecchia_llik vecchia.py:164-180 ; vecchia_nllik :182-242 (raw sums; the host
+ * finishes the scale_est / replicate branches) ; L_matrix :409-424 ;
+ * forward_solve_sp :111-120.  X: (n x D) ordered inputs; y: (n); nugget_diag: (n).
+ * out_llik (device, 2 doubles): {quad, logdet}.  out_nllik (device, 2+2P
+ * doubles): {quad, logdet, dquad[P], dlogdet[P]}, P = nlen (+1 iff nugget_est). */
+int dgpamd_vecchia_llik(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, const double *y,
+                        const int64_t *NNarray, const double *length_h, int nlen, double nugget,
+                        const double *nugget_diag, double *out_llik);
+int dgpamd_vecchia_nllik(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, const double *y,
+                         const int64_t *NNarray, const double *length_h, int nlen, double nugget,
+                         const double *nugget_diag, int nugget_est, double *out_nllik);
+int dgpamd_vecchia_lmatrix(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X,
+                           const int64_t *NNarray, const double *length_h, int nlen, double nugget, double *Lmat);
+int dgpamd_vecchia_spsolve(dgpamd_ctx *ctx, int64_t n, int m, const double *Lmat, const int64_t *NNarray,
+                           double inv_sqrt_scale, const double *b, double *x);
+
+/* ---- a22/a23  Vecchia prediction -------------------------------------------------
+ * gp_vecch vecchia.py:635-654 ; link_gp_vecch :758-796 (IJ_nb :838-907).          */
+int dgpamd_vecchia_gp(dgpamd_ctx *ctx, int kind, int64_t M, int64_t n, int D, int pm, const double *x,
+                      const double *w, const int64_t *NN, const double *y, double scale,
+                      const double *length_h, int nlen, double nugget, const double *nugget_diag,
+                      double *mean, double *var);
+int dgpamd_vecchia_linkgp(dgpamd_ctx *ctx, int kind, int64_t M, int64_t n, int Dw, int Dz, int pm,
+                          const double *m, const double *v, const double *z, const double *w1, const double *wg,
+                          const int64_t *NN, const double *y, double scale, const double *length_h, int nlen,
+                          double nugget, const double *nugget_diag, double *mean, double *var);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGP_AMD_H */
