@@ -18,16 +18,9 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     if (!ctx) return DGPAMD_HIP_ERROR;
     ctx->device = device;
     ctx->err[0] = 0;
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
-        ctx->own_stream = false;
-    } else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete ctx;
-            return DGPAMD_HIP_ERROR;
-        }
-        ctx->own_stream = true;
-    }
+    // NULL = the device's default (null) stream, which is also torch's default current stream
+    ctx->stream = (hipStream_t)stream;
+    ctx->own_stream = false;
     *out = ctx;
     return DGPAMD_OK;
 }

@@ -1,0 +1,513 @@
+// Imputed-GP prediction.
+//   gp      (functions.py:379-394)  m = ry.r , v = |scale(1+eta - r^T Rinv r)|
+//           as  cross_corr -> symmetric MFMA quadratic form (lower tiles of Rinv, x2) -> finalize
+//   link_gp (functions.py:396-430)  m = I.ry , v = |sum_ij J_ij (ry_i ry_j - scale Rinv_ij) - m^2 + scale(1+eta)|
+//           one workgroup per (lower 64x64 tile of C = ry ry^T - scale Rinv) x (chunk of test points);
+//           Psexp / R2sexp (functions.py:259-272, kernel_class.py:752-764) are never materialised.
+#include "common.hpp"
+#include "tile.hpp"
+#include "linkfun.hpp"
+
+#include <math.h>
+
+#define MC_MAX 2048   // test points per workspace chunk
+#define TCH 32        // test points per linked-GP workgroup
+
+__device__ __forceinline__ double wave_sum_p(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// r[i][t] = k(W_i, x_t)   (K_vec_nb, vecchia.py:244-265)
+// ---------------------------------------------------------------------------
+struct CrossArgs {
+    int kind, D;
+    double inv_len[DGPAMD_MAXD];
+    int64_t n, M, t0, Mc;
+    const double *W, *x;
+    double *R;   // [npad][Mc]
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void cross_corr_kernel(CrossArgs a) {
+    extern __shared__ double lds[];
+    const int D = a.D;
+    double *WT = lds, *XT = lds + D * 64;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+        int row = idx / D, d = idx - row * D;
+        int64_t gi = i0 + row, gt = a.t0 + c0 + row;
+        WT[d * 64 + row] = (gi < a.n ? a.W[gi * D + d] : 0.0) * a.inv_len[d];
+        XT[d * 64 + row] = (gt < a.M ? a.x[gt * D + d] : 0.0) * a.inv_len[d];
+    }
+    __syncthreads();
+    double s[4][4], pr[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s[p][q] = 0.0;
+            pr[p][q] = 1.0;
+        }
+    for (int d = 0; d < D; ++d) {
+        double xi[4], xj[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            xi[p] = WT[d * 64 + ty + 16 * p];
+            xj[p] = XT[d * 64 + tx + 16 * p];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double df = xi[p] - xj[q];
+                if (KIND == DGPAMD_SEXP)
+                    corr_accum_sexp(df, s[p][q]);
+                else
+                    corr_accum_matern(df, pr[p][q], s[p][q]);
+            }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t gi = i0 + ty + 16 * p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = (KIND == DGPAMD_SEXP) ? exp(-s[p][q]) : pr[p][q] * exp(-SQRT5 * s[p][q]);
+            if (gi >= a.n) v = 0.0;
+            a.R[gi * a.Mc + c0 + tx + 16 * q] = v;
+        }
+    }
+}
+
+// partial[bi][t] = sum_{i in block bi} r_it * ( Rinv[bi][bi] r_bi + 2 sum_{kb<bi} Rinv[bi][kb] r_kb )_it
+struct GpQuadArgs {
+    const double *Rinv;
+    int64_t ldr, n, Mc;
+    const double *R;
+    double *partial;
+};
+
+__global__ __launch_bounds__(256) void gp_quad_kernel(GpQuadArgs a) {
+    __shared__ double As[64 * LDM];
+    __shared__ double Bs[KC * LDK];
+    __shared__ double red[4][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bi = blockIdx.x, tj = blockIdx.y;
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int64_t rlim = a.n - (int64_t)bi * 64;
+    for (int kb = 0; kb <= bi; ++kb) {
+        const double *Ag = a.Rinv + ((int64_t)bi * 64) * a.ldr + (int64_t)kb * 64;
+        const double *Bg = a.R + ((int64_t)kb * 64) * a.Mc + (int64_t)tj * 64;
+        const int64_t clim = a.n - (int64_t)kb * 64;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            load_mk_masked(Ag, a.ldr, As, tid, h, rlim > 64 ? 64 : (int)rlim, clim > 64 ? 64 : (int)clim);
+            load_km(Bg, a.Mc, Bs, tid, h, 64);
+            __syncthreads();
+            mfma_tile<OP_MK, OP_KM>(As, Bs, acc, wave, lane, kb < bi ? 2.0 : 1.0);
+        }
+    }
+    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            v = fma(acc[t][r], a.R[((int64_t)bi * 64 + crow + 4 * r) * a.Mc + (int64_t)tj * 64 + 16 * t + ccol], v);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) red[wave][16 * t + lane] = v;
+    }
+    __syncthreads();
+    if (tid < 64) a.partial[(int64_t)bi * a.Mc + (int64_t)tj * 64 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+__global__ __launch_bounds__(256) void gp_finalize_kernel(const double *R, const double *partial, const double *ry,
+                                                          int nry, int64_t n, int nb, int64_t Mc, int64_t t0, int64_t M,
+                                                          double scale, double nugget, double *mean, double *var) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Mc || t0 + t >= M) return;
+    for (int s = blockIdx.y; s < nry; s += gridDim.y) {
+        const double *rys = ry + (int64_t)s * n;
+        double m = 0.0;
+        for (int64_t i = 0; i < n; ++i) m = fma(rys[i], R[i * Mc + t], m);
+        mean[(int64_t)s * M + t0 + t] = m;
+    }
+    if (blockIdx.y == 0) {
+        double q = 0.0;
+        for (int b = 0; b < nb; ++b) q += partial[(int64_t)b * Mc + t];
+        var[t0 + t] = fabs(scale * (1.0 + nugget - q));
+    }
+}
+
+extern "C" size_t dgpamd_gp_workspace(int64_t n, int64_t M) {
+    int64_t nb = (n + 63) / 64;
+    int64_t Mc = ((M + 63) / 64) * 64;
+    if (Mc > MC_MAX) Mc = MC_MAX;
+    return (size_t)((nb * 64 + nb) * Mc) * sizeof(double);
+}
+
+extern "C" int dgpamd_gp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int D, const double *x,
+                                 const double *Wtr, const double *length_h, int nlen, const double *Rinv, int64_t ldr,
+                                 const double *ry, int nry, double scale, double nugget, double *mean, double *var,
+                                 void *work) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || M <= 0 || nry <= 0 || !x || !Wtr || !length_h || !Rinv || !ry || !mean || !var || !work)
+        BAD_ARG(ctx, "null pointer or empty problem");
+    if (kind != DGPAMD_SEXP && kind != DGPAMD_MATERN25) BAD_ARG(ctx, "kind must be 0 or 1");
+    if (D <= 0 || D > DGPAMD_MAXD || (nlen != 1 && nlen != D)) BAD_ARG(ctx, "bad D / nlen");
+    if (ldr < n) BAD_ARG(ctx, "ldr < n");
+    const int nb = (int)((n + 63) / 64);
+    int64_t Mc = ((M + 63) / 64) * 64;
+    if (Mc > MC_MAX) Mc = MC_MAX;
+    double *R = (double *)work, *partial = R + (int64_t)nb * 64 * Mc;
+    CrossArgs c;
+    c.kind = kind; c.D = D; c.n = n; c.M = M; c.Mc = Mc; c.W = Wtr; c.x = x; c.R = R;
+    for (int d = 0; d < D; ++d) c.inv_len[d] = 1.0 / length_h[nlen == 1 ? 0 : d];
+    GpQuadArgs q;
+    q.Rinv = Rinv; q.ldr = ldr; q.n = n; q.Mc = Mc; q.R = R; q.partial = partial;
+    const size_t shm = (size_t)2 * D * 64 * sizeof(double);
+    for (int64_t t0 = 0; t0 < M; t0 += Mc) {
+        c.t0 = t0;
+        int64_t mc = M - t0 < Mc ? M - t0 : Mc;
+        unsigned tb = (unsigned)((mc + 63) / 64);
+        if (kind == DGPAMD_SEXP)
+            hipLaunchKernelGGL(cross_corr_kernel<DGPAMD_SEXP>, dim3(nb, tb), dim3(256), shm, ctx->stream, c);
+        else
+            hipLaunchKernelGGL(cross_corr_kernel<DGPAMD_MATERN25>, dim3(nb, tb), dim3(256), shm, ctx->stream, c);
+        hipLaunchKernelGGL(gp_quad_kernel, dim3(nb, tb), dim3(256), 0, ctx->stream, q);
+        hipLaunchKernelGGL(gp_finalize_kernel, dim3((unsigned)((mc + 255) / 256), (unsigned)(nry < 64 ? nry : 64)),
+                           dim3(256), 0, ctx->stream, (const double *)R, (const double *)partial, ry, nry, n, nb, Mc,
+                           t0, M, scale, nugget, mean, var);
+    }
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// linked GP: closed forms of E[k(x,Z)] and E[k(x,Z) k(x',Z)], Z ~ N(m, v)
+// ---------------------------------------------------------------------------
+struct LinkArgs {
+    int kind, Dw, Dz;
+    int64_t n, M, t0, Mc;
+    const double *m, *v, *z;
+    const double *W, *Wg;
+    double len[DGPAMD_MAXD];
+    const double *Rinv;
+    int64_t ldr;
+    const double *ry;
+    double scale, nugget;
+    double *partial;   // [ntiles][Mc]
+    double *mean, *var;
+};
+
+// mean_t = sum_i I_i(t) ry_i : one wave per test point
+template <int KIND>
+__global__ __launch_bounds__(256) void linkgp_mean_kernel(LinkArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t t = a.t0 + (int64_t)blockIdx.x * 4 + wave;
+    if (t >= a.M || t >= a.t0 + a.Mc) return;
+    const double *mt = a.m + t * a.Dw, *vt = a.v + t * a.Dw;
+    const double *zt = a.Dz ? a.z + t * a.Dz : nullptr;
+    double acc = 0.0;
+    for (int64_t i = lane; i < a.n; i += 64) {
+        double I;
+        if (KIND == DGPAMD_SEXP) {
+            double e = 0.0;
+            for (int k = 0; k < a.Dw; ++k) {
+                double l = a.len[k], d = a.W[i * a.Dw + k] - mt[k];
+                e += d * d / (2.0 * vt[k] + l * l);
+            }
+            for (int g = 0; g < a.Dz; ++g) {
+                double d = (a.Wg[i * a.Dz + g] - zt[g]) / a.len[a.Dw + g];
+                e += d * d;
+            }
+            I = exp(-e);
+        } else {
+            I = 1.0;
+            for (int k = 0; k < a.Dw; ++k) I *= matern_I_dim(a.W[i * a.Dw + k], mt[k], vt[k], a.len[k]);
+            double pr = 1.0, s = 0.0;
+            for (int g = 0; g < a.Dz; ++g) corr_accum_matern((a.Wg[i * a.Dz + g] - zt[g]) / a.len[a.Dw + g], pr, s);
+            I *= pr * exp(-SQRT5 * s);
+        }
+        acc = fma(I, a.ry[i], acc);
+    }
+    acc = wave_sum_p(acc);
+    if (lane == 0) {
+        if (KIND == DGPAMD_SEXP) {
+            double c = 1.0;
+            for (int k = 0; k < a.Dw; ++k) c *= 1.0 + 2.0 * vt[k] / (a.len[k] * a.len[k]);
+            acc *= 1.0 / sqrt(c);
+        }
+        a.mean[t] = acc;
+    }
+}
+
+// partial[tile][t] = sum_{(i,j) in tile} wt (ry_i ry_j - scale Rinv_ij) Jhat_ij(t)
+// (sexp: Jhat = J / J_coef1, the prefactor is applied in the finalize kernel)
+template <int KIND>
+__global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
+    extern __shared__ double lds[];
+    const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
+    double *WiT = lds;                    // [DT][64]
+    double *WjT = WiT + DT * 64;          // [DT][64]
+    double *tm = WjT + DT * 64;           // [TCH][Dw]
+    double *tv = tm + TCH * Dw;           // [TCH][Dw]
+    double *tz = tv + TCH * Dw;           // [TCH][Dz]
+    double *red = tz + TCH * Dz;          // [TCH][4]
+    double *Cs = red + TCH * 4;           // [64][65]  (matern only)
+    int bi, bj;
+    tri_decode(blockIdx.x, bi, bj);
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, wave = tid >> 6, lane = tid & 63;
+    const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
+    const int64_t tbase = a.t0 + (int64_t)blockIdx.y * TCH;
+    int nt = TCH;
+    if (tbase + nt > a.M) nt = (int)(a.M - tbase);
+    if (tbase + nt > a.t0 + a.Mc) nt = (int)(a.t0 + a.Mc - tbase);
+
+    for (int idx = tid; idx < 64 * DT; idx += 256) {
+        int row = idx / DT, d = idx - row * DT;
+        int64_t gi = i0 + row, gj = j0 + row;
+        double vi = 0.0, vj = 0.0;
+        if (d < Dw) {
+            if (gi < n) vi = a.W[gi * Dw + d];
+            if (gj < n) vj = a.W[gj * Dw + d];
+        } else {
+            if (gi < n) vi = a.Wg[gi * Dz + d - Dw];
+            if (gj < n) vj = a.Wg[gj * Dz + d - Dw];
+        }
+        WiT[d * 64 + row] = vi;
+        WjT[d * 64 + row] = vj;
+    }
+    for (int idx = tid; idx < nt * Dw; idx += 256) {
+        tm[idx] = a.m[tbase * Dw + idx];
+        tv[idx] = a.v[tbase * Dw + idx];
+    }
+    for (int idx = tid; idx < nt * Dz; idx += 256) tz[idx] = a.z[tbase * Dz + idx];
+
+    const double wt = (bi == bj) ? 1.0 : 2.0;
+    double Cr[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t gi = i0 + ty + 16 * p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t gj = j0 + tx + 16 * q;
+            double c = 0.0;
+            if (gi < n && gj < n) c = wt * (a.ry[gi] * a.ry[gj] - a.scale * a.Rinv[gi * a.ldr + gj]);
+            Cr[p][q] = c;
+            if (KIND == DGPAMD_MATERN25) Cs[(ty + 16 * p) * 65 + tx + 16 * q] = c;
+        }
+    }
+    __syncthreads();
+
+    if (KIND == DGPAMD_SEXP) {
+        // t-independent part of the exponent: sum_k (w_ik - w_jk)^2 / (2 l_k^2)  (= -log R2sexp, kernel_class.py:761-763)
+        double base[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) base[p][q] = 0.0;
+        for (int k = 0; k < Dw; ++k) {
+            const double c2 = 1.0 / (2.0 * a.len[k] * a.len[k]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double d = WiT[k * 64 + ty + 16 * p] - WjT[k * 64 + tx + 16 * q];
+                    base[p][q] = fma(d * d, c2, base[p][q]);
+                }
+        }
+        for (int t = 0; t < nt; ++t) {
+            double e[4][4], ei[4], ej[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ei[p] = 0.0;
+                ej[p] = 0.0;
+            }
+            for (int g = 0; g < Dz; ++g) {
+                const double il = 1.0 / a.len[Dw + g], zz = tz[t * Dz + g];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    double di = (WiT[(Dw + g) * 64 + ty + 16 * p] - zz) * il;
+                    double dj = (WjT[(Dw + g) * 64 + tx + 16 * p] - zz) * il;
+                    ei[p] = fma(di, di, ei[p]);
+                    ej[p] = fma(dj, dj, ej[p]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[p][q] = base[p][q] + ei[p] + ej[q];
+            for (int k = 0; k < Dw; ++k) {
+                const double l = a.len[k];
+                const double c1 = 1.0 / (8.0 * tv[t * Dw + k] + 2.0 * l * l), m2 = 2.0 * tm[t * Dw + k];
+                double wi[4], wj[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    wi[p] = WiT[k * 64 + ty + 16 * p] - m2;
+                    wj[p] = WjT[k * 64 + tx + 16 * p];
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        double sgm = wi[p] + wj[q];
+                        e[p][q] = fma(sgm * sgm, c1, e[p][q]);
+                    }
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = fma(Cr[p][q], exp(-e[p][q]), acc);
+            acc = wave_sum_p(acc);
+            if (lane == 0) red[t * 4 + wave] = acc;
+        }
+    } else {
+        for (int t = 0; t < nt; ++t) {
+            double acc = 0.0;
+#pragma unroll 1
+            for (int e = 0; e < 16; ++e) {
+                const int r = ty + 16 * (e >> 2), c = tx + 16 * (e & 3);
+                const double cij = Cs[r * 65 + c];
+                if (cij == 0.0) continue;
+                const bool diag = (i0 + r == j0 + c);
+                double prod = 1.0;
+                for (int k = 0; k < Dw; ++k) {
+                    const double l = a.len[k], zm = tm[t * Dw + k], zv = tv[t * Dw + k];
+                    const double xi = WiT[k * 64 + r], xj = WjT[k * 64 + c];
+                    if (zv != 0.0)
+                        prod *= diag ? matern_Jd0(xi, zm, zv, l) : matern_Jd(xj, xi, zm, zv, l);
+                    else
+                        prod *= matern_point(zm - xi, l) * matern_point(zm - xj, l);
+                }
+                double pi_ = 1.0, si = 0.0, pj = 1.0, sj = 0.0;
+                for (int g = 0; g < Dz; ++g) {
+                    const double il = 1.0 / a.len[Dw + g], zz = tz[t * Dz + g];
+                    corr_accum_matern((WiT[(Dw + g) * 64 + r] - zz) * il, pi_, si);
+                    corr_accum_matern((WjT[(Dw + g) * 64 + c] - zz) * il, pj, sj);
+                }
+                if (Dz) prod *= pi_ * pj * exp(-SQRT5 * (si + sj));
+                acc = fma(cij, prod, acc);
+            }
+            acc = wave_sum_p(acc);
+            if (lane == 0) red[t * 4 + wave] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid < nt)
+        a.partial[(int64_t)blockIdx.x * a.Mc + (tbase - a.t0) + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void linkgp_finalize_kernel(LinkArgs a, int ntiles) {
+    const int64_t tt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = a.t0 + tt;
+    if (tt >= a.Mc || t >= a.M) return;
+    double s = 0.0;
+    for (int b = 0; b < ntiles; ++b) s += a.partial[(int64_t)b * a.Mc + tt];
+    if (KIND == DGPAMD_SEXP) {
+        double c = 1.0;
+        for (int k = 0; k < a.Dw; ++k) c *= 1.0 + 4.0 * a.v[t * a.Dw + k] / (a.len[k] * a.len[k]);
+        s *= 1.0 / sqrt(c);
+    }
+    const double mu = a.mean[t];
+    a.var[t] = fabs(s - mu * mu + a.scale * (1.0 + a.nugget));
+}
+
+extern "C" size_t dgpamd_linkgp_workspace(int64_t n, int64_t M) {
+    int64_t nb = (n + 63) / 64;
+    int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
+    if (Mc > MC_MAX) Mc = MC_MAX;
+    return (size_t)(nb * (nb + 1) / 2 * Mc) * sizeof(double);
+}
+
+extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz, const double *m,
+                                     const double *v, const double *z, const double *Wtr, const double *Wg,
+                                     const double *length_h, int nlen, const double *Rinv, int64_t ldr,
+                                     const double *ry, double scale, double nugget, double *mean, double *var,
+                                     void *work) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || M <= 0 || !m || !v || !Wtr || !length_h || !Rinv || !ry || !mean || !var || !work)
+        BAD_ARG(ctx, "null pointer or empty problem");
+    if (kind != DGPAMD_SEXP && kind != DGPAMD_MATERN25) BAD_ARG(ctx, "kind must be 0 or 1");
+    if (Dw <= 0 || Dz < 0 || Dw + Dz > DGPAMD_MAXD) BAD_ARG(ctx, "bad Dw / Dz");
+    if (Dz > 0 && (!z || !Wg)) BAD_ARG(ctx, "Dz > 0 needs z and Wg");
+    if (nlen != 1 && nlen != Dw + Dz) BAD_ARG(ctx, "nlen must be 1 or Dw+Dz");
+    if (ldr < n) BAD_ARG(ctx, "ldr < n");
+    LinkArgs a;
+    a.kind = kind; a.Dw = Dw; a.Dz = Dz; a.n = n; a.M = M; a.m = m; a.v = v; a.z = z; a.W = Wtr; a.Wg = Wg;
+    for (int d = 0; d < Dw + Dz; ++d) a.len[d] = length_h[nlen == 1 ? 0 : d];   // functions.py:402-410 broadcast
+    a.Rinv = Rinv; a.ldr = ldr; a.ry = ry; a.scale = scale; a.nugget = nugget; a.mean = mean; a.var = var;
+    a.partial = (double *)work;
+    int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
+    if (Mc > MC_MAX) Mc = MC_MAX;
+    a.Mc = Mc;
+    const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
+    const int DT = Dw + Dz;
+    size_t shm = ((size_t)2 * DT * 64 + (size_t)TCH * (2 * Dw + Dz) + TCH * 4) * sizeof(double);
+    if (kind == DGPAMD_MATERN25) shm += 64 * 65 * sizeof(double);
+    for (int64_t t0 = 0; t0 < M; t0 += Mc) {
+        a.t0 = t0;
+        const int64_t mc = M - t0 < Mc ? M - t0 : Mc;
+        const unsigned tb = (unsigned)((mc + TCH - 1) / TCH);
+        if (kind == DGPAMD_SEXP) {
+            hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_SEXP>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_SEXP>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_SEXP>, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, a, ntiles);
+        } else {
+            hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_MATERN25>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_MATERN25>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_MATERN25>, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, a, ntiles);
+        }
+    }
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a15  moments over imputations (emulation.py:846-847)
+// ---------------------------------------------------------------------------
+__global__ void moments_acc_kernel(int64_t count, const double *mu, const double *var, double *s1, double *s2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        double m = mu[i];
+        s1[i] += m;
+        s2[i] += m * m + var[i];
+    }
+}
+__global__ void moments_fin_kernel(int64_t count, double S, double *s1, double *s2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        double m = s1[i] / S;
+        s1[i] = m;
+        s2[i] = s2[i] / S - m * m;
+    }
+}
+
+extern "C" int dgpamd_moments_accumulate(dgpamd_ctx *ctx, int64_t count, const double *mu, const double *var,
+                                         double *sum_mu, double *sum_m2) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (count <= 0 || !mu || !var || !sum_mu || !sum_m2) BAD_ARG(ctx, "null pointer or empty");
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(moments_acc_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, count, mu, var, sum_mu, sum_m2);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_moments_finalize(dgpamd_ctx *ctx, int64_t count, double S, double *sum_mu_to_mu,
+                                       double *sum_m2_to_var) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (count <= 0 || !(S > 0.0) || !sum_mu_to_mu || !sum_m2_to_var) BAD_ARG(ctx, "bad arguments");
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(moments_fin_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, count, S, sum_mu_to_mu, sum_m2_to_var);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}

@@ -1,0 +1,755 @@
+// Vecchia-approximation kernels (reference dgpsi/vecchia.py).
+//
+// Thousands of tiny (m+1)x(m+1) problems: ONE WAVE (a 64-thread workgroup) per
+// row / test point, the block matrix lives in LDS, the right-hand side rides
+// along as an extra row of the factorisation (same trick as chol.hip), so
+// forward solves cost nothing extra.  Neighbour search is exact brute force on
+// device (multi-pass selection in (distance, index) order -> deterministic).
+#include "common.hpp"
+#include "linkfun.hpp"
+
+#include <math.h>
+
+#define VW 64   // threads per item (one wave)
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return __shfl(v, 0, 64);
+}
+
+struct VParams {
+    int kind, D, nlen;
+    double inv_len[DGPAMD_MAXD];
+    double nugget;
+};
+
+static int fill_vparams(dgpamd_ctx *ctx, VParams &p, int kind, int D, const double *length_h, int nlen, double nugget) {
+    if (kind != DGPAMD_SEXP && kind != DGPAMD_MATERN25) BAD_ARG(ctx, "kind must be 0 or 1");
+    if (D <= 0 || D > DGPAMD_MAXD || !length_h || (nlen != 1 && nlen != D)) BAD_ARG(ctx, "bad D / nlen / length");
+    p.kind = kind; p.D = D; p.nlen = nlen; p.nugget = nugget;
+    for (int d = 0; d < D; ++d) p.inv_len[d] = 1.0 / length_h[nlen == 1 ? 0 : d];
+    return DGPAMD_OK;
+}
+
+static int set_lds(dgpamd_ctx *ctx, const void *fn, size_t shm) {
+    if (shm > 160 * 1024) BAD_ARG(ctx, "conditioning set too large for LDS (160 KiB)");
+    if (shm > 48 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    return DGPAMD_OK;
+}
+
+// correlation of two SCALED points held in LDS
+template <int KIND>
+__device__ __forceinline__ double corr_pts(const double *xa, const double *xb, int D) {
+    double s = 0.0, pr = 1.0;
+    for (int d = 0; d < D; ++d) {
+        double df = xa[d] - xb[d];
+        if (KIND == DGPAMD_SEXP)
+            corr_accum_sexp(df, s);
+        else
+            corr_accum_matern(df, pr, s);
+    }
+    return (KIND == DGPAMD_SEXP) ? exp(-s) : pr * exp(-SQRT5 * s);
+}
+
+template <int KIND>
+__device__ __forceinline__ double dcoef_v(double df) {
+    if (KIND == DGPAMD_SEXP) return 2.0 * df * df;
+    double r = fabs(df);
+    double e1 = fma(r, SQRT5, 1.0), e2 = (5.0 / 3.0) * r * r;
+    return e2 * e1 / (e1 + e2);
+}
+
+// In-LDS right-looking Cholesky of the leading npiv columns of a `rows` x `rows` lower matrix (ld = lda).
+// Rows beyond npiv are carried (right-hand sides / prediction rows).  Returns 0 or 1+index of a bad pivot.
+__device__ int lds_chol(double *A, int lda, int rows, int npiv, int lane) {
+    int bad = 0;
+    for (int j = 0; j < npiv; ++j) {
+        __syncthreads();
+        double d = A[j * lda + j];
+        if (!(d > 0.0)) {
+            if (!bad) bad = j + 1;
+            d = 1.0;
+        }
+        const double sd = sqrt(d), inv = 1.0 / sd;
+        __syncthreads();
+        for (int r = j + 1 + lane; r < rows; r += VW) A[r * lda + j] *= inv;
+        if (lane == 0) A[j * lda + j] = sd;
+        __syncthreads();
+        for (int r = j + 1 + lane; r < rows; r += VW) {
+            const double lr = A[r * lda + j];
+            const int cmax = r < rows ? r : rows - 1;
+            for (int c = j + 1; c <= cmax; ++c) A[r * lda + c] = fma(-lr, A[c * lda + j], A[r * lda + c]);
+        }
+    }
+    __syncthreads();
+    return bad;
+}
+
+// x <- L^-T x for nrhs vectors stored as rows X[q][.] (ld = ldx); column-oriented back substitution
+__device__ void lds_backsolve_T(const double *L, int lda, int b, double *X, int ldx, int nrhs, int lane) {
+    for (int c = b - 1; c >= 0; --c) {
+        __syncthreads();
+        if (lane < nrhs) X[lane * ldx + c] /= L[c * lda + c];
+        __syncthreads();
+        for (int q = 0; q < nrhs; ++q) {
+            const double xc = X[q * ldx + c];
+            for (int r = lane; r < c; r += VW) X[q * ldx + r] = fma(-L[c * lda + r], xc, X[q * ldx + r]);
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// a17  neighbour search
+// ---------------------------------------------------------------------------
+// One 256-thread workgroup per query.  Pass p selects the p-th smallest (dist, index) pair.
+__device__ __forceinline__ bool pair_less(double d1, int64_t i1, double d2, int64_t i2) {
+    return d1 < d2 || (d1 == d2 && i1 < i2);
+}
+
+__global__ __launch_bounds__(256) void nn_select_kernel(int64_t nq, int64_t nx, int D, const double *q, const double *x,
+                                                        int m_out, int ordered, int64_t *out) {
+    extern __shared__ double lds[];
+    double *qs = lds;                                  // [D]
+    double *rd = lds + D;                              // [4] wave minima (dist)
+    int64_t *ri = reinterpret_cast<int64_t *>(rd + 4); // [4] wave minima (index)
+    int64_t *sel = ri + 4;                             // [m_out] selected indices
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t iq = blockIdx.x;
+    const int64_t ncand = ordered ? iq + 1 : nx;       // ordered: only points with index <= own
+    const int k = (int)(ncand < m_out ? ncand : m_out);
+    for (int d = tid; d < D; d += 256) qs[d] = q[iq * D + d];
+    __syncthreads();
+    double pd = -1.0;
+    int64_t pi = -1;
+    for (int pass = 0; pass < k; ++pass) {
+        double bd = INFINITY;
+        int64_t bidx = INT64_MAX;
+        for (int64_t j = tid; j < ncand; j += 256) {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) {
+                double df = x[j * D + d] - qs[d];
+                s = fma(df, df, s);
+            }
+            if (pair_less(pd, pi, s, j) && pair_less(s, j, bd, bidx)) {
+                bd = s;
+                bidx = j;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            double od = __shfl_down(bd, off, 64);
+            int64_t oi = __shfl_down(bidx, off, 64);
+            if (pair_less(od, oi, bd, bidx)) {
+                bd = od;
+                bidx = oi;
+            }
+        }
+        if (lane == 0) {
+            rd[wave] = bd;
+            ri[wave] = bidx;
+        }
+        __syncthreads();
+        bd = rd[0];
+        bidx = ri[0];
+        for (int w = 1; w < 4; ++w)
+            if (pair_less(rd[w], ri[w], bd, bidx)) {
+                bd = rd[w];
+                bidx = ri[w];
+            }
+        pd = bd;
+        pi = bidx;
+        if (tid == 0) sel[pass] = bidx;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (ordered) {   // vecchia.py:108  np.fliplr(np.sort(NNarray)): index-descending, -1 padded
+            for (int a = 1; a < k; ++a) {
+                int64_t v = sel[a];
+                int b = a - 1;
+                while (b >= 0 && sel[b] < v) {
+                    sel[b + 1] = sel[b];
+                    --b;
+                }
+                sel[b + 1] = v;
+            }
+        }
+        for (int a = 0; a < m_out; ++a) out[iq * m_out + a] = a < k ? sel[a] : -1;
+    }
+}
+
+extern "C" int dgpamd_nn_ordered(dgpamd_ctx *ctx, int64_t n, int D, const double *x, int m, int64_t *NNarray) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || D <= 0 || !x || !NNarray || m < 0) BAD_ARG(ctx, "bad arguments");
+    if (m > n - 1) m = (int)(n - 1);
+    size_t shm = (D + 4) * sizeof(double) + (4 + (size_t)m + 1) * sizeof(int64_t);
+    hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, n, n, D, x, x, m + 1, 1, NNarray);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+__global__ void nn_cyclic_kernel(int64_t M, int m, int64_t *NN) {   // vecchia.py:23-26 (m == n shortcut)
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < M * m) NN[e] = ((e % m) + (e / m)) % m;
+}
+
+extern "C" int dgpamd_nn_query(dgpamd_ctx *ctx, int64_t M, int64_t n, int D, const double *q, const double *x, int m,
+                               int64_t *NN) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (M <= 0 || n <= 0 || D <= 0 || !q || !x || !NN || m <= 0) BAD_ARG(ctx, "bad arguments");
+    if (m >= n) {
+        m = (int)n;
+        hipLaunchKernelGGL(nn_cyclic_kernel, dim3((unsigned)((M * m + 255) / 256)), dim3(256), 0, ctx->stream, M, m, NN);
+    } else {
+        size_t shm = (D + 4) * sizeof(double) + (4 + (size_t)m) * sizeof(int64_t);
+        hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)M), dim3(256), shm, ctx->stream, M, n, D, q, x, m, 0, NN);
+    }
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a19-a21  per-row kernels on the ordered data
+// ---------------------------------------------------------------------------
+enum { V_LLIK = 0, V_NLLIK = 1, V_LMAT = 2 };
+
+struct VRowArgs {
+    VParams vp;
+    int64_t n;
+    int m;            // NNarray has m+1 columns
+    const double *X, *y, *nugget_diag;
+    const int64_t *NN;
+    int nugget_est, P;
+    double *partial;  // [n][2 + 2P] (LLIK: [n][2])
+    double *Lmat;     // [n][m+1]
+};
+
+// gather the row's conditioning block (ascending index, self last) into LDS; returns its size
+__device__ int gather_block(const int64_t *NNrow, int mp1, int *idx, int lane) {
+    int b = 0;
+    for (int a = 0; a < mp1; ++a) b += (NNrow[a] >= 0);
+    for (int a = lane; a < b; a += VW) idx[a] = (int)NNrow[b - 1 - a];   // idx[idx>=0][::-1]
+    return b;
+}
+
+template <int KIND, int MODE>
+__global__ __launch_bounds__(VW) void vecchia_row_kernel(VRowArgs a) {
+    extern __shared__ double lds[];
+    const int mp1 = a.m + 1, D = a.vp.D, lda = mp1 + 2;
+    double *A = lds;                         // [(mp1+1)][lda]  block + one right-hand-side row
+    double *xs = A + (mp1 + 1) * lda;        // [mp1][D] scaled inputs
+    double *V = xs + mp1 * D;                // [2][lda]  u = L^-T e_last, alpha = L^-T w
+    int *idx = reinterpret_cast<int *>(V + 2 * lda);
+    const int lane = threadIdx.x;
+    const int64_t i = blockIdx.x;
+    const int b = gather_block(a.NN + i * mp1, mp1, idx, lane);
+    __syncthreads();
+    for (int e = lane; e < b * D; e += VW) {
+        int r = e / D, d = e - r * D;
+        xs[e] = a.X[(int64_t)idx[r] * D + d] * a.vp.inv_len[d];
+    }
+    __syncthreads();
+    for (int e = lane; e < b * b; e += VW) {
+        int r = e / b, c = e - r * b;
+        if (c > r) continue;
+        double v;
+        if (r == c)
+            v = 1.0 + a.vp.nugget * (MODE == V_LMAT ? 1.0 : a.nugget_diag[idx[r]]);
+        else
+            v = corr_pts<KIND>(xs + r * D, xs + c * D, D);
+        A[r * lda + c] = v;
+    }
+    const int rows = (MODE == V_LMAT) ? b : b + 1;
+    if (MODE != V_LMAT)
+        for (int c = lane; c <= b; c += VW) A[b * lda + c] = c < b ? a.y[idx[c]] : 0.0;
+    lds_chol(A, lda, rows, b, lane);
+
+    if (MODE == V_LLIK) {
+        if (lane == 0) {
+            const double wl = A[b * lda + b - 1], ll = A[(b - 1) * lda + b - 1];
+            a.partial[i * 2] = wl * wl;                 // (L^-1 y)_last^2      vecchia.py:177
+            a.partial[i * 2 + 1] = 2.0 * log(fabs(ll)); // 2 log L_last,last   vecchia.py:178
+        }
+        return;
+    }
+    // u = L^-T e_last (and alpha = L^-T w for the gradient)
+    for (int c = lane; c < b; c += VW) {
+        V[c] = (c == b - 1) ? 1.0 : 0.0;
+        if (MODE == V_NLLIK) V[lda + c] = A[b * lda + c];
+    }
+    lds_backsolve_T(A, lda, b, V, lda, MODE == V_NLLIK ? 2 : 1, lane);
+    if (MODE == V_LMAT) {
+        for (int c = lane; c < mp1; c += VW) a.Lmat[i * mp1 + c] = c < b ? V[b - 1 - c] : 0.0;   // reversed, self first
+        return;
+    }
+    // vecchia.py:216-219 restated: t_last = u^T dK u ; s = alpha^T dK u
+    //   dquad_k = 2 s w_last - t_last w_last^2 ; dlogdet_k = t_last
+    const int P = a.P, npl = (a.vp.nlen == 1) ? 1 : D;
+    const double wl = A[b * lda + b - 1];
+    double *out = a.partial + i * (2 + 2 * P);
+    if (lane == 0) {
+        out[0] = wl * wl;
+        out[1] = 2.0 * log(fabs(A[(b - 1) * lda + b - 1]));
+    }
+    const double *u = V, *al = V + lda;
+    for (int k = 0; k < npl; ++k) {
+        double tl = 0.0, s = 0.0;
+        for (int e = lane; e < b * b; e += VW) {
+            int r = e / b, c = e - r * b;
+            if (c >= r) continue;
+            double kv = corr_pts<KIND>(xs + r * D, xs + c * D, D), cf = 0.0;
+            if (a.vp.nlen == 1)
+                for (int d = 0; d < D; ++d) cf += dcoef_v<KIND>(xs[r * D + d] - xs[c * D + d]);
+            else
+                cf = dcoef_v<KIND>(xs[r * D + k] - xs[c * D + k]);
+            const double dk = cf * kv;
+            tl = fma(2.0 * dk, u[r] * u[c], tl);
+            s = fma(dk, al[r] * u[c] + al[c] * u[r], s);
+        }
+        tl = wsum(tl);
+        s = wsum(s);
+        if (lane == 0) {
+            out[2 + k] = 2.0 * s * wl - tl * wl * wl;
+            out[2 + P + k] = tl;
+        }
+    }
+    if (a.nugget_est) {   // dK/dlog eta = diag(nugget * nugget_diag)   vecchia.py:329-332
+        double tl = 0.0, s = 0.0;
+        for (int r = lane; r < b; r += VW) {
+            const double dk = a.vp.nugget * a.nugget_diag[idx[r]];
+            tl = fma(dk, u[r] * u[r], tl);
+            s = fma(dk, al[r] * u[r], s);
+        }
+        tl = wsum(tl);
+        s = wsum(s);
+        if (lane == 0) {
+            out[2 + npl] = 2.0 * s * wl - tl * wl * wl;
+            out[2 + P + npl] = tl;
+        }
+    }
+}
+
+// deterministic column sums of partial[n][w] -> out[w]
+__global__ __launch_bounds__(256) void colsum_kernel(const double *partial, int64_t n, int w, double *out) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double v = 0.0;
+    for (int64_t r = tid; r < n; r += 256) v += partial[r * w + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) out[c] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+static size_t vrow_lds(int m, int D) {
+    const int mp1 = m + 1, lda = mp1 + 2;
+    return ((size_t)(mp1 + 1) * lda + (size_t)mp1 * D + 2 * lda) * sizeof(double) + (size_t)mp1 * sizeof(int);
+}
+
+template <int MODE>
+static int launch_vrow(dgpamd_ctx *ctx, VRowArgs &a) {
+    const size_t shm = vrow_lds(a.m, a.vp.D);
+    const void *fn = a.vp.kind == DGPAMD_SEXP ? (const void *)vecchia_row_kernel<DGPAMD_SEXP, MODE>
+                                              : (const void *)vecchia_row_kernel<DGPAMD_MATERN25, MODE>;
+    int rc = set_lds(ctx, fn, shm);
+    if (rc) return rc;
+    if (a.vp.kind == DGPAMD_SEXP)
+        hipLaunchKernelGGL((vecchia_row_kernel<DGPAMD_SEXP, MODE>), dim3((unsigned)a.n), dim3(VW), shm, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((vecchia_row_kernel<DGPAMD_MATERN25, MODE>), dim3((unsigned)a.n), dim3(VW), shm, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+// scratch for the per-row partials lives behind the public outputs: the caller passes device buffers sized
+// for the reduced result only, so the library keeps one growable scratch per context-less call via hipMallocAsync.
+static int with_partials(dgpamd_ctx *ctx, size_t bytes, double **p) {
+    HIP_TRY(ctx, hipMallocAsync((void **)p, bytes, ctx->stream));
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_vecchia_llik(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, const double *y,
+                                   const int64_t *NNarray, const double *length_h, int nlen, double nugget,
+                                   const double *nugget_diag, double *out_llik) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || m < 0 || !X || !y || !NNarray || !nugget_diag || !out_llik) BAD_ARG(ctx, "bad arguments");
+    VRowArgs a;
+    int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, nugget);
+    if (rc) return rc;
+    a.n = n; a.m = m; a.X = X; a.y = y; a.nugget_diag = nugget_diag; a.NN = NNarray; a.nugget_est = 0; a.P = 0;
+    a.Lmat = nullptr;
+    rc = with_partials(ctx, (size_t)n * 2 * sizeof(double), &a.partial);
+    if (rc) return rc;
+    rc = launch_vrow<V_LLIK>(ctx, a);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3(2), dim3(256), 0, ctx->stream, (const double *)a.partial, n, 2, out_llik);
+    HIP_TRY(ctx, hipFreeAsync(a.partial, ctx->stream));
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_vecchia_nllik(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X,
+                                    const double *y, const int64_t *NNarray, const double *length_h, int nlen,
+                                    double nugget, const double *nugget_diag, int nugget_est, double *out_nllik) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || m < 0 || !X || !y || !NNarray || !nugget_diag || !out_nllik) BAD_ARG(ctx, "bad arguments");
+    VRowArgs a;
+    int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, nugget);
+    if (rc) return rc;
+    a.n = n; a.m = m; a.X = X; a.y = y; a.nugget_diag = nugget_diag; a.NN = NNarray; a.nugget_est = nugget_est ? 1 : 0;
+    a.P = (nlen == 1 ? 1 : D) + a.nugget_est;
+    a.Lmat = nullptr;
+    const int w = 2 + 2 * a.P;
+    rc = with_partials(ctx, (size_t)n * w * sizeof(double), &a.partial);
+    if (rc) return rc;
+    rc = launch_vrow<V_NLLIK>(ctx, a);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3(w), dim3(256), 0, ctx->stream, (const double *)a.partial, n, w, out_nllik);
+    HIP_TRY(ctx, hipFreeAsync(a.partial, ctx->stream));
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_vecchia_lmatrix(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X,
+                                      const int64_t *NNarray, const double *length_h, int nlen, double nugget,
+                                      double *Lmat) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || m < 0 || !X || !NNarray || !Lmat) BAD_ARG(ctx, "bad arguments");
+    VRowArgs a;
+    int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, nugget);
+    if (rc) return rc;
+    a.n = n; a.m = m; a.X = X; a.y = nullptr; a.nugget_diag = nullptr; a.NN = NNarray; a.nugget_est = 0; a.P = 0;
+    a.partial = nullptr; a.Lmat = Lmat;
+    return launch_vrow<V_LMAT>(ctx, a);
+}
+
+// ---------------------------------------------------------------------------
+// forward_solve_sp (vecchia.py:111-120): x_i = (b_i - sum_j L[i,j] x[NN[i,j]]) / L[i,0], rows in order.
+// One persistent 1024-thread workgroup walks the rows in windows; inside a window every row whose
+// in-window dependencies are published computes in the same sweep (wavefront over the dependency DAG).
+// ---------------------------------------------------------------------------
+#define SPW 1024
+__global__ __launch_bounds__(SPW) void spsolve_kernel(int64_t n, int mp1, const double *L, const int64_t *NN,
+                                                      double lscale, const double *b, double *x) {
+    __shared__ double xs[SPW];
+    __shared__ int rdy[SPW];
+    const int tid = threadIdx.x;
+    for (int64_t base = 0; base < n; base += SPW) {
+        const int64_t i = base + tid;
+        const bool active = i < n;
+        rdy[tid] = 0;
+        double acc = 0.0;
+        int cnt = 0;
+        if (active) {
+            cnt = (int)(i + 1 < mp1 ? i + 1 : mp1);
+            for (int j = 1; j < cnt; ++j) {   // dependencies finished in earlier windows
+                const int64_t dep = NN[i * mp1 + j];
+                if (dep < base) acc = fma(L[i * mp1 + j] * lscale, ((const volatile double *)x)[dep], acc);
+            }
+        }
+        bool done = !active;
+        __syncthreads();
+        while (true) {
+            bool fire = false;
+            if (!done) {
+                fire = true;
+                for (int j = 1; j < cnt; ++j) {
+                    const int64_t dep = NN[i * mp1 + j];
+                    if (dep >= base && !rdy[dep - base]) {
+                        fire = false;
+                        break;
+                    }
+                }
+            }
+            double xi = 0.0;
+            if (fire) {
+                double s = acc;
+                for (int j = 1; j < cnt; ++j) {
+                    const int64_t dep = NN[i * mp1 + j];
+                    if (dep >= base) s = fma(L[i * mp1 + j] * lscale, xs[dep - base], s);
+                }
+                xi = (b[i] - s) / (L[i * mp1] * lscale);
+            }
+            __syncthreads();
+            if (fire) {
+                xs[tid] = xi;
+                rdy[tid] = 1;
+                x[i] = xi;
+                done = true;
+            }
+            if (__syncthreads_and(done)) break;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+extern "C" int dgpamd_vecchia_spsolve(dgpamd_ctx *ctx, int64_t n, int m, const double *Lmat, const int64_t *NNarray,
+                                      double inv_sqrt_scale, const double *b, double *x) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || m < 0 || !Lmat || !NNarray || !b || !x) BAD_ARG(ctx, "bad arguments");
+    hipLaunchKernelGGL(spsolve_kernel, dim3(1), dim3(SPW), 0, ctx->stream, n, m + 1, Lmat, NNarray, inv_sqrt_scale, b, x);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a22  gp_vecch (vecchia.py:635-654): block = [pm neighbours ; test point], rhs row y
+// ---------------------------------------------------------------------------
+struct VGpArgs {
+    VParams vp;
+    int64_t M, n;
+    int pm;
+    const double *x, *w, *y, *nugget_diag;
+    const int64_t *NN;
+    double scale;
+    double *mean, *var;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(VW) void vecchia_gp_kernel(VGpArgs a) {
+    extern __shared__ double lds[];
+    const int pm = a.pm, D = a.vp.D, lda = pm + 3;
+    double *A = lds;                       // [(pm+2)][lda]
+    double *xs = A + (pm + 2) * lda;       // [pm+1][D]
+    int *idx = reinterpret_cast<int *>(xs + (pm + 1) * D);
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    int b = 0;
+    for (int c = 0; c < pm; ++c) b += (a.NN[t * pm + c] >= 0);
+    for (int c = lane; c < b; c += VW) idx[c] = (int)a.NN[t * pm + c];
+    __syncthreads();
+    for (int e = lane; e < (b + 1) * D; e += VW) {
+        int r = e / D, d = e - r * D;
+        xs[e] = (r < b ? a.w[(int64_t)idx[r] * D + d] : a.x[t * D + d]) * a.vp.inv_len[d];
+    }
+    __syncthreads();
+    const int bb = b + 1;
+    for (int e = lane; e < bb * bb; e += VW) {
+        int r = e / bb, c = e - r * bb;
+        if (c > r) continue;
+        double v;
+        if (r == c)
+            v = 1.0 + a.vp.nugget * (r < b ? a.nugget_diag[idx[r]] : 1.0);
+        else
+            v = corr_pts<KIND>(xs + r * D, xs + c * D, D);
+        A[r * lda + c] = v;
+    }
+    for (int c = lane; c <= bb; c += VW) A[bb * lda + c] = c < b ? a.y[idx[c]] : 0.0;
+    lds_chol(A, lda, bb + 1, b, lane);
+    if (lane == 0) {
+        // after eliminating the b neighbour columns: Schur complement of the test point and -l21.w
+        a.mean[t] = -A[bb * lda + b];
+        a.var[t] = a.scale * A[b * lda + b];
+    }
+}
+
+extern "C" int dgpamd_vecchia_gp(dgpamd_ctx *ctx, int kind, int64_t M, int64_t n, int D, int pm, const double *x,
+                                 const double *w, const int64_t *NN, const double *y, double scale,
+                                 const double *length_h, int nlen, double nugget, const double *nugget_diag,
+                                 double *mean, double *var) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (M <= 0 || n <= 0 || pm <= 0 || !x || !w || !NN || !y || !nugget_diag || !mean || !var) BAD_ARG(ctx, "bad arguments");
+    VGpArgs a;
+    int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, nugget);
+    if (rc) return rc;
+    a.M = M; a.n = n; a.pm = pm; a.x = x; a.w = w; a.y = y; a.nugget_diag = nugget_diag; a.NN = NN; a.scale = scale;
+    a.mean = mean; a.var = var;
+    const size_t shm = ((size_t)(pm + 2) * (pm + 3) + (size_t)(pm + 1) * D) * sizeof(double) + (size_t)pm * sizeof(int);
+    const void *fn = kind == DGPAMD_SEXP ? (const void *)vecchia_gp_kernel<DGPAMD_SEXP> : (const void *)vecchia_gp_kernel<DGPAMD_MATERN25>;
+    rc = set_lds(ctx, fn, shm);
+    if (rc) return rc;
+    if (kind == DGPAMD_SEXP)
+        hipLaunchKernelGGL(vecchia_gp_kernel<DGPAMD_SEXP>, dim3((unsigned)M), dim3(VW), shm, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(vecchia_gp_kernel<DGPAMD_MATERN25>, dim3((unsigned)M), dim3(VW), shm, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a23  link_gp_vecch (vecchia.py:758-796) with IJ_nb (vecchia.py:838-907)
+// ---------------------------------------------------------------------------
+
+struct VLinkArgs {
+    int kind, Dw, Dz, pm;
+    int64_t M, n;
+    const double *m, *v, *z, *w1, *wg, *y, *nugget_diag;
+    const int64_t *NN;
+    double len[DGPAMD_MAXD];
+    double scale, nugget;
+    double *mean, *var;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(VW) void vecchia_linkgp_kernel(VLinkArgs a) {
+    extern __shared__ double lds[];
+    const int pm = a.pm, Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz, lda = pm + 2;
+    double *A = lds;                      // [(pm+1)][lda]   K block + rhs row y
+    double *J = A + (pm + 1) * lda;       // [pm][lda]       J, then L^-1 J, then L^-1 (L^-1 J)^T
+    double *xs = J + pm * lda;            // [pm][DT]        raw (unscaled) neighbour inputs
+    double *Iv = xs + pm * DT;            // [pm]
+    double *Ry = Iv + pm;                 // [lda]
+    int *idx = reinterpret_cast<int *>(Ry + lda);
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    int b = 0;
+    for (int c = 0; c < pm; ++c) b += (a.NN[t * pm + c] >= 0);
+    for (int c = lane; c < b; c += VW) idx[c] = (int)a.NN[t * pm + c];
+    __syncthreads();
+    for (int e = lane; e < b * DT; e += VW) {
+        int r = e / DT, d = e - r * DT;
+        xs[e] = d < Dw ? a.w1[(int64_t)idx[r] * Dw + d] : a.wg[(int64_t)idx[r] * Dz + d - Dw];
+    }
+    __syncthreads();
+    const double *mt = a.m + t * Dw, *vt = a.v + t * Dw;
+    const double *zt = Dz ? a.z + t * Dz : nullptr;
+    // I and the global-input factor
+    for (int r = lane; r < b; r += VW) {
+        double I, Iz = 1.0;
+        if (KIND == DGPAMD_SEXP) {
+            double e = 0.0, c1 = 1.0;
+            for (int k = 0; k < Dw; ++k) {
+                double l = a.len[k], d = xs[r * DT + k] - mt[k];
+                e += d * d / (2.0 * vt[k] + l * l);
+                c1 *= 1.0 + 2.0 * vt[k] / (l * l);
+            }
+            I = exp(-e) / sqrt(c1);
+            double s = 0.0;
+            for (int g = 0; g < Dz; ++g) {
+                double d = (xs[r * DT + Dw + g] - zt[g]) / a.len[Dw + g];
+                s = fma(d, d, s);
+            }
+            if (Dz) Iz = exp(-s);
+        } else {
+            I = 1.0;
+            for (int k = 0; k < Dw; ++k) I *= matern_I_dim(xs[r * DT + k], mt[k], vt[k], a.len[k]);
+            double pr = 1.0, s = 0.0;
+            for (int g = 0; g < Dz; ++g) corr_accum_matern((xs[r * DT + Dw + g] - zt[g]) / a.len[Dw + g], pr, s);
+            if (Dz) Iz = pr * exp(-SQRT5 * s);
+        }
+        Iv[r] = I * Iz;
+        Ry[r] = Iz;   // park the global factor
+    }
+    __syncthreads();
+    // K block (all DT columns) and J (local columns, times the global factors)
+    double jc1 = 1.0;
+    if (KIND == DGPAMD_SEXP) {
+        for (int k = 0; k < Dw; ++k) jc1 *= 1.0 + 4.0 * vt[k] / (a.len[k] * a.len[k]);
+        jc1 = 1.0 / sqrt(jc1);
+    }
+    for (int e = lane; e < b * b; e += VW) {
+        int r = e / b, c = e - r * b;
+        if (c > r) continue;
+        double s = 0.0, pr = 1.0;
+        for (int d = 0; d < DT; ++d) {
+            double df = (xs[r * DT + d] - xs[c * DT + d]) / a.len[d];
+            if (KIND == DGPAMD_SEXP)
+                corr_accum_sexp(df, s);
+            else
+                corr_accum_matern(df, pr, s);
+        }
+        double kv = (KIND == DGPAMD_SEXP) ? exp(-s) : pr * exp(-SQRT5 * s);
+        if (r == c) kv = 1.0 + a.nugget * a.nugget_diag[idx[r]];
+        A[r * lda + c] = kv;
+        double jv;
+        if (KIND == DGPAMD_SEXP) {
+            double ex = 0.0;
+            for (int k = 0; k < Dw; ++k) {
+                double l = a.len[k], ai = xs[r * DT + k] - mt[k], aj = xs[c * DT + k] - mt[k];
+                ex += (ai + aj) * (ai + aj) / (8.0 * vt[k] + 2.0 * l * l) + (ai - aj) * (ai - aj) / (2.0 * l * l);
+            }
+            jv = jc1 * exp(-ex);
+        } else {
+            jv = 1.0;
+            for (int k = 0; k < Dw; ++k) {
+                const double l = a.len[k], xi = xs[r * DT + k], xj = xs[c * DT + k];
+                if (vt[k] != 0.0)
+                    jv *= (r == c) ? matern_Jd0(xi, mt[k], vt[k], l) : matern_Jd(xj, xi, mt[k], vt[k], l);
+                else {
+                    double di = mt[k] - xi, dj = mt[k] - xj;
+                    double pi_ = (1.0 + SQRT5 * fabs(di) / l + 5.0 * di * di / (3.0 * l * l)) * exp(-SQRT5 * fabs(di) / l);
+                    double pj = (1.0 + SQRT5 * fabs(dj) / l + 5.0 * dj * dj / (3.0 * l * l)) * exp(-SQRT5 * fabs(dj) / l);
+                    jv *= pi_ * pj;
+                }
+            }
+        }
+        jv *= Ry[r] * Ry[c];
+        J[r * lda + c] = jv;
+        J[c * lda + r] = jv;
+    }
+    for (int c = lane; c <= b; c += VW) A[b * lda + c] = c < b ? a.y[idx[c]] : 0.0;
+    lds_chol(A, lda, b + 1, b, lane);
+    // Rinv_y = L^-T w
+    for (int c = lane; c < b; c += VW) Ry[c] = A[b * lda + c];
+    lds_backsolve_T(A, lda, b, Ry, lda, 1, lane);
+    // mean and Ry^T J Ry on the untouched J
+    double mu = 0.0, qd = 0.0;
+    for (int r = lane; r < b; r += VW) {
+        mu = fma(Iv[r], Ry[r], mu);
+        double s = 0.0;
+        for (int c = 0; c < b; ++c) s = fma(J[r * lda + c], Ry[c], s);
+        qd = fma(Ry[r], s, qd);
+    }
+    mu = wsum(mu);
+    qd = wsum(qd);
+    __syncthreads();
+    // tr(K^-1 J) = tr(L^-1 (L^-1 J)^T): two rounds of column-parallel forward substitutions
+    for (int c = lane; c < b; c += VW)
+        for (int r = 0; r < b; ++r) {
+            double s = J[r * lda + c];
+            for (int k = 0; k < r; ++k) s = fma(-A[r * lda + k], J[k * lda + c], s);
+            J[r * lda + c] = s / A[r * lda + r];
+        }
+    __syncthreads();
+    double tr = 0.0;
+    for (int c = lane; c < b; c += VW) {
+        // column c of G^T is row c of G; solve L h = G[c,:]^T and keep h_c
+        double hc = 0.0;
+        for (int r = 0; r <= c; ++r) {
+            double s = J[c * lda + r];
+            for (int k = 0; k < r; ++k) s = fma(-A[r * lda + k], J[c * lda + k], s);
+            s /= A[r * lda + r];
+            J[c * lda + r] = s;   // row c is private to this lane from here on
+            hc = s;
+        }
+        tr += hc;
+    }
+    tr = wsum(tr);
+    if (lane == 0) {
+        a.mean[t] = mu;
+        a.var[t] = fabs(qd - mu * mu + a.scale * (1.0 + a.nugget - tr));
+    }
+}
+
+extern "C" int dgpamd_vecchia_linkgp(dgpamd_ctx *ctx, int kind, int64_t M, int64_t n, int Dw, int Dz, int pm,
+                                     const double *m, const double *v, const double *z, const double *w1,
+                                     const double *wg, const int64_t *NN, const double *y, double scale,
+                                     const double *length_h, int nlen, double nugget, const double *nugget_diag,
+                                     double *mean, double *var) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (M <= 0 || n <= 0 || pm <= 0 || !m || !v || !w1 || !NN || !y || !nugget_diag || !mean || !var || !length_h)
+        BAD_ARG(ctx, "bad arguments");
+    if (kind != DGPAMD_SEXP && kind != DGPAMD_MATERN25) BAD_ARG(ctx, "kind must be 0 or 1");
+    if (Dw <= 0 || Dz < 0 || Dw + Dz > DGPAMD_MAXD || (nlen != 1 && nlen != Dw + Dz)) BAD_ARG(ctx, "bad dimensions");
+    if (Dz > 0 && (!z || !wg)) BAD_ARG(ctx, "Dz > 0 needs z and wg");
+    VLinkArgs a;
+    a.kind = kind; a.Dw = Dw; a.Dz = Dz; a.pm = pm; a.M = M; a.n = n; a.m = m; a.v = v; a.z = z; a.w1 = w1; a.wg = wg;
+    a.y = y; a.nugget_diag = nugget_diag; a.NN = NN; a.scale = scale; a.nugget = nugget; a.mean = mean; a.var = var;
+    for (int d = 0; d < Dw + Dz; ++d) a.len[d] = length_h[nlen == 1 ? 0 : d];
+    const int lda = pm + 2;
+    const size_t shm = ((size_t)(pm + 1) * lda + (size_t)pm * lda + (size_t)pm * (Dw + Dz) + pm + lda) * sizeof(double) +
+                       (size_t)pm * sizeof(int);
+    const void *fn = kind == DGPAMD_SEXP ? (const void *)vecchia_linkgp_kernel<DGPAMD_SEXP>
+                                         : (const void *)vecchia_linkgp_kernel<DGPAMD_MATERN25>;
+    int rc = set_lds(ctx, fn, shm);
+    if (rc) return rc;
+    if (kind == DGPAMD_SEXP)
+        hipLaunchKernelGGL(vecchia_linkgp_kernel<DGPAMD_SEXP>, dim3((unsigned)M), dim3(VW), shm, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(vecchia_linkgp_kernel<DGPAMD_MATERN25>, dim3((unsigned)M), dim3(VW), shm, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}

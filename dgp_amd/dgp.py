@@ -1,0 +1,263 @@
+"""Stochastic-EM trainer of a deep GP -- host driver mirroring dgpsi.dgp
+(dgp.py:71-129 construction, :154-691 wiring, :1364-1412 train, :1517-1541 estimate).
+
+The driver is plain Python like the reference's; what it drives is not: the I-step
+is the device-resident ESS imputer (dgp_amd.imputation) and the M-step optimises
+all GP nodes concurrently, one HIP stream per node, with scipy L-BFGS-B calling
+the device objective (kernel.llik).  Optimising nodes concurrently instead of one
+after another does not change any result: given the imputed latents every node's
+objective involves only its own hyper-parameters (dgp.py:1391-1398).
+"""
+import copy
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+from tqdm import trange, tqdm
+
+from .kernel_class import kernel as ker, combine
+from .imputation import imputer, DrawStream
+from .ops import Engine, default_engine
+from . import utils
+
+
+class dgp:
+    """Args as dgpsi.dgp (dgp.py:71): X (n x d), Y (n x q), all_layer, check_rep, block, vecchia, m, ord_fun;
+    plus `seed` (sampler streams) and `device`."""
+
+    def __init__(self, X, Y, all_layer=None, check_rep=True, block=True, vecchia=False, m=25, ord_fun=None, seed=None,
+                 device=None):
+        if isinstance(Y, list):
+            if len(Y) != 1:
+                raise Exception('Y has to be a numpy 2d-array rather than a list. The list version of Y (for linked '
+                                'emulation) has been reduced. Please use the dedicated lgp class for linked emulation.')
+            Y = Y[0]
+        if Y.ndim == 1 or X.ndim == 1:
+            raise Exception('The input and output data have to be numpy 2d-arrays.')
+        self.Y = Y
+        self.check_rep = check_rep
+        self.indices = None
+        self.counts = None
+        self.X = X
+        if check_rep:
+            X0, inv, counts = np.unique(X, return_inverse=True, return_counts=True, axis=0)
+            if len(X0) != len(X):
+                self.X, self.indices, self.counts = X0, np.asarray(inv).reshape(-1), counts
+        self.vecch = vecchia
+        self.n_data = self.X.shape[0]
+        self.nn_method = 'exact'
+        self.m = min(m, self.n_data - 1)
+        self.ord_fun = ord_fun
+        self.engine = default_engine(device)
+        if all_layer is None:
+            D, q = self.X.shape[1], self.Y.shape[1]
+            all_layer = combine([ker(length=np.array([1.])) for _ in range(D)],
+                                [ker(length=np.array([1.]), scale_est=True, connect=np.arange(D)) for _ in range(q)])
+        self.all_layer = all_layer
+        self.n_layer = len(all_layer)
+        for layer in all_layer:
+            for nd in layer:
+                if nd.type == 'likelihood' and nd.name in ('Categorical', 'Hetero', 'ZIP', 'ZINB', 'NegBin', 'Poisson'):
+                    raise NotImplementedError('likelihood-specific warm starts (dgp.py:163-564) are outside the '
+                                              'accelerated path; GP-only hierarchies are supported')
+        self.initialize()
+        self.block = block
+        self.draws = DrawStream(seed)
+        self.imp = imputer(self.all_layer, self.block, draws=self.draws, engine=self.engine)
+        self.imp.sample(burnin=10)
+        self.compute_r2()
+        self.N = 0
+        self.burnin = None
+        self._pool = None
+
+    # ------------------------------------------------------------------ wiring
+    def _warm_start(self, In, num_kernel):
+        """Latent initial values of a hidden layer (dgp.py:565-576)."""
+        d = In.shape[1]
+        if d == num_kernel:
+            return copy.copy(In)
+        if d > num_kernel:
+            if self.vecch or self.n_data >= 500:
+                return utils.NystromKPCA(n_components=num_kernel).fit_transform(In)
+            from sklearn.decomposition import KernelPCA
+            return KernelPCA(n_components=num_kernel, kernel='sigmoid').fit_transform(In)
+        return np.concatenate((In, In[:, np.random.choice(d, num_kernel - d)]), 1)
+
+    def initialize(self):
+        """Assign input / global_input / output / D / para_path to every node (dgp.py:154-691, GP nodes)."""
+        global_in = In = self.X
+        for l, layer in enumerate(self.all_layer):
+            last = l == self.n_layer - 1
+            Out = None if last else self._warm_start(In, len(layer))
+            for k, nd in enumerate(layer):
+                if last and self.indices is not None:
+                    nd.rep = self.indices
+                if nd.input_dim is None:
+                    nd.input_dim = np.arange(In.shape[1])
+                    nd.input = copy.copy(In)
+                else:
+                    nd.input = In[:, nd.input_dim]
+                if nd.type == 'gp':
+                    if nd.connect is not None:
+                        if l == 0 and len(np.intersect1d(nd.connect, nd.input_dim)) != 0:
+                            raise Exception('The local input and global input should not have any overlap. Change '
+                                            'input_dim or connect so they do not have any common indices.')
+                        nd.global_input = global_in[:, nd.connect]
+                    nd.vecch, nd.m, nd.nn_method = self.vecch, self.m, self.nn_method
+                    if self.ord_fun is not None:
+                        nd.ord_fun = self.ord_fun
+                    nd.D = nd.input.shape[1] + (0 if nd.connect is None else len(nd.connect))
+                    nd.engine = self.engine
+                if last:
+                    if nd.type == 'gp' and nd.rep is not None:
+                        G = nd.rep.max() + 1
+                        cnt = np.bincount(nd.rep, minlength=G)
+                        nd.W_diag = 1.0 / cnt
+                        nd.output = (np.bincount(nd.rep, weights=self.Y[:, k], minlength=G) * nd.W_diag).reshape(-1, 1)
+                        res = self.Y[:, [k]] - nd.output[nd.rep, :]
+                        nd.sum_residual = (res.T @ res).flatten()
+                    else:
+                        nd.output = self.Y[:, [k]].copy()
+                else:
+                    nd.output = Out[:, [k]].copy()
+                if nd.type == 'gp':
+                    if nd.prior_name == 'ref':
+                        p = nd.D
+                        nd.prior_coef = np.concatenate((nd.prior_coef, 1 / len(nd.output) ** (1 / p) * (nd.prior_coef + p)))
+                        nd.compute_cl()
+                    nd.para_path = np.atleast_2d(np.concatenate((nd.scale, nd.length, nd.nugget)))
+            if self.vecch:
+                self._layer_ord_nn(layer)
+            if not last:
+                In = copy.copy(Out)
+
+    def _layer_ord_nn(self, layer):
+        imputer([layer], engine=self.engine).update_ord_nn()
+
+    def to_vecchia(self, m=25, ord_fun=None):
+        if self.vecch:
+            raise Exception('The DGP structure is already in Vecchia mode.')
+        self.vecch, self.m, self.ord_fun = True, min(m, self.n_data - 1), ord_fun
+        for layer in self.all_layer:
+            for nd in layer:
+                if nd.type == 'gp':
+                    nd.vecch, nd.m, nd.ord_fun = True, self.m, ord_fun
+            self._layer_ord_nn(layer)
+
+    def remove_vecchia(self):
+        if not self.vecch:
+            raise Exception('The DGP structure is already in non-Vecchia mode.')
+        self.vecch = False
+        for layer in self.all_layer:
+            for nd in layer:
+                if nd.type == 'gp':
+                    nd.vecch = False
+
+    def compute_r2(self):
+        for layer in self.all_layer[1:]:
+            for nd in layer:
+                if nd.type == 'gp':
+                    nd.r2(overwritten=True)
+
+    # ------------------------------------------------------------------ training
+    def _streams(self, count):
+        """One engine (HIP stream + workspaces) per concurrently optimised node."""
+        want = max(1, min(count, utils.get_thread()))
+        if self._pool is None or len(self._pool[1]) != want:
+            dev = self.engine.device.index
+            engines = [Engine(dev, torch.cuda.Stream(self.engine.device)) for _ in range(want)]
+            self._pool = (ThreadPoolExecutor(max_workers=want), engines)
+        return self._pool
+
+    def _m_step(self):
+        nodes = [(l, nd) for l, layer in enumerate(self.all_layer) for nd in layer if nd.type == 'gp']
+        pool, engines = self._streams(len(nodes))
+        free = list(range(len(engines)))
+
+        def work(args):
+            l, nd = args
+            idx = free.pop()
+            eng = engines[idx]
+            try:
+                nd.engine = eng
+                with eng.stream():
+                    if nd.prior_name == 'ref':
+                        nd.compute_cl()
+                    if l != 0:
+                        nd.r2()
+                    nd.maximise()
+            finally:
+                nd.engine = self.engine
+                free.append(idx)
+        list(pool.map(work, nodes))
+
+    def train(self, N=500, ess_burn=10, disable=False):
+        """N iterations of stochastic EM (dgp.py:1364-1412) with the same restart policy on LinAlgError."""
+        N0, restarts, max_restarts = self.N, 0, 3
+        while True:
+            pgb = None
+            try:
+                pgb = trange(1, N + 1, disable=disable)
+                for i in pgb:
+                    self.imp.sample(burnin=ess_burn)
+                    it = self.N + i
+                    if self.vecch and (it & (it - 1)) == 0 and it > 1:   # NN refresh at iterations 2,4,8,.. (dgp.py:1388)
+                        self.imp.update_ord_nn()
+                    self._m_step()
+                    pgb.set_description('Iteration %i: Layer %i' % (i, self.n_layer))
+                self.N += N
+                return
+            except (np.linalg.LinAlgError, SystemError):
+                restarts += 1
+                if pgb is not None:
+                    pgb.close()
+                if restarts > max_restarts:
+                    raise RuntimeError(f"Training failed after {max_restarts} restarts.")
+                if not disable:
+                    tqdm.write(f"Restart {restarts}/{max_restarts}:")
+                self.N = N0
+                self.reinit_all_layer(reset_lengthscale=True, row=self.N)
+
+    ptrain = train   # nodes are already optimised concurrently (dgp.py:1414-1472 used a process pool)
+
+    def reinit_all_layer(self, reset_lengthscale, row=0):
+        """Fresh latent warm start, hyper-parameters back to para_path[row] (dgp.py:1097-1362, GP nodes)."""
+        In = self.X
+        for l, layer in enumerate(self.all_layer):
+            last = l == self.n_layer - 1
+            Out = None if last else self._warm_start(In, len(layer))
+            for k, nd in enumerate(layer):
+                nd.input = In[:, nd.input_dim]
+                if not last:
+                    nd.output = Out[:, [k]].copy()
+                if nd.type == 'gp':
+                    if reset_lengthscale:
+                        est = nd.para_path[row]
+                        nd.scale, nd.length, nd.nugget = np.atleast_1d(est[0]), np.atleast_1d(est[1:-1]), np.atleast_1d(est[-1])
+                        nd.para_path = nd.para_path[:row + 1]
+                    if nd.prior_name == 'ref':
+                        nd.compute_cl()
+            if not last:
+                In = copy.copy(Out)
+        self.imp.sample(burnin=10)
+        self.compute_r2()
+
+    def estimate(self, burnin=None):
+        """Point estimates = mean of para_path[burnin:], burnin default int(0.75 N) (dgp.py:1517-1541)."""
+        self.burnin = int(self.N * (3 / 4)) if burnin is None else burnin
+        final = copy.deepcopy(self.all_layer)
+        for layer in final:
+            for nd in layer:
+                if nd.type == 'gp':
+                    est = np.mean(nd.para_path[self.burnin:, :], axis=0)
+                    nd.scale, nd.length, nd.nugget = np.atleast_1d(est[0]), np.atleast_1d(est[1:-1]), np.atleast_1d(est[-1])
+        return final
+
+    def aggregate_r2(self, burnin=0.75, agg='median'):
+        if burnin < 0 or burnin > 1:
+            raise Exception('burnin must be between 0 and 1.')
+        f = {'mean': np.mean, 'median': np.median}.get(agg)
+        if f is None:
+            raise Exception("agg must be either 'median' or 'mean'.")
+        return [[None if (nd.type != 'gp' or nd.R2 is None) else f(nd.R2[int(len(nd.R2) * burnin):, :], axis=0)
+                 for nd in layer] for layer in self.all_layer]

@@ -1,0 +1,58 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on
+the GPU box, "gloo" in CPU tests).  The SI path shards embarrassingly over imputation
+samples; the only data-path collective is the sum of the two predictive-moment arrays
+(emulation.py:846-847 aggregated across ranks)."""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def is_active():
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+
+def rank():
+    return td.get_rank() if td.is_available() and td.is_initialized() else 0
+
+
+def world():
+    return td.get_world_size() if td.is_available() and td.is_initialized() else 1
+
+
+def share(total, r, w):
+    """Number of the `total` imputations (or other independent units) owned by rank r of w."""
+    return total // w + (1 if r < total % w else 0)
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
+    if td.is_initialized() or int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    td.init_process_group(backend=backend)
+
+
+def allreduce_sum(*tensors):
+    """In-place sum over ranks of each tensor (device tensors under nccl/RCCL, CPU tensors under gloo)."""
+    if not is_active():
+        return
+    for t in tensors:
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+
+
+def allreduce_max_scalar(value, device=None):
+    """max over ranks of a python float (bench.py: the slowest rank's time)."""
+    if not is_active():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else 'cpu')
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if is_active():
+        td.barrier()

@@ -1,0 +1,229 @@
+"""Prediction from a trained DGP by stochastic imputation -- mirror of dgpsi.emulator
+(emulation.py:24-44 construction, :631-854 predict(method='mean_var')).
+
+Construction draws the N imputations from one ESS chain after a burn-in
+(emulation.py:31-44).  Instead of deep-copying the whole structure with an n x n
+R^-1 (and D n x n Psexp) per node per imputation, the emulator keeps per
+imputation only the latent columns and builds device-resident statistics:
+  * first-layer nodes: inputs and hyper-parameters are identical in every
+    imputation, so R^-1 is factored ONCE and the N vectors R^-1 y_s ride along as
+    right-hand sides of that single factorisation; the predictive variance is
+    shared, only the mean differs;
+  * deeper nodes: one factorisation per imputation (their inputs differ).
+`predict` walks the layers on the device and accumulates the imputation moments
+mu = mean_s mu_s, var = mean_s(mu_s^2 + v_s) - mu^2 (emulation.py:846-847) in place.
+
+Multi-GPU: with torch.distributed initialised, each rank draws its share of the N
+imputations from its own chain (own burn-in) and one all-reduce(sum) of the two
+moment arrays precedes the finalisation (RCCL over xGMI on the GPU box).
+"""
+import copy
+
+import numpy as np
+import torch
+
+from .imputation import imputer, DrawStream
+from .ops import default_engine
+from . import dist as ddist
+
+
+class emulator:
+    """Args as dgpsi.emulator (emulation.py:24): all_layer (from dgp.estimate()), N, block;
+    plus `seed`, `device` and `shard` (None: shard iff torch.distributed is initialised)."""
+
+    def __init__(self, all_layer, N=10, block=True, seed=None, device=None, shard=None):
+        self.all_layer = all_layer
+        self.n_layer = len(all_layer)
+        self.vecch = bool(all_layer[0][0].vecch)
+        self.engine = default_engine(device)
+        for layer in all_layer:
+            for nd in layer:
+                if nd.type == 'gp':
+                    nd.engine = self.engine
+        self.N_total = int(N)
+        self.shard = ddist.is_active() if shard is None else bool(shard)
+        rank, world = (ddist.rank(), ddist.world()) if self.shard else (0, 1)
+        self.N = ddist.share(self.N_total, rank, world)
+        ss = np.random.SeedSequence(seed)
+        self.imp = imputer(all_layer, block, draws=DrawStream(ss.spawn(world)[rank]), engine=self.engine)
+        if self.vecch:
+            self.imp.update_ord_nn()
+            self.imp.sample(burnin=20)
+        else:
+            self.imp.sample(burnin=50)
+        # per imputation: the latent columns of every hidden layer (n x M_l), small
+        self.latents = []
+        self.orders = []
+        for _ in range(self.N):
+            if self.vecch:
+                self.imp.update_ord_nn()
+            self.imp.sample()
+            self.latents.append([np.stack([np.asarray(nd.output, float).reshape(-1) for nd in layer], 1)
+                                 for layer in all_layer[:-1]])
+            if self.vecch:
+                self.orders.append([[(nd.ord.copy(), nd.NNarray.copy()) if nd.type == 'gp' else None for nd in layer]
+                                    for layer in all_layer])
+        self._stats = None
+
+    # dgpsi keeps `all_layer_set`: N deep copies of the structure.  Built on demand (arrays only, no R^-1).
+    @property
+    def all_layer_set(self):
+        out = []
+        for s in range(self.N):
+            out.append(self._structure(s))
+        return out
+
+    def _structure(self, s):
+        al = copy.deepcopy(self.all_layer)
+        lat = self.latents[s]
+        for l, layer in enumerate(al):
+            for k, nd in enumerate(layer):
+                if l < self.n_layer - 1:
+                    nd.output = lat[l][:, [k]].copy()
+                if l > 0:
+                    nd.input = lat[l - 1][:, nd.input_dim].copy()
+        return al
+
+    # ------------------------------------------------------------------ statistics
+    def _build_stats(self):
+        """R^-1 (device, ld = Np) and R^-1 y for every GP node and imputation."""
+        e = self.engine
+        S = self.N
+        stats = {}
+        Yall = np.asarray([np.asarray(nd.output, float).reshape(-1) for nd in self.all_layer[-1]])
+        for l, layer in enumerate(self.all_layer):
+            for k, nd in enumerate(layer):
+                if nd.type != 'gp':
+                    continue
+                n = len(nd.output)
+                Np = e.padded_dim(n)
+                cap = Np - n
+                Xg = None if nd.global_input is None else e.tensor(nd.global_input)
+                W = None if nd.rep is None else e.tensor(nd.W_diag)
+
+                def ys(s):
+                    return self.latents[s][l][:, k] if l < self.n_layer - 1 else Yall[k]
+
+                def factor(Xl, Y):
+                    A = e.workspace(('emuA', n), Np * Np * 8)
+                    Ainv = e.empty(Np, Np)
+                    e.kmatrix(nd.name, Xl, None, Xg, nd.length, nd.nugget[0], W=W, out=A, full=False, Y=Y)
+                    work = e.potrf_workspace(n, 1)
+                    _, info = e.potrf(n, A, work=work)
+                    r = Y.shape[0]
+                    e.potri(n, A, Ainv, r, work)
+                    bad = int(info.cpu().numpy()[0])
+                    if bad:
+                        raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite' % bad)
+                    return Ainv, (-Ainv[n:n + r, :n]).contiguous()
+
+                if l == 0:
+                    Xl = e.tensor(nd.input)
+                    rys, Rinv = [], None
+                    for c0 in range(0, S, cap):   # all imputations' y as right-hand sides of ONE factorisation
+                        Y = e.tensor(np.stack([ys(s) for s in range(c0, min(S, c0 + cap))]))
+                        Rinv, ry = factor(Xl, Y)
+                        rys.append(ry)
+                    stats[(l, k)] = dict(shared=True, Rinv=Rinv, ld=Np, ry=torch.cat(rys), n=n, Wall=e.tensor(nd._X()))
+                else:
+                    per = []
+                    for s in range(S):
+                        Xin = self.latents[s][l - 1][:, nd.input_dim]
+                        Rinv, ry = factor(e.tensor(Xin), e.tensor(ys(s)[None, :]))
+                        per.append(dict(Rinv=Rinv, ry=ry[0].contiguous(), W=e.tensor(Xin)))
+                    stats[(l, k)] = dict(shared=False, per=per, ld=Np, n=n, Wg=Xg)
+        self._stats = stats
+
+    # ------------------------------------------------------------------ prediction
+    def predict(self, x, method='mean_var', full_layer=False, sample_size=50, m=50, aggregation=True):
+        """Mean and variance at the rows of x (emulation.py:631-854, method='mean_var').
+        Returns (mu, sigma2) as numpy arrays (M x D_out), or per-layer lists if full_layer, or the
+        per-imputation lists if aggregation=False."""
+        if x.ndim == 1:
+            raise Exception('The testing input has to be a numpy 2d-array')
+        if method != 'mean_var':
+            raise NotImplementedError("method='sampling' (emulation.py:780-822) is outside the accelerated path")
+        if self.vecch:
+            return self._predict_vecchia(x, full_layer, m, aggregation)
+        if self._stats is None:
+            self._build_stats()
+        e = self.engine
+        M, S = len(x), self.N
+        xd = e.tensor(x)
+        per_layer = []   # per layer: (mean (S,M,K), var (S,M,K)) device tensors
+        for l, layer in enumerate(self.all_layer):
+            K = len(layer)
+            mean = e.empty(S, M, K)
+            var = e.empty(S, M, K)
+            for k, nd in enumerate(layer):
+                if nd.type != 'gp':
+                    raise NotImplementedError('likelihood-node prediction is outside the accelerated path')
+                st = self._stats[(l, k)]
+                z = None if nd.connect is None else xd[:, torch.as_tensor(nd.connect, device=xd.device)].contiguous()
+                if l == 0:
+                    xin = xd[:, torch.as_tensor(nd.input_dim, device=xd.device)]
+                    xin = (xin if z is None else torch.cat((xin, z), 1)).contiguous()
+                    mk, vk = e.gp_predict(nd.name, xin, st['Wall'], nd.length, st['Rinv'], st['ld'], st['ry'], nd.scale[0],
+                                          nd.nugget[0])
+                    mean[:, :, k] = mk
+                    var[:, :, k] = vk[None, :]
+                else:
+                    pm, pv = per_layer[-1]
+                    idx = torch.as_tensor(nd.input_dim, device=xd.device)
+                    for s in range(S):
+                        ps = st['per'][s]
+                        mk, vk = e.linkgp_predict(nd.name, pm[s][:, idx].contiguous(), pv[s][:, idx].contiguous(), z, ps['W'],
+                                                  st['Wg'], nd.length, ps['Rinv'], st['ld'], ps['ry'], nd.scale[0],
+                                                  nd.nugget[0])
+                        mean[s, :, k] = mk
+                        var[s, :, k] = vk
+            per_layer.append((mean, var))
+        if not aggregation and not full_layer:
+            mu_s, v_s = per_layer[-1]
+            return [t.cpu().numpy() for t in mu_s], [t.cpu().numpy() for t in v_s]
+        outs = []
+        for mean, var in (per_layer if full_layer else per_layer[-1:]):
+            s1, s2 = e.zeros(M, mean.shape[2]), e.zeros(M, mean.shape[2])
+            for s in range(S):
+                e.moments_accumulate(mean[s].contiguous(), var[s].contiguous(), s1, s2)
+            if self.shard:
+                ddist.allreduce_sum(s1, s2)
+            e.moments_finalize(self.N_total if self.shard else S, s1, s2)
+            outs.append((s1.cpu().numpy(), s2.cpu().numpy()))
+        if full_layer:
+            return [o[0] for o in outs], [o[1] for o in outs]
+        return outs[0]
+
+    def _predict_vecchia(self, x, full_layer, m, aggregation):
+        """Vecchia mode: no stored statistics; every node conditions on its pred_m nearest neighbours
+        (kernel_class.py:603-619,647-664) with the imputation's own latents."""
+        M, S = len(x), self.N
+        mus, vs = [], []
+        for s in range(S):
+            al = self._structure(s)
+            m_in = v_in = None
+            for l, layer in enumerate(al):
+                mo, vo = np.empty((M, len(layer))), np.empty((M, len(layer)))
+                for k, nd in enumerate(layer):
+                    nd.engine = self.engine
+                    nd.pred_m = m
+                    z = None if nd.connect is None else x[:, nd.connect]
+                    if l == 0:
+                        mo[:, k], vo[:, k] = nd.gp_prediction(x[:, nd.input_dim], z)
+                    else:
+                        mo[:, k], vo[:, k] = nd.linkgp_prediction(m_in[:, nd.input_dim], v_in[:, nd.input_dim], z)
+                m_in, v_in = mo, vo
+            mus.append(m_in)
+            vs.append(v_in)
+        if not aggregation:
+            return mus, vs
+        e = self.engine
+        s1, s2 = e.zeros(*mus[0].shape), e.zeros(*mus[0].shape)
+        for a, b in zip(mus, vs):
+            e.moments_accumulate(e.tensor(a), e.tensor(b), s1, s2)
+        if self.shard:
+            ddist.allreduce_sum(s1, s2)
+        e.moments_finalize(self.N_total if self.shard else S, s1, s2)
+        return s1.cpu().numpy(), s2.cpu().numpy()
+
+    ppredict = predict   # test points / imputations already run in parallel on the device (emulation.py:578-629)

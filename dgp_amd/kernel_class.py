@@ -1,0 +1,467 @@
+"""GP node of the DGP hierarchy -- host mirror of dgpsi's `kernel` plugin surface.
+
+Same constructor, attributes and method names as the reference class
+(kernel_class.py:9-764) so that imputers / trainers / emulators written against
+dgpsi find what they expect; every numerical method is a thin call into the HIP
+library through dgp_amd.ops.Engine.  Nothing here computes a kernel matrix, a
+factorisation or a prediction on the CPU.
+
+Differences that do not change results: `llik` obtains
+tr(K^-1 dK_p) and y^T K^-1 dK_p K^-1 y from one inverse and fused in-flight
+reductions instead of one n x n solve per parameter; `compute_stats` keeps
+R^-1 / R^-1 y on the device and never materialises Psexp.
+"""
+import numpy as np
+from numpy.linalg import LinAlgError
+from scipy.optimize import minimize, Bounds
+
+from .ops import default_engine
+
+_KINDS = ('sexp', 'matern2.5')
+
+
+def combine(*layers):
+    """Stack layers (lists of nodes) into a DGP structure (kernel_class.py:766-780)."""
+    return [layer for layer in layers]
+
+
+class kernel:
+    """A GP node.  Arguments as dgpsi.kernel (kernel_class.py:86); `engine` selects the
+    device context (default: the process-wide engine of LOCAL_RANK)."""
+
+    def __init__(self, length, scale=1., nugget=1e-6, name='sexp', prior_name='ga', prior_coef=None, bds=None,
+                 nugget_est=False, scale_est=False, input_dim=None, connect=None, engine=None):
+        if name not in _KINDS:
+            raise Exception("name must be 'sexp' or 'matern2.5'.")
+        self.type = 'gp'
+        self.length = np.atleast_1d(np.asarray(length, dtype=float))
+        self.scale = np.atleast_1d(np.asarray(scale, dtype=float))
+        self.nugget = np.atleast_1d(np.asarray(nugget, dtype=float))
+        self.name = name
+        self.prior_name = prior_name
+        # stored coefficients: ga -> (shape-1, rate); inv_ga -> (shape+1, scale); ref -> (a[, b])
+        # (kernel_class.py:93-110; like the reference, a caller-supplied array is adjusted in place)
+        if prior_name in ('ga', 'inv_ga'):
+            self.prior_coef = np.array([1.6, 0.3]) if prior_coef is None else prior_coef
+            self.prior_coef[0] += -1 if prior_name == 'ga' else 1
+        elif prior_name == 'ref':
+            self.prior_coef = np.array([0.2]) if prior_coef is None else prior_coef
+            self.cl = None
+        self.nugget_est, self.scale_est = nugget_est, scale_est
+        self.input_dim, self.connect, self.bds = input_dim, connect, bds
+        self.para_path = None
+        self.global_input = self.input = self.output = None
+        self.rep = self.rep_hetero = self.W_diag = self.sum_residual = None
+        self.vecch = None
+        self.D = None
+        self.ord = self.rev_ord = self.NNarray = None
+        self.m = self.pred_m = self.max_rep = None
+        self.imp_NNarray = self.imp_pointer_row = self.imp_pointer_col = None
+        self.nn_method, self.ord_fun = 'exact', None
+        self.iter_count = 0
+        self.target = 'dgp'
+        self.R2 = None
+        self.loo_state = False
+        self._engine = engine
+        self._stats = None       # device-side prediction statistics (compute_stats)
+        self._staged = None
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = default_engine()
+        return self._engine
+
+    @engine.setter
+    def engine(self, e):
+        self._engine = e
+        self._staged = None
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st['_engine'] = None
+        st['_staged'] = None
+        st['_stats'] = None
+        return st
+
+    def _X(self):
+        return self.input if self.global_input is None else np.concatenate((self.input, self.global_input), 1)
+
+    def _stage(self):
+        """Upload the node's current numpy state (inputs, output, replicate weights)."""
+        e = self.engine
+        s = dict(Xl=e.tensor(self.input), Xg=None if self.global_input is None else e.tensor(self.global_input),
+                 y=e.tensor(np.asarray(self.output, dtype=float).reshape(-1)),
+                 W=None if self.rep is None else e.tensor(self.W_diag))
+        self._staged = s
+        return s
+
+    def _raise_if_not_pd(self, info):
+        bad = int(info)
+        if bad != 0:
+            raise LinAlgError('%d-th leading minor of the array is not positive definite' % bad)
+
+    # ---------------------------------------------------------------- parameters
+    def log_t(self):
+        """log(lengthscales[, nugget]) -- the optimiser's variables (kernel_class.py:279-289)."""
+        theta = np.concatenate((self.length, self.nugget)) if self.nugget_est else self.length
+        return np.log(theta)
+
+    def update(self, log_theta):
+        theta = np.exp(log_theta)
+        if self.nugget_est:
+            self.length, self.nugget = theta[:-1], theta[[-1]]
+        else:
+            self.length = theta
+
+    def compute_cl(self):
+        """Scaling constant of the reference prior (kernel_class.py:207-225)."""
+        n_out = len(self.output)
+        if len(self.length) == 1:
+            X = self._X()
+            if self.vecch:
+                rg = X.max(0) - X.min(0)
+                self.cl = np.sqrt(rg @ rg) / n_out
+            else:
+                from scipy.spatial.distance import pdist
+                self.cl = np.max(pdist(X, metric='euclidean')) / n_out
+        else:
+            X = self._X()
+            self.cl = (X.max(0) - X.min(0)) / n_out ** (1 / len(self.length))
+
+    def r2(self, overwritten=False):
+        """R2 of the linear regression of `input` on `global_input` (kernel_class.py:227-243)."""
+        if self.global_input is None:
+            return
+        G = self.global_input
+        Xd = np.concatenate((G, np.ones((len(G), 1))), axis=1)
+        if np.linalg.matrix_rank(G) == np.linalg.matrix_rank(Xd):
+            Xd = G
+        if Xd.shape[0] == Xd.shape[1]:
+            resid = np.zeros(self.input.shape[1])
+        else:
+            resid = np.linalg.lstsq(Xd, self.input, rcond=None)[1]
+        rsq = 1 - resid / (len(self.input) * np.var(self.input, axis=0))
+        self.R2 = np.atleast_2d(rsq) if overwritten else np.vstack((self.R2, rsq))
+
+    def log_prior(self):
+        """kernel_class.py:367-381."""
+        c = self.prior_coef
+        if self.prior_name == 'ref':
+            t = np.sum(self.cl / self.length) + self.nugget
+            return c[0] * np.log(t) - c[1] * t
+        xs = np.concatenate((self.length, self.nugget)) if self.nugget_est else self.length
+        if self.prior_name == 'ga':
+            return np.sum(c[0] * np.log(xs) - c[1] * xs)
+        return np.sum(-c[0] * np.log(xs) - c[1] / xs)
+
+    def log_prior_fod(self):
+        """d log prior / d log(parameters) (kernel_class.py:383-401)."""
+        c = self.prior_coef
+        if self.prior_name == 'ref':
+            t = np.sum(self.cl / self.length) + self.nugget
+            fod = (c[1] - c[0] / t) * self.cl / self.length
+            if self.nugget_est:
+                fod = np.concatenate((np.atleast_1d(fod), (c[0] / t - c[1]) * self.nugget))
+            return np.atleast_1d(fod)
+        xs = np.concatenate((self.length, self.nugget)) if self.nugget_est else self.length
+        return c[0] - c[1] * xs if self.prior_name == 'ga' else -c[0] + c[1] / xs
+
+    # ------------------------------------------------------------- kernel matrix
+    def k_matrix(self, fod_eval=False):
+        """Correlation matrix (and, if asked, its log-parameter derivatives) as numpy arrays
+        (kernel_class.py:304-359).  The training loop never calls this; it exists for API parity."""
+        e, s = self.engine, self._stage()
+        K = e.kmatrix(self.name, s['Xl'], None, s['Xg'], self.length, self.nugget[0], W=s['W'])
+        K = K.cpu().numpy()
+        if not fod_eval:
+            return K
+        # derivative stack for callers that want it materialised: dK_p = c_p o K, elementwise from K itself
+        X = self._X() / self.length
+        n, D = X.shape
+        P = 1 if len(self.length) == 1 else D
+        fod = np.zeros((P, n, n))
+        Koff = K.copy()
+        np.fill_diagonal(Koff, 0.0)
+        for d in range(D):
+            r = np.abs(X[:, d][:, None] - X[:, d][None, :])
+            if self.name == 'sexp':
+                c = 2 * r * r
+            else:
+                e1, e2 = 1 + np.sqrt(5) * r, (5 / 3) * r * r
+                c = e2 * e1 / (e1 + e2)
+            fod[0 if P == 1 else d] += c * Koff
+        if self.nugget_est:
+            w = np.ones(n) if self.rep is None else self.W_diag
+            fod = np.concatenate((fod, np.diag(self.nugget[0] * w)[None]), axis=0)
+        return K, fod
+
+    # ------------------------------------------------------------ log-likelihoods
+    def log_likelihood_func(self):
+        """ESS target (kernel_class.py:481-492)."""
+        e, s = self.engine, self._stage()
+        ll, info = e.loglik(self.name, s['Xl'], None, s['Xg'], self.length, self.nugget[0], self.scale[0], s['y'], W=s['W'])
+        ll, info = ll.cpu().numpy(), info.cpu().numpy()
+        self._raise_if_not_pd(info[0])
+        out = ll[0]
+        if self.prior_name == 'ref':
+            self.compute_cl()
+            out = out + self.log_prior()
+        return np.atleast_2d(out) if np.ndim(out) == 0 else out
+
+    def llik(self, x):
+        """Negative log-likelihood and gradient wrt log-parameters (kernel_class.py:403-449)."""
+        self.update(x)
+        e = self.engine
+        s = self._staged if getattr(self, '_in_maximise', False) and self._staged is not None else self._stage()
+        n = len(self.output)
+        Np = e.padded_dim(n)
+        A = e.workspace(('llikA', n), Np * Np * 8)
+        Ainv = e.workspace(('llikAinv', n), Np * Np * 8)
+        e.kmatrix(self.name, s['Xl'], None, s['Xg'], self.length, self.nugget[0], W=s['W'], out=A, full=False, Y=s['y'])
+        work = e.potrf_workspace(n, 1)
+        logdet, info = e.potrf(n, A, work=work)
+        quad = e.aug_quad(n, A, 1, 1)
+        e.potri(n, A, Ainv, 1, work)
+        red, P = e.grad_reduce(self.name, s['Xl'], None, s['Xg'], self.length, self.nugget[0], self.nugget_est, Ainv, W=s['W'])
+        import torch
+        host = torch.cat((logdet, quad.reshape(-1), red, info.to(torch.float64))).cpu().numpy()
+        self._raise_if_not_pd(host[-1])
+        logdet, YKinvY, tr, ykky = host[0], host[1], host[2:2 + P], host[2 + P:2 + 2 * P]
+        P1, P2 = -0.5 * tr, 0.5 * ykky
+        rep = self.rep is not None
+        if self.scale_est:
+            if not rep:
+                self.scale = np.atleast_1d(YKinvY / n)
+                nll = 0.5 * (logdet + n * np.log(self.scale))
+            else:
+                self.scale = np.atleast_1d((YKinvY + self.sum_residual / self.nugget) / len(self.rep)).flatten()
+                nll = 0.5 * (logdet + len(self.rep) * np.log(self.scale))
+            g = -P1 - P2 / self.scale
+            if rep and self.nugget_est:
+                nll = nll + 0.5 * (len(self.rep) - n) * np.log(self.nugget)
+                g[-1] += (0.5 * (-self.sum_residual / (self.scale * self.nugget) + (len(self.rep) - n)))[0]
+        else:
+            nll = 0.5 * (logdet + YKinvY / self.scale)
+            g = -P1 - P2 / self.scale
+            if rep and self.nugget_est:
+                nll = nll + 0.5 * (self.sum_residual / (self.scale * self.nugget) + (len(self.rep) - n) * np.log(self.nugget))
+                g[-1] += (0.5 * (-self.sum_residual / (self.scale * self.nugget) + (len(self.rep) - n)))[0]
+        nll = np.atleast_1d(nll).flatten()
+        if self.prior_name is not None:
+            nll = nll - self.log_prior()
+            g = g - self.log_prior_fod()
+        return nll, g
+
+    # ---------------------------------------------------------------- Vecchia twins
+    def ord_nn(self, ord=None, NNarray=None, pointer=False):
+        """Ordering and ordered nearest neighbours (kernel_class.py:245-277); NN search on device."""
+        if ord is None:
+            if self.ord_fun is None:
+                self.ord = np.random.permutation(self.input.shape[0])
+            else:
+                self.ord = self.ord_fun(self._X() / self.length)
+        else:
+            self.ord = ord
+        self.rev_ord = np.argsort(self.ord)
+        if NNarray is None:
+            e = self.engine
+            Xs = (self._X() / self.length)[self.ord]
+            self.NNarray = e.nn_ordered(e.tensor(Xs), self.m).cpu().numpy()
+        else:
+            self.NNarray = NNarray
+        if pointer:
+            raise NotImplementedError('Hetero exact-posterior pointers (imp_pointers) are outside the accelerated path')
+
+    def _vecch_stage(self):
+        e = self.engine
+        import torch
+        X = self._X()[self.ord]
+        nd = np.ones(len(self.output)) if self.rep is None else self.W_diag
+        return dict(X=e.tensor(X), y=e.tensor(np.asarray(self.output, float).reshape(-1)[self.ord]),
+                    NN=e.tensor(self.NNarray, dtype=torch.int64), nd=e.tensor(nd))
+
+    def log_likelihood_func_vecch(self):
+        """kernel_class.py:494-509 -> vecchia_llik (vecchia.py:164-180)."""
+        e, s = self.engine, self._vecch_stage()
+        out = e.vecchia_llik(self.name, s['X'], s['y'], s['NN'], self.length, self.nugget[0], s['nd']).cpu().numpy()
+        ll = -0.5 * (out[1] + out[0] / self.scale[0])
+        if self.prior_name == 'ref':
+            self.compute_cl()
+            ll = ll + self.log_prior()
+        return np.atleast_1d(ll)
+
+    def llik_vecch(self, x):
+        """kernel_class.py:451-479 -> vecchia_nllik (vecchia.py:182-242); the closing scale_est /
+        replicate algebra (vecchia.py:224-241) runs here on the reduced sums."""
+        self.update(x)
+        e, s = self.engine, self._vecch_stage()
+        n = len(self.output)
+        if self.rep is None:
+            origin_n, rr = n, -1.0
+        else:
+            origin_n, rr = len(self.rep), float(self.sum_residual[0])
+            s['nd'] = e.tensor(self.W_diag[self.ord])
+        o, P = e.vecchia_nllik(self.name, s['X'], s['y'], s['NN'], self.length, self.nugget[0], s['nd'], self.nugget_est)
+        o = o.cpu().numpy()
+        quad, logdet, dquad, dlogdet = o[0], o[1], o[2:2 + P].copy(), o[2 + P:].copy()
+        nug = self.nugget[0]
+        if self.scale_est:
+            if n == origin_n:
+                scale = quad / n
+                nll = 0.5 * (logdet + n * np.log(scale))
+                g = 0.5 * (dlogdet - dquad / scale)
+            else:
+                scale = (quad + rr / nug) / origin_n
+                nll = 0.5 * (logdet + origin_n * np.log(scale))
+                g = 0.5 * (dlogdet - dquad / scale)
+                if self.nugget_est:
+                    nll += 0.5 * (origin_n - n) * np.log(nug)
+                    g[-1] += 0.5 * (-rr / (scale * nug) + (origin_n - n))
+        else:
+            scale = self.scale[0]
+            nll = 0.5 * (logdet + quad / scale)
+            g = 0.5 * (dlogdet - dquad / scale)
+            if n != origin_n and self.nugget_est:
+                nll += 0.5 * (rr / (nug * scale) + (origin_n - n) * np.log(nug))
+                g[-1] += 0.5 * (-rr / (scale * nug) + (origin_n - n))
+        self.scale = np.atleast_1d(scale)
+        nll = np.atleast_1d(nll)
+        if self.prior_name is not None:
+            nll = nll - self.log_prior()
+            g = g - self.log_prior_fod()
+        return nll, g
+
+    def callback(self, xk):
+        self.iter_count += 1
+        if self.iter_count & (self.iter_count - 1) == 0:
+            self.ord_nn()
+
+    # --------------------------------------------------------------------- M-step
+    def maximise(self, method='L-BFGS-B'):
+        """One M-step of the node: scipy L-BFGS-B over log-parameters driving the device objective
+        (kernel_class.py:516-579; same bounds, maxiter and maxfun)."""
+        x0 = self.log_t()
+        p = len(x0)
+        nl = p - 1 if self.nugget_est else p
+        lb, ub = np.full(p, -np.inf), np.full(p, np.inf)
+        bounded = False
+        if self.bds is not None:
+            with np.errstate(divide='ignore'):
+                lb[:nl], ub[:nl] = np.log(self.bds[0]), np.log(self.bds[1])
+            bounded = True
+        elif self.prior_name == 'ref':
+            ub[:nl] = 13.
+            bounded = True
+        if self.nugget_est:
+            lb[-1] = np.log(1e-8)
+            bounded = True
+        opts = {'maxiter': 100, 'maxfun': int(max(30, 20 + 5 * self.D))}
+        kw = dict(method=method, jac=True)
+        if bounded:
+            kw['bounds'] = Bounds(lb, ub)
+        fun = self.llik
+        if self.vecch:
+            fun = self.llik_vecch
+            if self.target == 'gp' and len(self.length) != 1:
+                opts = {'maxfun': int(max(50, 20 + 5 * self.D))}
+                kw['callback'] = self.callback
+        self._stage()
+        self._in_maximise = True
+        try:
+            minimize(fun, x0, options=opts, **kw)
+        finally:
+            self._in_maximise = False
+            self.iter_count = 0
+        self.add_to_path()
+
+    def add_to_path(self):
+        self.para_path = np.vstack((self.para_path, np.concatenate((self.scale, self.length, self.nugget))))
+
+    # ----------------------------------------------------------------- prediction
+    def compute_stats(self):
+        """R^-1 and R^-1 y for prediction (kernel_class.py:735-764), device resident.
+        The reference's pinvh fallback for a non-PD R is not reproduced: LinAlgError is raised."""
+        e, s = self.engine, self._stage()
+        n = len(self.output)
+        Np = e.padded_dim(n)
+        A = e.workspace(('llikA', n), Np * Np * 8)
+        Ainv = e.empty(Np, Np)
+        e.kmatrix(self.name, s['Xl'], None, s['Xg'], self.length, self.nugget[0], W=s['W'], out=A, full=False, Y=s['y'])
+        work = e.potrf_workspace(n, 1)
+        _, info = e.potrf(n, A, work=work)
+        e.potri(n, A, Ainv, 1, work)
+        self._raise_if_not_pd(info.cpu().numpy()[0])
+        ry = (-Ainv[n, :n]).contiguous()
+        self._stats = dict(Rinv=Ainv, ld=Np, ry=ry, W=e.tensor(self.input),
+                           Wg=None if self.global_input is None else e.tensor(self.global_input),
+                           Wall=e.tensor(self._X()), n=n)
+
+    @property
+    def Rinv(self):
+        return None if self._stats is None else self._stats['Rinv'][:self._stats['n'], :self._stats['n']].cpu().numpy()
+
+    @property
+    def Rinv_y(self):
+        return None if self._stats is None else self._stats['ry'].cpu().numpy()
+
+    @property
+    def R2sexp(self):
+        """exp(-sqdist/2) on the scaled local inputs (kernel_class.py:752-763); built on demand, never used internally."""
+        if self.name != 'sexp' or self.input is None:
+            return None
+        e = self.engine
+        ll = self.length if len(self.length) == 1 else self.length[:self.input.shape[1]]
+        K = e.kmatrix('sexp', e.tensor(self.input), None, None, ll * np.sqrt(2.0), 0.0).cpu().numpy()
+        np.fill_diagonal(K, 1.0)
+        return K
+
+    @property
+    def Psexp(self):
+        if self.name != 'sexp' or self.input is None:
+            return None
+        ll = self.length if len(self.length) == 1 else self.length[:self.input.shape[1]]
+        Xl = self.input / ll
+        return np.stack([Xl[:, d][:, None] + Xl[:, d][None, :] for d in range(Xl.shape[1])])
+
+    def _pred_nn(self, x, w):
+        e = self.engine
+        NN = e.nn_query(e.tensor(x / self.length), e.tensor(w / self.length), self.pred_m)
+        if self.loo_state:
+            NN = NN[:, 1:].contiguous()
+        return NN
+
+    def gp_prediction(self, x, z):
+        """Mean/variance at deterministic inputs (kernel_class.py:587-625)."""
+        e = self.engine
+        xa = x if z is None else np.concatenate((x, z), 1)
+        if self.vecch:
+            w = self._X()
+            nd = np.ones(len(self.output)) if self.rep is None else self.W_diag
+            m, v = e.vecchia_gp(self.name, e.tensor(xa), e.tensor(w), self._pred_nn(xa, w),
+                                e.tensor(np.asarray(self.output, float).reshape(-1)), self.scale[0], self.length,
+                                self.nugget[0], e.tensor(nd))
+        else:
+            st = self._stats
+            m, v = e.gp_predict(self.name, e.tensor(xa), st['Wall'], self.length, st['Rinv'], st['ld'], st['ry'],
+                                self.scale[0], self.nugget[0])
+        return m.cpu().numpy(), v.cpu().numpy()
+
+    def linkgp_prediction(self, m, v, z):
+        """Mean/variance at Gaussian-distributed inputs (kernel_class.py:627-670)."""
+        e = self.engine
+        zt = None if z is None else e.tensor(z)
+        if self.vecch:
+            x = m if z is None else np.concatenate((m, z), 1)
+            w = self._X()
+            nd = np.ones(len(self.output)) if self.rep is None else self.W_diag
+            mo, vo = e.vecchia_linkgp(self.name, e.tensor(m), e.tensor(v), zt, e.tensor(self.input),
+                                      None if self.global_input is None else e.tensor(self.global_input),
+                                      self._pred_nn(x, w), e.tensor(np.asarray(self.output, float).reshape(-1)),
+                                      self.scale[0], self.length, self.nugget[0], e.tensor(nd))
+        else:
+            st = self._stats
+            mo, vo = e.linkgp_predict(self.name, e.tensor(m), e.tensor(v), zt, st['W'], st['Wg'], self.length, st['Rinv'],
+                                      st['ld'], st['ry'], self.scale[0], self.nugget[0])
+        return mo.cpu().numpy(), vo.cpu().numpy()

@@ -1,0 +1,332 @@
+"""Typed Python front of the C-ABI (include/dgp_amd.h).
+
+`Engine` owns one libdgp_amd context bound to a device and a HIP stream.  Device
+memory is plain torch tensors (torch is plumbing here: allocation, streams,
+torch.distributed); every numerical operation is a HIP kernel behind the C-ABI.
+Host-side small parameters (lengthscales, angles) are numpy arrays.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, KIND
+
+
+class DgpAmdError(RuntimeError):
+    pass
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+
+
+class Engine:
+    def __init__(self, device=0, stream=None):
+        if not torch.cuda.is_available():
+            raise DgpAmdError('dgp_amd needs a HIP device: torch.cuda.is_available() is False and there is no CPU path')
+        self.device = torch.device('cuda', device)
+        torch.cuda.set_device(self.device)
+        self._torch_stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        rc = lib.dgpamd_create(int(device), C.c_void_p(self._torch_stream.cuda_stream), C.byref(h))
+        if rc != 0:
+            raise DgpAmdError('dgpamd_create failed (rc=%d)' % rc)
+        self.h = h
+        self._ws = {}
+
+    def close(self):
+        if getattr(self, 'h', None):
+            lib.dgpamd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ utils
+    def _chk(self, rc):
+        if rc != 0:
+            raise DgpAmdError('libdgp_amd rc=%d: %s' % (rc, lib.dgpamd_last_error(self.h).decode()))
+
+    def sync(self):
+        self._chk(lib.dgpamd_sync(self.h))
+
+    def stream(self):
+        """Context manager making this engine's HIP stream torch's current stream (so that torch's
+        allocator and copies are ordered with the library's launches)."""
+        return torch.cuda.stream(self._torch_stream)
+
+    def tensor(self, a, dtype=torch.float64):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device, non_blocking=False)
+
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def workspace(self, key, nbytes):
+        """Cached byte workspace (grown on demand) -- no allocation inside hot loops."""
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._ws[key] = t
+        return t
+
+    @staticmethod
+    def padded_dim(n):
+        return int(lib.dgpamd_padded_dim(int(n)))
+
+    def event(self):
+        e = C.c_void_p()
+        self._chk(lib.dgpamd_event_create(self.h, C.byref(e)))
+        return e
+
+    def record(self, ev):
+        self._chk(lib.dgpamd_event_record(self.h, ev))
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float()
+        self._chk(lib.dgpamd_event_elapsed_ms(self.h, start, stop, C.byref(ms)))
+        return float(ms.value)
+
+    # --------------------------------------------------------------- kernels
+    @staticmethod
+    def _colmap(colmap, Dl):
+        if colmap is None:
+            return None, None
+        cm = np.ascontiguousarray(np.asarray(colmap, dtype=np.int32))
+        assert cm.shape == (Dl,)
+        return cm, _hp(cm)
+
+    def kmatrix(self, kind, Xloc, colmap, Xglob, length, nugget, W=None, out=None, full=True, Y=None, batch=1):
+        """K (full=True: n x n, both triangles; full=False: augmented Np x Np buffer with rows of Y).
+        Xloc: (batch?, n, ldloc) tensor; colmap: gathered columns (None = all)."""
+        n, ldloc = Xloc.shape[-2], Xloc.shape[-1]
+        Dl = ldloc if colmap is None else len(colmap)
+        Dg = 0 if Xglob is None else Xglob.shape[1]
+        cm, cmp_ = self._colmap(colmap, Dl)
+        length = _f64(length)
+        stride_loc = n * ldloc if Xloc.dim() == 3 else 0
+        if full:
+            ld = n
+            r = 0
+        else:
+            ld = self.padded_dim(n)
+            r = 0 if Y is None else (1 if Y.dim() == 1 else Y.shape[-2])
+        if out is None:
+            out = self.empty((batch, ld, ld) if batch > 1 else (ld, ld))
+        stride_k = ld * ld if batch > 1 else 0
+        stride_y = 0
+        if Y is not None and Y.dim() == 3:
+            stride_y = Y.shape[-2] * Y.shape[-1]
+        self._chk(lib.dgpamd_kmatrix(self.h, KIND[kind], n, _dp(Xloc), ldloc, stride_loc, cmp_, Dl, _dp(Xglob), Dg,
+                                     _hp(length), len(length), float(nugget), _dp(W), _dp(out), ld, stride_k,
+                                     1 if full else 0, _dp(Y), n, stride_y, r, batch))
+        return out
+
+    def potrf_workspace(self, n, batch):
+        return self.workspace(('potrf', n, batch), lib.dgpamd_potrf_workspace(n, batch))
+
+    def potrf(self, n, A, batch=1, work=None):
+        """In-place factorisation of augmented buffers.  Returns (logdet, info) device tensors."""
+        Np = self.padded_dim(n)
+        if work is None:
+            work = self.potrf_workspace(n, batch)
+        logdet = self.empty(batch)
+        info = self.empty(batch, dtype=torch.int32)
+        self._chk(lib.dgpamd_potrf(self.h, n, _dp(A), Np * Np, batch, _dp(logdet), _dp(info), _dp(work)))
+        return logdet, info
+
+    def aug_quad(self, n, A, batch, r):
+        Np = self.padded_dim(n)
+        out = self.empty(batch, r, r)
+        self._chk(lib.dgpamd_aug_quad(self.h, n, _dp(A), Np * Np, batch, r, _dp(out)))
+        return out
+
+    def loglik(self, kind, Xloc, colmap, Xglob, length, nugget, scale, y, W=None, batch=1, A=None, ll=None, info=None):
+        """Batched ESS target (kernel_class.py:481-492).  Returns (ll, info) device tensors (no sync)."""
+        n, ldloc = Xloc.shape[-2], Xloc.shape[-1]
+        Dl = ldloc if colmap is None else len(colmap)
+        Dg = 0 if Xglob is None else Xglob.shape[1]
+        cm, cmp_ = self._colmap(colmap, Dl)
+        length = _f64(length)
+        Np = self.padded_dim(n)
+        if A is None:
+            A = self.workspace(('loglikA', n, batch), batch * Np * Np * 8)
+        work = self.potrf_workspace(n, batch)
+        if ll is None:
+            ll = self.empty(batch)
+        if info is None:
+            info = self.empty(batch, dtype=torch.int32)
+        stride_loc = n * ldloc if Xloc.dim() == 3 else 0
+        self._chk(lib.dgpamd_loglik(self.h, KIND[kind], n, _dp(Xloc), ldloc, stride_loc, cmp_, Dl, _dp(Xglob), Dg,
+                                    _hp(length), len(length), float(nugget), _dp(W), float(scale), _dp(y), _dp(A),
+                                    Np * Np, batch, _dp(ll), _dp(info), _dp(work)))
+        return ll, info
+
+    def trmv_lower(self, n, L, scale, z, batch=1, out=None):
+        Np = self.padded_dim(n)
+        sc = _f64(scale)
+        if len(sc) == 1 and batch > 1:
+            sc = np.repeat(sc, batch)
+        if out is None:
+            out = self.empty(batch, n)
+        self._chk(lib.dgpamd_trmv_lower(self.h, n, _dp(L), Np * Np, _hp(sc), _dp(z), _dp(out), batch))
+        return out
+
+    def ess_propose(self, F, NU, thetas, out=None):
+        n, M = F.shape
+        th = _f64(thetas)
+        B = len(th)
+        if out is None:
+            out = self.empty(B, n, M)
+        self._chk(lib.dgpamd_ess_propose(self.h, n, M, _dp(F), _dp(NU), _hp(th), B, _dp(out)))
+        return out
+
+    def potri(self, n, A, Ainv, r, work):
+        self._chk(lib.dgpamd_potri(self.h, n, _dp(A), _dp(Ainv), r, _dp(work)))
+        return Ainv
+
+    def grad_reduce(self, kind, Xloc, colmap, Xglob, length, nugget, nugget_est, Ainv, W=None):
+        n, ldloc = Xloc.shape[-2], Xloc.shape[-1]
+        Dl = ldloc if colmap is None else len(colmap)
+        Dg = 0 if Xglob is None else Xglob.shape[1]
+        cm, cmp_ = self._colmap(colmap, Dl)
+        length = _f64(length)
+        P = (1 if len(length) == 1 else Dl + Dg) + (1 if nugget_est else 0)
+        work = self.workspace(('grad', n, P), lib.dgpamd_grad_workspace(n, P))
+        out = self.empty(2 * P)
+        self._chk(lib.dgpamd_grad_reduce(self.h, KIND[kind], n, _dp(Xloc), ldloc, cmp_, Dl, _dp(Xglob), Dg, _hp(length),
+                                         len(length), float(nugget), _dp(W), 1 if nugget_est else 0, _dp(Ainv), _dp(out),
+                                         _dp(work)))
+        return out, P
+
+    def gp_predict(self, kind, x, Wtr, length, Rinv, ldr, ry, scale, nugget, mean=None, var=None):
+        """ry: (n,) -> mean (M,) ; ry: (S, n) -> mean (S, M).  var is (M,) either way."""
+        M, D = x.shape
+        n = Wtr.shape[0]
+        length = _f64(length)
+        nry = 1 if ry.dim() == 1 else ry.shape[0]
+        work = self.workspace(('gp', n, M), lib.dgpamd_gp_workspace(n, M))
+        if mean is None:
+            mean = self.empty(M) if ry.dim() == 1 else self.empty(nry, M)
+        if var is None:
+            var = self.empty(M)
+        self._chk(lib.dgpamd_gp_predict(self.h, KIND[kind], n, M, D, _dp(x), _dp(Wtr), _hp(length), len(length), _dp(Rinv),
+                                        ldr, _dp(ry), nry, float(scale), float(nugget), _dp(mean), _dp(var), _dp(work)))
+        return mean, var
+
+    def linkgp_predict(self, kind, m, v, z, Wtr, Wg, length, Rinv, ldr, ry, scale, nugget, mean=None, var=None):
+        M, Dw = m.shape
+        Dz = 0 if z is None else z.shape[1]
+        n = Wtr.shape[0]
+        length = _f64(length)
+        work = self.workspace(('link', n, M), lib.dgpamd_linkgp_workspace(n, M))
+        if mean is None:
+            mean = self.empty(M)
+        if var is None:
+            var = self.empty(M)
+        self._chk(lib.dgpamd_linkgp_predict(self.h, KIND[kind], n, M, Dw, Dz, _dp(m), _dp(v), _dp(z), _dp(Wtr), _dp(Wg),
+                                            _hp(length), len(length), _dp(Rinv), ldr, _dp(ry), float(scale),
+                                            float(nugget), _dp(mean), _dp(var), _dp(work)))
+        return mean, var
+
+    def moments_accumulate(self, mu, var, sum_mu, sum_m2):
+        self._chk(lib.dgpamd_moments_accumulate(self.h, mu.numel(), _dp(mu), _dp(var), _dp(sum_mu), _dp(sum_m2)))
+
+    def moments_finalize(self, S, sum_mu, sum_m2):
+        self._chk(lib.dgpamd_moments_finalize(self.h, sum_mu.numel(), float(S), _dp(sum_mu), _dp(sum_m2)))
+
+    # --------------------------------------------------------------- vecchia
+    def nn_ordered(self, x, m):
+        n, D = x.shape
+        m = min(m, n - 1)
+        out = self.empty(n, m + 1, dtype=torch.int64)
+        self._chk(lib.dgpamd_nn_ordered(self.h, n, D, _dp(x), m, _dp(out)))
+        return out
+
+    def nn_query(self, q, x, m):
+        M, D = q.shape
+        n = x.shape[0]
+        m = min(m, n)
+        out = self.empty(M, m, dtype=torch.int64)
+        self._chk(lib.dgpamd_nn_query(self.h, M, n, D, _dp(q), _dp(x), m, _dp(out)))
+        return out
+
+    def vecchia_llik(self, kind, X, y, NN, length, nugget, nugget_diag):
+        n, D = X.shape
+        length = _f64(length)
+        out = self.empty(2)
+        self._chk(lib.dgpamd_vecchia_llik(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(y), _dp(NN), _hp(length),
+                                          len(length), float(nugget), _dp(nugget_diag), _dp(out)))
+        return out
+
+    def vecchia_nllik(self, kind, X, y, NN, length, nugget, nugget_diag, nugget_est):
+        n, D = X.shape
+        length = _f64(length)
+        P = (1 if len(length) == 1 else D) + (1 if nugget_est else 0)
+        out = self.empty(2 + 2 * P)
+        self._chk(lib.dgpamd_vecchia_nllik(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(y), _dp(NN),
+                                           _hp(length), len(length), float(nugget), _dp(nugget_diag),
+                                           1 if nugget_est else 0, _dp(out)))
+        return out, P
+
+    def vecchia_lmatrix(self, kind, X, NN, length, nugget):
+        n, D = X.shape
+        length = _f64(length)
+        out = self.empty(n, NN.shape[1])
+        self._chk(lib.dgpamd_vecchia_lmatrix(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(NN), _hp(length),
+                                             len(length), float(nugget), _dp(out)))
+        return out
+
+    def vecchia_spsolve(self, Lmat, NN, inv_sqrt_scale, b):
+        n = Lmat.shape[0]
+        out = self.empty(n)
+        self._chk(lib.dgpamd_vecchia_spsolve(self.h, n, NN.shape[1] - 1, _dp(Lmat), _dp(NN), float(inv_sqrt_scale), _dp(b),
+                                             _dp(out)))
+        return out
+
+    def vecchia_gp(self, kind, x, w, NN, y, scale, length, nugget, nugget_diag):
+        M, D = x.shape
+        length = _f64(length)
+        mean, var = self.empty(M), self.empty(M)
+        self._chk(lib.dgpamd_vecchia_gp(self.h, KIND[kind], M, w.shape[0], D, NN.shape[1], _dp(x), _dp(w), _dp(NN), _dp(y),
+                                        float(scale), _hp(length), len(length), float(nugget), _dp(nugget_diag),
+                                        _dp(mean), _dp(var)))
+        return mean, var
+
+    def vecchia_linkgp(self, kind, m, v, z, w1, wg, NN, y, scale, length, nugget, nugget_diag):
+        M, Dw = m.shape
+        Dz = 0 if z is None else z.shape[1]
+        length = _f64(length)
+        mean, var = self.empty(M), self.empty(M)
+        self._chk(lib.dgpamd_vecchia_linkgp(self.h, KIND[kind], M, w1.shape[0], Dw, Dz, NN.shape[1], _dp(m), _dp(v), _dp(z),
+                                            _dp(w1), _dp(wg), _dp(NN), _dp(y), float(scale), _hp(length), len(length),
+                                            float(nugget), _dp(nugget_diag), _dp(mean), _dp(var)))
+        return mean, var
+
+
+_default = {}
+
+
+def default_engine(device=None):
+    """Process-wide engine for `device` (LOCAL_RANK-aware default)."""
+    import os
+    if device is None:
+        device = int(os.environ.get('LOCAL_RANK', '0'))
+    if device not in _default:
+        _default[device] = Engine(device)
+    return _default[device]

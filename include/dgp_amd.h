@@ -53,8 +53,8 @@ extern "C" {
 typedef struct dgpamd_ctx dgpamd_ctx;
 
 /* ---- context ------------------------------------------------------------ */
-/* stream: a hipStream_t created by the caller (e.g. torch's current stream),
- * or NULL to let the library create (and own) one.                           */
+/* stream: a hipStream_t created by the caller (e.g. a torch side stream), or
+ * NULL for the device's default (null) stream -- torch's default current stream. */
 int dgpamd_create(int device, void *stream, dgpamd_ctx **out);
 int dgpamd_destroy(dgpamd_ctx *ctx);
 const char *dgpamd_last_error(const dgpamd_ctx *ctx);
@@ -151,12 +151,15 @@ size_t dgpamd_grad_workspace(int64_t n, int nparam);
  * functions.gp  functions.py:379-394 (+ K_vec_nb vecchia.py:244-265):
  *   m_t = Rinv_y . r_t ,  v_t = | scale (1 + nugget - r_t^T Rinv r_t) |
  * x: (M x D) test inputs already concatenated [local | global]; Wtr: (n x D)
- * training inputs; Rinv: n x n symmetric with leading dimension ldr; ry: (n).
- * mean/var: (M).  work: dgpamd_gp_workspace(n, M) bytes.                      */
+ * training inputs; Rinv: n x n symmetric with leading dimension ldr.
+ * ry: (nry x n) -- several R^-1 y at once: for a first-layer node R^-1 and the
+ * variance are identical in every imputation, only y (hence the mean) differs
+ * (emulation.py:701-734 recomputes both per imputation).  mean: (nry x M); var: (M).
+ * work: dgpamd_gp_workspace(n, M) bytes.                                       */
 size_t dgpamd_gp_workspace(int64_t n, int64_t M);
 int dgpamd_gp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int D,
                       const double *x, const double *Wtr, const double *length_h, int nlen,
-                      const double *Rinv, int64_t ldr, const double *ry, double scale, double nugget,
+                      const double *Rinv, int64_t ldr, const double *ry, int nry, double scale, double nugget,
                       double *mean, double *var, void *work);
 
 /* ---- a12-a14  linked-GP prediction ------------------------------------------

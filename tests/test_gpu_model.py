@@ -1,0 +1,152 @@
+"""Model-level parity on the GPU: the device imputer replays the reference's logged ESS
+trajectory, the emulator reproduces the reference's predictions from dumped imputations,
+and train -> estimate -> emulator -> predict recovers a step function.  -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    from dgp_amd.ops import Engine
+    return Engine(0)
+
+
+def close(a, b, rtol=1e-9, atol=1e-12):
+    np.testing.assert_allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol)
+
+
+def build_structure(d, pre, eng):
+    """dgp_amd nodes from a structure dumped by oracle/gen_golden.py:dump_structure."""
+    from dgp_amd import kernel
+    layers = []
+    for l in range(int(d[pre + 'n_layer'])):
+        layer = []
+        for k in range(int(d[pre + 'l%d_n' % l])):
+            c = case(d, pre + 'l%d_k%d_' % (l, k))
+            nd = kernel(length=c['length'].copy(), scale=c['scale'][0], nugget=c['nugget'][0], name=str(c['name']),
+                        scale_est=bool(c['scale_est']), nugget_est=bool(c['nugget_est']), input_dim=c['input_dim'].copy(),
+                        connect=c['connect'].copy() if bool(c['has_global']) else None, engine=eng)
+            nd.input = c['input'].copy()
+            nd.output = c['output'].copy()
+            nd.global_input = c['global_input'].copy() if bool(c['has_global']) else None
+            nd.vecch = False
+            nd.D = nd.input.shape[1] + (0 if nd.global_input is None else nd.global_input.shape[1])
+            layer.append(nd)
+        layers.append(layer)
+    return layers
+
+
+@pytest.mark.parametrize('tag', ['sexp', 'matern', 'deep'])
+@pytest.mark.parametrize('batch', [1, 3, 8])
+def test_ess_trajectory_matches_reference(eng, golden, tag, batch):
+    """imputer.sample(burnin=2) with the reference's own draws: same accepted latents, and the
+    speculative batches consume exactly the uniforms the sequential sampler consumed."""
+    from dgp_amd.imputation import imputer, DrawStream
+    d = golden('g5_ess_' + tag)
+    layers = build_structure(d, 'pre_', eng)
+    draws = DrawStream(z=list(d['z']), u=list(d['u']))
+    imp = imputer(layers, block=True, draws=draws, engine=eng, batch=batch)
+    imp.sample(burnin=2)
+    assert draws.exhausted(), 'all logged draws must be consumed, no more and no fewer'
+    post = build_structure(d, 'post_', eng)
+    for la, lb in zip(layers, post):
+        for a, b in zip(la, lb):
+            close(a.output, b.output, rtol=1e-8, atol=1e-10)
+            close(a.input, b.input, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize('tag', ['sexp', 'matern'])
+def test_emulator_predict_matches_reference(eng, golden, tag):
+    from dgp_amd.emulation import emulator
+    d = golden('g9_emulator_' + tag)
+    S = int(d['n_imp'])
+    est = build_structure(d, 's0_', eng)
+    emu = emulator.__new__(emulator)
+    emu.all_layer, emu.n_layer, emu.vecch, emu.engine = est, len(est), False, eng
+    emu.N = emu.N_total = S
+    emu.shard = False
+    emu.latents = []
+    for s in range(S):
+        ls = build_structure(d, 's%d_' % s, eng)
+        emu.latents.append([np.stack([nd.output[:, 0] for nd in layer], 1) for layer in ls[:-1]])
+    emu.orders = []
+    emu._stats = None
+    mu_s, var_s = emu.predict(d['xt'], aggregation=False)
+    for s in range(S):
+        close(mu_s[s], d['mu_s'][s], rtol=1e-6, atol=1e-8)
+        # variance = O(scale) terms cancelling through R^-1 (cond ~1e6): absolute tolerance 1e-6 * prior variance
+        close(var_s[s], d['var_s'][s], rtol=1e-5, atol=1e-6)
+    mu, var = emu.predict(d['xt'])
+    close(mu, d['mu'], rtol=1e-6, atol=1e-8)
+    close(var, d['var'], rtol=1e-5, atol=1e-6)
+    ml, vl = emu.predict(d['xt'], full_layer=True)
+    assert len(ml) == 2 and ml[0].shape == (len(d['xt']), 2)
+    close(ml[-1], d['mu'], rtol=1e-6, atol=1e-8)
+
+
+def test_estimate_is_path_mean(eng, golden):
+    """dgp.estimate (dgp.py:1529-1540)."""
+    from dgp_amd.dgp import dgp
+    d = golden('g9_emulator_sexp')
+    layers = build_structure(d, 'est_', eng)
+    for l, layer in enumerate(layers):
+        for k, nd in enumerate(layer):
+            nd.para_path = d['path_l%d_k%d' % (l, k)].copy()
+    obj = dgp.__new__(dgp)
+    obj.all_layer, obj.N = layers, 6
+    est = obj.estimate()
+    ref = build_structure(d, 'est_', eng)
+    for la, lb in zip(est, ref):
+        for a, b in zip(la, lb):
+            close(a.scale, b.scale)
+            close(a.length, b.length)
+            close(a.nugget, b.nugget)
+
+
+def test_step_function_end_to_end(eng):
+    """BASELINE config 1: step function, n=30, 2 layers x 1 SExp node (demo/step_fct.ipynb scaled as
+    BASELINE.json states).  Statistical: the emulator must recover the two plateaus."""
+    from dgp_amd import dgp, kernel, combine, emulator
+    np.random.seed(3)
+    n = 30
+    X = np.linspace(0, 1, n)[:, None]
+    Y = np.where(X > 0.5, 1.0, -1.0)
+    layers = combine([kernel(length=np.array([1.0]), name='sexp')],
+                     [kernel(length=np.array([1.0]), name='sexp', scale_est=True)])
+    model = dgp(X, Y, layers, seed=7)
+    model.train(N=60, ess_burn=10, disable=True)
+    assert model.N == 60 and model.all_layer[0][0].para_path.shape == (61, 3)
+    emu = emulator(model.estimate(), N=6, seed=11)
+    xt = np.array([[0.1], [0.3], [0.7], [0.9]])
+    mu, var = emu.predict(xt)
+    assert mu.shape == (4, 1) and var.shape == (4, 1)
+    assert np.all(mu[:2] < -0.7) and np.all(mu[2:] > 0.7), mu
+    assert np.all(var > -1e-6) and np.all(var < 0.5)
+    # the sampler's speculative batches: more than one proposal per update on average
+    st = model.imp.stats
+    assert st['proposals'] >= st['updates'] > 0
+
+
+def test_matern_2layer_train_predict_small(eng):
+    """Shape of BASELINE config 2 at a small n: d inputs -> d Matern nodes -> 1 Matern node with global connection."""
+    from dgp_amd import dgp, kernel, combine, emulator
+    rng = np.random.default_rng(2026)
+    n, d = 120, 3
+    X = rng.uniform(size=(n, d))
+    f = np.sin(1.0 / ((0.7 * X[:, 0] + 0.3) * (0.7 * X[:, 1] + 0.3))) + 0.5 * X[:, 2] ** 2
+    Y = ((f - f.mean()) / f.std())[:, None]
+    layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                     [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(d))])
+    model = dgp(X, Y, layers, seed=1)
+    model.train(N=8, ess_burn=5, disable=True)
+    emu = emulator(model.estimate(), N=3, seed=2)
+    mu, var = emu.predict(X[:40])
+    assert np.sqrt(np.mean((mu - Y[:40]) ** 2)) < 0.3          # interpolates its own training data
+    assert np.all(np.isfinite(var))

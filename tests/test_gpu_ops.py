@@ -1,0 +1,317 @@
+"""Parity of every C-ABI operator (HIP, through ctypes) against the oracle and the
+golden vectors recorded from the reference.  Needs an MI355X: -m gpu.
+
+Tolerances (f64): 1e-10 relative on kernel matrices and likelihood scalars;
+1e-8 where a Cholesky at n >= 1000 or the Jd-based Matern J is involved;
+variances that are differences of O(scale) terms carry an absolute tolerance
+of 1e-7*scale (cond(R) ~ 1e6 at nugget 1e-6); index arrays are bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    from dgp_amd.ops import Engine
+    return Engine(0)
+
+
+def close(a, b, rtol=1e-10, atol=1e-13):
+    np.testing.assert_allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def split(eng, X, nl):
+    """device tensors (Xloc, Xglob) of X = [local | global]"""
+    Xl = eng.tensor(X[:, :nl])
+    Xg = eng.tensor(X[:, nl:]) if X.shape[1] > nl else None
+    return Xl, Xg
+
+
+# ---------------------------------------------------------------- a1/a2/a5/a8
+def test_kmatrix_golden(eng, golden):
+    g = golden('g1_kernel_llik')
+    for c in range(int(g['n_cases'])):
+        d = case(g, 'c%d_' % c)
+        nl = 3
+        Xl, Xg = split(eng, d['X'], nl)
+        W = eng.tensor(d['W_diag']) if 'W_diag' in d else None
+        K = eng.kmatrix(str(d['name']), Xl, None, Xg, d['length'], d['nugget'][0], W=W)
+        eng.sync()
+        close(npy(K), d['K'], rtol=1e-12, atol=1e-15)
+
+
+def gpu_nll_grad(eng, d):
+    """kernel.llik (kernel_class.py:403-449) assembled from the HIP pieces, host arithmetic as in dgp_amd.kernel."""
+    from dgp_amd.kernel_class import kernel as K
+    name = str(d['name'])
+    prior = str(d['prior'])
+    prior = None if prior == 'none' else prior
+    nl = 3
+    k = K(length=d['length'].copy(), scale=d['scale'][0], nugget=d['nugget'][0], name=name, prior_name=prior,
+          prior_coef=None, nugget_est=bool(d['flags'][2]), scale_est=bool(d['flags'][4]), engine=eng)
+    if prior is not None:
+        k.prior_coef = d['prior_coef'].copy()   # stored coefficients
+    k.input = d['X'][:, :nl].copy()
+    k.global_input = d['X'][:, nl:].copy() if d['X'].shape[1] > nl else None
+    k.output = d['y'].copy()
+    if 'cl' in d:
+        k.cl = d['cl'] if len(d['cl']) > 1 else d['cl'][0]
+    if bool(d['flags'][3]):
+        k.rep = np.zeros(int(d['n_rep']), dtype=int)   # only len(rep) enters llik
+        k.W_diag = d['W_diag'].copy()
+        k.sum_residual = d['sum_residual'].copy()
+    return k
+
+
+def test_llik_and_loglik_golden(eng, golden):
+    g = golden('g1_kernel_llik')
+    for c in range(int(g['n_cases'])):
+        d = case(g, 'c%d_' % c)
+        k = gpu_nll_grad(eng, d)
+        if 'loglik' in d:
+            close(k.log_likelihood_func(), d['loglik'][0], rtol=1e-9)
+        nll, grad = k.llik(d['x'].copy())
+        close(nll, d['nll'], rtol=1e-9)
+        close(grad, d['grad'], rtol=1e-7, atol=1e-8)
+        close(k.scale, d['scale_after'], rtol=1e-9)
+        Kf, fod = k.k_matrix(fod_eval=True)
+        close(Kf, d['K'].copy() if False else k.k_matrix(), rtol=0, atol=0)
+        # fod after llik(x): parameters moved to exp(x); compare against the oracle at those parameters
+        from oracle import dgp_oracle as O
+        X = d['X']
+        _, fod_ref = O.k_matrix_fod(X, k.length, k.nugget[0], str(d['name']), bool(d['flags'][2]), d.get('W_diag'))
+        close(fod, fod_ref, rtol=1e-10, atol=1e-14)
+
+
+@pytest.mark.parametrize('name', ['sexp', 'matern2.5'])
+@pytest.mark.parametrize('n', [65, 500, 2000])
+def test_potrf_potri_sizes(eng, name, n):
+    """Factor / inverse / alpha / logdet / quad against LAPACK at sizes around the tile edges and the bench size."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(n)
+    D = 4
+    X = rng.uniform(size=(n, D))
+    y = rng.normal(size=n)
+    length = np.array([0.8])
+    Kref = O.k_matrix(X, length, 1e-4, name)
+    Xl = eng.tensor(X)
+    A = eng.kmatrix(name, Xl, None, None, length, 1e-4, full=False, Y=eng.tensor(y))
+    logdet, info = eng.potrf(n, A)
+    work = eng.potrf_workspace(n, 1)
+    quad = eng.aug_quad(n, A, 1, 1)
+    eng.sync()
+    Np = eng.padded_dim(n)
+    L = np.tril(npy(A)[:n, :n])
+    Lref = np.linalg.cholesky(Kref)
+    assert int(npy(info)[0]) == 0
+    close(L, Lref, rtol=1e-8, atol=1e-10)
+    w = np.linalg.solve(Lref, y)
+    close(npy(quad)[0, 0, 0], w @ w, rtol=1e-8)
+    close(npy(logdet)[0], 2 * np.log(np.diag(Lref)).sum(), rtol=1e-10, atol=1e-9)
+    Ainv = eng.empty(Np, Np)
+    eng.potri(n, A, Ainv, 1, work)
+    eng.sync()
+    Kinv = np.linalg.inv(Kref)
+    Ai = npy(Ainv)
+    sc = np.abs(Kinv).max()
+    close(Ai[:n, :n], Kinv, rtol=1e-7, atol=1e-8 * sc)
+    close(Ai[:n, :n], Ai[:n, :n].T, rtol=0, atol=0)   # symmetric by construction
+    alpha = Kinv @ y
+    close(-Ai[n, :n], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
+
+
+def test_potrf_reports_not_pd(eng):
+    import torch
+    n = 100
+    Np = eng.padded_dim(n)
+    M = np.eye(Np)
+    M[70, 70] = -1.0
+    A = eng.tensor(M)
+    logdet, info = eng.potrf(n, A)
+    eng.sync()
+    assert int(npy(info)[0]) == 71   # LAPACK convention: leading minor of order 71
+
+
+def test_loglik_batched_vs_oracle(eng):
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(3)
+    n, B = 300, 5
+    F = rng.normal(size=(n, 3))
+    NU = rng.normal(size=(n, 3))
+    G = rng.uniform(size=(n, 2))
+    y = rng.normal(size=n)
+    th = rng.uniform(-3, 3, size=B)
+    FP = eng.ess_propose(eng.tensor(F), eng.tensor(NU), th)
+    eng.sync()
+    for b in range(B):
+        close(npy(FP)[b], O.update_f(F, NU, th[b]), rtol=1e-14, atol=1e-15)
+    length = np.array([1.2, 0.7, 0.9, 1.1])
+    colmap = [2, 0]
+    ll, info = eng.loglik('matern2.5', FP, colmap, eng.tensor(G), length, 1e-5, 1.3, eng.tensor(y), batch=B)
+    eng.sync()
+    assert not npy(info).any()
+    for b in range(B):
+        Xb = np.concatenate((O.update_f(F, NU, th[b])[:, colmap], G), 1)
+        close(npy(ll)[b], O.log_likelihood(Xb, y, length, 1.3, 1e-5, 'matern2.5'), rtol=1e-10)
+
+
+def test_trmv_is_fmvn(eng, golden):
+    g = golden('g4_fmvn')
+    # cov = scale*K: factor K = cov/scale on device, nu = sqrt(scale) L z  (functions.py:113-121)
+    cov, z = g['cov'], g['z']
+    n = len(z)
+    Np = eng.padded_dim(n)
+    A = np.zeros((Np, Np))
+    A[:n, :n] = cov / 1.3
+    Ad = eng.tensor(A)
+    eng.potrf(n, Ad)
+    nu = eng.trmv_lower(n, Ad, [1.3], eng.tensor(z))
+    eng.sync()
+    close(npy(nu)[0], g['sample'], rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------- a10-a14
+def test_gp_and_linkgp_golden(eng, golden):
+    g = golden('g7_predict')
+    for c in range(int(g['n_cases'])):
+        d = case(g, 'c%d_' % c)
+        name = str(d['name'])
+        nl = int(d['n_local'])
+        X = d['X']
+        n = len(X)
+        x = d['x'] if 'z' not in d else np.concatenate((d['x'], d['z']), 1)
+        Rinv = eng.tensor(d['Rinv'])
+        ry = eng.tensor(d['Rinv_y'])
+        m, v = eng.gp_predict(name, eng.tensor(x), eng.tensor(X), d['length'], Rinv, n, ry, d['scale'][0], d['nugget'][0])
+        eng.sync()
+        close(npy(m), d['gp_m'], rtol=1e-9, atol=1e-11)
+        close(npy(v), d['gp_v'], rtol=1e-7, atol=1e-9)
+        z = eng.tensor(d['z']) if 'z' in d else None
+        Wg = eng.tensor(X[:, nl:]) if 'z' in d else None
+        lm, lv = eng.linkgp_predict(name, eng.tensor(d['lm_in']), eng.tensor(d['lv_in']), z, eng.tensor(X[:, :nl]), Wg,
+                                    d['length'], Rinv, n, ry, d['scale'][0], d['nugget'][0])
+        eng.sync()
+        close(npy(lm), d['link_m'], rtol=1e-8, atol=1e-10)
+        close(npy(lv), d['link_v'], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize('name', ['sexp', 'matern2.5'])
+def test_gp_linkgp_larger_vs_oracle(eng, name):
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(8)
+    n, M, Dw, Dz = 150, 70, 3, 2
+    X = rng.uniform(size=(n, Dw + Dz))
+    y = rng.normal(size=n)
+    length = rng.uniform(0.6, 1.4, size=Dw + Dz)
+    st = O.compute_stats(X, y, length, 1e-3, name, Dw)
+    x = rng.uniform(size=(M, Dw + Dz))
+    mr, vr = O.gp_predict(x, X, st['Rinv'], st['Rinv_y'], 1.4, length, 1e-3, name)
+    Rinv, ry = eng.tensor(st['Rinv']), eng.tensor(st['Rinv_y'])
+    m, v = eng.gp_predict(name, eng.tensor(x), eng.tensor(X), length, Rinv, n, ry, 1.4, 1e-3)
+    eng.sync()
+    close(npy(m), mr, rtol=1e-9, atol=1e-11)
+    close(npy(v), vr, rtol=1e-7, atol=1e-9)
+    mm = rng.uniform(size=(M, Dw))
+    vv = rng.uniform(0.001, 0.2, size=(M, Dw))
+    vv[3] = 0.0
+    z = rng.uniform(size=(M, Dz))
+    lmr, lvr = O.link_gp_predict(mm, vv, z, X[:, :Dw], X[:, Dw:], st['Rinv'], st['Rinv_y'], 1.4, length, 1e-3, name)
+    lm, lv = eng.linkgp_predict(name, eng.tensor(mm), eng.tensor(vv), eng.tensor(z), eng.tensor(X[:, :Dw]),
+                                eng.tensor(X[:, Dw:]), length, Rinv, n, ry, 1.4, 1e-3)
+    eng.sync()
+    close(npy(lm), lmr, rtol=1e-8, atol=1e-10)
+    close(npy(lv), lvr, rtol=1e-6, atol=1e-8)
+
+
+def test_moments(eng):
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(5)
+    mus, vs = rng.normal(size=(4, 50, 2)), rng.uniform(size=(4, 50, 2))
+    s1, s2 = eng.zeros(50, 2), eng.zeros(50, 2)
+    for a, b in zip(mus, vs):
+        eng.moments_accumulate(eng.tensor(a), eng.tensor(b), s1, s2)
+    eng.moments_finalize(4, s1, s2)
+    eng.sync()
+    mu, var = O.aggregate_moments(mus, vs)
+    close(npy(s1), mu, rtol=1e-13)
+    close(npy(s2), var, rtol=1e-11, atol=1e-13)
+
+
+# ---------------------------------------------------------------- a17-a23
+def test_vecchia_nn_bit_exact(eng, golden):
+    import torch
+    g = golden('g8_vecchia')
+    NN = eng.nn_ordered(eng.tensor(g['nn_x']), int(g['nn_m']))
+    PN = eng.nn_query(eng.tensor(g['pq']), eng.tensor(g['nn_x']), 12)
+    eng.sync()
+    assert NN.dtype == torch.int64
+    np.testing.assert_array_equal(npy(NN), g['NNarray'])
+    np.testing.assert_array_equal(npy(PN), g['pred_nn'])
+    # m == n shortcut of get_pred_nn (vecchia.py:23-26)
+    from oracle import dgp_oracle as O
+    q = g['pq'][:5]
+    np.testing.assert_array_equal(npy(eng.nn_query(eng.tensor(q), eng.tensor(g['nn_x'][:7]), 50)), O.pred_nn(q, g['nn_x'][:7], 50))
+
+
+def test_vecchia_kernels_golden(eng, golden):
+    g = golden('g8_vecchia')
+    for c in range(int(g['n_cases'])):
+        d = case(g, 'v%d_' % c)
+        name = str(d['name'])
+        X, y, NN = d['X'], d['y'], d['NN']
+        n = len(X)
+        sc, ng, ln = float(d['scale']), float(d['nugget']), d['length']
+        nugget_est, scale_est = bool(d['flags'][0]), bool(d['flags'][1])
+        dX, dy, dNN, ones = eng.tensor(X), eng.tensor(y[:, 0]), eng.tensor(NN, dtype=__import__('torch').int64), eng.tensor(np.ones(n))
+        np.testing.assert_array_equal(npy(eng.nn_ordered(eng.tensor(X / ln), 6)), NN)
+        out = npy(eng.vecchia_llik(name, dX, dy, dNN, ln, ng, ones))
+        close(-0.5 * (out[1] + out[0] / sc), d['llik'][0], rtol=1e-9)
+        o, P = eng.vecchia_nllik(name, dX, dy, dNN, ln, ng, ones, nugget_est)
+        o = npy(o)
+        quad, logdet, dquad, dlogdet = o[0], o[1], o[2:2 + P], o[2 + P:]
+        if scale_est:
+            s2 = quad / n
+            nll = 0.5 * (logdet + n * np.log(s2))
+        else:
+            s2 = sc
+            nll = 0.5 * (logdet + quad / sc)
+        close(nll, d['nll'][0], rtol=1e-9)
+        close(0.5 * (dlogdet - dquad / s2), d['grad'], rtol=1e-7, atol=1e-8)
+        close(s2, d['scale_out'][0], rtol=1e-9)
+        Lm = eng.vecchia_lmatrix(name, dX, dNN, ln, ng)
+        close(npy(Lm), d['Lmat'], rtol=1e-8, atol=1e-8 * np.abs(d['Lmat']).max())
+        xs = eng.vecchia_spsolve(eng.tensor(d['Lmat']), dNN, 1 / np.sqrt(sc), eng.tensor(d['b']))
+        close(npy(xs), d['spsolve'], rtol=1e-9, atol=1e-11)
+        pNN = eng.tensor(d['pNN'], dtype=__import__('torch').int64)
+        gm, gv = eng.vecchia_gp(name, eng.tensor(d['xq']), dX, pNN, dy, sc, ln, ng, ones)
+        close(npy(gm), d['gpv_m'], rtol=1e-8, atol=1e-10)
+        close(npy(gv), d['gpv_v'], rtol=1e-7, atol=1e-10)
+        lm, lv = eng.vecchia_linkgp(name, eng.tensor(d['lm_in']), eng.tensor(d['lv_in']), eng.tensor(d['lz_in']),
+                                    eng.tensor(X[:, :2]), eng.tensor(X[:, 2:]), pNN, dy, sc, ln, ng, ones)
+        close(npy(lm), d['lgv_m'], rtol=1e-7, atol=1e-9)
+        close(npy(lv), d['lgv_v'], rtol=1e-6, atol=1e-8)
+
+
+def test_vecchia_spsolve_long_chain(eng):
+    """Rows span many 1024-row windows and deep in-window dependency chains."""
+    from oracle import dgp_oracle as O
+    import torch
+    rng = np.random.default_rng(12)
+    n, m = 3000, 5
+    x = np.sort(rng.uniform(size=(n, 1)), axis=0)   # ordered 1-D points: every row depends on its predecessor
+    NN = O.nn_ordered(x, m)
+    L = rng.uniform(0.5, 1.5, size=(n, m + 1))
+    b = rng.normal(size=n)
+    ref = O.forward_solve_sp(L, NN, b)
+    out = eng.vecchia_spsolve(eng.tensor(L), eng.tensor(NN, dtype=torch.int64), 1.0, eng.tensor(b))
+    close(npy(out), ref, rtol=1e-10, atol=1e-12)
