@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): SI iterations/sec (train) + predict pts/sec,
+2-layer DGP n=2000 d=5, Matern-2.5 (configs[1]) on synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE stochastic-imputation iteration: I-step (ESS-within-Gibbs, ess_burn=10 -> 11
+layer sweeps) + M-step (L-BFGS-B on every GP node).  All inputs are resident in HBM before
+the timed region.  N > 1 (torch.distributed.run, one rank per GPU, RCCL): the SI chain of ONE
+model does not shard, so every rank trains its own replica (weak scaling, no data-path
+collective); the prediction leg shards the imputations over the ranks with one all-reduce.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_PEAK_TFLOPS = 78.6   # MI355X f64 matrix (= vector) peak, AMD datasheet; MI355X_MICROARCH.md has no f64 row
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synthetic(n, d, seed=2026):
+    """X ~ U[0,1]^(n x d), standardised smooth non-stationary response."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(size=(n, d))
+    f = np.sin(1.0 / ((0.7 * X[:, 0] + 0.3) * (0.7 * X[:, 1] + 0.3)))
+    for k in range(2, d):
+        f = f + (0.3 + 0.2 * k) * X[:, k] ** 2
+    Y = ((f - f.mean()) / f.std())[:, None]
+    return X, Y
+
+
+def build_model(n, d, seed, device):
+    from dgp_amd import dgp, kernel, combine
+    X, Y = synthetic(n, d)
+    layers = combine([kernel(np.array([1.0]), name='matern2.5') for _ in range(d)],
+                     [kernel(np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(d))])
+    np.random.seed(seed)
+    return dgp(X, Y, layers, seed=seed, device=device), X, Y
+
+
+def cpu_baseline(model, counts, ess_burn):
+    """The oracle (numpy/scipy-LAPACK restatement of dgpsi's formulation, kind 'port') timed on this
+    host on a bounded sample of the same workload: a few prior draws, ESS log-likelihoods and M-step
+    objective evaluations at the bench sizes, scaled by the call counts one SI iteration makes
+    (counted in the GPU run).  Reported beside the GPU number; never the thing measured."""
+    from oracle import dgp_oracle as O
+    import psutil
+    rng = np.random.default_rng(1)
+    l1, l2 = model.all_layer[0][0], model.all_layer[1][0]
+    n = len(l1.output)
+    t0 = time.perf_counter()
+    reps_f = 2
+    for _ in range(reps_f):   # fmvn(scale*k_matrix()) of a first-layer node   (imputation.py:63)
+        O.fmvn(l1.scale[0] * O.k_matrix(l1._X(), l1.length, l1.nugget[0], l1.name), rng.standard_normal(n))
+    t_fmvn = (time.perf_counter() - t0) / reps_f
+    t0 = time.perf_counter()
+    reps_l = 3
+    for _ in range(reps_l):   # log_likelihood_func of the second-layer node   (imputation.py:76,104)
+        O.log_likelihood(l2._X(), l2.output, l2.length, l2.scale, l2.nugget[0], l2.name)
+    t_ll = (time.perf_counter() - t0) / reps_l
+    t_llik = []
+    for nd in (l1, l2):       # kernel.llik: objective + gradient, one cho_solve(n x n) per parameter
+        t0 = time.perf_counter()
+        for _ in range(2):
+            O.nll_grad(nd.log_t(), nd._X(), nd.output, nd.name, nd.scale, nd.nugget[0], nd.nugget_est, nd.scale_est,
+                       nd.prior_name, nd.prior_coef)
+        t_llik.append((time.perf_counter() - t0) / 2)
+    sweeps = ess_burn + 1
+    n_l1 = len(model.all_layer[0])
+    per_iter = (sweeps * n_l1 * t_fmvn                                   # reference refactors every sweep
+                + (sweeps + counts['proposals_per_iter']) * t_ll          # threshold + proposals
+                + counts['llik_l1_per_iter'] * t_llik[0] + counts['llik_l2_per_iter'] * t_llik[1])
+    return dict(value=1.0 / per_iter, unit='SI it/s', cores=psutil.cpu_count(logical=False), kind='port',
+                sample=('%d fmvn + %d log_likelihood_func + 2x2 llik at n=%d timed (%.1f s), scaled by the per-iteration '
+                        'call counts of the GPU run: %d sweeps x %d fmvn, %.1f+%d log-liks, %.1f/%.1f llik calls (layer 1/2)'
+                        % (reps_f, reps_l, n, reps_f * t_fmvn + reps_l * t_ll + 2 * sum(t_llik), sweeps, n_l1,
+                           counts['proposals_per_iter'], sweeps, counts['llik_l1_per_iter'], counts['llik_l2_per_iter'])),
+                seconds_per_call=dict(fmvn=t_fmvn, log_likelihood_func=t_ll, llik_layer1=t_llik[0], llik_layer2=t_llik[1]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--n', type=int, default=2000)
+    ap.add_argument('--d', type=int, default=5)
+    ap.add_argument('--ess-burn', type=int, default=10)
+    ap.add_argument('--predict-points', type=int, default=256)
+    ap.add_argument('--imputations', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-predict', action='store_true')
+    ap.add_argument('--prof-kernel', default='syrk', help='kernel class timed with HIP events for the roofline')
+    args = ap.parse_args()
+
+    import torch
+    from dgp_amd import dist as dd
+    from dgp_amd import kernel_class
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        dd.init_from_env('nccl')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    model, X, Y = build_model(args.n, args.d, 100 + rank, local)
+    eng = model.engine
+
+    # count M-step objective evaluations per layer (for the CPU baseline's scaling)
+    calls = {'l1': 0, 'l2': 0}
+    layer_of = {id(nd): ('l1' if l == 0 else 'l2') for l, layer in enumerate(model.all_layer) for nd in layer}
+    orig_llik = kernel_class.kernel.llik
+
+    def counted(self, x):
+        calls[layer_of[id(self)]] += 1
+        return orig_llik(self, x)
+    kernel_class.kernel.llik = counted
+
+    def step():
+        model.imp.sample(burnin=args.ess_burn)
+        model._m_step()
+
+    for _ in range(args.warmup):
+        step()
+    calls['l1'] = calls['l2'] = 0
+    st0 = dict(model.imp.stats)
+    dd.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = eng.event(), eng.event()
+    eng.record(ev0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.record(ev1)
+    torch.cuda.synchronize()
+    dd.barrier()
+    wall = time.perf_counter() - t0
+    wall = dd.allreduce_max_scalar(wall, dev if world > 1 else None)
+    steps_total = args.steps * world
+    value = steps_total / wall
+    st1 = model.imp.stats
+    upd = max(1, st1['updates'] - st0['updates'])
+    counts = dict(proposals_per_iter=(st1['proposals'] - st0['proposals']) / args.steps,
+                  batches_per_update=(st1['batches'] - st0['batches']) / upd,
+                  llik_l1_per_iter=calls['l1'] / args.steps, llik_l2_per_iter=calls['l2'] / args.steps)
+
+    # ---- roofline of the dominant kernel: HIP events around each of its launches, same steps ----
+    roof = None
+    if rank == 0:
+        engines = [eng] + (list(model._pool[1]) if model._pool else [])
+        for e in engines:
+            e.prof_enable(args.prof_kernel)
+        for _ in range(max(1, min(2, args.steps))):
+            step()
+        tot_n, tot_ms, tot_w = 0, 0.0, 0.0
+        for e in engines:
+            k, ms, w = e.prof_collect()
+            tot_n, tot_ms, tot_w = tot_n + k, tot_ms + ms, tot_w + w
+        if tot_n:
+            if args.prof_kernel == 'kmatrix':
+                ach = tot_w / (tot_ms * 1e-3) / 1e9
+                roof = dict(bound='hbm', kernel='kmatrix_kernel', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
+                            frac=ach / HBM_PEAK_GBS, traffic=None)
+            else:
+                ach = tot_w / (tot_ms * 1e-3) / 1e12
+                roof = dict(bound='mfma', kernel='tile_gemm_kernel<%s>' % args.prof_kernel, achieved=ach,
+                            peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None)
+            roof.update(launches=tot_n, avg_launch_us=1e3 * tot_ms / tot_n, work_per_launch=tot_w / tot_n)
+    kernel_class.kernel.llik = orig_llik
+
+    # ---- prediction leg: emulator with the imputations sharded over the ranks --------------------
+    pred = None
+    if not args.no_predict:
+        from dgp_amd import emulator
+        model.N = max(model.N, 1)
+        for layer in model.all_layer:
+            for nd in layer:
+                nd.engine = eng
+        est = model.estimate(burnin=0)
+        emu = emulator(est, N=args.imputations, seed=7, device=local)
+        xt = np.random.default_rng(5).uniform(size=(args.predict_points, args.d))
+        emu.predict(xt[:32])   # builds the per-imputation statistics + warms the kernels
+        dd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mu, var = emu.predict(xt)
+        torch.cuda.synchronize()
+        dd.barrier()
+        tp = dd.allreduce_max_scalar(time.perf_counter() - t0, dev if world > 1 else None)
+        pred = dict(points=args.predict_points, imputations=args.imputations, seconds=tp,
+                    pts_per_s=args.predict_points / tp, finite=bool(np.all(np.isfinite(mu)) and np.all(np.isfinite(var))))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model, counts, args.ess_burn)
+
+    if rank == 0:
+        out = {
+            'metric': 'SI iterations/sec (train) + predict pts/sec, 2-layer DGP n=2000 d=5',
+            'value': value, 'unit': 'SI it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * wall / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: 2-layer DGP, d=%d in / 1 out, n=%d, Matern-2.5, %d+1 GP nodes, '
+                                   'train(ess_burn=%d): one step = one SI iteration' % (args.d, args.n, args.d, args.ess_burn),
+                       'parallelism': 'replicas x%d (SI chain does not shard); predict: imputations sharded, 1 all-reduce' % world},
+            'predict': pred, 'counts': counts, 'roofline': roof, 'cpu_baseline': cpu,
+            'speedup_vs_cpu_baseline': (value / world / cpu['value']) if cpu else None,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

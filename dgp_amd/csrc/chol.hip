@@ -289,13 +289,20 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     g.A = A; g.B = nullptr; g.ws = ws; g.ld = Np; g.stride_a = stride_a; g.stride_ws = stride_ws;
     g.n = n; g.nbk = nbk; g.k = 0; g.s = 0;
     for (int k = 0; k < nbk; ++k) {
+        PROF_BEGIN(ctx, PROF_POTRF_DIAG, (double)batch * (64.0 * 64.0 * 64.0));   // potrf n^3/3 + inverse 2n^3/3... = n^3 at n=64
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, ctx->stream, A, Np, stride_a, k, n, ws,
                            stride_ws, logdet, info);
+        PROF_END(ctx, PROF_POTRF_DIAG);
         const int m = nbk - k - 1;
         if (m > 0 && (int64_t)k * 64 < n) {
             g.k = k;
+            const double tile_flops = 2.0 * 64.0 * 64.0 * 64.0;
+            PROF_BEGIN(ctx, PROF_TRSM, (double)batch * m * tile_flops);
             hipLaunchKernelGGL(tile_gemm_kernel<G_TRSM>, dim3(m, 1, batch), dim3(256), 0, ctx->stream, g);
+            PROF_END(ctx, PROF_TRSM);
+            PROF_BEGIN(ctx, PROF_SYRK, (double)batch * (m * (m + 1) / 2) * tile_flops);
             hipLaunchKernelGGL(tile_gemm_kernel<G_SYRK>, dim3(m * (m + 1) / 2, 1, batch), dim3(256), 0, ctx->stream, g);
+            PROF_END(ctx, PROF_SYRK);
         }
     }
     LAUNCH_CHECK(ctx);

@@ -10,12 +10,44 @@
 #define NB 64          // factorisation block / tile edge
 #define LDT 66         // LDS leading dimension of a 64-wide f64 tile (conflict-free ds_read_b64 fragments)
 
+#include <vector>
+
+// kernel classes for the launch-timing facility (dgpamd_prof_*)
+enum { PROF_NONE = 0, PROF_KMATRIX = 1, PROF_POTRF_DIAG = 2, PROF_TRSM = 3, PROF_SYRK = 4, PROF_TRTRI = 5,
+       PROF_LAUUM = 6, PROF_GRAD = 7, PROF_LINKGP_J = 8, PROF_GP_QUAD = 9 };
+
 struct dgpamd_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
     char err[512];
+    int prof_class;                                   // PROF_* being timed (0 = off)
+    double prof_work;                                 // algorithmic flops (or bytes) of the timed launches
+    std::vector<hipEvent_t> prof_events;              // start/stop pairs
 };
+
+// bracket one launch with HIP events on the launching stream when its class is being timed
+#define PROF_BEGIN(ctx, cls, work)                                            \
+    do {                                                                      \
+        if ((ctx)->prof_class == (cls)) {                                     \
+            hipEvent_t e0__;                                                  \
+            if (hipEventCreate(&e0__) == hipSuccess) {                        \
+                (void)hipEventRecord(e0__, (ctx)->stream);                    \
+                (ctx)->prof_events.push_back(e0__);                           \
+                (ctx)->prof_work += (double)(work);                           \
+            }                                                                 \
+        }                                                                     \
+    } while (0)
+#define PROF_END(ctx, cls)                                                    \
+    do {                                                                      \
+        if ((ctx)->prof_class == (cls) && ((ctx)->prof_events.size() & 1)) {  \
+            hipEvent_t e1__;                                                  \
+            if (hipEventCreate(&e1__) == hipSuccess) {                        \
+                (void)hipEventRecord(e1__, (ctx)->stream);                    \
+                (ctx)->prof_events.push_back(e1__);                           \
+            }                                                                 \
+        }                                                                     \
+    } while (0)
 
 #define HIP_TRY(ctx, expr)                                                                         \
     do {                                                                                           \

@@ -18,6 +18,8 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     if (!ctx) return DGPAMD_HIP_ERROR;
     ctx->device = device;
     ctx->err[0] = 0;
+    ctx->prof_class = PROF_NONE;
+    ctx->prof_work = 0.0;
     // NULL = the device's default (null) stream, which is also torch's default current stream
     ctx->stream = (hipStream_t)stream;
     ctx->own_stream = false;
@@ -64,5 +66,35 @@ extern "C" int dgpamd_event_elapsed_ms(dgpamd_ctx *ctx, void *start, void *stop,
 extern "C" int dgpamd_event_destroy(dgpamd_ctx *ctx, void *ev) {
     if (!ctx || !ev) return DGPAMD_BAD_ARG;
     HIP_TRY(ctx, hipEventDestroy((hipEvent_t)ev));
+    return DGPAMD_OK;
+}
+
+// ---- launch timing of one kernel class (bench.py: roofline of the dominant kernel) -----------------
+extern "C" int dgpamd_prof_enable(dgpamd_ctx *ctx, int kernel_class) {
+    if (!ctx || kernel_class < 0 || kernel_class > PROF_GP_QUAD) return DGPAMD_BAD_ARG;
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    ctx->prof_events.clear();
+    ctx->prof_work = 0.0;
+    ctx->prof_class = kernel_class;
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_prof_collect(dgpamd_ctx *ctx, int64_t *launches_h, double *total_ms_h, double *work_h) {
+    if (!ctx || !launches_h || !total_ms_h || !work_h) return DGPAMD_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    const size_t pairs = ctx->prof_events.size() / 2;
+    for (size_t i = 0; i < pairs; ++i) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+        total += ms;
+    }
+    *launches_h = (int64_t)pairs;
+    *total_ms_h = total;
+    *work_h = ctx->prof_work;
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    ctx->prof_events.clear();
+    ctx->prof_work = 0.0;
+    ctx->prof_class = PROF_NONE;
     return DGPAMD_OK;
 }

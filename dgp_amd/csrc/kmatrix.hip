@@ -110,10 +110,13 @@ int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch) {
     int ntiles = nbk * (nbk + 1) / 2;
     size_t shm = (size_t)2 * D * 64 * sizeof(double);
     dim3 grid(ntiles, 1, batch);
+    // algorithmic bytes: the stored triangle(s) of K (8 n^2, or 4 n^2 for the lower tiles) + X once
+    PROF_BEGIN(ctx, PROF_KMATRIX, (double)batch * ((a.full ? 8.0 : 4.0) * (double)rows * (double)rows + 8.0 * (double)a.n * D));
     if (a.kp.kind == DGPAMD_SEXP)
         hipLaunchKernelGGL(kmatrix_kernel<DGPAMD_SEXP>, grid, dim3(256), shm, ctx->stream, a);
     else
         hipLaunchKernelGGL(kmatrix_kernel<DGPAMD_MATERN25>, grid, dim3(256), shm, ctx->stream, a);
+    PROF_END(ctx, PROF_KMATRIX);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }

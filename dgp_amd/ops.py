@@ -102,6 +102,17 @@ class Engine:
         self._chk(lib.dgpamd_event_elapsed_ms(self.h, start, stop, C.byref(ms)))
         return float(ms.value)
 
+    PROF = dict(kmatrix=1, potrf_diag=2, trsm=3, syrk=4, trtri=5, lauum=6, grad=7, linkgp_j=8, gp_quad=9)
+
+    def prof_enable(self, name):
+        self._chk(lib.dgpamd_prof_enable(self.h, self.PROF[name] if name else 0))
+
+    def prof_collect(self):
+        """(launches, total_ms, algorithmic work) of the launches timed since prof_enable."""
+        n, ms, w = C.c_int64(), C.c_double(), C.c_double()
+        self._chk(lib.dgpamd_prof_collect(self.h, C.byref(n), C.byref(ms), C.byref(w)))
+        return int(n.value), float(ms.value), float(w.value)
+
     # --------------------------------------------------------------- kernels
     @staticmethod
     def _colmap(colmap, Dl):

@@ -68,6 +68,13 @@ int dgpamd_event_record(dgpamd_ctx *ctx, void *ev);
 int dgpamd_event_elapsed_ms(dgpamd_ctx *ctx, void *start, void *stop, float *ms_h); /* syncs on stop */
 int dgpamd_event_destroy(dgpamd_ctx *ctx, void *ev);
 
+/* Launch timing of ONE kernel class with HIP events on the launching stream (bench.py's roofline):
+ * classes 1 kmatrix, 2 potrf diagonal block, 3 panel TRSM, 4 trailing SYRK, 5 trtri, 6 lauum,
+ * 7 grad_reduce, 8 linked-GP J, 9 gp quadratic form.  collect() syncs and returns the number of
+ * timed launches, their summed duration and their summed algorithmic work (flops; bytes for 1). */
+int dgpamd_prof_enable(dgpamd_ctx *ctx, int kernel_class);
+int dgpamd_prof_collect(dgpamd_ctx *ctx, int64_t *launches_h, double *total_ms_h, double *work_h);
+
 /* ---- a1/a2  kernel-matrix assembly ---------------------------------------
  * kernel.k_matrix()  kernel_class.py:304-359 (pdist/squareform + functions.py:16-34).
  * X = [Xloc[:, colmap] | Xglob]: Xloc is (n x ldloc) with batch stride

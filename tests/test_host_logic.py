@@ -1,0 +1,127 @@
+"""Host logic that needs no GPU: the speculative-proposal bookkeeping of the device imputer equals
+the sequential ESS loop (imputation.py:81-119), draw streams, sharding arithmetic, the 2-rank gloo
+moment reduction."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import dgp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_speculative_angles_equal_sequential():
+    from dgp_amd.imputation import shrink, speculative_angles, TWO_PI
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        u = rng.random(12)
+        ref = O.ess_angles(u)
+        theta = TWO_PI * u[0]
+        th, br = speculative_angles(theta, theta - TWO_PI, theta, u[1:])
+        np.testing.assert_array_equal(np.array(th), ref)      # bit-exact: same expressions
+        # continuing from the bracket after a fully rejected batch reproduces the tail
+        th5, br5 = speculative_angles(theta, theta - TWO_PI, theta, u[1:5])
+        t, lo, hi = shrink(th5[-1], *br5[-1], u[5])
+        assert t == ref[5]
+
+
+def sequential_reference(ll_fun, log_y, u):
+    """imputation.py:85-119 with injected uniforms; returns (accepted index, uniforms consumed)."""
+    th = O.ess_angles(u)
+    for i, t in enumerate(th):
+        if ll_fun(t) > log_y:
+            return i, i + 1   # theta0's uniform + one per rejection
+    raise RuntimeError
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 8])
+def test_batched_acceptance_consumes_like_sequential(B):
+    """Emulate one_sample_block's control flow on the host with a synthetic log-likelihood."""
+    from dgp_amd.imputation import DrawStream, shrink, speculative_angles, TWO_PI
+    rng = np.random.default_rng(B)
+    for trial in range(40):
+        u = rng.random(40)
+        ll = lambda t: -abs(np.sin(3 * t)) * 5.0 * (1 + trial % 3)   # ll(0) = 0 > log_y: the bracket always ends in acceptance
+        log_y = -1.0
+        idx, used = sequential_reference(ll, log_y, u)
+        ds = DrawStream(z=[], u=list(u))
+        theta = TWO_PI * ds.uniform_take(1)[0]
+        lo, hi = theta - TWO_PI, theta
+        consumed_before = 40 - len(ds._ubuf)
+        found = None
+        base = 0
+        while found is None:
+            us = ds.uniform_peek(B - 1)
+            th, br = speculative_angles(theta, lo, hi, us)
+            for b, t in enumerate(th):
+                if ll(t) > log_y:
+                    ds.uniform_take(b)
+                    found = base + b
+                    break
+            else:
+                ds.uniform_take(len(th) - 1)
+                base += len(th)
+                theta, (lo, hi) = th[-1], br[-1]
+                theta, lo, hi = shrink(theta, lo, hi, ds.uniform_take(1)[0])
+        assert found == idx
+        assert 40 - len(ds._ubuf) == used
+
+
+def test_drawstream_streams_are_independent_and_reproducible():
+    from dgp_amd.imputation import DrawStream
+    a, b = DrawStream(5), DrawStream(5)
+    a.uniform_peek(7)                       # look-ahead must not disturb the normal stream
+    np.testing.assert_array_equal(a.normal(4), b.normal(4))
+    assert a.uniform_take(3) == b.uniform_take(3)
+    c = DrawStream(6)
+    assert c.uniform_take(1) != DrawStream(5).uniform_take(1)
+
+
+def test_share_partitions_exactly():
+    from dgp_amd.dist import share
+    for total in (0, 1, 7, 10, 50):
+        for w in (1, 2, 3, 8):
+            parts = [share(total, r, w) for r in range(w)]
+            assert sum(parts) == total and max(parts) - min(parts) <= 1
+
+
+def test_gloo_two_rank_moment_reduction(tmp_path):
+    """world_size 2 over gloo: each rank accumulates its share of the reference's per-imputation
+    predictions (golden g9); one all-reduce(sum); equals emulation.py:846-847 on all imputations."""
+    script = tmp_path / 'worker.py'
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as td
+from dgp_amd import dist as dd
+dd.init_from_env('gloo')
+assert dd.is_active() and dd.world() == 2
+g = np.load(os.path.join(%r, 'tests', 'golden', 'g9_emulator_matern.npz'))
+mu_s, var_s = g['mu_s'], g['var_s']
+S = len(mu_s)
+lo = sum(dd.share(S, r, 2) for r in range(dd.rank()))
+cnt = dd.share(S, dd.rank(), 2)
+s1 = torch.zeros(mu_s[0].shape, dtype=torch.float64); s2 = torch.zeros_like(s1)
+for s in range(lo, lo + cnt):
+    s1 += torch.from_numpy(mu_s[s]); s2 += torch.from_numpy(mu_s[s] ** 2 + var_s[s])
+dd.allreduce_sum(s1, s2)
+mu = s1 / S; var = s2 / S - mu ** 2
+t = dd.allreduce_max_scalar(float(dd.rank()))
+assert t == 1.0
+np.testing.assert_allclose(mu.numpy(), g['mu'], rtol=1e-12, atol=1e-14)
+np.testing.assert_allclose(var.numpy(), g['var'], rtol=1e-9, atol=1e-14)
+dd.barrier()
+print('rank', dd.rank(), 'ok')
+''' % (ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', WORLD_SIZE='2')
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert 'ok' in o
