@@ -18,11 +18,24 @@
 // ----------------------------------------------------------------------------
 // diagonal block: Cholesky + inverse of the factor, in registers
 // ----------------------------------------------------------------------------
+__device__ __forceinline__ double rsqrt_f64(double d) {
+    // hardware estimate + two Newton steps (full f64); sqrt(d) is then d * rsqrt(d)
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    return y;
+}
+
+// The 64 pivots are taken FOUR at a time: the 4x4 pivot block is factored redundantly in every thread's
+// registers (that is the serial chain), the scaled 64x4 panel and the four finished rows of the running
+// inverse go through LDS once, and the trailing update is rank-4: two barriers per four pivots.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, int64_t stride_a, int k, int64_t n,
                                                          double *ws, int64_t stride_ws, double *logdet,
                                                          int32_t *info) {
-    __shared__ double colbuf[2][64];
-    __shared__ double rowbuf[2][64];
+    __shared__ double colraw[4][64];    // raw pivot columns j0..j0+3
+    __shared__ double rowraw[4][64];    // raw rows j0..j0+3 of the running inverse
+    __shared__ double panL[64][4];      // scaled panel  L[r][j0+u]
+    __shared__ double panY[64][4];      // finished rows Linv[j0+u][c]
     __shared__ double piv[64];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -45,52 +58,111 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, 
 
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
-        for (int jx = 0; jx < 16; ++jx) {
-            const int j = jb * 16 + jx;
-            if (j >= ncol) break;
-            const int cur = j & 1;
-            if (tx == jx) {
+        // in block jb only register rows p >= jb / columns q >= jb of A are live; inverse rows have columns q <= jb
+        for (int jq = 0; jq < 4; ++jq) {
+            const int j0 = jb * 16 + jq * 4;
+            if (j0 >= ncol) break;
+            const int nact = ncol - j0 >= 4 ? 4 : ncol - j0;   // active pivots of this panel
+            if ((tx >> 2) == jq) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) colbuf[cur][ty + 16 * p] = a[p][jb];
+                for (int p = jb; p < 4; ++p) colraw[tx & 3][ty + 16 * p] = a[p][jb];
             }
-            if (ty == jx) {
+            if ((ty >> 2) == jq) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rowbuf[cur][tx + 16 * q] = y[jb][q];
+                for (int q = 0; q <= jb; ++q) rowraw[ty & 3][tx + 16 * q] = y[jb][q];
             }
             __syncthreads();
-            double d = colbuf[cur][j];
-            if (!(d > 0.0)) {
-                if (!bad) bad = j + 1;
-                d = 1.0;
+            // ---- 4x4 pivot block, redundantly in every thread ----
+            double d00 = colraw[0][j0], d10 = colraw[0][j0 + 1], d20 = colraw[0][j0 + 2], d30 = colraw[0][j0 + 3];
+            double d11 = colraw[1][j0 + 1], d21 = colraw[1][j0 + 2], d31 = colraw[1][j0 + 3];
+            double d22 = colraw[2][j0 + 2], d32 = colraw[2][j0 + 3], d33 = colraw[3][j0 + 3];
+            if (!(d00 > 0.0)) { if (!bad) bad = j0 + 1; d00 = 1.0; }
+            const double i0 = rsqrt_f64(d00);
+            double L10 = d10 * i0, L20 = d20 * i0, L30 = d30 * i0;
+            double p1 = fma(-L10, L10, d11);
+            if (nact < 2) { p1 = 1.0; L10 = 0.0; }
+            if (!(p1 > 0.0)) { if (!bad) bad = j0 + 2; p1 = 1.0; }
+            const double i1 = rsqrt_f64(p1);
+            double L21 = fma(-L20, L10, d21) * i1, L31 = fma(-L30, L10, d31) * i1;
+            double p2 = fma(-L21, L21, fma(-L20, L20, d22));
+            if (nact < 3) { p2 = 1.0; L20 = 0.0; L21 = 0.0; }
+            if (!(p2 > 0.0)) { if (!bad) bad = j0 + 3; p2 = 1.0; }
+            const double i2 = rsqrt_f64(p2);
+            double L32 = fma(-L31, L21, fma(-L30, L20, d32)) * i2;
+            double p3 = fma(-L32, L32, fma(-L31, L31, fma(-L30, L30, d33)));
+            if (nact < 4) { p3 = 1.0; L30 = 0.0; L31 = 0.0; L32 = 0.0; }
+            if (!(p3 > 0.0)) { if (!bad) bad = j0 + 4; p3 = 1.0; }
+            const double i3 = rsqrt_f64(p3);
+            if (tid == 0) {
+                piv[j0] = d00;
+                if (nact > 1) piv[j0 + 1] = p1;
+                if (nact > 2) piv[j0 + 2] = p2;
+                if (nact > 3) piv[j0 + 3] = p3;
             }
-            const double sd = sqrt(d);
-            const double inv = 1.0 / sd;
-            double lr[4], lc[4], yj[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                lr[p] = colbuf[cur][ty + 16 * p] * inv;
-                lc[p] = colbuf[cur][tx + 16 * p] * inv;
-                yj[p] = rowbuf[cur][tx + 16 * p] * inv;
+            // ---- scaled panel (one row per thread) and finished inverse rows (one column per thread) ----
+            if (tid < 64) {
+                const int r = tid;
+                const double a0 = colraw[0][r], a1 = colraw[1][r], a2 = colraw[2][r], a3 = colraw[3][r];
+                const double x0 = a0 * i0;
+                const double x1 = nact > 1 ? fma(-x0, L10, a1) * i1 : 0.0;
+                const double x2 = nact > 2 ? fma(-x1, L21, fma(-x0, L20, a2)) * i2 : 0.0;
+                const double x3 = nact > 3 ? fma(-x2, L32, fma(-x1, L31, fma(-x0, L30, a3))) * i3 : 0.0;
+                panL[r][0] = x0; panL[r][1] = x1; panL[r][2] = x2; panL[r][3] = x3;
+            } else if (tid < 128) {
+                const int c = tid - 64;
+                const bool in = c < 16 * (jb + 1);
+                const double y0 = in ? rowraw[0][c] : 0.0, y1 = in ? rowraw[1][c] : 0.0;
+                const double y2 = in ? rowraw[2][c] : 0.0, y3 = in ? rowraw[3][c] : 0.0;
+                const double f0 = y0 * i0;
+                const double f1 = fma(-L10, f0, y1) * i1;
+                const double f2 = fma(-L21, f1, fma(-L20, f0, y2)) * i2;
+                const double f3 = fma(-L32, f2, fma(-L31, f1, fma(-L30, f0, y3))) * i3;
+                panY[c][0] = f0; panY[c][1] = f1; panY[c][2] = f2; panY[c][3] = f3;
             }
-            if (tid == 0) piv[j] = d;
+            __syncthreads();
+            // ---- rank-4 trailing update, assignment of the finished columns / inverse rows ----
+            double Lr[4][4], Lc[4][4], Yf[4][4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int r = ty + 16 * p;
+            for (int p = jb; p < 4; ++p)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = tx + 16 * q;
-                    if (r > j) {
-                        if (c > j) a[p][q] = fma(-lr[p], lc[q], a[p][q]);
-                        y[p][q] = fma(-lr[p], yj[q], y[p][q]);
-                    } else if (r == j) {
-                        y[p][q] = yj[q];
+                for (int u = 0; u < 4; ++u) {
+                    Lr[p][u] = panL[ty + 16 * p][u];
+                    Lc[p][u] = panL[tx + 16 * p][u];
+                }
+#pragma unroll
+            for (int q = 0; q <= jb; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Yf[q][u] = panY[tx + 16 * q][u];
+            const int ur = ty & 3, uc = tx & 3;
+#pragma unroll
+            for (int p = jb; p < 4; ++p) {
+                const bool below = (p > jb) || (ty >= 4 * jq + nact);            // row beyond the active pivots
+                const bool inblk = (p == jb) && ((ty >> 2) == jq) && (ur < nact); // row j0+ur of the pivot block
+#pragma unroll
+                for (int q = jb; q < 4; ++q) {
+                    const bool right = (q > jb) || (tx >= 4 * jq + nact);
+                    if (below && right) {
+                        double v = a[p][q];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v = fma(-Lr[p][u], Lc[q][u], v);
+                        a[p][q] = v;
                     }
                 }
-                if (tx == jx) {
-                    if (r > j)
-                        a[p][jb] = lr[p];
-                    else if (r == j)
-                        a[p][jb] = sd;
+#pragma unroll
+                for (int q = 0; q <= jb; ++q) {
+                    if (below) {
+                        double v = y[p][q];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v = fma(-Lr[p][u], Yf[q][u], v);
+                        y[p][q] = v;
+                    } else if (inblk) {
+                        y[p][q] = ur == 0 ? Yf[q][0] : (ur == 1 ? Yf[q][1] : (ur == 2 ? Yf[q][2] : Yf[q][3]));
+                    }
+                }
+                // finished column c = j0+uc: rows r >= c take the panel value (diagonal = sqrt(pivot))
+                if ((tx >> 2) == jq && uc < nact) {
+                    const bool onorbelow = below || (inblk && (ur >= uc));
+                    if (onorbelow) a[p][jb] = uc == 0 ? Lr[p][0] : (uc == 1 ? Lr[p][1] : (uc == 2 ? Lr[p][2] : Lr[p][3]));
                 }
             }
         }
