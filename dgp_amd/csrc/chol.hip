@@ -352,8 +352,8 @@ extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
     return potrf_ws_doubles(n, batch) * sizeof(double) + DGPAMD_MAXB * sizeof(int32_t);
 }
 
-int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
-              double *ws) {
+static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet,
+                          int32_t *info, double *ws) {
     const int64_t Np = padded_dim(n);
     const int nbk = (int)(Np / 64);
     const int64_t stride_ws = (int64_t)nbk * 4096;
@@ -379,6 +379,14 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     }
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
+}
+
+int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
+              double *ws) {
+    // 3 launches per 64-column block step with a static shape: replayed as one hipGraph
+    const std::array<uint64_t, 10> key = {1, (uint64_t)n, (uint64_t)batch, (uint64_t)A, (uint64_t)stride_a,
+                                          (uint64_t)logdet, (uint64_t)info, (uint64_t)ws, 0, 0};
+    return graph_run(ctx, key, [&]() { return potrf_launches(ctx, n, A, stride_a, batch, logdet, info, ws); });
 }
 
 extern "C" int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet,
@@ -413,11 +421,19 @@ extern "C" int dgpamd_trmv_lower(dgpamd_ctx *ctx, int64_t n, const double *L, in
     return DGPAMD_OK;
 }
 
+static int potri_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work);
+
 extern "C" int dgpamd_potri(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work) {
     if (!ctx) return DGPAMD_BAD_ARG;
     if (n <= 0 || !A || !Ainv || !work || r < 0) BAD_ARG(ctx, "null pointer or n <= 0");
     const int64_t Np = padded_dim(n);
     if (n + r > Np) BAD_ARG(ctx, "too many right-hand sides");
+    const std::array<uint64_t, 10> key = {2, (uint64_t)n, (uint64_t)r, (uint64_t)A, (uint64_t)Ainv, (uint64_t)work, 0, 0, 0, 0};
+    return graph_run(ctx, key, [&]() { return potri_launches(ctx, n, A, Ainv, r, work); });
+}
+
+static int potri_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work) {
+    const int64_t Np = padded_dim(n);
     const int nbk = (int)(Np / 64);
     GemmArgs g;
     g.A = A; g.B = Ainv; g.ws = (const double *)work; g.ld = Np; g.stride_a = 0; g.stride_ws = 0;

@@ -10,6 +10,8 @@
 #define NB 64          // factorisation block / tile edge
 #define LDT 66         // LDS leading dimension of a 64-wide f64 tile (conflict-free ds_read_b64 fragments)
 
+#include <array>
+#include <map>
 #include <vector>
 
 // kernel classes for the launch-timing facility (dgpamd_prof_*)
@@ -24,7 +26,60 @@ struct dgpamd_ctx {
     int prof_class;                                   // PROF_* being timed (0 = off)
     double prof_work;                                 // algorithmic flops (or bytes) of the timed launches
     std::vector<hipEvent_t> prof_events;              // start/stop pairs
+    int use_graphs;                                   // replay static launch sequences as hipGraphs
+    std::map<std::array<uint64_t, 10>, hipGraphExec_t> graphs;
 };
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,  \
+                     hipGetErrorString(e__));                                                      \
+            return DGPAMD_HIP_ERROR;                                                               \
+        }                                                                                          \
+    } while (0)
+
+#define LAUNCH_CHECK(ctx) HIP_TRY(ctx, hipGetLastError())
+
+#define BAD_ARG(ctx, msg)                                                     \
+    do {                                                                      \
+        snprintf((ctx)->err, sizeof((ctx)->err), "%s: %s", __func__, msg);    \
+        return DGPAMD_BAD_ARG;                                                \
+    } while (0)
+
+// Run `body` (a sequence of launches on ctx->stream with a static shape) through a cached hipGraph.
+// Falls back to direct launches on the null stream (not capturable), while a kernel class is being
+// timed, or if capture fails.
+template <typename F>
+static inline int graph_run(dgpamd_ctx *ctx, const std::array<uint64_t, 10> &key, F body) {
+    if (!ctx->use_graphs || ctx->stream == nullptr || ctx->prof_class != PROF_NONE) return body();
+    auto it = ctx->graphs.find(key);
+    if (it == ctx->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return body();
+        }
+        int rc = body();
+        hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        if (rc != DGPAMD_OK || e != hipSuccess || !graph) {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc != DGPAMD_OK ? rc : body();
+        }
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return body();
+        }
+        it = ctx->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(ctx, hipGraphLaunch(it->second, ctx->stream));
+    return DGPAMD_OK;
+}
 
 // bracket one launch with HIP events on the launching stream when its class is being timed
 #define PROF_BEGIN(ctx, cls, work)                                            \
@@ -49,23 +104,6 @@ struct dgpamd_ctx {
         }                                                                     \
     } while (0)
 
-#define HIP_TRY(ctx, expr)                                                                         \
-    do {                                                                                           \
-        hipError_t e__ = (expr);                                                                   \
-        if (e__ != hipSuccess) {                                                                   \
-            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,  \
-                     hipGetErrorString(e__));                                                      \
-            return DGPAMD_HIP_ERROR;                                                               \
-        }                                                                                          \
-    } while (0)
-
-#define LAUNCH_CHECK(ctx) HIP_TRY(ctx, hipGetLastError())
-
-#define BAD_ARG(ctx, msg)                                                     \
-    do {                                                                      \
-        snprintf((ctx)->err, sizeof((ctx)->err), "%s: %s", __func__, msg);    \
-        return DGPAMD_BAD_ARG;                                                \
-    } while (0)
 
 static inline int64_t padded_dim(int64_t n) { return ((n + 1 + NB - 1) / NB) * NB; }
 

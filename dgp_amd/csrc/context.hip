@@ -20,6 +20,7 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->err[0] = 0;
     ctx->prof_class = PROF_NONE;
     ctx->prof_work = 0.0;
+    ctx->use_graphs = 1;
     // NULL = the device's default (null) stream, which is also torch's default current stream
     ctx->stream = (hipStream_t)stream;
     ctx->own_stream = false;
@@ -29,6 +30,7 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
 
 extern "C" int dgpamd_destroy(dgpamd_ctx *ctx) {
     if (!ctx) return DGPAMD_BAD_ARG;
+    for (auto &kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return DGPAMD_OK;
@@ -96,5 +98,11 @@ extern "C" int dgpamd_prof_collect(dgpamd_ctx *ctx, int64_t *launches_h, double 
     ctx->prof_events.clear();
     ctx->prof_work = 0.0;
     ctx->prof_class = PROF_NONE;
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_set_graphs(dgpamd_ctx *ctx, int enable) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    ctx->use_graphs = enable ? 1 : 0;
     return DGPAMD_OK;
 }

@@ -36,7 +36,12 @@ class Engine:
             raise DgpAmdError('dgp_amd needs a HIP device: torch.cuda.is_available() is False and there is no CPU path')
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
-        self._torch_stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if stream is None:
+            # a dedicated side stream (hipGraph capture is illegal on the null stream); it becomes this
+            # thread's current torch stream so that torch's copies/allocator are ordered with our launches
+            stream = torch.cuda.Stream(self.device)
+            torch.cuda.set_stream(stream)
+        self._torch_stream = stream
         h = C.c_void_p()
         rc = lib.dgpamd_create(int(device), C.c_void_p(self._torch_stream.cuda_stream), C.byref(h))
         if rc != 0:
@@ -62,6 +67,9 @@ class Engine:
 
     def sync(self):
         self._chk(lib.dgpamd_sync(self.h))
+
+    def set_graphs(self, enable):
+        self._chk(lib.dgpamd_set_graphs(self.h, 1 if enable else 0))
 
     def stream(self):
         """Context manager making this engine's HIP stream torch's current stream (so that torch's

@@ -62,6 +62,11 @@ int dgpamd_sync(dgpamd_ctx *ctx);
 const char *dgpamd_version(void);
 int64_t dgpamd_padded_dim(int64_t n); /* Np for an n x n problem (>= n+1, multiple of 64) */
 
+/* Static launch sequences (the ~100 launches of one blocked factorisation / inverse) are captured once per
+ * (shape, buffers) and replayed as hipGraphs; enable = 0 turns that off (direct launches).  Graphs need a
+ * real stream: with the null stream the library always launches directly.                              */
+int dgpamd_set_graphs(dgpamd_ctx *ctx, int enable);
+
 /* Timing on the library's stream (bench.py: HIP events around the timed region). */
 int dgpamd_event_create(dgpamd_ctx *ctx, void **ev);
 int dgpamd_event_record(dgpamd_ctx *ctx, void *ev);
