@@ -27,6 +27,7 @@ struct dgpamd_ctx {
     double prof_work;                                 // algorithmic flops (or bytes) of the timed launches
     std::vector<hipEvent_t> prof_events;              // start/stop pairs
     int use_graphs;                                   // replay static launch sequences as hipGraphs
+    int linkgp_direct;                                // 1: evaluate the Matern J factor in the reference's direct form
     std::map<std::array<uint64_t, 10>, hipGraphExec_t> graphs;
 };
 

@@ -406,6 +406,193 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
         a.partial[(int64_t)blockIdx.x * a.Mc + (tbase - a.t0) + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
 }
 
+// Matern-2.5 J through the separable S/T form (linkfun.hpp): per (test point, dimension) the workgroup's 128
+// points get their role vectors in LDS (waves 0-1: S-role of 128 points, waves 2-3: T-role), then every pair
+// costs 30 FMAs (both orientations) and a select instead of 3 erf + 5 exp + ~300 flops.
+#define PST 30   // doubles per point record: S[0..11] T[12..26] f2[27] x[28]; stride 30 -> conflict-free column reads
+__global__ __launch_bounds__(256) void linkgp_Jsep_kernel(LinkArgs a) {
+    extern __shared__ double lds[];
+    const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
+    double *WiT = lds;                    // [DT][64]
+    double *WjT = WiT + DT * 64;          // [DT][64]
+    double *tm = WjT + DT * 64;           // [TCH][Dw]
+    double *tv = tm + TCH * Dw;
+    double *tz = tv + TCH * Dw;           // [TCH][Dz]
+    double *red = tz + TCH * Dz;          // [TCH][4]
+    double *PT = red + TCH * 4;           // [128][PST]
+    int bi, bj;
+    tri_decode(blockIdx.x, bi, bj);
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, wave = tid >> 6, lane = tid & 63;
+    const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
+    const int64_t tbase = a.t0 + (int64_t)blockIdx.y * TCH;
+    int nt = TCH;
+    if (tbase + nt > a.M) nt = (int)(a.M - tbase);
+    if (tbase + nt > a.t0 + a.Mc) nt = (int)(a.t0 + a.Mc - tbase);
+
+    for (int idx = tid; idx < 64 * DT; idx += 256) {
+        int row = idx / DT, d = idx - row * DT;
+        int64_t gi = i0 + row, gj = j0 + row;
+        double vi = 0.0, vj = 0.0;
+        if (d < Dw) {
+            if (gi < n) vi = a.W[gi * Dw + d];
+            if (gj < n) vj = a.W[gj * Dw + d];
+        } else {
+            if (gi < n) vi = a.Wg[gi * Dz + d - Dw];
+            if (gj < n) vj = a.Wg[gj * Dz + d - Dw];
+        }
+        WiT[d * 64 + row] = vi;
+        WjT[d * 64 + row] = vj;
+    }
+    for (int idx = tid; idx < nt * Dw; idx += 256) {
+        tm[idx] = a.m[tbase * Dw + idx];
+        tv[idx] = a.v[tbase * Dw + idx];
+    }
+    for (int idx = tid; idx < nt * Dz; idx += 256) tz[idx] = a.z[tbase * Dz + idx];
+    const double wt = (bi == bj) ? 1.0 : 2.0;
+    double Cr[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t gi = i0 + ty + 16 * p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t gj = j0 + tx + 16 * q;
+            Cr[p][q] = (gi < n && gj < n) ? wt * (a.ry[gi] * a.ry[gj] - a.scale * a.Rinv[gi * a.ldr + gj]) : 0.0;
+        }
+    }
+    const int pp = tid & 127, role = tid >> 7;
+    double *rec = PT + pp * PST;
+
+    for (int t = 0; t < nt; ++t) {
+        double prod[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) prod[p][q] = 1.0;
+#pragma unroll 1
+        for (int k = 0; k < Dw; ++k) {
+            const double l = a.len[k], zm = tm[t * Dw + k], zv = tv[t * Dw + k];
+            __syncthreads();   // the previous pair phase has finished reading PT
+            {
+                const double x = pp < 64 ? WiT[k * 64 + pp] : WjT[k * 64 + pp - 64];
+                if (zv != 0.0) {
+                    MaternDimConst kc;
+                    matern_dim_const(zm, zv, l, kc);
+                    if (role == 0) {
+                        double f2;
+                        matern_role_S(x, kc, rec, f2);
+                        rec[27] = f2;
+                        rec[28] = x;
+                    } else {
+                        matern_role_T(x, kc, rec + 12);
+                    }
+                } else {   // deterministic input in this dimension: J factor = k(x_i, m) k(x_j, m)  (functions.py:488-491)
+                    const double pt = matern_point(zm - x, l);
+                    if (role == 0) {
+                        rec[0] = pt;
+#pragma unroll
+                        for (int c = 1; c < 12; ++c) rec[c] = 0.0;
+                        rec[27] = 0.0;
+                        rec[28] = x;
+                    } else {
+                        rec[12] = pt;
+#pragma unroll
+                        for (int c = 13; c < 27; ++c) rec[c] = 0.0;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                double o1[4][2], o2[4][2], d1[4][2], d2[4][2];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) o1[p][q] = o2[p][q] = d1[p][q] = d2[p][q] = 0.0;
+                const double *Rr[4], *Rc[2];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) Rr[p] = PT + (ty + 16 * p) * PST;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) Rc[q] = PT + (64 + tx + 16 * (2 * h + q)) * PST;
+#pragma unroll 2
+                for (int c = 0; c < 12; ++c) {
+                    double Sr[4], Tr[4], Sc[2], Tc[2];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        Sr[p] = Rr[p][c];
+                        Tr[p] = Rr[p][12 + c];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        Sc[q] = Rc[q][c];
+                        Tc[q] = Rc[q][12 + c];
+                    }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            o1[p][q] = fma(Sr[p], Tc[q], o1[p][q]);
+                            o2[p][q] = fma(Sc[q], Tr[p], o2[p][q]);
+                        }
+                }
+#pragma unroll 1
+                for (int c = 0; c < 3; ++c) {
+                    double Sr[4], Tr[4], Sc[2], Tc[2];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        Sr[p] = Rr[p][6 + c];
+                        Tr[p] = Rr[p][24 + c];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        Sc[q] = Rc[q][6 + c];
+                        Tc[q] = Rc[q][24 + c];
+                    }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            d1[p][q] = fma(Sr[p], Tc[q], d1[p][q]);
+                            d2[p][q] = fma(Sc[q], Tr[p], d2[p][q]);
+                        }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const double f2r = Rr[p][27], xr = Rr[p][28];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const double f2c = Rc[q][27], xc = Rc[q][28];
+                        const double jd = (xr <= xc) ? fma(f2c - f2r, d1[p][q], o1[p][q]) : fma(f2r - f2c, d2[p][q], o2[p][q]);
+                        if (h == 0) prod[p][q] *= jd; else prod[p][2 + q] *= jd;
+                    }
+                }
+            }
+        }
+        // deterministic global inputs: separable Matern factor (functions.py:413-420)
+        double gi_[4], gj_[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            double pi_ = 1.0, si = 0.0, pj = 1.0, sj = 0.0;
+            for (int g = 0; g < Dz; ++g) {
+                const double il = 1.0 / a.len[Dw + g], zz = tz[t * Dz + g];
+                corr_accum_matern((WiT[(Dw + g) * 64 + ty + 16 * p] - zz) * il, pi_, si);
+                corr_accum_matern((WjT[(Dw + g) * 64 + tx + 16 * p] - zz) * il, pj, sj);
+            }
+            gi_[p] = Dz ? pi_ * exp(-SQRT5 * si) : 1.0;
+            gj_[p] = Dz ? pj * exp(-SQRT5 * sj) : 1.0;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = fma(Cr[p][q], prod[p][q] * gi_[p] * gj_[q], acc);
+        acc = wave_sum_p(acc);
+        if (lane == 0) red[t * 4 + wave] = acc;
+    }
+    __syncthreads();
+    if (tid < nt)
+        a.partial[(int64_t)blockIdx.x * a.Mc + (tbase - a.t0) + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void linkgp_finalize_kernel(LinkArgs a, int ntiles) {
     const int64_t tt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -464,7 +651,16 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
             hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_SEXP>, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, a, ntiles);
         } else {
             hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_MATERN25>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_MATERN25>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            if (ctx->linkgp_direct) {
+                hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_MATERN25>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            } else {
+                const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)TCH * (2 * Dw + Dz) + TCH * 4 + 128 * PST) * sizeof(double);
+                if (shm_sep > 48 * 1024)
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_sep));
+                PROF_BEGIN(ctx, PROF_LINKGP_J, (double)mc * (double)n * (double)n * 0.5 * Dw * 30.0 * 2.0);
+                hipLaunchKernelGGL(linkgp_Jsep_kernel, dim3(ntiles, tb), dim3(256), shm_sep, ctx->stream, a);
+                PROF_END(ctx, PROF_LINKGP_J);
+            }
             hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_MATERN25>, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, a, ntiles);
         }
     }

@@ -68,6 +68,10 @@ class Engine:
     def sync(self):
         self._chk(lib.dgpamd_sync(self.h))
 
+    def set_linkgp_direct(self, enable):
+        """Matern linked-GP J factor: reference's direct expression (True) or its separable form (default)."""
+        self._chk(lib.dgpamd_set_linkgp_direct(self.h, 1 if enable else 0))
+
     def set_graphs(self, enable):
         self._chk(lib.dgpamd_set_graphs(self.h, 1 if enable else 0))
 

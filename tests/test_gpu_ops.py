@@ -181,7 +181,10 @@ def test_trmv_is_fmvn(eng, golden):
 
 
 # ---------------------------------------------------------------- a10-a14
-def test_gp_and_linkgp_golden(eng, golden):
+@pytest.mark.parametrize('direct', [False, True])
+def test_gp_and_linkgp_golden(eng, golden, direct):
+    """direct=True: the Matern J factor in the reference's own expression order; False: its separable form."""
+    eng.set_linkgp_direct(direct)
     g = golden('g7_predict')
     for c in range(int(g['n_cases'])):
         d = case(g, 'c%d_' % c)
@@ -203,6 +206,36 @@ def test_gp_and_linkgp_golden(eng, golden):
         eng.sync()
         close(npy(lm), d['link_m'], rtol=1e-8, atol=1e-10)
         close(npy(lv), d['link_v'], rtol=1e-6, atol=1e-8)
+    eng.set_linkgp_direct(False)
+
+
+def test_linkgp_separable_equals_direct(eng):
+    """Same inputs through both evaluations of the Matern J factor, incl. tiny and zero input variances."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(21)
+    n, M, Dw, Dz = 130, 40, 4, 1
+    X = rng.uniform(size=(n, Dw + Dz))
+    y = rng.normal(size=n)
+    length = rng.uniform(0.3, 1.5, size=Dw + Dz)
+    st = O.compute_stats(X, y, length, 1e-4, 'matern2.5', Dw)
+    mm = rng.uniform(-0.2, 1.2, size=(M, Dw))
+    vv = 10.0 ** rng.uniform(-6, 0, size=(M, Dw))
+    vv[0] = 0.0
+    vv[1, 2] = 0.0
+    z = rng.uniform(size=(M, Dz))
+    args = (eng.tensor(mm), eng.tensor(vv), eng.tensor(z), eng.tensor(X[:, :Dw]), eng.tensor(X[:, Dw:]), length,
+            eng.tensor(st['Rinv']), n, eng.tensor(st['Rinv_y']), 1.3, 1e-4)
+    eng.set_linkgp_direct(True)
+    m1, v1 = eng.linkgp_predict('matern2.5', *args)
+    m1, v1 = npy(m1), npy(v1)
+    eng.set_linkgp_direct(False)
+    m2, v2 = eng.linkgp_predict('matern2.5', *args)
+    close(npy(m2), m1, rtol=1e-12, atol=1e-14)
+    close(npy(v2), v1, rtol=1e-6, atol=1e-8)
+    lmr, lvr = O.link_gp_predict(mm, vv, z, X[:, :Dw], X[:, Dw:], st['Rinv'], st['Rinv_y'], 1.3, length, 1e-4, 'matern2.5')
+    close(m1, lmr, rtol=1e-8, atol=1e-10)
+    close(v1, lvr, rtol=1e-6, atol=1e-8)
+    close(npy(v2), lvr, rtol=1e-6, atol=1e-8)
 
 
 @pytest.mark.parametrize('name', ['sexp', 'matern2.5'])
