@@ -54,7 +54,7 @@ SIGNATURES = {
     'dgpamd_grad_reduce': (_i, [_p, _i, _l, _p, _l, _p, _i, _p, _i, _p, _i, _d, _p, _i, _p, _p, _p]),
     'dgpamd_gp_workspace': (_z, [_l, _l]),
     'dgpamd_gp_predict': (_i, [_p, _i, _l, _l, _i, _p, _p, _p, _i, _p, _l, _p, _i, _d, _d, _p, _p, _p]),
-    'dgpamd_linkgp_workspace': (_z, [_l, _l]),
+    'dgpamd_linkgp_workspace': (_z, [_l, _l, _i]),
     'dgpamd_linkgp_predict': (_i, [_p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p, _d, _d, _p, _p, _p]),
     'dgpamd_moments_accumulate': (_i, [_p, _l, _p, _p, _p, _p]),
     'dgpamd_moments_finalize': (_i, [_p, _l, _d, _p, _p]),

@@ -204,6 +204,8 @@ struct LinkArgs {
     const double *ry;
     double scale, nugget;
     double *partial;   // [ntiles][Mc]
+    double *recs;      // [Mc][Dw][npad][REC] separable Matern records (linkgp_Jsep)
+    int64_t npad;
     double *mean, *var;
 };
 
@@ -406,23 +408,68 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
         a.partial[(int64_t)blockIdx.x * a.Mc + (tbase - a.t0) + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
 }
 
-// Matern-2.5 J through the separable S/T form (linkfun.hpp): per (test point, dimension) the workgroup's 128
-// points get their role vectors in LDS (waves 0-1: S-role of 128 points, waves 2-3: T-role), then every pair
-// costs 30 FMAs (both orientations) and a select instead of 3 erf + 5 exp + ~300 flops.
-#define PST 30   // doubles per point record: S[0..11] T[12..26] f2[27] x[28]; stride 30 -> conflict-free column reads
+// Matern-2.5 J through the separable S/T form (linkfun.hpp).
+//   matern_records_kernel : once per (test point, dimension, training point): S[0..11] T[12..26] f2[27]  (REC = 28)
+//   linkgp_Jsep_kernel    : one WG per (lower 64x64 tile of C) x (chunk of TCH test points); per (t, k) the 128
+//                           records of its two point blocks are streamed global -> registers -> LDS one step
+//                           ahead of the pair phase; every pair costs 30 FMAs (both orientations) and a select
+//                           instead of 3 erf + 5 exp + ~300 flops.  The grid runs tiles fastest so that a
+//                           test-chunk's records (TCH*Dw*n*224 B) are re-read from the Infinity Cache.
+#define REC 28
+#define PST 30   // LDS stride of a record (+x at [28]); stride 30 doubles -> conflict-free column reads
+#define MC_SEP 256
+
+__global__ __launch_bounds__(256) void matern_records_kernel(LinkArgs a) {
+    const int tid = threadIdx.x, pp = tid & 127, role = tid >> 7;
+    const int64_t i = (int64_t)blockIdx.x * 128 + pp;
+    const int k = blockIdx.y;
+    const int64_t tt = blockIdx.z, t = a.t0 + tt;
+    if (i >= a.npad || t >= a.M) return;
+    const double x = i < a.n ? a.W[i * a.Dw + k] : 0.0;
+    const double l = a.len[k], zm = a.m[t * a.Dw + k], zv = a.v[t * a.Dw + k];
+    double *rec = a.recs + ((tt * a.Dw + k) * a.npad + i) * REC;
+    if (zv != 0.0) {
+        MaternDimConst kc;
+        matern_dim_const(zm, zv, l, kc);
+        if (role == 0) {
+            double f2;
+            double out[12];
+            matern_role_S(x, kc, out, f2);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) rec[c] = out[c];
+            rec[27] = f2;
+        } else {
+            double out[15];
+            matern_role_T(x, kc, out);
+#pragma unroll
+            for (int c = 0; c < 15; ++c) rec[12 + c] = out[c];
+        }
+    } else {   // deterministic input in this dimension: J factor = k(x_i, m) k(x_j, m)  (functions.py:488-491)
+        const double pt = matern_point(zm - x, l);
+        if (role == 0) {
+            rec[0] = pt;
+#pragma unroll
+            for (int c = 1; c < 12; ++c) rec[c] = 0.0;
+            rec[27] = 0.0;
+        } else {
+            rec[12] = pt;
+#pragma unroll
+            for (int c = 13; c < 27; ++c) rec[c] = 0.0;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void linkgp_Jsep_kernel(LinkArgs a) {
     extern __shared__ double lds[];
     const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
     double *WiT = lds;                    // [DT][64]
     double *WjT = WiT + DT * 64;          // [DT][64]
-    double *tm = WjT + DT * 64;           // [TCH][Dw]
-    double *tv = tm + TCH * Dw;
-    double *tz = tv + TCH * Dw;           // [TCH][Dz]
+    double *tz = WjT + DT * 64;           // [TCH][Dz]
     double *red = tz + TCH * Dz;          // [TCH][4]
     double *PT = red + TCH * 4;           // [128][PST]
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
     const int64_t tbase = a.t0 + (int64_t)blockIdx.y * TCH;
     int nt = TCH;
@@ -443,148 +490,113 @@ __global__ __launch_bounds__(256) void linkgp_Jsep_kernel(LinkArgs a) {
         WiT[d * 64 + row] = vi;
         WjT[d * 64 + row] = vj;
     }
-    for (int idx = tid; idx < nt * Dw; idx += 256) {
-        tm[idx] = a.m[tbase * Dw + idx];
-        tv[idx] = a.v[tbase * Dw + idx];
-    }
     for (int idx = tid; idx < nt * Dz; idx += 256) tz[idx] = a.z[tbase * Dz + idx];
+    // MFMA accumulator layout of the 64x64 tile: wave w owns rows 16w..16w+15; element (tile tt, reg r) of a lane is
+    // row 16w + (lane>>4) + 4r, column 16tt + (lane&15)  (v_mfma_f64_16x16x4_f64 C/D map).
+    const int mrow = 16 * wave + (lane >> 4), mcol = lane & 15, kq = lane >> 4, mi = lane & 15;
     const double wt = (bi == bj) ? 1.0 : 2.0;
-    double Cr[4][4];
+    d4 Cr[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int64_t gi = i0 + ty + 16 * p;
+    for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t gj = j0 + tx + 16 * q;
-            Cr[p][q] = (gi < n && gj < n) ? wt * (a.ry[gi] * a.ry[gj] - a.scale * a.Rinv[gi * a.ldr + gj]) : 0.0;
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = i0 + mrow + 4 * r, gj = j0 + 16 * tt + mcol;
+            Cr[tt][r] = (gi < n && gj < n) ? wt * (a.ry[gi] * a.ry[gj] - a.scale * a.Rinv[gi * a.ldr + gj]) : 0.0;
         }
-    }
-    const int pp = tid & 127, role = tid >> 7;
-    double *rec = PT + pp * PST;
+    // streaming of the 2 x 64 records of step (t, k): 1792 double2, 7 per thread
+    double2 pre[7];
+    auto fetch = [&](int t, int k) {
+        const double *base = a.recs + (((tbase - a.t0) + t) * Dw + k) * a.npad * REC;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int e = tid + 256 * u;
+            const int half = e >= 896, r = (e - half * 896) / 14, w = (e - half * 896) - r * 14;
+            const int64_t pt = (half ? j0 : i0) + r;
+            pre[u] = *reinterpret_cast<const double2 *>(base + pt * REC + 2 * w);
+        }
+    };
+    auto stash = [&](int k) {
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int e = tid + 256 * u;
+            const int half = e >= 896, r = (e - half * 896) / 14, w = (e - half * 896) - r * 14;
+            double *d = PT + (half * 64 + r) * PST + 2 * w;
+            d[0] = pre[u].x;
+            d[1] = pre[u].y;
+        }
+        if (tid < 128) PT[tid * PST + 28] = tid < 64 ? WiT[k * 64 + tid] : WjT[k * 64 + tid - 64];
+    };
+    __syncthreads();
+    if (nt > 0) fetch(0, 0);
 
+    const double *Arow = PT + (16 * wave + mi) * PST;   // this lane's row record as an MFMA A operand (i = lane&15)
     for (int t = 0; t < nt; ++t) {
-        double prod[4][4];
+        d4 prod[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) prod[p][q] = 1.0;
+        for (int tt = 0; tt < 4; ++tt) prod[tt] = (d4){1.0, 1.0, 1.0, 1.0};
 #pragma unroll 1
         for (int k = 0; k < Dw; ++k) {
-            const double l = a.len[k], zm = tm[t * Dw + k], zv = tv[t * Dw + k];
             __syncthreads();   // the previous pair phase has finished reading PT
-            {
-                const double x = pp < 64 ? WiT[k * 64 + pp] : WjT[k * 64 + pp - 64];
-                if (zv != 0.0) {
-                    MaternDimConst kc;
-                    matern_dim_const(zm, zv, l, kc);
-                    if (role == 0) {
-                        double f2;
-                        matern_role_S(x, kc, rec, f2);
-                        rec[27] = f2;
-                        rec[28] = x;
-                    } else {
-                        matern_role_T(x, kc, rec + 12);
-                    }
-                } else {   // deterministic input in this dimension: J factor = k(x_i, m) k(x_j, m)  (functions.py:488-491)
-                    const double pt = matern_point(zm - x, l);
-                    if (role == 0) {
-                        rec[0] = pt;
-#pragma unroll
-                        for (int c = 1; c < 12; ++c) rec[c] = 0.0;
-                        rec[27] = 0.0;
-                        rec[28] = x;
-                    } else {
-                        rec[12] = pt;
-#pragma unroll
-                        for (int c = 13; c < 27; ++c) rec[c] = 0.0;
-                    }
-                }
-            }
+            stash(k);
             __syncthreads();
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
-                double o1[4][2], o2[4][2], d1[4][2], d2[4][2];
+            {   // issue the loads of the next step before computing on this one
+                int k2 = k + 1, t2 = t;
+                if (k2 == Dw) { k2 = 0; ++t2; }
+                if (t2 < nt) fetch(t2, k2);
+            }
+            // A fragments (rows): S[0..11] and T[0..11] in three k-steps each, the erf-difference pair in one (k=3 padded with 0)
+            double aS[3], aT[3];
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+            for (int ks = 0; ks < 3; ++ks) {
+                aS[ks] = Arow[4 * ks + kq];
+                aT[ks] = Arow[12 + 4 * ks + kq];
+            }
+            const double aSd = kq < 3 ? Arow[6 + kq] : 0.0, aTd = kq < 3 ? Arow[24 + kq] : 0.0;
+            double f2r[4], xr[4];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) o1[p][q] = o2[p][q] = d1[p][q] = d2[p][q] = 0.0;
-                const double *Rr[4], *Rc[2];
+            for (int r = 0; r < 4; ++r) {
+                f2r[r] = PT[(mrow + 4 * r) * PST + 27];
+                xr[r] = PT[(mrow + 4 * r) * PST + 28];
+            }
 #pragma unroll
-                for (int p = 0; p < 4; ++p) Rr[p] = PT + (ty + 16 * p) * PST;
+            for (int tt = 0; tt < 4; ++tt) {
+                const double *Bcol = PT + (64 + 16 * tt + mi) * PST;   // column record as an MFMA B operand (j = lane&15)
+                d4 o1 = {0.0, 0.0, 0.0, 0.0}, o2 = o1, e1 = o1, e2 = o1;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) Rc[q] = PT + (64 + tx + 16 * (2 * h + q)) * PST;
-#pragma unroll 2
-                for (int c = 0; c < 12; ++c) {
-                    double Sr[4], Tr[4], Sc[2], Tc[2];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        Sr[p] = Rr[p][c];
-                        Tr[p] = Rr[p][12 + c];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        Sc[q] = Rc[q][c];
-                        Tc[q] = Rc[q][12 + c];
-                    }
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            o1[p][q] = fma(Sr[p], Tc[q], o1[p][q]);
-                            o2[p][q] = fma(Sc[q], Tr[p], o2[p][q]);
-                        }
+                for (int ks = 0; ks < 3; ++ks) {
+                    o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[ks], Bcol[12 + 4 * ks + kq], o1, 0, 0, 0);   // S_row . T_col
+                    o2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[ks], Bcol[4 * ks + kq], o2, 0, 0, 0);        // T_row . S_col
                 }
-#pragma unroll 1
-                for (int c = 0; c < 3; ++c) {
-                    double Sr[4], Tr[4], Sc[2], Tc[2];
+                e1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aSd, kq < 3 ? Bcol[24 + kq] : 0.0, e1, 0, 0, 0);
+                e2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aTd, kq < 3 ? Bcol[6 + kq] : 0.0, e2, 0, 0, 0);
+                const double f2c = PT[(64 + 16 * tt + mcol) * PST + 27], xc = PT[(64 + 16 * tt + mcol) * PST + 28];
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        Sr[p] = Rr[p][6 + c];
-                        Tr[p] = Rr[p][24 + c];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        Sc[q] = Rc[q][6 + c];
-                        Tc[q] = Rc[q][24 + c];
-                    }
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            d1[p][q] = fma(Sr[p], Tc[q], d1[p][q]);
-                            d2[p][q] = fma(Sc[q], Tr[p], d2[p][q]);
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    const double jd = (xr[r] <= xc) ? fma(f2c - f2r[r], e1[r], o1[r]) : fma(f2r[r] - f2c, e2[r], o2[r]);
+                    prod[tt][r] *= jd;
                 }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const double f2r = Rr[p][27], xr = Rr[p][28];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const double f2c = Rc[q][27], xc = Rc[q][28];
-                        const double jd = (xr <= xc) ? fma(f2c - f2r, d1[p][q], o1[p][q]) : fma(f2r - f2c, d2[p][q], o2[p][q]);
-                        if (h == 0) prod[p][q] *= jd; else prod[p][2 + q] *= jd;
-                    }
-                }
+                __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: keeps the accumulators to 16 registers
             }
         }
         // deterministic global inputs: separable Matern factor (functions.py:413-420)
-        double gi_[4], gj_[4];
+        double gr[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            double pi_ = 1.0, si = 0.0, pj = 1.0, sj = 0.0;
-            for (int g = 0; g < Dz; ++g) {
-                const double il = 1.0 / a.len[Dw + g], zz = tz[t * Dz + g];
-                corr_accum_matern((WiT[(Dw + g) * 64 + ty + 16 * p] - zz) * il, pi_, si);
-                corr_accum_matern((WjT[(Dw + g) * 64 + tx + 16 * p] - zz) * il, pj, sj);
-            }
-            gi_[p] = Dz ? pi_ * exp(-SQRT5 * si) : 1.0;
-            gj_[p] = Dz ? pj * exp(-SQRT5 * sj) : 1.0;
+        for (int r = 0; r < 4; ++r) {
+            double pi_ = 1.0, si = 0.0;
+            for (int g = 0; g < Dz; ++g)
+                corr_accum_matern((WiT[(Dw + g) * 64 + mrow + 4 * r] - tz[t * Dz + g]) / a.len[Dw + g], pi_, si);
+            gr[r] = Dz ? pi_ * exp(-SQRT5 * si) : 1.0;
         }
         double acc = 0.0;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int tt = 0; tt < 4; ++tt) {
+            double pj = 1.0, sj = 0.0;
+            for (int g = 0; g < Dz; ++g)
+                corr_accum_matern((WjT[(Dw + g) * 64 + 16 * tt + mcol] - tz[t * Dz + g]) / a.len[Dw + g], pj, sj);
+            const double gc = Dz ? pj * exp(-SQRT5 * sj) : 1.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = fma(Cr[p][q], prod[p][q] * gi_[p] * gj_[q], acc);
+            for (int r = 0; r < 4; ++r) acc = fma(Cr[tt][r], prod[tt][r] * gr[r] * gc, acc);
+        }
         acc = wave_sum_p(acc);
         if (lane == 0) red[t * 4 + wave] = acc;
     }
@@ -609,11 +621,12 @@ __global__ __launch_bounds__(256) void linkgp_finalize_kernel(LinkArgs a, int nt
     a.var[t] = fabs(s - mu * mu + a.scale * (1.0 + a.nugget));
 }
 
-extern "C" size_t dgpamd_linkgp_workspace(int64_t n, int64_t M) {
+extern "C" size_t dgpamd_linkgp_workspace(int64_t n, int64_t M, int Dw) {
     int64_t nb = (n + 63) / 64;
     int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
     if (Mc > MC_MAX) Mc = MC_MAX;
-    return (size_t)(nb * (nb + 1) / 2 * Mc) * sizeof(double);
+    int64_t Ms = Mc > MC_SEP ? MC_SEP : Mc;
+    return (size_t)(nb * (nb + 1) / 2 * Mc + Ms * (int64_t)Dw * nb * 64 * REC) * sizeof(double);
 }
 
 extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz, const double *m,
@@ -636,8 +649,12 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
     a.partial = (double *)work;
     int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
     if (Mc > MC_MAX) Mc = MC_MAX;
-    a.Mc = Mc;
     const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
+    const bool sep = (kind == DGPAMD_MATERN25) && !ctx->linkgp_direct;
+    a.recs = a.partial + (int64_t)ntiles * Mc;
+    a.npad = (int64_t)nb * 64;
+    if (sep && Mc > MC_SEP) Mc = MC_SEP;   // records of one chunk: Mc*Dw*npad*224 B
+    a.Mc = Mc;
     const int DT = Dw + Dz;
     size_t shm = ((size_t)2 * DT * 64 + (size_t)TCH * (2 * Dw + Dz) + TCH * 4) * sizeof(double);
     if (kind == DGPAMD_MATERN25) shm += 64 * 65 * sizeof(double);
@@ -654,9 +671,10 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
             if (ctx->linkgp_direct) {
                 hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_MATERN25>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else {
-                const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)TCH * (2 * Dw + Dz) + TCH * 4 + 128 * PST) * sizeof(double);
+                const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)TCH * Dz + TCH * 4 + 128 * PST) * sizeof(double);
                 if (shm_sep > 48 * 1024)
                     HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_sep));
+                hipLaunchKernelGGL(matern_records_kernel, dim3((unsigned)((a.npad + 127) / 128), Dw, (unsigned)mc), dim3(256), 0, ctx->stream, a);
                 PROF_BEGIN(ctx, PROF_LINKGP_J, (double)mc * (double)n * (double)n * 0.5 * Dw * 30.0 * 2.0);
                 hipLaunchKernelGGL(linkgp_Jsep_kernel, dim3(ntiles, tb), dim3(256), shm_sep, ctx->stream, a);
                 PROF_END(ctx, PROF_LINKGP_J);

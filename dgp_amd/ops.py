@@ -257,7 +257,7 @@ class Engine:
         Dz = 0 if z is None else z.shape[1]
         n = Wtr.shape[0]
         length = _f64(length)
-        work = self.workspace(('link', n, M), lib.dgpamd_linkgp_workspace(n, M))
+        work = self.workspace(('link', n, M, Dw), lib.dgpamd_linkgp_workspace(n, M, Dw))
         if mean is None:
             mean = self.empty(M)
         if var is None:

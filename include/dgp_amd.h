@@ -180,7 +180,7 @@ int dgpamd_gp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int D,
  *   mean_t = I_t . ry ,  var_t = | ry^T J_t ry - mean_t^2 + scale (1 + nugget - tr(Rinv J_t)) |
  * m, v: (M x Dw) input moments; z: (M x Dz) deterministic global inputs (NULL iff
  * Dz == 0); Wtr: (n x Dw), Wg: (n x Dz).  Psexp/R2sexp are never materialised. */
-size_t dgpamd_linkgp_workspace(int64_t n, int64_t M);
+size_t dgpamd_linkgp_workspace(int64_t n, int64_t M, int Dw);
 /* Matern-2.5: by default the J factor is evaluated through its separable form (every erf/exp depends on one
  * training point: Jd = <S(x_min), T(x_max)> + (erf_hi - erf_lo) <S', T'>, csrc/linkfun.hpp), which agrees with the
  * reference's expression to ~1e-11; enable = 1 evaluates the reference's direct expression (vecchia.py:915-959). */
