@@ -41,6 +41,7 @@ SIGNATURES = {
     'dgpamd_set_graphs': (_i, [_p, _i]),
     'dgpamd_set_linkgp_direct': (_i, [_p, _i]),
     'dgpamd_prof_enable': (_i, [_p, _i]),
+    'dgpamd_prof_event_overhead_us': (_i, [_p, C.POINTER(_d)]),
     'dgpamd_prof_collect': (_i, [_p, C.POINTER(_l), C.POINTER(_d), C.POINTER(_d)]),
     'dgpamd_kmatrix': (_i, [_p, _i, _l, _p, _l, _l, _p, _i, _p, _i, _p, _i, _d, _p, _p, _l, _l, _i, _p, _l, _l, _i, _i]),
     'dgpamd_potrf_workspace': (_z, [_l, _i]),

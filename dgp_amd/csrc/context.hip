@@ -82,6 +82,29 @@ extern "C" int dgpamd_prof_enable(dgpamd_ctx *ctx, int kernel_class) {
     return DGPAMD_OK;
 }
 
+// Elapsed time reported by an event pair with NOTHING between the two records: the fixed cost that
+// bracketing a launch adds to its measured duration (bench.py subtracts it per launch).
+extern "C" int dgpamd_prof_event_overhead_us(dgpamd_ctx *ctx, double *us_h) {
+    if (!ctx || !us_h) return DGPAMD_BAD_ARG;
+    const int reps = 64;
+    hipEvent_t ev[2 * reps];
+    for (int i = 0; i < 2 * reps; ++i) HIP_TRY(ctx, hipEventCreate(&ev[i]));
+    for (int i = 0; i < reps; ++i) {
+        HIP_TRY(ctx, hipEventRecord(ev[2 * i], ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ev[2 * i + 1], ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (int i = 0; i < reps; ++i) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        tot += ms;
+    }
+    for (int i = 0; i < 2 * reps; ++i) (void)hipEventDestroy(ev[i]);
+    *us_h = 1e3 * tot / reps;
+    return DGPAMD_OK;
+}
+
 extern "C" int dgpamd_prof_collect(dgpamd_ctx *ctx, int64_t *launches_h, double *total_ms_h, double *work_h) {
     if (!ctx || !launches_h || !total_ms_h || !work_h) return DGPAMD_BAD_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

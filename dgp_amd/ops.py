@@ -119,6 +119,11 @@ class Engine:
     def prof_enable(self, name):
         self._chk(lib.dgpamd_prof_enable(self.h, self.PROF[name] if name else 0))
 
+    def prof_event_overhead_us(self):
+        v = C.c_double()
+        self._chk(lib.dgpamd_prof_event_overhead_us(self.h, C.byref(v)))
+        return float(v.value)
+
     def prof_collect(self):
         """(launches, total_ms, algorithmic work) of the launches timed since prof_enable."""
         n, ms, w = C.c_int64(), C.c_double(), C.c_double()

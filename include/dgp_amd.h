@@ -79,6 +79,7 @@ int dgpamd_event_destroy(dgpamd_ctx *ctx, void *ev);
  * timed launches, their summed duration and their summed algorithmic work (flops; bytes for 1). */
 int dgpamd_prof_enable(dgpamd_ctx *ctx, int kernel_class);
 int dgpamd_prof_collect(dgpamd_ctx *ctx, int64_t *launches_h, double *total_ms_h, double *work_h);
+int dgpamd_prof_event_overhead_us(dgpamd_ctx *ctx, double *us_h); /* duration an EMPTY event pair reports */
 
 /* ---- a1/a2  kernel-matrix assembly ---------------------------------------
  * kernel.k_matrix()  kernel_class.py:304-359 (pdist/squareform + functions.py:16-34).
