@@ -19,11 +19,17 @@
 // diagonal block: Cholesky + inverse of the factor, in registers
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ double rsqrt_f64(double d) {
-    // hardware estimate + two Newton steps (full f64); sqrt(d) is then d * rsqrt(d)
-    double y = __builtin_amdgcn_rsq(d);
-    y = y * fma(-0.5 * d * y, y, 1.5);
-    y = y * fma(-0.5 * d * y, y, 1.5);
-    return y;
+    // Goldschmidt: g -> sqrt(d), h -> 1/(2 sqrt(d)) refined in parallel from the hardware estimate (two rounds
+    // reach full f64); dependency depth 6 instead of 9 for Newton on the reciprocal alone.  The pivot chain of the
+    // factorisation is latency bound (a dependent f64 op is ~13 ns on MI355X), so depth is what counts.
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    return h + h;
 }
 
 // The 64 pivots are taken FOUR at a time: the 4x4 pivot block is factored redundantly in every thread's

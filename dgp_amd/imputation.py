@@ -88,7 +88,7 @@ class imputer:
     """Args as dgpsi.imputer (imputation.py:13) plus `draws` (a DrawStream), `engine`, and
     `batch` (speculative proposals per launch)."""
 
-    def __init__(self, all_layer, block=True, draws=None, engine=None, batch=8):
+    def __init__(self, all_layer, block=True, draws=None, engine=None, batch=12):
         self.all_layer = all_layer
         self.block = block
         self.draws = draws if draws is not None else DrawStream()

@@ -1,0 +1,58 @@
+"""Scale probes for BASELINE configs 3 and 4 (run on the GPU box)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import synthetic
+from dgp_amd import dgp, kernel, combine, emulator
+from dgp_amd.ops import default_engine
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
+eng = default_engine(0)
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+if which == 'cfg3':
+    n, d, q = int(os.environ.get('N', '5000')), 10, 3
+    rng = np.random.default_rng(2026)
+    X = rng.uniform(size=(n, d))
+    Y = np.stack([np.sin(1.0 / ((0.7 * X[:, 0] + 0.3) * (0.7 * X[:, 1] + 0.3))) + (0.2 + 0.1 * j) * (X[:, 2 + j:] ** 2).sum(1) for j in range(q)], 1)
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    t = time.perf_counter()
+    model = dgp(X, Y, seed=1)          # default structure: d SExp nodes (shared lengthscale) -> q SExp nodes with global connection
+    sync(); print('cfg3 n=%d: construct (11 sweeps) %.2f s' % (n, time.perf_counter() - t))
+    t = time.perf_counter(); model.train(N=2, ess_burn=10, disable=True); sync()
+    print('cfg3: 2 SI iterations %.2f s -> %.2f it/s' % (time.perf_counter() - t, 2 / (time.perf_counter() - t)))
+    S, M = int(os.environ.get('S', '6')), int(os.environ.get('M', '4096'))
+    t = time.perf_counter(); emu = emulator(model.estimate(burnin=0), N=S, seed=3); sync()
+    print('cfg3: emulator(N=%d) %.2f s' % (S, time.perf_counter() - t))
+    xt = rng.uniform(size=(M, d))
+    t = time.perf_counter(); emu.predict(xt[:64]); sync(); print('cfg3: stats + first predict %.2f s' % (time.perf_counter() - t))
+    t = time.perf_counter(); mu, var = emu.predict(xt); sync(); dt = time.perf_counter() - t
+    print('cfg3: predict %d pts x %d imputations %.2f s -> %.0f pts/s (x%d imputations = %.0f pt-imputations/s); finite=%s; mem %.1f GB'
+          % (M, S, dt, M / dt, S, M * S / dt, np.all(np.isfinite(mu)) and np.all(np.isfinite(var)), torch.cuda.max_memory_allocated() / 2**30))
+else:
+    n, d, m = int(os.environ.get('N', '50000')), 8, 25
+    rng = np.random.default_rng(7)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X[:, 0]) + X[:, 1] ** 2 + 0.1 * rng.normal(size=n)
+    length = np.full(d, 0.8)
+    Xs = eng.tensor(X / length)
+    t = time.perf_counter(); NN = eng.nn_ordered(Xs, m); sync(); t_nn = time.perf_counter() - t
+    print('cfg4 n=%d: ordered %d-NN %.3f s (%.0f rows/s)' % (n, m, t_nn, n / t_nn))
+    dX, dy, ones = eng.tensor(X), eng.tensor(y), eng.tensor(np.ones(n))
+    for name in ('sexp', 'matern2.5'):
+        for rep in range(2):
+            t = time.perf_counter(); out = eng.vecchia_llik(name, dX, dy, NN, length, 1e-4, ones); sync(); t1 = time.perf_counter() - t
+            t = time.perf_counter(); o, P = eng.vecchia_nllik(name, dX, dy, NN, length, 1e-4, ones, True); sync(); t2 = time.perf_counter() - t
+            t = time.perf_counter(); Lm = eng.vecchia_lmatrix(name, dX, NN, length, 1e-4); sync(); t3 = time.perf_counter() - t
+            t = time.perf_counter(); xs = eng.vecchia_spsolve(Lm, NN, 1.0, eng.tensor(rng.normal(size=n))); sync(); t4 = time.perf_counter() - t
+        print('cfg4 %s: llik %.1f ms (%.2f Mrows/s) | nllik(P=%d) %.1f ms (%.2f Mrows/s) | L_matrix %.1f ms | sparse solve %.1f ms | finite %s'
+              % (name, 1e3 * t1, n / t1 / 1e6, P, 1e3 * t2, n / t2 / 1e6, 1e3 * t3, 1e3 * t4, bool(torch.isfinite(out).all() and torch.isfinite(xs).all())))
+    xq = rng.uniform(size=(10000, d))
+    t = time.perf_counter(); PN = eng.nn_query(eng.tensor(xq / length), Xs, 50); sync(); t5 = time.perf_counter() - t
+    t = time.perf_counter(); gm, gv = eng.vecchia_gp('matern2.5', eng.tensor(xq), dX, PN, dy, 1.0, length, 1e-4, ones); sync(); t6 = time.perf_counter() - t
+    print('cfg4: pred NN (50 of %d) for 1e4 queries %.1f ms | gp_vecch 1e4 pts %.1f ms (%.0f pts/s)' % (n, 1e3 * t5, 1e3 * t6, 1e4 / t6))
