@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(TrmvArgs a) {
 // ----------------------------------------------------------------------------
 size_t potrf_ws_doubles(int64_t n, int batch) {
     int64_t nbk = padded_dim(n) / 64;
-    return (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB;   // diagonal inverses + {logdet, quad} scratch
+    return (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB;   // diagonal inverses + {logdet (loglik), logdet (graph)} scratch; info words follow
 }
 
 extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
@@ -387,12 +387,30 @@ static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_
     return DGPAMD_OK;
 }
 
+__global__ void potrf_copy_out_kernel(const double *ld_ws, const int32_t *info_ws, double *logdet, int32_t *info, int batch) {
+    const int b = threadIdx.x;
+    if (b < batch) {
+        logdet[b] = ld_ws[b];
+        info[b] = info_ws[b];
+    }
+}
+
 int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
               double *ws) {
-    // 3 launches per 64-column block step with a static shape: replayed as one hipGraph
-    const std::array<uint64_t, 10> key = {1, (uint64_t)n, (uint64_t)batch, (uint64_t)A, (uint64_t)stride_a,
-                                          (uint64_t)logdet, (uint64_t)info, (uint64_t)ws, 0, 0};
-    return graph_run(ctx, key, [&]() { return potrf_launches(ctx, n, A, stride_a, batch, logdet, info, ws); });
+    // 3 launches per 64-column block step with a static shape: replayed as one hipGraph.  The graph writes
+    // logdet/info into the workspace tail (fixed addresses -> the cached graph does not depend on where the
+    // caller wants them); a tiny kernel outside the graph copies them out.
+    const int64_t nbk = padded_dim(n) / 64;
+    double *ld_ws = ws + (size_t)batch * nbk * 4096 + DGPAMD_MAXB;
+    int32_t *info_ws = reinterpret_cast<int32_t *>(ws + (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB);
+    const std::array<uint64_t, 10> key = {1, (uint64_t)n, (uint64_t)batch, (uint64_t)A, (uint64_t)stride_a, (uint64_t)ws,
+                                          0, 0, 0, 0};
+    int rc = graph_run(ctx, key, [&]() { return potrf_launches(ctx, n, A, stride_a, batch, ld_ws, info_ws, ws); });
+    if (rc) return rc;
+    hipLaunchKernelGGL(potrf_copy_out_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)ld_ws,
+                       (const int32_t *)info_ws, logdet, info, batch);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
 }
 
 extern "C" int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet,

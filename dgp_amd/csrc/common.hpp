@@ -76,6 +76,10 @@ static inline int graph_run(dgpamd_ctx *ctx, const std::array<uint64_t, 10> &key
             (void)hipGetLastError();
             return body();
         }
+        if (ctx->graphs.size() >= 64) {   // callers that keep changing buffers: do not let the cache grow without bound
+            for (auto &kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+            ctx->graphs.clear();
+        }
         it = ctx->graphs.emplace(key, exec).first;
     }
     HIP_TRY(ctx, hipGraphLaunch(it->second, ctx->stream));

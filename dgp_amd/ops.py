@@ -37,10 +37,14 @@ class Engine:
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
         if stream is None:
-            # a dedicated side stream (hipGraph capture is illegal on the null stream); it becomes this
-            # thread's current torch stream so that torch's copies/allocator are ordered with our launches
-            stream = torch.cuda.Stream(self.device)
-            torch.cuda.set_stream(stream)
+            # Use the thread's CURRENT torch stream so that torch's copies / allocator and the library's launches
+            # are ordered on one stream (every engine created in a thread without an explicit stream shares it).
+            # hipGraph capture is illegal on the null stream: if that is the current one, switch the thread to a
+            # side stream first.
+            stream = torch.cuda.current_stream(self.device)
+            if stream.cuda_stream == 0:
+                stream = torch.cuda.Stream(self.device)
+                torch.cuda.set_stream(stream)
         self._torch_stream = stream
         h = C.c_void_p()
         rc = lib.dgpamd_create(int(device), C.c_void_p(self._torch_stream.cuda_stream), C.byref(h))
