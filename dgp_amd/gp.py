@@ -1,0 +1,104 @@
+"""Single-GP emulator -- mirror of dgpsi.gp (gp.py:12-453; training, export, mean/variance prediction)."""
+import copy
+
+import numpy as np
+
+from .ops import default_engine
+
+
+class gp:
+    """Args as dgpsi.gp (gp.py:26): X (n x d), Y (n x 1), kernel, check_rep, vecchia, m, ord_fun; plus `device`."""
+
+    def __init__(self, X, Y, kernel, check_rep=True, vecchia=False, m=25, ord_fun=None, device=None):
+        if Y.ndim == 1 or X.ndim == 1:
+            raise Exception('The input and output data have to be numpy 2d-arrays.')
+        self.check_rep, self.indices = check_rep, None
+        self.X, self.Y = X, Y
+        if check_rep:
+            X0, inv = np.unique(X, return_inverse=True, axis=0)
+            if len(X0) != len(X):   # replicates: site means, weights 1/count and the pooled residual (gp.py:32-42)
+                inv = np.asarray(inv).reshape(-1)
+                G = inv.max() + 1
+                self.X, self.indices = X0, inv
+                self.W_diag = 1.0 / np.bincount(inv, minlength=G)
+                self.Y = (np.bincount(inv, weights=Y.flatten(), minlength=G) * self.W_diag).reshape(-1, 1)
+                res = Y - self.Y[inv, :]
+                self.sum_residual = (res.T @ res).flatten()
+        self.kernel = kernel
+        self.kernel.engine = default_engine(device)
+        self.vecch = vecchia
+        self.n_data = self.X.shape[0]
+        self.m = min(m, self.n_data - 1)
+        self.ord_fun = ord_fun
+        self.initialize()
+        if self.vecch:
+            self.kernel.ord_nn()
+        else:
+            self.kernel.compute_stats()
+
+    def initialize(self):
+        """Hand the data to the node (gp.py:80-113)."""
+        k = self.kernel
+        if k.input_dim is None:
+            k.input_dim = np.arange(self.X.shape[1])
+            k.input = self.X.copy()
+        else:
+            k.input = self.X[:, k.input_dim]
+        if self.indices is not None:
+            k.rep, k.W_diag, k.sum_residual = self.indices, self.W_diag, self.sum_residual
+        if k.connect is not None:
+            if len(np.intersect1d(k.connect, k.input_dim)) != 0:
+                raise Exception('The local input and global input should not have any overlap. Change input_dim or '
+                                'connect so they do not have any common indices.')
+            k.global_input = self.X[:, k.connect]
+        k.output = self.Y.copy()
+        k.D = k.input.shape[1] + (0 if k.connect is None else len(k.connect))
+        k.para_path = np.atleast_2d(np.concatenate((k.scale, k.length, k.nugget)))
+        k.vecch, k.m = self.vecch, self.m
+        if self.ord_fun is not None:
+            k.ord_fun = self.ord_fun
+        if k.prior_name == 'ref':
+            k.prior_coef = np.concatenate((k.prior_coef, 1 / self.n_data ** (1 / k.D) * (k.prior_coef + k.D)))
+            k.compute_cl()
+        k.target = 'gp'
+
+    def to_vecchia(self, m=25, ord_fun=None):
+        if self.vecch:
+            raise Exception('The GP emulator is already in Vecchia mode.')
+        self.vecch, self.m, self.ord_fun = True, min(m, self.n_data - 1), ord_fun
+        self.kernel.vecch, self.kernel.m, self.kernel.ord_fun = True, self.m, ord_fun
+        self.kernel.ord_nn()
+
+    def remove_vecchia(self):
+        if not self.vecch:
+            raise Exception('The GP emulator is already in non-Vecchia mode.')
+        self.vecch = self.kernel.vecch = False
+        self.kernel.compute_stats()
+
+    def train(self):
+        """One L-BFGS-B fit of the hyper-parameters (gp.py:211-216)."""
+        self.kernel.maximise()
+        if not self.vecch:
+            self.kernel.compute_stats()
+
+    def export(self):
+        """The trained node as a one-element structure for `container` (gp.py:218-222)."""
+        k = copy.deepcopy(self.kernel)
+        k.engine = self.kernel.engine
+        return [k]
+
+    def predict(self, x, method='mean_var', sample_size=50, m=50):
+        """(mean, variance) as (M x 1) arrays, or samples (M x sample_size)  (gp.py:412-453)."""
+        if x.ndim == 1:
+            raise Exception('The testing input has to be a numpy 2d-array')
+        k = self.kernel
+        z = None if k.connect is None else x[:, k.connect]
+        k.pred_m = m
+        mu, s2 = k.gp_prediction(x=x[:, k.input_dim], z=z)
+        if method == 'mean_var':
+            return mu.reshape(-1, 1), s2.reshape(-1, 1)
+        if method == 'sampling':
+            return np.random.normal(mu, np.sqrt(s2), size=(sample_size, len(x))).T
+        raise Exception("method must be 'mean_var' or 'sampling'.")
+
+    ppredict = predict

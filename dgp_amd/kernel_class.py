@@ -465,3 +465,27 @@ class kernel:
             mo, vo = e.linkgp_predict(self.name, e.tensor(m), e.tensor(v), zt, st['W'], st['Wg'], self.length, st['Rinv'],
                                       st['ld'], st['ry'], self.scale[0], self.nugget[0])
         return mo.cpu().numpy(), vo.cpu().numpy()
+
+    def linkgp_prediction_full(self, m, v, m_z, v_z, z):
+        """Linked prediction when part of the node's GLOBAL input is itself uncertain (outputs of feeding
+        emulators): those columns join the Gaussian inputs, the rest stays deterministic (kernel_class.py:672-733).
+        No R2sexp/Psexp bookkeeping is needed here -- the device kernel never uses them."""
+        e = self.engine
+        nz = m_z.shape[1]
+        mm, vv = np.concatenate((m, m_z), axis=1), np.concatenate((v, v_z), axis=1)
+        W = np.concatenate((self.input, self.global_input[:, :nz]), axis=1)
+        Wg = self.global_input[:, nz:]
+        zt = None if z is None else e.tensor(z)
+        Wgt = None if z is None else e.tensor(Wg)
+        if self.vecch:
+            x = mm if z is None else np.concatenate((mm, z), 1)
+            w = self._X()
+            nd = np.ones(len(self.output)) if self.rep is None else self.W_diag
+            mo, vo = e.vecchia_linkgp(self.name, e.tensor(mm), e.tensor(vv), zt, e.tensor(W), Wgt, self._pred_nn(x, w),
+                                      e.tensor(np.asarray(self.output, float).reshape(-1)), self.scale[0], self.length,
+                                      self.nugget[0], e.tensor(nd))
+        else:
+            st = self._stats
+            mo, vo = e.linkgp_predict(self.name, e.tensor(mm), e.tensor(vv), zt, e.tensor(W), Wgt, self.length, st['Rinv'],
+                                      st['ld'], st['ry'], self.scale[0], self.nugget[0])
+        return mo.cpu().numpy(), vo.cpu().numpy()

@@ -369,8 +369,59 @@ def gen_emulator():
         save('g9_emulator_' + tag, **out)
 
 
+def gen_lgp():
+    """G10: feed-forward chain GP -> DGP -> GP (+ one external input on the last emulator), lgp.predict
+    (linkgp.py:285-501) from the reference's own imputations (dumped)."""
+    from dgpsi import gp as rgp, lgp as rlgp, container as rcontainer
+    for tag, name in (('sexp', 'sexp'), ('matern', 'matern2.5')):
+        np.random.seed(17)
+        rng = np.random.default_rng(17)
+        n = 18
+        X1 = rng.uniform(size=(n, 2))
+        Y1 = (np.sin(3 * X1[:, :1]) + X1[:, 1:] ** 2)
+        Y1 = (Y1 - Y1.mean()) / Y1.std()
+        g1 = rgp(X1, Y1, kernel(length=np.array([0.8, 1.2]), name=name, scale_est=True, nugget_est=False, nugget=1e-4))
+        g1.train()
+        Y2 = np.tanh(2 * Y1) + 0.3 * Y1 ** 2
+        Y2 = (Y2 - Y2.mean()) / Y2.std()
+        l1 = [kernel(length=np.array([1.0]), name=name)]
+        l2 = [kernel(length=np.array([1.0]), name=name, scale_est=True, connect=np.arange(1))]
+        d2 = dgp(Y1, Y2, combine(l1, l2))
+        d2.train(N=5, ess_burn=2, disable=True)
+        E = rng.uniform(size=(n, 1))
+        Y3 = np.cos(2 * Y2) + E
+        Y3 = (Y3 - Y3.mean()) / Y3.std()
+        g3 = rgp(np.concatenate((Y2, E), 1), Y3, kernel(length=np.array([1.0, 0.7]), name=name, scale_est=True, nugget=1e-4,
+                                                        input_dim=np.array([0]), connect=np.array([1])))
+        g3.train()
+        c1 = rcontainer(g1.export(), np.array([0, 1]))
+        c2 = rcontainer(d2.estimate(), np.array([0]))
+        c3 = rcontainer(g3.export(), np.array([0]))
+        sys_ = rlgp(combine([c1], [c2], [c3]), N=3)
+        out = {'n_imp': np.array(len(sys_.all_layer_set))}
+        for s, one in enumerate(sys_.all_layer_set):
+            for l, layer in enumerate(one):
+                cont = layer[0]
+                st = [[cont.structure]] if cont.type == 'gp' else cont.structure
+                out.update(dump_structure(st, 's%d_m%d_' % (s, l)))
+        M = 9
+        xt = rng.uniform(size=(M, 2))
+        ext = rng.uniform(size=(M, 1))
+        xin = [xt, [None], [ext]]
+        mu, var = sys_.predict(xin)
+        mul, varl = sys_.predict(xin, full_layer=True)
+        out.update(xt=xt, ext=ext, mu=mu[0], var=var[0])
+        for l in range(3):
+            out['mu_l%d' % l] = mul[l][0]
+            out['var_l%d' % l] = varl[l][0]
+        # the single-GP emulator on its own (gp.predict, gp.py:412-453)
+        m1, v1 = g1.predict(xt)
+        out.update(gp1_mu=m1, gp1_var=v1, X1=X1, Y1=Y1, gp1_path=g1.kernel.para_path.copy())
+        save('g10_lgp_' + tag, **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator']
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp']
     if 'kernel' in which:
         gen_kernel_cases()
     if 'fmvn' in which:
@@ -383,3 +434,5 @@ if __name__ == '__main__':
         gen_vecchia()
     if 'emulator' in which:
         gen_emulator()
+    if 'lgp' in which:
+        gen_lgp()

@@ -189,3 +189,58 @@ def test_vecchia_llik_matches_dense_when_m_is_full(eng):
     nd.vecch, nd.m = True, n - 1
     nd.ord_nn()
     close(np.ravel(nd.log_likelihood_func_vecch())[0], dense + 0.5 * n * np.log(1.3), rtol=1e-9)
+
+
+@pytest.mark.parametrize('tag', ['sexp', 'matern'])
+def test_linked_chain_matches_reference(eng, golden, tag):
+    """BASELINE config 5 shape at small n: GP -> DGP -> GP (+ external input), lgp.predict (linkgp.py:285-501)
+    from the reference's dumped imputations; the DGP's second layer sees its uncertain global input through
+    linkgp_prediction_full (kernel_class.py:672-733)."""
+    from dgp_amd.linkgp import container, lgp
+    d = golden('g10_lgp_' + tag)
+    S = int(d['n_imp'])
+    idx = [np.array([0, 1]), np.array([0]), np.array([0])]
+    sets = []
+    for s in range(S):
+        one = []
+        for l in range(3):
+            st = build_structure(d, 's%d_m%d_' % (s, l), eng)
+            c = container.__new__(container)
+            c.vecch, c.local_input_idx = False, idx[l]
+            if len(st) == 1:
+                c.type, c.structure = 'gp', st[0][0]
+            else:
+                c.type, c.structure = 'dgp', st
+            one.append([c])
+        sets.append(one)
+    sysm = lgp.__new__(lgp)
+    sysm.L, sysm.all_layer, sysm.num_model, sysm.all_layer_set = 3, sets[0], [1, 1], sets
+    xin = [d['xt'], [None], [d['ext']]]
+    mu, var = sysm.predict(xin)
+    close(mu[0], d['mu'], rtol=1e-6, atol=1e-8)
+    close(var[0], d['var'], rtol=1e-5, atol=1e-6)
+    mul, varl = sysm.predict(xin, full_layer=True)
+    for l in range(3):
+        close(mul[l][0], d['mu_l%d' % l], rtol=1e-6, atol=1e-8)
+        close(varl[l][0], d['var_l%d' % l], rtol=1e-5, atol=1e-6)
+
+
+def test_gp_class_predict_matches_reference(eng, golden):
+    """gp.predict (gp.py:412-453) at the reference's trained hyper-parameters; and gp.train() improves the objective."""
+    from dgp_amd import gp, kernel
+    d = golden('g10_lgp_matern')
+    est = d['gp1_path'][-1]
+    k = kernel(length=est[1:-1].copy(), scale=est[0], nugget=est[-1], name='matern2.5', scale_est=True)
+    model = gp(d['X1'], d['Y1'], k)
+    mu, var = model.predict(d['xt'])
+    close(mu, d['gp1_mu'], rtol=1e-7, atol=1e-9)
+    close(var, d['gp1_var'], rtol=1e-5, atol=1e-7)
+    k2 = kernel(length=np.array([0.8, 1.2]), name='matern2.5', scale_est=True, nugget=1e-4)
+    m2 = gp(d['X1'], d['Y1'], k2)
+    before = float(k2.llik(k2.log_t())[0][0])
+    m2.train()
+    after = float(k2.llik(k2.log_t())[0][0])
+    assert after <= before + 1e-9 and k2.para_path.shape == (2, 4)
+    assert len(m2.export()) == 1
+    smp = m2.predict(d['xt'], method='sampling', sample_size=7)
+    assert smp.shape == (len(d['xt']), 7)
