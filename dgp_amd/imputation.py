@@ -163,22 +163,27 @@ class imputer:
             for l in range(n_layer - 1):
                 upper = self.all_layer[l + 1]
                 hetero = any(nd.type == 'likelihood' and nd.exact_post_idx is not None for nd in upper)
-                if self.block and not hetero:
+                if hetero:
+                    raise NotImplementedError('the Hetero exact-posterior step (imputation.py:141-164) is outside the '
+                                              'accelerated path')
+                if self.block:
                     self.one_sample_block(l)
                 else:
-                    raise NotImplementedError('node-wise ESS (block=False) and the Hetero exact-posterior step '
-                                              '(imputation.py:121-221) are outside the accelerated path')
+                    for k in range(len(self.all_layer[l])):
+                        self.one_sample(l, k)
         self._detach()
 
-    def _prior_draw(self, l):
-        """nu[:, k] = chol(scale_k K_k) z_k for every node of layer l (imputation.py:54-63, functions.py:113-121)."""
+    def _prior_draw(self, l, cols=None):
+        """nu[:, k] = chol(scale_k K_k) z_k for the nodes `cols` of layer l (default: all)
+        (imputation.py:54-63,166-172, functions.py:113-121)."""
         e = self.engine
         layer = self.all_layer[l]
         n, M = self.F[l].shape
         Np = e.padded_dim(n)
-        nu = e.empty(n, M)
-        dense = [k for k, nd in enumerate(layer) if not nd.vecch]
-        Z = {k: self.draws.normal(n) for k in range(M)}
+        nu = e.zeros(n, M)
+        cols = list(range(M)) if cols is None else list(cols)
+        dense = [k for k in cols if not layer[k].vecch]
+        Z = {k: self.draws.normal(n) for k in cols}
         if dense:
             need = []
             for k in dense:
@@ -209,7 +214,8 @@ class imputer:
                 nu[:, k] = out[0]
                 if l != 0:
                     del self._factor_cache[(l, k)]
-        for k, nd in enumerate(layer):
+        for k in cols:
+            nd = layer[k]
             if nd.vecch:
                 Xl, cm = self._node_input(l, k, nd)
                 X = Xl if cm is None else Xl[:, torch.as_tensor(cm, device=Xl.device, dtype=torch.long)]
@@ -222,9 +228,9 @@ class imputer:
                 nu[:, k] = xs[torch.as_tensor(nd.rev_ord, device=X.device, dtype=torch.long)]
         return nu
 
-    def _upper_loglik(self, l, FP):
-        """sum over the nodes of layer l+1 of their log-likelihood for each candidate block FP[b]
-        (imputation.py:70-78,91-106).  Returns (ll (B,) numpy, info (B,) numpy)."""
+    def _upper_loglik(self, l, FP, only=None):
+        """sum over the nodes of layer l+1 (or those listed in `only`) of their log-likelihood for each candidate
+        block FP[b] (imputation.py:70-78,91-106).  Returns (ll (B,) numpy, info (B,) numpy)."""
         e = self.engine
         B = FP.shape[0]
         upper = self.all_layer[l + 1]
@@ -232,6 +238,8 @@ class imputer:
         host = np.zeros(B)
         FPh = None
         for k, nd in enumerate(upper):
+            if only is not None and k not in only:
+                continue
             if nd.type == 'gp' and not nd.vecch:
                 ll, info = e.loglik(nd.name, FP, np.asarray(nd.input_dim, dtype=np.int32), self._glob[(l + 1, k)], nd.length,
                                     nd.nugget[0], nd.scale[0], self._node_y(l + 1, k),
@@ -306,6 +314,45 @@ class imputer:
                     F.copy_(FP[b])
                     self._ll_cache[l] = ll[b]
                     self._ll_cache.pop(l - 1, None)   # outputs of layer l feed layer l-1's upper log-likelihood
+                    return
+            self.draws.uniform_take(nb - 1)
+            self.stats['proposals'] += nb
+            theta, (lo, hi) = thetas[-1], brackets[-1]
+            theta, lo, hi = shrink(theta, lo, hi, self.draws.uniform_take(1)[0])
+
+    def one_sample(self, l, k):
+        """Node-wise ESS update of latent column k of layer l given the nodes of layer l+1 it feeds
+        (imputation.py:121-221, the non-Hetero branch): same speculative batches, one column rotated."""
+        e = self.engine
+        F = self.F[l]
+        linked = [j for j, nd in enumerate(self.all_layer[l + 1]) if k in np.asarray(nd.input_dim)]
+        nu = self._prior_draw(l, [k])
+        ll, info = self._upper_loglik(l, F[None], only=linked)
+        if info[0] != 0:
+            raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[0]))
+        log_y = ll[0] + np.log(self.draws.uniform_take(1)[0])
+        theta = TWO_PI * self.draws.uniform_take(1)[0]
+        lo, hi = theta - TWO_PI, theta
+        fk, nk = F[:, k:k + 1].contiguous(), nu[:, k:k + 1].contiguous()
+        self.stats['updates'] += 1
+        while True:
+            us = self.draws.uniform_peek(self.batch - 1)
+            thetas, brackets = speculative_angles(theta, lo, hi, us)
+            nb = len(thetas)
+            col = e.ess_propose(fk, nk, thetas)            # (nb, n, 1)
+            FP = F.unsqueeze(0).repeat(nb, 1, 1)
+            FP[:, :, k] = col[:, :, 0]
+            ll, info = self._upper_loglik(l, FP, only=linked)
+            self.stats['batches'] += 1
+            for b in range(nb):
+                if info[b] != 0:
+                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[b]))
+                if ll[b] > log_y:
+                    self.draws.uniform_take(b)
+                    self.stats['proposals'] += b + 1
+                    F.copy_(FP[b])
+                    self._ll_cache.pop(l, None)
+                    self._ll_cache.pop(l - 1, None)
                     return
             self.draws.uniform_take(nb - 1)
             self.stats['proposals'] += nb

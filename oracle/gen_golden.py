@@ -218,6 +218,25 @@ def gen_ess():
         out['Y'] = Y
         save('g5_ess_' + tag, **out)
         print('   ess', tag, 'z draws', nz, 'u draws', len(log.u))
+    # node-wise sampler (block=False): imputation.py:121-221
+    X, Y, layers = build_small_dgp(13, 16, 2, ('matern2.5', 'sexp'), n_out=2)
+    model = dgp(X, Y, layers, block=False)
+    log = DrawLog(6)
+    oldr, oldu = RF.randn, RI.uniform
+    RI.fmvn.__globals__['randn'] = log.randn
+    RI.uniform = log.uniform
+    try:
+        before = dump_structure(model.all_layer, 'pre_')
+        model.imp.sample(burnin=1)
+        after = dump_structure(model.all_layer, 'post_')
+    finally:
+        RI.fmvn.__globals__['randn'] = oldr
+        RI.uniform = oldu
+    out = dict(before)
+    out.update(after)
+    out['z'] = np.stack(log.z)
+    out['u'] = np.array(log.u)
+    save('g5_ess_nodewise', **out)
 
 
 # ---------------------------------------------------------------- G6/G7

@@ -62,6 +62,22 @@ def test_ess_trajectory_matches_reference(eng, golden, tag, batch):
             close(a.input, b.input, rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize('batch', [1, 5])
+def test_nodewise_ess_matches_reference(eng, golden, batch):
+    """block=False: imputer.one_sample per node (imputation.py:121-221) replayed with the reference's draws."""
+    from dgp_amd.imputation import imputer, DrawStream
+    d = golden('g5_ess_nodewise')
+    layers = build_structure(d, 'pre_', eng)
+    draws = DrawStream(z=list(d['z']), u=list(d['u']))
+    imputer(layers, block=False, draws=draws, engine=eng, batch=batch).sample(burnin=1)
+    assert draws.exhausted()
+    post = build_structure(d, 'post_', eng)
+    for la, lb in zip(layers, post):
+        for a, b in zip(la, lb):
+            close(a.output, b.output, rtol=1e-8, atol=1e-10)
+            close(a.input, b.input, rtol=1e-8, atol=1e-10)
+
+
 @pytest.mark.parametrize('tag', ['sexp', 'matern'])
 def test_emulator_predict_matches_reference(eng, golden, tag):
     from dgp_amd.emulation import emulator
