@@ -35,31 +35,26 @@ __device__ __forceinline__ double rsqrt_f64(double d) {
 // The 64 pivots are taken FOUR at a time: the 4x4 pivot block is factored redundantly in every thread's
 // registers (that is the serial chain), the scaled 64x4 panel and the four finished rows of the running
 // inverse go through LDS once, and the trailing update is rank-4: two barriers per four pivots.
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, int64_t stride_a, int k, int64_t n,
-                                                         double *ws, int64_t stride_ws, double *logdet,
-                                                         int32_t *info) {
-    __shared__ double colraw[4][64];    // raw pivot columns j0..j0+3
-    __shared__ double rowraw[4][64];    // raw rows j0..j0+3 of the running inverse
-    __shared__ double panL[64][4];      // scaled panel  L[r][j0+u]
-    __shared__ double panY[64][4];      // finished rows Linv[j0+u][c]
-    __shared__ double piv[64];
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    double *Ab = A + (int64_t)b * stride_a + ((int64_t)k * 64) * ld + (int64_t)k * 64;
-    double *Wb = ws + (int64_t)b * stride_ws + (int64_t)k * 4096;
-    int64_t rem = n - (int64_t)k * 64;
-    const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+struct DiagShared {
+    double colraw[4][64];    // raw pivot columns j0..j0+3
+    double rowraw[4][64];    // raw rows j0..j0+3 of the running inverse
+    double panL[64][4];      // scaled panel  L[r][j0+u]
+    double panY[64][4];      // finished rows Linv[j0+u][c]
+    double piv[64];
+};
 
-    double a[4][4], y[4][4];
+// Factor the 64x64 tile held in registers (thread (tx,ty) owns rows ty+16p, columns tx+16q), write the factor to
+// Ab (ld) and the inverse of the factor to Wb (64x64), accumulate logdet / info of matrix b.  ncol = pivots in
+// this block (rows/columns beyond are carried right-hand sides).
+__device__ __forceinline__ void diag_factor(double (&a)[4][4], DiagShared &sh, double *Ab, int64_t ld, double *Wb,
+                                            int ncol, int k, int b, double *logdet, int32_t *info) {
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    double y[4][4];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int r = ty + 16 * p, c = tx + 16 * q;
-            a[p][q] = Ab[(int64_t)r * ld + c];
-            y[p][q] = (r == c) ? 1.0 : 0.0;
-        }
-    if (tid < 64) piv[tid] = 1.0;
+        for (int q = 0; q < 4; ++q) y[p][q] = (ty + 16 * p == tx + 16 * q) ? 1.0 : 0.0;
+    if (tid < 64) sh.piv[tid] = 1.0;
     int bad = 0;
 
 #pragma unroll
@@ -71,17 +66,17 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, 
             const int nact = ncol - j0 >= 4 ? 4 : ncol - j0;   // active pivots of this panel
             if ((tx >> 2) == jq) {
 #pragma unroll
-                for (int p = jb; p < 4; ++p) colraw[tx & 3][ty + 16 * p] = a[p][jb];
+                for (int p = jb; p < 4; ++p) sh.colraw[tx & 3][ty + 16 * p] = a[p][jb];
             }
             if ((ty >> 2) == jq) {
 #pragma unroll
-                for (int q = 0; q <= jb; ++q) rowraw[ty & 3][tx + 16 * q] = y[jb][q];
+                for (int q = 0; q <= jb; ++q) sh.rowraw[ty & 3][tx + 16 * q] = y[jb][q];
             }
             __syncthreads();
             // ---- 4x4 pivot block, redundantly in every thread ----
-            double d00 = colraw[0][j0], d10 = colraw[0][j0 + 1], d20 = colraw[0][j0 + 2], d30 = colraw[0][j0 + 3];
-            double d11 = colraw[1][j0 + 1], d21 = colraw[1][j0 + 2], d31 = colraw[1][j0 + 3];
-            double d22 = colraw[2][j0 + 2], d32 = colraw[2][j0 + 3], d33 = colraw[3][j0 + 3];
+            double d00 = sh.colraw[0][j0], d10 = sh.colraw[0][j0 + 1], d20 = sh.colraw[0][j0 + 2], d30 = sh.colraw[0][j0 + 3];
+            double d11 = sh.colraw[1][j0 + 1], d21 = sh.colraw[1][j0 + 2], d31 = sh.colraw[1][j0 + 3];
+            double d22 = sh.colraw[2][j0 + 2], d32 = sh.colraw[2][j0 + 3], d33 = sh.colraw[3][j0 + 3];
             if (!(d00 > 0.0)) { if (!bad) bad = j0 + 1; d00 = 1.0; }
             const double i0 = rsqrt_f64(d00);
             double L10 = d10 * i0, L20 = d20 * i0, L30 = d30 * i0;
@@ -100,30 +95,30 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, 
             if (!(p3 > 0.0)) { if (!bad) bad = j0 + 4; p3 = 1.0; }
             const double i3 = rsqrt_f64(p3);
             if (tid == 0) {
-                piv[j0] = d00;
-                if (nact > 1) piv[j0 + 1] = p1;
-                if (nact > 2) piv[j0 + 2] = p2;
-                if (nact > 3) piv[j0 + 3] = p3;
+                sh.piv[j0] = d00;
+                if (nact > 1) sh.piv[j0 + 1] = p1;
+                if (nact > 2) sh.piv[j0 + 2] = p2;
+                if (nact > 3) sh.piv[j0 + 3] = p3;
             }
             // ---- scaled panel (one row per thread) and finished inverse rows (one column per thread) ----
             if (tid < 64) {
                 const int r = tid;
-                const double a0 = colraw[0][r], a1 = colraw[1][r], a2 = colraw[2][r], a3 = colraw[3][r];
+                const double a0 = sh.colraw[0][r], a1 = sh.colraw[1][r], a2 = sh.colraw[2][r], a3 = sh.colraw[3][r];
                 const double x0 = a0 * i0;
                 const double x1 = nact > 1 ? fma(-x0, L10, a1) * i1 : 0.0;
                 const double x2 = nact > 2 ? fma(-x1, L21, fma(-x0, L20, a2)) * i2 : 0.0;
                 const double x3 = nact > 3 ? fma(-x2, L32, fma(-x1, L31, fma(-x0, L30, a3))) * i3 : 0.0;
-                panL[r][0] = x0; panL[r][1] = x1; panL[r][2] = x2; panL[r][3] = x3;
+                sh.panL[r][0] = x0; sh.panL[r][1] = x1; sh.panL[r][2] = x2; sh.panL[r][3] = x3;
             } else if (tid < 128) {
                 const int c = tid - 64;
                 const bool in = c < 16 * (jb + 1);
-                const double y0 = in ? rowraw[0][c] : 0.0, y1 = in ? rowraw[1][c] : 0.0;
-                const double y2 = in ? rowraw[2][c] : 0.0, y3 = in ? rowraw[3][c] : 0.0;
+                const double y0 = in ? sh.rowraw[0][c] : 0.0, y1 = in ? sh.rowraw[1][c] : 0.0;
+                const double y2 = in ? sh.rowraw[2][c] : 0.0, y3 = in ? sh.rowraw[3][c] : 0.0;
                 const double f0 = y0 * i0;
                 const double f1 = fma(-L10, f0, y1) * i1;
                 const double f2 = fma(-L21, f1, fma(-L20, f0, y2)) * i2;
                 const double f3 = fma(-L32, f2, fma(-L31, f1, fma(-L30, f0, y3))) * i3;
-                panY[c][0] = f0; panY[c][1] = f1; panY[c][2] = f2; panY[c][3] = f3;
+                sh.panY[c][0] = f0; sh.panY[c][1] = f1; sh.panY[c][2] = f2; sh.panY[c][3] = f3;
             }
             __syncthreads();
             // ---- rank-4 trailing update, assignment of the finished columns / inverse rows ----
@@ -132,13 +127,13 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, 
             for (int p = jb; p < 4; ++p)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    Lr[p][u] = panL[ty + 16 * p][u];
-                    Lc[p][u] = panL[tx + 16 * p][u];
+                    Lr[p][u] = sh.panL[ty + 16 * p][u];
+                    Lc[p][u] = sh.panL[tx + 16 * p][u];
                 }
 #pragma unroll
             for (int q = 0; q <= jb; ++q)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) Yf[q][u] = panY[tx + 16 * q][u];
+                for (int u = 0; u < 4; ++u) Yf[q][u] = sh.panY[tx + 16 * q][u];
             const int ur = ty & 3, uc = tx & 3;
 #pragma unroll
             for (int p = jb; p < 4; ++p) {
@@ -183,7 +178,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, 
         }
     __syncthreads();
     if (tid < 64) {
-        double v = (tid < ncol) ? log(piv[tid]) : 0.0;
+        double v = (tid < ncol) ? log(sh.piv[tid]) : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (tid == 0) {
@@ -192,6 +187,25 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, 
             if (bad && info[b] == 0) info[b] = k * 64 + bad;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, int64_t stride_a, int k, int64_t n,
+                                                         double *ws, int64_t stride_ws, double *logdet,
+                                                         int32_t *info, int32_t *flags) {
+    __shared__ DiagShared sh;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    double *Ab = A + (int64_t)b * stride_a + ((int64_t)k * 64) * ld + (int64_t)k * 64;
+    double *Wb = ws + (int64_t)b * stride_ws + (int64_t)k * 4096;
+    int64_t rem = n - (int64_t)k * 64;
+    const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+    double a[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[p][q] = Ab[(int64_t)(ty + 16 * p) * ld + tx + 16 * q];
+    diag_factor(a, sh, Ab, ld, Wb, ncol, k, b, logdet, info);
+    if (tid == 0 && flags) flags[b] = k + 1;   // visible to the next launch (kernel boundary)
 }
 
 // ----------------------------------------------------------------------------
@@ -302,6 +316,139 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
         }
 }
 
+// ----------------------------------------------------------------------------
+// One block step of the factorisation as ONE launch (k >= 1):
+//   every trailing tile (i,j), i >= j >= k, takes its update with panel k-1;
+//   the workgroup of tile (k,k) then factors it (diag_factor) and publishes the block's inverse with an
+//   agent-scope release; the workgroups of column k (tiles (i,k), i > k) wait for that flag and apply
+//   P_i = A_ik Linv_k^T.  The serial pivot chain of step k thus overlaps the bulk of the trailing update,
+//   and a factorisation is nbk+1 launches instead of 3 nbk.
+// Deadlock freedom: only the <= (nbk-k-1)*batch <= 31*64 column-k workgroups ever wait, and they wait for a
+// workgroup of the SAME launch that never waits itself; waiting workgroups are far fewer than the resident
+// capacity whenever batch <= 8 and otherwise every non-waiting workgroup terminates, so the diagonal workgroup
+// is scheduled under any dispatch order.  The spin is bounded (info = -1 on timeout).
+// ----------------------------------------------------------------------------
+struct StepArgs {
+    double *A;
+    double *ws;
+    int64_t ld, stride_a, stride_ws, n;
+    int nbk, k, batch;
+    double *logdet;
+    int32_t *info;
+    int32_t *flags;
+};
+
+__global__ __launch_bounds__(256) void potrf_step_kernel(StepArgs g) {
+    __shared__ double tiles[2 * 64 * LDM];   // As | Bs ; the diagonal workgroup reuses it as its 64x64 tile
+    __shared__ DiagShared sh;
+    double *As = tiles, *Bs = tiles + 64 * LDM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // 1-D grid ordered by urgency: the diagonal tiles of ALL matrices first, then their column-k tiles, then the
+    // bulk of the trailing update (dispatch follows the block index in practice, so the serial pivot chain of every
+    // matrix starts at once and the bulk fills the machine behind it).
+    const int k = g.k, kp = g.k - 1, m = g.nbk - g.k, batch = g.batch;
+    int b, ti, tj;
+    {
+        const int idx = blockIdx.x;
+        if (idx < batch * m) {
+            b = idx % batch; ti = idx / batch; tj = 0;
+        } else {
+            const int bulk = m * (m - 1) / 2, r = idx - batch * m;
+            b = r / bulk;
+            tri_decode(r - b * bulk, ti, tj);
+            ++ti; ++tj;
+        }
+    }
+    const int bi = k + ti, bj = k + tj;
+    const int64_t ld = g.ld;
+    double *A = g.A + (int64_t)b * g.stride_a;
+    double *C = A + ((int64_t)bi * 64) * ld + (int64_t)bj * 64;
+    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
+
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = C[(int64_t)(crow + 4 * r) * ld + 16 * t + ccol];
+    const double *Pi = A + ((int64_t)bi * 64) * ld + (int64_t)kp * 64;
+    const double *Pj = A + ((int64_t)bj * 64) * ld + (int64_t)kp * 64;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        load_mk(Pi, ld, As, tid, h);
+        load_mk(Pj, ld, Bs, tid, h);
+        __syncthreads();
+        mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, -1.0);
+    }
+    if (tj != 0) {   // plain trailing tile
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(int64_t)(crow + 4 * r) * ld + 16 * t + ccol] = acc[t][r];
+        return;
+    }
+    if (ti == 0) {   // the next diagonal tile: factor it right away
+        __syncthreads();
+        double *S = tiles;   // [64][64]
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(crow + 4 * r) * 64 + 16 * t + ccol] = acc[t][r];
+        __syncthreads();
+        const int tx = tid & 15, ty = tid >> 4;
+        double a[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[p][q] = S[(ty + 16 * p) * 64 + tx + 16 * q];
+        int64_t rem = g.n - (int64_t)k * 64;
+        const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+        diag_factor(a, sh, C, ld, g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096, ncol, k, b, g.logdet, g.info);
+        // publish the inverse: every storing wave drains its stores, one agent-scope release, then the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&g.flags[b], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // panel tile (bi, k): wait for Linv_k, then P_i = A_ik * Linv_k^T
+    if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&g.flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 1) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 24)) {
+                g.info[b] = -1;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const double *Linv = g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096;
+    d4 out[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) As[(crow + 4 * r) * LDM + 16 * t + ccol] = acc[2 * h + t][r];
+        load_mk(Linv, 64, Bs, tid, h);
+        __syncthreads();
+        mfma_tile<OP_MK, OP_MK>(As, Bs, out, wave, lane, 1.0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(int64_t)(crow + 4 * r) * ld + 16 * t + ccol] = out[t][r];
+}
+
 // place the diagonal-block inverses on the diagonal of the (to be inverted) factor
 __global__ __launch_bounds__(256) void put_diag_inverse_kernel(double *A, int64_t ld, const double *ws) {
     const int kb = blockIdx.x, tid = threadIdx.x;
@@ -355,33 +502,38 @@ size_t potrf_ws_doubles(int64_t n, int batch) {
 }
 
 extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
-    return potrf_ws_doubles(n, batch) * sizeof(double) + DGPAMD_MAXB * sizeof(int32_t);
+    return potrf_ws_doubles(n, batch) * sizeof(double) + 2 * DGPAMD_MAXB * sizeof(int32_t);   // + info, step flags
 }
 
 static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet,
-                          int32_t *info, double *ws) {
+                          int32_t *info, double *ws, int32_t *flags) {
     const int64_t Np = padded_dim(n);
     const int nbk = (int)(Np / 64);
     const int64_t stride_ws = (int64_t)nbk * 4096;
-    GemmArgs g;
-    g.A = A; g.B = nullptr; g.ws = ws; g.ld = Np; g.stride_a = stride_a; g.stride_ws = stride_ws;
-    g.n = n; g.nbk = nbk; g.k = 0; g.s = 0;
-    for (int k = 0; k < nbk; ++k) {
-        PROF_BEGIN(ctx, PROF_POTRF_DIAG, (double)batch * (64.0 * 64.0 * 64.0));   // potrf n^3/3 + inverse 2n^3/3... = n^3 at n=64
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, ctx->stream, A, Np, stride_a, k, n, ws,
-                           stride_ws, logdet, info);
-        PROF_END(ctx, PROF_POTRF_DIAG);
-        const int m = nbk - k - 1;
-        if (m > 0 && (int64_t)k * 64 < n) {
-            g.k = k;
-            const double tile_flops = 2.0 * 64.0 * 64.0 * 64.0;
-            PROF_BEGIN(ctx, PROF_TRSM, (double)batch * m * tile_flops);
-            hipLaunchKernelGGL(tile_gemm_kernel<G_TRSM>, dim3(m, 1, batch), dim3(256), 0, ctx->stream, g);
-            PROF_END(ctx, PROF_TRSM);
-            PROF_BEGIN(ctx, PROF_SYRK, (double)batch * (m * (m + 1) / 2) * tile_flops);
-            hipLaunchKernelGGL(tile_gemm_kernel<G_SYRK>, dim3(m * (m + 1) / 2, 1, batch), dim3(256), 0, ctx->stream, g);
-            PROF_END(ctx, PROF_SYRK);
-        }
+    const double tile_flops = 2.0 * 64.0 * 64.0 * 64.0;
+    // step 0: diagonal block and first panel as two launches
+    PROF_BEGIN(ctx, PROF_POTRF_DIAG, (double)batch * (64.0 * 64.0 * 64.0));
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, ctx->stream, A, Np, stride_a, 0, n, ws, stride_ws,
+                       logdet, info, flags);
+    PROF_END(ctx, PROF_POTRF_DIAG);
+    if (nbk > 1) {
+        GemmArgs g;
+        g.A = A; g.B = nullptr; g.ws = ws; g.ld = Np; g.stride_a = stride_a; g.stride_ws = stride_ws;
+        g.n = n; g.nbk = nbk; g.k = 0; g.s = 0;
+        PROF_BEGIN(ctx, PROF_TRSM, (double)batch * (nbk - 1) * tile_flops);
+        hipLaunchKernelGGL(tile_gemm_kernel<G_TRSM>, dim3(nbk - 1, 1, batch), dim3(256), 0, ctx->stream, g);
+        PROF_END(ctx, PROF_TRSM);
+    }
+    // steps 1..nbk-1: trailing update with panel k-1 + factorisation of block k + panel k, fused
+    StepArgs st;
+    st.A = A; st.ws = ws; st.ld = Np; st.stride_a = stride_a; st.stride_ws = stride_ws; st.n = n; st.nbk = nbk;
+    st.logdet = logdet; st.info = info; st.flags = flags; st.batch = batch;
+    for (int k = 1; k < nbk; ++k) {
+        const int m = nbk - k;
+        st.k = k;
+        PROF_BEGIN(ctx, PROF_SYRK, (double)batch * (m * (m + 1) / 2 + (m - 1)) * tile_flops);
+        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(batch * (m * (m + 1) / 2))), dim3(256), 0, ctx->stream, st);
+        PROF_END(ctx, PROF_SYRK);
     }
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
@@ -403,9 +555,10 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     const int64_t nbk = padded_dim(n) / 64;
     double *ld_ws = ws + (size_t)batch * nbk * 4096 + DGPAMD_MAXB;
     int32_t *info_ws = reinterpret_cast<int32_t *>(ws + (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB);
+    int32_t *flags = info_ws + DGPAMD_MAXB;
     const std::array<uint64_t, 10> key = {1, (uint64_t)n, (uint64_t)batch, (uint64_t)A, (uint64_t)stride_a, (uint64_t)ws,
                                           0, 0, 0, 0};
-    int rc = graph_run(ctx, key, [&]() { return potrf_launches(ctx, n, A, stride_a, batch, ld_ws, info_ws, ws); });
+    int rc = graph_run(ctx, key, [&]() { return potrf_launches(ctx, n, A, stride_a, batch, ld_ws, info_ws, ws, flags); });
     if (rc) return rc;
     hipLaunchKernelGGL(potrf_copy_out_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)ld_ws,
                        (const int32_t *)info_ws, logdet, info, batch);
