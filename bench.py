@@ -156,7 +156,7 @@ def main():
     # ---- roofline of the dominant kernel: HIP events around each of its launches, same steps ----
     roof = None
     if rank == 0:
-        engines = [eng] + (list(model._pool[1]) if model._pool else [])
+        engines = [eng]
         for e in engines:
             e.prof_enable(args.prof_kernel)
         for _ in range(max(1, min(2, args.steps))):

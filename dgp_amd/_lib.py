@@ -51,6 +51,7 @@ SIGNATURES = {
     'dgpamd_trmv_lower': (_i, [_p, _l, _p, _l, _p, _p, _p, _i]),
     'dgpamd_ess_propose': (_i, [_p, _l, _i, _p, _p, _p, _i, _p]),
     'dgpamd_potri': (_i, [_p, _l, _p, _p, _i, _p]),
+    'dgpamd_potri_batched': (_i, [_p, _l, _p, _p, _l, _i, _i, _p]),
     'dgpamd_grad_workspace': (_z, [_l, _i]),
     'dgpamd_grad_reduce': (_i, [_p, _i, _l, _p, _l, _p, _i, _p, _i, _p, _i, _d, _p, _i, _p, _p, _p]),
     'dgpamd_gp_workspace': (_z, [_l, _l]),

@@ -450,17 +450,20 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(StepArgs g) {
 }
 
 // place the diagonal-block inverses on the diagonal of the (to be inverted) factor
-__global__ __launch_bounds__(256) void put_diag_inverse_kernel(double *A, int64_t ld, const double *ws) {
+__global__ __launch_bounds__(256) void put_diag_inverse_kernel(double *A, int64_t ld, const double *ws,
+                                                               int64_t stride_a, int64_t stride_ws) {
     const int kb = blockIdx.x, tid = threadIdx.x;
-    double *Ab = A + ((int64_t)kb * 64) * ld + (int64_t)kb * 64;
-    const double *W = ws + (int64_t)kb * 4096;
+    double *Ab = A + (int64_t)blockIdx.y * stride_a + ((int64_t)kb * 64) * ld + (int64_t)kb * 64;
+    const double *W = ws + (int64_t)blockIdx.y * stride_ws + (int64_t)kb * 4096;
     for (int idx = tid; idx < 4096; idx += 256) Ab[(int64_t)(idx >> 6) * ld + (idx & 63)] = W[idx];
 }
 
 // rows [n, n+r) of L^-1 (columns < n) are -alpha^T: copy them beside K^-1
-__global__ void copy_aug_rows_kernel(const double *A, double *B, int64_t ld, int64_t n, int r) {
+__global__ void copy_aug_rows_kernel(const double *A, double *B, int64_t ld, int64_t n, int r, int64_t stride_a) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    A += (int64_t)blockIdx.y * stride_a;
+    B += (int64_t)blockIdx.y * stride_a;
     for (int q = 0; q < r; ++q) B[(n + q) * ld + j] = A[(n + q) * ld + j];
 }
 
@@ -598,35 +601,47 @@ extern "C" int dgpamd_trmv_lower(dgpamd_ctx *ctx, int64_t n, const double *L, in
     return DGPAMD_OK;
 }
 
-static int potri_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work);
+static int potri_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int64_t stride_a, int r, int batch,
+                          void *work);
 
-extern "C" int dgpamd_potri(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work) {
+extern "C" int dgpamd_potri_batched(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int64_t stride_a, int r,
+                                    int batch, void *work) {
     if (!ctx) return DGPAMD_BAD_ARG;
     if (n <= 0 || !A || !Ainv || !work || r < 0) BAD_ARG(ctx, "null pointer or n <= 0");
+    if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
     const int64_t Np = padded_dim(n);
     if (n + r > Np) BAD_ARG(ctx, "too many right-hand sides");
-    const std::array<uint64_t, 10> key = {2, (uint64_t)n, (uint64_t)r, (uint64_t)A, (uint64_t)Ainv, (uint64_t)work, 0, 0, 0, 0};
-    return graph_run(ctx, key, [&]() { return potri_launches(ctx, n, A, Ainv, r, work); });
+    if (batch > 1 && stride_a < Np * Np) BAD_ARG(ctx, "stride_a < Np*Np");
+    const std::array<uint64_t, 10> key = {2, (uint64_t)n, (uint64_t)r, (uint64_t)A, (uint64_t)Ainv, (uint64_t)work,
+                                          (uint64_t)batch, (uint64_t)stride_a, 0, 0};
+    return graph_run(ctx, key, [&]() { return potri_launches(ctx, n, A, Ainv, stride_a, r, batch, work); });
 }
 
-static int potri_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work) {
+extern "C" int dgpamd_potri(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work) {
+    return dgpamd_potri_batched(ctx, n, A, Ainv, 0, r, 1, work);
+}
+
+static int potri_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int64_t stride_a, int r, int batch,
+                          void *work) {
     const int64_t Np = padded_dim(n);
     const int nbk = (int)(Np / 64);
+    const int64_t stride_ws = (int64_t)nbk * 4096;
     GemmArgs g;
-    g.A = A; g.B = Ainv; g.ws = (const double *)work; g.ld = Np; g.stride_a = 0; g.stride_ws = 0;
+    g.A = A; g.B = Ainv; g.ws = (const double *)work; g.ld = Np; g.stride_a = stride_a; g.stride_ws = stride_ws;
     g.n = n; g.nbk = nbk; g.k = 0; g.s = 0;
-    hipLaunchKernelGGL(put_diag_inverse_kernel, dim3(nbk), dim3(256), 0, ctx->stream, A, Np, (const double *)work);
+    hipLaunchKernelGGL(put_diag_inverse_kernel, dim3(nbk, batch), dim3(256), 0, ctx->stream, A, Np, (const double *)work,
+                       stride_a, stride_ws);
     for (int s = 1; s < nbk; s *= 2) {
         const int np = (nbk + 2 * s - 1) / (2 * s);
         g.s = s;
-        hipLaunchKernelGGL(tile_gemm_kernel<G_TRTRI1>, dim3(np * s * s), dim3(256), 0, ctx->stream, g);
-        hipLaunchKernelGGL(tile_gemm_kernel<G_TRTRI2>, dim3(np * s * s), dim3(256), 0, ctx->stream, g);
+        hipLaunchKernelGGL(tile_gemm_kernel<G_TRTRI1>, dim3(np * s * s, 1, batch), dim3(256), 0, ctx->stream, g);
+        hipLaunchKernelGGL(tile_gemm_kernel<G_TRTRI2>, dim3(np * s * s, 1, batch), dim3(256), 0, ctx->stream, g);
     }
     const int nbn = (int)((n + 63) / 64);
-    hipLaunchKernelGGL(tile_gemm_kernel<G_LAUUM>, dim3(nbn * (nbn + 1) / 2), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(tile_gemm_kernel<G_LAUUM>, dim3(nbn * (nbn + 1) / 2, 1, batch), dim3(256), 0, ctx->stream, g);
     if (r > 0)
-        hipLaunchKernelGGL(copy_aug_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, Ainv,
-                           Np, n, r);
+        hipLaunchKernelGGL(copy_aug_rows_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, ctx->stream, A,
+                           Ainv, Np, n, r, stride_a);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }

@@ -160,36 +160,35 @@ class dgp:
                     nd.r2(overwritten=True)
 
     # ------------------------------------------------------------------ training
-    def _streams(self, count):
-        """One engine (HIP stream + workspaces) per concurrently optimised node."""
-        want = max(1, min(count, utils.get_thread()))
-        if self._pool is None or len(self._pool[1]) != want:
-            dev = self.engine.device.index
-            engines = [Engine(dev, torch.cuda.Stream(self.engine.device)) for _ in range(want)]
-            self._pool = (ThreadPoolExecutor(max_workers=want), engines)
-        return self._pool
-
     def _m_step(self):
+        """One L-BFGS-B fit per GP node (dgp.py:1391-1398); the nodes' objective evaluations are batched in
+        lock-step on the device (dgp_amd.mstep.LlikBatcher).  Vecchia nodes evaluate on their own."""
+        from .mstep import LlikBatcher
         nodes = [(l, nd) for l, layer in enumerate(self.all_layer) for nd in layer if nd.type == 'gp']
-        pool, engines = self._streams(len(nodes))
-        free = list(range(len(engines)))
+        dense = [nd for _, nd in nodes if not nd.vecch]
+        batcher = LlikBatcher(self.engine, len(dense)) if len(dense) > 1 else None
+        if self._pool is None or self._pool[1] != len(nodes):
+            self._pool = (ThreadPoolExecutor(max_workers=len(nodes)), len(nodes))
+        eng = self.engine
 
         def work(args):
             l, nd = args
-            idx = free.pop()
-            eng = engines[idx]
+            joined = batcher is not None and not nd.vecch
             try:
-                nd.engine = eng
                 with eng.stream():
+                    nd.engine = eng
+                    nd._batcher = batcher if joined else None
                     if nd.prior_name == 'ref':
                         nd.compute_cl()
                     if l != 0:
                         nd.r2()
                     nd.maximise()
             finally:
-                nd.engine = self.engine
-                free.append(idx)
-        list(pool.map(work, nodes))
+                nd._batcher = None
+                if joined:
+                    batcher.done()
+        list(self._pool[0].map(work, nodes))
+        self.last_mstep = None if batcher is None else (batcher.rounds, batcher.evals)
 
     def train(self, N=500, ess_burn=10, disable=False):
         """N iterations of stochastic EM (dgp.py:1364-1412) with the same restart policy on LinAlgError."""

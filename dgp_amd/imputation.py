@@ -185,35 +185,32 @@ class imputer:
         dense = [k for k in cols if not layer[k].vecch]
         Z = {k: self.draws.normal(n) for k in cols}
         if dense:
-            need = []
-            for k in dense:
-                nd = layer[k]
-                key = (l, k)
-                sig = (nd.name, tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), id(nd.input) if l == 0 else None)
-                hit = self._factor_cache.get(key)
-                if l == 0 and hit is not None and hit[0] == sig:
-                    continue
-                need.append((k, sig))
-            if need:
-                # factor the stale nodes as one batched Cholesky
-                buf = e.empty(len(need), Np, Np)
-                for j, (k, sig) in enumerate(need):
+            # Factors of the whole layer live in ONE batched buffer (stride Np^2) so that the draws are a single
+            # batched triangular product; the buffer is reused while inputs and hyper-parameters are unchanged
+            # (first layer: the whole I-step and beyond; deeper layers: their inputs change every sweep).
+            sigs = tuple((k, layer[k].name, tuple(np.asarray(layer[k].length, float)), float(layer[k].nugget[0]),
+                          id(layer[k].input) if l == 0 else None) for k in dense)
+            hit = self._factor_cache.get(l)
+            if l != 0 or hit is None or hit[0] != sigs:
+                buf = hit[1] if hit is not None and hit[1].shape[0] == len(dense) else e.empty(len(dense), Np, Np)
+                for j, k in enumerate(dense):
                     nd = layer[k]
                     Xl, cm = self._node_input(l, k, nd)
                     e.kmatrix(nd.name, Xl, cm, self._glob[(l, k)], nd.length, nd.nugget[0], out=buf[j], full=False)
-                _, info = e.potrf(n, buf, batch=len(need))
-                info = info.cpu().numpy()
-                if info.any():
-                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[info != 0][0]))
-                for j, (k, sig) in enumerate(need):
-                    self._factor_cache[(l, k)] = (sig, buf[j])
-            for k in dense:
-                nd = layer[k]
-                Lk = self._factor_cache[(l, k)][1]
-                out = e.trmv_lower(n, Lk, [nd.scale[0]], e.tensor(Z[k]))
-                nu[:, k] = out[0]
-                if l != 0:
-                    del self._factor_cache[(l, k)]
+                for c0 in range(0, len(dense), 64):
+                    nb = min(64, len(dense) - c0)
+                    _, info = e.potrf(n, buf[c0:c0 + nb], batch=nb)
+                    info = info.cpu().numpy()
+                    if info.any():
+                        raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[info != 0][0]))
+                self._factor_cache[l] = (sigs, buf)
+            buf = self._factor_cache[l][1]
+            Zd = e.tensor(np.stack([Z[k] for k in dense]))
+            scales = [float(layer[k].scale[0]) for k in dense]
+            for c0 in range(0, len(dense), 64):
+                nb = min(64, len(dense) - c0)
+                out = e.trmv_lower(n, buf[c0:c0 + nb], scales[c0:c0 + nb], Zd[c0:c0 + nb], batch=nb)
+                nu[:, torch.as_tensor(dense[c0:c0 + nb], device=nu.device)] = out.t()
         for k in cols:
             nd = layer[k]
             if nd.vecch:

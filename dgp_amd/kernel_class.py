@@ -65,6 +65,7 @@ class kernel:
         self._engine = engine
         self._stats = None       # device-side prediction statistics (compute_stats)
         self._staged = None
+        self._batcher = None
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -83,6 +84,7 @@ class kernel:
         st['_engine'] = None
         st['_staged'] = None
         st['_stats'] = None
+        st['_batcher'] = None
         return st
 
     def _X(self):
@@ -213,6 +215,16 @@ class kernel:
     def llik(self, x):
         """Negative log-likelihood and gradient wrt log-parameters (kernel_class.py:403-449)."""
         self.update(x)
+        batcher = getattr(self, '_batcher', None)
+        if batcher is not None:      # M-step rendezvous: evaluated together with the other nodes' objectives
+            host = batcher.evaluate(self)
+        else:
+            host = self._llik_device()
+        return self._llik_finish(host)
+
+    def _llik_device(self):
+        """K -> Cholesky (y as augmented row) -> inverse -> in-flight derivative reductions for THIS node alone.
+        Returns the host vector [logdet, y'K^-1y, tr_p.., quad_p.., info]."""
         e = self.engine
         s = self._staged if getattr(self, '_in_maximise', False) and self._staged is not None else self._stage()
         n = len(self.output)
@@ -226,7 +238,12 @@ class kernel:
         e.potri(n, A, Ainv, 1, work)
         red, P = e.grad_reduce(self.name, s['Xl'], None, s['Xg'], self.length, self.nugget[0], self.nugget_est, Ainv, W=s['W'])
         import torch
-        host = torch.cat((logdet, quad.reshape(-1), red, info.to(torch.float64))).cpu().numpy()
+        return torch.cat((logdet, quad.reshape(-1), red, info.to(torch.float64))).cpu().numpy()
+
+    def _llik_finish(self, host):
+        """Closing host arithmetic of kernel.llik (kernel_class.py:421-448) on the reduced device results."""
+        n = len(self.output)
+        P = (len(host) - 3) // 2
         self._raise_if_not_pd(host[-1])
         logdet, YKinvY, tr, ykky = host[0], host[1], host[2:2 + P], host[2 + P:2 + 2 * P]
         P1, P2 = -0.5 * tr, 0.5 * ykky

@@ -228,8 +228,9 @@ class Engine:
         self._chk(lib.dgpamd_ess_propose(self.h, n, M, _dp(F), _dp(NU), _hp(th), B, _dp(out)))
         return out
 
-    def potri(self, n, A, Ainv, r, work):
-        self._chk(lib.dgpamd_potri(self.h, n, _dp(A), _dp(Ainv), r, _dp(work)))
+    def potri(self, n, A, Ainv, r, work, batch=1):
+        Np = self.padded_dim(n)
+        self._chk(lib.dgpamd_potri_batched(self.h, n, _dp(A), _dp(Ainv), Np * Np if batch > 1 else 0, r, batch, _dp(work)))
         return Ainv
 
     def grad_reduce(self, kind, Xloc, colmap, Xglob, length, nugget, nugget_est, Ainv, W=None):

@@ -144,6 +144,9 @@ int dgpamd_ess_propose(dgpamd_ctx *ctx, int64_t n, int M, const double *F, const
  * Ainv (Np x Np buffer) holds K^-1 in BOTH triangles of [0,n)x[0,n) and row n+q
  * of columns [0,n) holds -alpha_q^T = -(K^-1 y_q)^T.  A is overwritten with L^-1. */
 int dgpamd_potri(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work);
+/* Same on `batch` buffers (A and Ainv share the batch stride stride_a; work = the batched potrf workspace). */
+int dgpamd_potri_batched(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int64_t stride_a, int r, int batch,
+                         void *work);
 
 /* ---- a8  M-step objective pieces -------------------------------------------
  * kernel.llik  kernel_class.py:403-449 restructured:
