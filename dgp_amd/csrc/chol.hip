@@ -32,159 +32,179 @@ __device__ __forceinline__ double rsqrt_f64(double d) {
     return h + h;
 }
 
-// The 64 pivots are taken FOUR at a time: the 4x4 pivot block is factored redundantly in every thread's
-// registers (that is the serial chain), the scaled 64x4 panel and the four finished rows of the running
-// inverse go through LDS once, and the trailing update is rank-4: two barriers per four pivots.
+__device__ __forceinline__ double rcp_f64(double d) {
+    // hardware estimate (~23 bits) + two Newton rounds: depth 5
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    return fma(x, e, x);
+}
+
+// The 64 pivots are taken FOUR at a time.  The tile and the running inverse stay in registers in the MFMA
+// accumulator layout (wave w owns rows 16w..16w+15; a[t][r] = A[16w + (lane>>4) + 4r][16t + (lane&15)]), so the
+// rank-4 trailing update of a group is ONE v_mfma_f64_16x16x4 per 16x16 tile.  Per group:
+//   * the four raw pivot columns (64x4) and the four raw rows of the running inverse (4x64) sit in LDS;
+//   * every lane redoes the 4x4 pivot block (LDL^T with reciprocals on the serial chain, the square roots beside
+//     it: depth 28 instead of 36) and forms M = (4x4 Cholesky factor)^-1;
+//   * each lane turns the raw rows it needs into MFMA operands with one 4-term dot product each
+//     (panel L = raw M^T, finished inverse rows = M raw), stores the finished column / inverse-row entries straight
+//     to global memory, issues the MFMAs and publishes the next group's raw columns / rows: ONE barrier per group.
 struct DiagShared {
-    double colraw[4][64];    // raw pivot columns j0..j0+3
-    double rowraw[4][64];    // raw rows j0..j0+3 of the running inverse
-    double panL[64][4];      // scaled panel  L[r][j0+u]
-    double panY[64][4];      // finished rows Linv[j0+u][c]
+    double colraw[2][64][4];   // [ping-pong][row][v]  = A[row][j0+v]
+    double rowraw[2][64][4];   // [ping-pong][col][v]  = Y[j0+v][col]   (Y = running inverse)
     double piv[64];
 };
 
-// Factor the 64x64 tile held in registers (thread (tx,ty) owns rows ty+16p, columns tx+16q), write the factor to
-// Ab (ld) and the inverse of the factor to Wb (64x64), accumulate logdet / info of matrix b.  ncol = pivots in
-// this block (rows/columns beyond are carried right-hand sides).
-__device__ __forceinline__ void diag_factor(double (&a)[4][4], DiagShared &sh, double *Ab, int64_t ld, double *Wb,
-                                            int ncol, int k, int b, double *logdet, int32_t *info) {
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    double y[4][4];
+// Factor the 64x64 tile held in registers, write the factor to Ab (ld; strictly upper part zeroed) and the inverse
+// of the factor to Wb (64x64), accumulate logdet / info of matrix b.  ncol = pivots in this block (rows/columns
+// beyond are carried right-hand sides).
+__device__ __forceinline__ void diag_factor(d4 (&a)[4], DiagShared &sh, double *Ab, int64_t ld, double *Wb, int ncol,
+                                            int k, int b, double *logdet, int32_t *info) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lm = l & 15, lu = l >> 4;
+    const int myrow = 16 * w + lm;   // row this lane serves as MFMA A operand / stores as finished column
+    d4 y[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) y[p][q] = (ty + 16 * p == tx + 16 * q) ? 1.0 : 0.0;
+        for (int r = 0; r < 4; ++r) y[t][r] = (16 * w + lu + 4 * r == 16 * t + lm) ? 1.0 : 0.0;
     if (tid < 64) sh.piv[tid] = 1.0;
     int bad = 0;
+    if ((lm >> 2) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh.colraw[0][16 * w + lu + 4 * r][lm & 3] = a[0][r];
+    }
+    if (w == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sh.rowraw[0][16 * t + lm][lu] = y[t][0];
+    }
+    __syncthreads();
 
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-        // in block jb only register rows p >= jb / columns q >= jb of A are live; inverse rows have columns q <= jb
-        for (int jq = 0; jq < 4; ++jq) {
-            const int j0 = jb * 16 + jq * 4;
-            if (j0 >= ncol) break;
-            const int nact = ncol - j0 >= 4 ? 4 : ncol - j0;   // active pivots of this panel
-            if ((tx >> 2) == jq) {
+    for (int g = 0; g < 16; ++g) {
+        const int jb = g >> 2, j0 = 4 * g, buf = g & 1;
+        if (j0 >= ncol) break;
+        const int nact = ncol - j0 >= 4 ? 4 : ncol - j0;   // active pivots of this group
+        if (w >= jb) {
+            // ---- operands from LDS (issued ahead of the chain) ----
+            const double2 *cr = reinterpret_cast<const double2 *>(&sh.colraw[buf][0][0]);
+            const double2 *rr = reinterpret_cast<const double2 *>(&sh.rowraw[buf][0][0]);
+            const double2 C0 = cr[2 * j0], C1 = cr[2 * (j0 + 1)], C2a = cr[2 * (j0 + 2)], C2b = cr[2 * (j0 + 2) + 1];
+            const double2 C3a = cr[2 * (j0 + 3)], C3b = cr[2 * (j0 + 3) + 1];
+            const double2 rAa = cr[2 * myrow], rAb = cr[2 * myrow + 1];
+            double2 rBa[4], rBb[4], rYa[4], rYb[4];
 #pragma unroll
-                for (int p = jb; p < 4; ++p) sh.colraw[tx & 3][ty + 16 * p] = a[p][jb];
+            for (int t = jb; t < 4; ++t) {
+                rBa[t] = cr[2 * (16 * t + lm)];
+                rBb[t] = cr[2 * (16 * t + lm) + 1];
             }
-            if ((ty >> 2) == jq) {
 #pragma unroll
-                for (int q = 0; q <= jb; ++q) sh.rowraw[ty & 3][tx + 16 * q] = y[jb][q];
+            for (int t = 0; t <= jb; ++t) {
+                rYa[t] = rr[2 * (16 * t + lm)];
+                rYb[t] = rr[2 * (16 * t + lm) + 1];
             }
-            __syncthreads();
-            // ---- 4x4 pivot block, redundantly in every thread ----
-            double d00 = sh.colraw[0][j0], d10 = sh.colraw[0][j0 + 1], d20 = sh.colraw[0][j0 + 2], d30 = sh.colraw[0][j0 + 3];
-            double d11 = sh.colraw[1][j0 + 1], d21 = sh.colraw[1][j0 + 2], d31 = sh.colraw[1][j0 + 3];
-            double d22 = sh.colraw[2][j0 + 2], d32 = sh.colraw[2][j0 + 3], d33 = sh.colraw[3][j0 + 3];
-            if (!(d00 > 0.0)) { if (!bad) bad = j0 + 1; d00 = 1.0; }
-            const double i0 = rsqrt_f64(d00);
-            double L10 = d10 * i0, L20 = d20 * i0, L30 = d30 * i0;
-            double p1 = fma(-L10, L10, d11);
-            if (nact < 2) { p1 = 1.0; L10 = 0.0; }
+            // ---- 4x4 pivot block: LDL^T, reciprocals on the chain ----
+            double p0 = C0.x;
+            const double c10 = C1.x, c11 = C1.y, c20 = C2a.x, c21 = C2a.y, c22 = C2b.x;
+            const double c30 = C3a.x, c31 = C3a.y, c32 = C3b.x, c33 = C3b.y;
+            if (!(p0 > 0.0)) { if (!bad) bad = j0 + 1; p0 = 1.0; }
+            const double r0 = rcp_f64(p0);
+            const double l10 = c10 * r0, l20 = c20 * r0, l30 = c30 * r0;
+            double p1 = fma(-l10, c10, c11);
+            const double w21 = fma(-l20, c10, c21), w31 = fma(-l30, c10, c31);
+            double q2 = fma(-l20, c20, c22), w32 = fma(-l30, c20, c32), q3 = fma(-l30, c30, c33);
+            if (nact < 2) p1 = 1.0;
             if (!(p1 > 0.0)) { if (!bad) bad = j0 + 2; p1 = 1.0; }
-            const double i1 = rsqrt_f64(p1);
-            double L21 = fma(-L20, L10, d21) * i1, L31 = fma(-L30, L10, d31) * i1;
-            double p2 = fma(-L21, L21, fma(-L20, L20, d22));
-            if (nact < 3) { p2 = 1.0; L20 = 0.0; L21 = 0.0; }
+            const double r1 = rcp_f64(p1);
+            const double l21 = w21 * r1, l31 = w31 * r1;
+            double p2 = fma(-l21, w21, q2);
+            w32 = fma(-l31, w21, w32);
+            q3 = fma(-l31, w31, q3);
+            if (nact < 3) p2 = 1.0;
             if (!(p2 > 0.0)) { if (!bad) bad = j0 + 3; p2 = 1.0; }
-            const double i2 = rsqrt_f64(p2);
-            double L32 = fma(-L31, L21, fma(-L30, L20, d32)) * i2;
-            double p3 = fma(-L32, L32, fma(-L31, L31, fma(-L30, L30, d33)));
-            if (nact < 4) { p3 = 1.0; L30 = 0.0; L31 = 0.0; L32 = 0.0; }
+            const double r2 = rcp_f64(p2);
+            const double l32 = w32 * r2;
+            double p3 = fma(-l32, w32, q3);
+            if (nact < 4) p3 = 1.0;
             if (!(p3 > 0.0)) { if (!bad) bad = j0 + 4; p3 = 1.0; }
-            const double i3 = rsqrt_f64(p3);
-            if (tid == 0) {
-                sh.piv[j0] = d00;
+            const double s0 = rsqrt_f64(p0);
+            const double s1 = nact > 1 ? rsqrt_f64(p1) : 0.0;
+            const double s2 = nact > 2 ? rsqrt_f64(p2) : 0.0;
+            const double s3 = nact > 3 ? rsqrt_f64(p3) : 0.0;
+            if (tid == 192) {
+                sh.piv[j0] = p0;
                 if (nact > 1) sh.piv[j0 + 1] = p1;
                 if (nact > 2) sh.piv[j0 + 2] = p2;
                 if (nact > 3) sh.piv[j0 + 3] = p3;
             }
-            // ---- scaled panel (one row per thread) and finished inverse rows (one column per thread) ----
-            if (tid < 64) {
-                const int r = tid;
-                const double a0 = sh.colraw[0][r], a1 = sh.colraw[1][r], a2 = sh.colraw[2][r], a3 = sh.colraw[3][r];
-                const double x0 = a0 * i0;
-                const double x1 = nact > 1 ? fma(-x0, L10, a1) * i1 : 0.0;
-                const double x2 = nact > 2 ? fma(-x1, L21, fma(-x0, L20, a2)) * i2 : 0.0;
-                const double x3 = nact > 3 ? fma(-x2, L32, fma(-x1, L31, fma(-x0, L30, a3))) * i3 : 0.0;
-                sh.panL[r][0] = x0; sh.panL[r][1] = x1; sh.panL[r][2] = x2; sh.panL[r][3] = x3;
-            } else if (tid < 128) {
-                const int c = tid - 64;
-                const bool in = c < 16 * (jb + 1);
-                const double y0 = in ? sh.rowraw[0][c] : 0.0, y1 = in ? sh.rowraw[1][c] : 0.0;
-                const double y2 = in ? sh.rowraw[2][c] : 0.0, y3 = in ? sh.rowraw[3][c] : 0.0;
-                const double f0 = y0 * i0;
-                const double f1 = fma(-L10, f0, y1) * i1;
-                const double f2 = fma(-L21, f1, fma(-L20, f0, y2)) * i2;
-                const double f3 = fma(-L32, f2, fma(-L31, f1, fma(-L30, f0, y3))) * i3;
-                sh.panY[c][0] = f0; sh.panY[c][1] = f1; sh.panY[c][2] = f2; sh.panY[c][3] = f3;
+            // unit-lower inverse N, then row lu of M = diag(s) N
+            const double n20 = fma(l21, l10, -l20), n31 = fma(l32, l21, -l31);
+            const double n30 = fma(-l32, n20, fma(l31, l10, -l30));
+            const double m0 = lu == 0 ? s0 : (lu == 1 ? -l10 * s1 : (lu == 2 ? n20 * s2 : n30 * s3));
+            const double m1 = lu == 0 ? 0.0 : (lu == 1 ? s1 : (lu == 2 ? -l21 * s2 : n31 * s3));
+            const double m2 = lu < 2 ? 0.0 : (lu == 2 ? s2 : -l32 * s3);
+            const double m3 = lu < 3 ? 0.0 : s3;
+            // ---- MFMA operands: panel value of (row, pivot lu), finished inverse row lu ----
+            const double xA = fma(rAb.y, m3, fma(rAb.x, m2, fma(rAa.y, m1, rAa.x * m0)));
+            const double opA = (myrow >= j0 + nact) ? -xA : 0.0;
+            if (lu < nact) Ab[(int64_t)myrow * ld + j0 + lu] = (myrow >= j0 + lu) ? xA : 0.0;
+            const int tn = (g + 1) >> 2;   // tile of the next group's columns: update it first
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = (tt == 0) ? (tn < 4 ? tn : 3) : ((tt <= (tn < 4 ? tn : 3)) ? tt - 1 : tt);
+                if (t < jb) continue;
+                const double xB = fma(rBb[t].y, m3, fma(rBb[t].x, m2, fma(rBa[t].y, m1, rBa[t].x * m0)));
+                const double opB = (16 * t + lm >= j0 + nact) ? xB : 0.0;
+                a[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opB, a[t], 0, 0, 0);
             }
-            __syncthreads();
-            // ---- rank-4 trailing update, assignment of the finished columns / inverse rows ----
-            double Lr[4][4], Lc[4][4], Yf[4][4];
 #pragma unroll
-            for (int p = jb; p < 4; ++p)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    Lr[p][u] = sh.panL[ty + 16 * p][u];
-                    Lc[p][u] = sh.panL[tx + 16 * p][u];
+            for (int t = 0; t < 4; ++t) {
+                double xY = 0.0;
+                if (t <= jb) {
+                    xY = fma(rYb[t].y, m3, fma(rYb[t].x, m2, fma(rYa[t].y, m1, rYa[t].x * m0)));
+                    y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, xY, y[t], 0, 0, 0);
                 }
+                if (w == 3 && lu < nact) Wb[(j0 + lu) * 64 + 16 * t + lm] = xY;
+            }
+        } else if (lu < nact) {
+            Ab[(int64_t)myrow * ld + j0 + lu] = 0.0;   // rows above the pivots: strictly upper part
+        }
+        // ---- raw columns / inverse rows of the next group ----
+        if (g + 1 < 16 && j0 + 4 < ncol) {
+            const int jbn = (g + 1) >> 2, jqn = (g + 1) & 3;
+            if (w >= jbn && (lm >> 2) == jqn) {
 #pragma unroll
-            for (int q = 0; q <= jb; ++q)
+                for (int r = 0; r < 4; ++r) sh.colraw[buf ^ 1][16 * w + lu + 4 * r][lm & 3] = a[jbn < 4 ? jbn : 3][r];
+            }
+            if (w == jbn) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) Yf[q][u] = sh.panY[tx + 16 * q][u];
-            const int ur = ty & 3, uc = tx & 3;
-#pragma unroll
-            for (int p = jb; p < 4; ++p) {
-                const bool below = (p > jb) || (ty >= 4 * jq + nact);            // row beyond the active pivots
-                const bool inblk = (p == jb) && ((ty >> 2) == jq) && (ur < nact); // row j0+ur of the pivot block
-#pragma unroll
-                for (int q = jb; q < 4; ++q) {
-                    const bool right = (q > jb) || (tx >= 4 * jq + nact);
-                    if (below && right) {
-                        double v = a[p][q];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) v = fma(-Lr[p][u], Lc[q][u], v);
-                        a[p][q] = v;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q <= jb; ++q) {
-                    if (below) {
-                        double v = y[p][q];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) v = fma(-Lr[p][u], Yf[q][u], v);
-                        y[p][q] = v;
-                    } else if (inblk) {
-                        y[p][q] = ur == 0 ? Yf[q][0] : (ur == 1 ? Yf[q][1] : (ur == 2 ? Yf[q][2] : Yf[q][3]));
-                    }
-                }
-                // finished column c = j0+uc: rows r >= c take the panel value (diagonal = sqrt(pivot))
-                if ((tx >> 2) == jq && uc < nact) {
-                    const bool onorbelow = below || (inblk && (ur >= uc));
-                    if (onorbelow) a[p][jb] = uc == 0 ? Lr[p][0] : (uc == 1 ? Lr[p][1] : (uc == 2 ? Lr[p][2] : Lr[p][3]));
-                }
+                for (int t = 0; t < 4; ++t) sh.rowraw[buf ^ 1][16 * t + lm][lu] = y[t][jqn];
             }
         }
+        __syncthreads();
     }
+    if (ncol < 64) {   // last block: carried right-hand-side rows / columns are still in registers
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int r = ty + 16 * p, c = tx + 16 * q;
-            Ab[(int64_t)r * ld + c] = a[p][q];
-            Wb[r * 64 + c] = y[p][q];
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * w + lu + 4 * r, col = 16 * t + lm;
+                if (col >= ncol) Ab[(int64_t)row * ld + col] = (row >= ncol) ? a[t][r] : 0.0;
+                if (row >= ncol) Wb[row * 64 + col] = y[t][r];
+            }
+    }
+    if (tid == 192 && bad) sh.piv[0] = -(double)bad;   // hand the failure to the reducing wave (a pivot is never < 0)
     __syncthreads();
     if (tid < 64) {
-        double v = (tid < ncol) ? log(sh.piv[tid]) : 0.0;
+        const double p00 = sh.piv[0];
+        const int badw = p00 < 0.0 ? (int)(-p00) : 0;
+        double v = (tid < ncol && !(tid == 0 && badw)) ? log(sh.piv[tid]) : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (tid == 0) {
             logdet[b] = (k == 0 ? 0.0 : logdet[b]) + v;
             if (k == 0) info[b] = 0;
-            if (bad && info[b] == 0) info[b] = k * 64 + bad;
+            if (badw && info[b] == 0) info[b] = k * 64 + badw;
         }
     }
 }
@@ -194,16 +214,17 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, 
                                                          int32_t *info, int32_t *flags) {
     __shared__ DiagShared sh;
     const int b = blockIdx.x;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x;
     double *Ab = A + (int64_t)b * stride_a + ((int64_t)k * 64) * ld + (int64_t)k * 64;
     double *Wb = ws + (int64_t)b * stride_ws + (int64_t)k * 4096;
     int64_t rem = n - (int64_t)k * 64;
     const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-    double a[4][4];
+    const int wave = tid >> 6, lane = tid & 63;
+    d4 a[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[p][q] = Ab[(int64_t)(ty + 16 * p) * ld + tx + 16 * q];
+        for (int r = 0; r < 4; ++r) a[t][r] = Ab[(int64_t)(16 * wave + (lane >> 4) + 4 * r) * ld + 16 * t + (lane & 15)];
     diag_factor(a, sh, Ab, ld, Wb, ncol, k, b, logdet, info);
     if (tid == 0 && flags) flags[b] = k + 1;   // visible to the next launch (kernel boundary)
 }
@@ -388,22 +409,9 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(StepArgs g) {
         return;
     }
     if (ti == 0) {   // the next diagonal tile: factor it right away
-        __syncthreads();
-        double *S = tiles;   // [64][64]
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) S[(crow + 4 * r) * 64 + 16 * t + ccol] = acc[t][r];
-        __syncthreads();
-        const int tx = tid & 15, ty = tid >> 4;
-        double a[4][4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[p][q] = S[(ty + 16 * p) * 64 + tx + 16 * q];
         int64_t rem = g.n - (int64_t)k * 64;
         const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        diag_factor(a, sh, C, ld, g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096, ncol, k, b, g.logdet, g.info);
+        diag_factor(acc, sh, C, ld, g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096, ncol, k, b, g.logdet, g.info);
         // publish the inverse: every storing wave drains its stores, one agent-scope release, then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
     const int D = a.kp.Dl + a.kp.Dg;
     double *XiT = lds;            // [D][64]
     double *XjT = lds + D * 64;   // [D][64]
+    double *TT = lds + 2 * D * 64;   // [64][65] transposition buffer for the mirrored tile (full mode only)
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int b = blockIdx.z;
@@ -72,33 +73,74 @@ __global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
 
     double *Kb = a.K + (int64_t)b * a.stride_k;
     const double *Yb = a.Y ? a.Y + (int64_t)b * a.stride_y : nullptr;
+    double v[4][4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int64_t gi = i0 + ty + 16 * p;
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t gj = j0 + tx + 16 * q;
-            double v;
-            if (KIND == DGPAMD_SEXP)
-                v = exp(-s[p][q]);
-            else
-                v = pr[p][q] * exp(-SQRT5 * s[p][q]);
-            if (gi == gj) v = 1.0 + a.kp.nugget * (a.W ? a.W[gi < a.n ? gi : 0] : 1.0);
-            if (a.full) {
-                if (gi < a.n && gj < a.n) {
-                    Kb[gi * a.ldk + gj] = v;
-                    if (bi != bj) Kb[gj * a.ldk + gi] = v;
+        for (int q = 0; q < 4; ++q)
+            v[p][q] = (KIND == DGPAMD_SEXP) ? exp(-s[p][q]) : pr[p][q] * exp(-SQRT5 * s[p][q]);
+    if (bi == bj) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ty + 16 * p == tx + 16 * q) {
+                    const int64_t gi = i0 + ty + 16 * p;
+                    v[p][q] = 1.0 + a.kp.nugget * (a.W ? a.W[gi < a.n ? gi : 0] : 1.0);
                 }
-            } else {
-                // augmented factorisation buffer: rows >= n carry right-hand sides, corner zero
+    }
+    const bool interior = i0 + 64 <= a.n;   // j0 <= i0: the whole tile lies inside the n x n correlation block
+    if (interior) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            double *row = Kb + (i0 + ty + 16 * p) * a.ldk + j0 + tx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) row[16 * q] = v[p][q];
+        }
+    } else if (a.full) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t gi = i0 + ty + 16 * p;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t gj = j0 + tx + 16 * q;
+                if (gi < a.n && gj < a.n) Kb[gi * a.ldk + gj] = v[p][q];
+            }
+        }
+    } else {
+        // augmented factorisation buffer: rows >= n carry right-hand sides, corner zero
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t gi = i0 + ty + 16 * p;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t gj = j0 + tx + 16 * q;
+                double val = v[p][q];
                 if (gi >= a.n) {
                     int64_t qy = gi - a.n;
-                    v = (gj < a.n && qy < a.r) ? Yb[qy * a.ldy + gj] : 0.0;
+                    val = (gj < a.n && qy < a.r) ? Yb[qy * a.ldy + gj] : 0.0;
                 } else if (gj >= a.n) {
-                    v = 0.0;
+                    val = 0.0;
                 }
-                Kb[gi * a.ldk + gj] = v;
+                Kb[gi * a.ldk + gj] = val;
             }
+        }
+    }
+    if (a.full && bi != bj) {
+        // mirrored tile K[j][i]: transposed through LDS so that these stores are row-contiguous too (naive transposed
+        // stores write 32-byte fragments and cost 40% of the kernel's bandwidth)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) TT[(ty + 16 * p) * 65 + tx + 16 * q] = v[p][q];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t gr = j0 + ty + 16 * p;   // j0 + 64 <= i0 <= n: always inside
+            double *row = Kb + gr * a.ldk + i0 + tx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (interior || i0 + tx + 16 * q < a.n) row[16 * q] = TT[(tx + 16 * q) * 65 + ty + 16 * p];
         }
     }
 }
@@ -108,7 +150,7 @@ int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch) {
     int64_t rows = a.full ? a.n : padded_dim(a.n);
     int nbk = (int)((rows + 63) / 64);
     int ntiles = nbk * (nbk + 1) / 2;
-    size_t shm = (size_t)2 * D * 64 * sizeof(double);
+    size_t shm = ((size_t)2 * D * 64 + (a.full ? 64 * 65 : 0)) * sizeof(double);
     dim3 grid(ntiles, 1, batch);
     // algorithmic bytes: the stored triangle(s) of K (8 n^2, or 4 n^2 for the lower tiles) + X once
     PROF_BEGIN(ctx, PROF_KMATRIX, (double)batch * ((a.full ? 8.0 : 4.0) * (double)rows * (double)rows + 8.0 * (double)a.n * D));
