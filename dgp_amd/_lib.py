@@ -40,6 +40,7 @@ SIGNATURES = {
     'dgpamd_event_destroy': (_i, [_p, _p]),
     'dgpamd_set_graphs': (_i, [_p, _i]),
     'dgpamd_set_linkgp_direct': (_i, [_p, _i]),
+    'dgpamd_debug_trace': (_i, [_p, _p]),
     'dgpamd_prof_enable': (_i, [_p, _i]),
     'dgpamd_prof_event_overhead_us': (_i, [_p, C.POINTER(_d)]),
     'dgpamd_prof_collect': (_i, [_p, C.POINTER(_l), C.POINTER(_d), C.POINTER(_d)]),

@@ -59,8 +59,12 @@ struct DiagShared {
 // Factor the 64x64 tile held in registers, write the factor to Ab (ld; strictly upper part zeroed) and the inverse
 // of the factor to Wb (64x64), accumulate logdet / info of matrix b.  ncol = pivots in this block (rows/columns
 // beyond are carried right-hand sides).
-__device__ __forceinline__ void diag_factor(d4 (&a)[4], DiagShared &sh, double *Ab, int64_t ld, double *Wb, int ncol,
+struct Tile64 {
+    d4 v[4];
+};
+__device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double *Ab, int64_t ld, double *Wb, int ncol,
                                             int k, int b, double *logdet, int32_t *info) {
+    d4 (&a)[4] = tile.v;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lm = l & 15, lu = l >> 4;
     const int myrow = 16 * w + lm;   // row this lane serves as MFMA A operand / stores as finished column
     d4 y[4];
@@ -220,11 +224,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, 
     int64_t rem = n - (int64_t)k * 64;
     const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
     const int wave = tid >> 6, lane = tid & 63;
-    d4 a[4];
+    Tile64 a;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[t][r] = Ab[(int64_t)(16 * wave + (lane >> 4) + 4 * r) * ld + 16 * t + (lane & 15)];
+        for (int r = 0; r < 4; ++r) a.v[t][r] = Ab[(int64_t)(16 * wave + (lane >> 4) + 4 * r) * ld + 16 * t + (lane & 15)];
     diag_factor(a, sh, Ab, ld, Wb, ncol, k, b, logdet, info);
     if (tid == 0 && flags) flags[b] = k + 1;   // visible to the next launch (kernel boundary)
 }
@@ -338,16 +342,18 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
 }
 
 // ----------------------------------------------------------------------------
-// One block step of the factorisation as ONE launch (k >= 1):
-//   every trailing tile (i,j), i >= j >= k, takes its update with panel k-1;
-//   the workgroup of tile (k,k) then factors it (diag_factor) and publishes the block's inverse with an
-//   agent-scope release; the workgroups of column k (tiles (i,k), i > k) wait for that flag and apply
-//   P_i = A_ik Linv_k^T.  The serial pivot chain of step k thus overlaps the bulk of the trailing update,
-//   and a factorisation is nbk+1 launches instead of 3 nbk.
-// Deadlock freedom: only the <= (nbk-k-1)*batch <= 31*64 column-k workgroups ever wait, and they wait for a
-// workgroup of the SAME launch that never waits itself; waiting workgroups are far fewer than the resident
-// capacity whenever batch <= 8 and otherwise every non-waiting workgroup terminates, so the diagonal workgroup
-// is scheduled under any dispatch order.  The spin is bounded (info = -1 on timeout).
+// One block step of the factorisation as ONE launch (k >= 1).  Roles, in dispatch (= urgency) order:
+//   chain   one workgroup per matrix: brings the diagonal tile (k,k) up to date, factors it (diag_factor) and
+//           publishes the block's inverse with an agent-scope release;
+//   panel   the workgroups of column k (tiles (i,k), i > k) update their tile, wait for that flag and apply
+//           P_i = A_ik Linv_k^T;
+//   bulk    trailing tiles (i,j) of the columns j = k+1, k+3, ...: LAZY update, two panels (k-2, k-1) = 128 pivots at
+//           a time.  A tile of column j is touched by the launches k = j-1, j-3, ... (two panels each) and finally
+//           by launch j (column k above, panel j-1 only), so C is read and written once per 128 pivots instead of
+//           once per 64 while the serial chain still applies a single panel.
+// The serial pivot chain of step k overlaps the bulk update, and a factorisation is nbk+1 launches.
+// Deadlock freedom: only column-k workgroups ever wait, and they wait for the chain workgroup of the SAME launch,
+// which has a lower block index (dispatched first) and never waits itself.  The spin is bounded (info = -1).
 // ----------------------------------------------------------------------------
 struct StepArgs {
     double *A;
@@ -357,78 +363,92 @@ struct StepArgs {
     double *logdet;
     int32_t *info;
     int32_t *flags;
+    long long *trace;
 };
+#define STAMP(slot)                                                                       \
+    do {                                                                                  \
+        if (g.trace && b == 0 && tid == 0) g.trace[16 * g.k + (slot)] = wall_clock64();   \
+    } while (0)
 
-__global__ __launch_bounds__(256) void potrf_step_kernel(StepArgs g) {
-    __shared__ double tiles[2 * 64 * LDM];   // As | Bs ; the diagonal workgroup reuses it as its 64x64 tile
-    __shared__ DiagShared sh;
-    double *As = tiles, *Bs = tiles + 64 * LDM;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // 1-D grid ordered by urgency: the diagonal tiles of ALL matrices first, then their column-k tiles, then the
-    // bulk of the trailing update (dispatch follows the block index in practice, so the serial pivot chain of every
-    // matrix starts at once and the bulk fills the machine behind it).
-    const int k = g.k, kp = g.k - 1, m = g.nbk - g.k, batch = g.batch;
-    int b, ti, tj;
-    {
-        const int idx = blockIdx.x;
-        if (idx < batch * m) {
-            b = idx % batch; ti = idx / batch; tj = 0;
-        } else {
-            const int bulk = m * (m - 1) / 2, r = idx - batch * m;
-            b = r / bulk;
-            tri_decode(r - b * bulk, ti, tj);
-            ++ti; ++tj;
-        }
-    }
-    const int bi = k + ti, bj = k + tj;
-    const int64_t ld = g.ld;
-    double *A = g.A + (int64_t)b * g.stride_a;
-    double *C = A + ((int64_t)bi * 64) * ld + (int64_t)bj * 64;
-    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
-
-    d4 acc[4];
+__device__ __forceinline__ void load_acc(d4 (&acc)[4], const double *C, int64_t ld, int crow, int ccol) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = C[(int64_t)(crow + 4 * r) * ld + 16 * t + ccol];
-    const double *Pi = A + ((int64_t)bi * 64) * ld + (int64_t)kp * 64;
-    const double *Pj = A + ((int64_t)bj * 64) * ld + (int64_t)kp * 64;
+}
+__device__ __forceinline__ void store_acc(const d4 (&acc)[4], double *C, int64_t ld, int crow, int ccol) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(int64_t)(crow + 4 * r) * ld + 16 * t + ccol] = acc[t][r];
+}
+// acc -= sum over nkb consecutive 64-blocks  Pi_kb Pj_kb^T.  Software pipelined: the global loads of the next
+// half tile are in flight (registers) while the MFMAs of the current one run.
+__device__ __forceinline__ void rank_update(d4 (&acc)[4], const double *Pi, const double *Pj, int64_t ld, int nkb,
+                                            double *As, double *Bs, int tid, int wave, int lane) {
+    const int c2 = (tid & 15) * 2, r0 = tid >> 4;
+    double2 pa[4], pb[4];
+    const int nh = 2 * nkb;
+    if (nh > 0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            pa[it] = *reinterpret_cast<const double2 *>(Pi + (int64_t)(r0 + 16 * it) * ld + c2);
+            pb[it] = *reinterpret_cast<const double2 *>(Pj + (int64_t)(r0 + 16 * it) * ld + c2);
+        }
+    }
+    for (int hh = 0; hh < nh; ++hh) {
         __syncthreads();
-        load_mk(Pi, ld, As, tid, h);
-        load_mk(Pj, ld, Bs, tid, h);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = r0 + 16 * it;
+            As[r * LDM + c2] = pa[it].x; As[r * LDM + c2 + 1] = pa[it].y;
+            Bs[r * LDM + c2] = pb[it].x; Bs[r * LDM + c2 + 1] = pb[it].y;
+        }
+        if (hh + 1 < nh) {
+            const int64_t off = 32 * (hh + 1);   // consecutive half tiles are consecutive 32-column slabs
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                pa[it] = *reinterpret_cast<const double2 *>(Pi + (int64_t)(r0 + 16 * it) * ld + off + c2);
+                pb[it] = *reinterpret_cast<const double2 *>(Pj + (int64_t)(r0 + 16 * it) * ld + off + c2);
+            }
+        }
         __syncthreads();
         mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, -1.0);
     }
-    if (tj != 0) {   // plain trailing tile
+}
+// out += sign * in * Bg^T   (in: accumulator-layout 64x64 tile, Bg: 64x64 row-major tile in global memory)
+__device__ __forceinline__ void mul_acc_bt(d4 (&out)[4], const d4 (&in)[4], const double *Bg, int64_t ldb, double sign,
+                                           double *As, double *Bs, int tid, int wave, int lane) {
+    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(int64_t)(crow + 4 * r) * ld + 16 * t + ccol] = acc[t][r];
-        return;
-    }
-    if (ti == 0) {   // the next diagonal tile: factor it right away
-        int64_t rem = g.n - (int64_t)k * 64;
-        const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        diag_factor(acc, sh, C, ld, g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096, ncol, k, b, g.logdet, g.info);
-        // publish the inverse: every storing wave drains its stores, one agent-scope release, then the flag
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int h = 0; h < 2; ++h) {
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&g.flags[b], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) As[(crow + 4 * r) * LDM + 16 * t + ccol] = in[2 * h + t][r];
+        load_mk(Bg, ldb, Bs, tid, h);
+        __syncthreads();
+        mfma_tile<OP_MK, OP_MK>(As, Bs, out, wave, lane, sign);
     }
-    // panel tile (bi, k): wait for Linv_k, then P_i = A_ik * Linv_k^T
+}
+__device__ __forceinline__ void wg_release_store(int32_t *flag, int value, int tid) {
+    // every storing wave drains its stores, one agent-scope release, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void wg_wait_acquire(int32_t *flag, int target, int32_t *info, int tid) {
     if (tid == 0) {
         int spins = 0;
-        while (__hip_atomic_load(&g.flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 1) {
-            __builtin_amdgcn_s_sleep(16);
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
             if (++spins > (1 << 24)) {
-                g.info[b] = -1;
+                *info = -1;
                 break;
             }
         }
@@ -436,25 +456,65 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(StepArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    const double *Linv = g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096;
+}
+
+__global__ __launch_bounds__(256) void potrf_step_kernel(StepArgs g) {
+    __shared__ double tiles[2 * 64 * LDM];   // As | Bs
+    __shared__ DiagShared sh;
+    double *As = tiles, *Bs = tiles + 64 * LDM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
+    const int k = g.k, m = g.nbk - g.k, batch = g.batch;
+    int b, ti, tj;
+    {
+        const int idx = blockIdx.x;
+        if (idx < batch * m) {                     // column k: chain (ti == 0) and panel workgroups
+            b = idx % batch; ti = idx / batch; tj = 0;
+        } else {                                   // bulk: columns k+1, k+3, ...
+            int bulk = 0;
+            for (int c = 1; c < m; c += 2) bulk += m - c;
+            int r = idx - batch * m;
+            b = r / bulk;
+            r -= b * bulk;
+            tj = 1;
+            while (r >= m - tj) { r -= m - tj; tj += 2; }
+            ti = tj + r;
+        }
+    }
+    const int nprev = (tj == 0 || k < 2) ? 1 : 2;   // panels (k-nprev .. k-1) are applied to this tile
+    const int bi = k + ti, bj = k + tj;
+    const int64_t ld = g.ld;
+    double *A = g.A + (int64_t)b * g.stride_a;
+    double *C = A + ((int64_t)bi * 64) * ld + (int64_t)bj * 64;
+    const int64_t pc = (int64_t)(k - nprev) * 64;
+    Tile64 acc;
+    if (tj == 0 && ti == 0) STAMP(0);
+    load_acc(acc.v, C, ld, crow, ccol);
+    rank_update(acc.v, A + ((int64_t)bi * 64) * ld + pc, A + ((int64_t)bj * 64) * ld + pc, ld, nprev, As, Bs, tid, wave, lane);
+    if (tj != 0) {   // plain trailing tile
+        store_acc(acc.v, C, ld, crow, ccol);
+        return;
+    }
+    double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096;
+    if (ti == 0) {   // the diagonal tile: factor it right away
+        STAMP(1);
+        const int64_t rem = g.n - (int64_t)k * 64;
+        diag_factor(acc, sh, C, ld, Wk, rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0), k, b, g.logdet, g.info);
+        STAMP(2);
+        wg_release_store(g.flags + b, k + 1, tid);
+        STAMP(3);
+        return;
+    }
+    // panel tile (bi, k): wait for Linv_k, then P_i = A_ik * Linv_k^T
+    if (ti == 1) STAMP(8);
+    wg_wait_acquire(g.flags + b, k + 1, g.info + b, tid);
+    if (ti == 1) STAMP(9);
     d4 out[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) out[t] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) As[(crow + 4 * r) * LDM + 16 * t + ccol] = acc[2 * h + t][r];
-        load_mk(Linv, 64, Bs, tid, h);
-        __syncthreads();
-        mfma_tile<OP_MK, OP_MK>(As, Bs, out, wave, lane, 1.0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) C[(int64_t)(crow + 4 * r) * ld + 16 * t + ccol] = out[t][r];
+    mul_acc_bt(out, acc.v, Wk, 64, 1.0, As, Bs, tid, wave, lane);
+    store_acc(out, C, ld, crow, ccol);
+    if (ti == 1) STAMP(10);
 }
 
 // place the diagonal-block inverses on the diagonal of the (to be inverted) factor
@@ -539,11 +599,14 @@ static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_
     StepArgs st;
     st.A = A; st.ws = ws; st.ld = Np; st.stride_a = stride_a; st.stride_ws = stride_ws; st.n = n; st.nbk = nbk;
     st.logdet = logdet; st.info = info; st.flags = flags; st.batch = batch;
+    st.trace = ctx->trace;
     for (int k = 1; k < nbk; ++k) {
-        const int m = nbk - k;
+        const int m = nbk - k, np = k >= 2 ? 2 : 1;
+        int bulk = 0;
+        for (int c = 1; c < m; c += 2) bulk += m - c;
         st.k = k;
-        PROF_BEGIN(ctx, PROF_SYRK, (double)batch * (m * (m + 1) / 2 + (m - 1)) * tile_flops);
-        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(batch * (m * (m + 1) / 2))), dim3(256), 0, ctx->stream, st);
+        PROF_BEGIN(ctx, PROF_SYRK, (double)batch * (bulk * np + m + (m - 1)) * tile_flops);
+        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(batch * (m + bulk))), dim3(256), 0, ctx->stream, st);
         PROF_END(ctx, PROF_SYRK);
     }
     LAUNCH_CHECK(ctx);

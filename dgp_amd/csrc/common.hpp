@@ -28,6 +28,7 @@ struct dgpamd_ctx {
     std::vector<hipEvent_t> prof_events;              // start/stop pairs
     int use_graphs;                                   // replay static launch sequences as hipGraphs
     int linkgp_direct;                                // 1: evaluate the Matern J factor in the reference's direct form
+    long long *trace;                                 // device buffer for in-kernel timestamps (diagnostics), or null
     std::map<std::array<uint64_t, 10>, hipGraphExec_t> graphs;
 };
 

@@ -22,6 +22,7 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->prof_work = 0.0;
     ctx->use_graphs = 1;
     ctx->linkgp_direct = 0;
+    ctx->trace = nullptr;
     // NULL = the device's default (null) stream, which is also torch's default current stream
     ctx->stream = (hipStream_t)stream;
     ctx->own_stream = false;
@@ -128,6 +129,12 @@ extern "C" int dgpamd_prof_collect(dgpamd_ctx *ctx, int64_t *launches_h, double 
 extern "C" int dgpamd_set_graphs(dgpamd_ctx *ctx, int enable) {
     if (!ctx) return DGPAMD_BAD_ARG;
     ctx->use_graphs = enable ? 1 : 0;
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_debug_trace(dgpamd_ctx *ctx, long long *device_buf) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    ctx->trace = device_buf;
     return DGPAMD_OK;
 }
 

@@ -189,6 +189,11 @@ size_t dgpamd_linkgp_workspace(int64_t n, int64_t M, int Dw);
  * training point: Jd = <S(x_min), T(x_max)> + (erf_hi - erf_lo) <S', T'>, csrc/linkfun.hpp), which agrees with the
  * reference's expression to ~1e-11; enable = 1 evaluates the reference's direct expression (vecchia.py:915-959). */
 int dgpamd_set_linkgp_direct(dgpamd_ctx *ctx, int enable);
+
+/* Diagnostics: when device_buf (>= 4096 int64 in device memory) is set, the factorisation kernels of matrix 0 write
+ * wall_clock64() stamps of their phases into it (16 slots per launch; tools/gpu_potrf_trace.py decodes them).
+ * NULL switches it off (the default). */
+int dgpamd_debug_trace(dgpamd_ctx *ctx, long long *device_buf);
 int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz,
                           const double *m, const double *v, const double *z,
                           const double *Wtr, const double *Wg, const double *length_h, int nlen,
