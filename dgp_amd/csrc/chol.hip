@@ -43,18 +43,57 @@ __device__ __forceinline__ double rcp_f64(double d) {
 
 // The 64 pivots are taken FOUR at a time.  The tile and the running inverse stay in registers in the MFMA
 // accumulator layout (wave w owns rows 16w..16w+15; a[t][r] = A[16w + (lane>>4) + 4r][16t + (lane&15)]), so the
-// rank-4 trailing update of a group is ONE v_mfma_f64_16x16x4 per 16x16 tile.  Per group:
-//   * the four raw pivot columns (64x4) and the four raw rows of the running inverse (4x64) sit in LDS;
-//   * every lane redoes the 4x4 pivot block (LDL^T with reciprocals on the serial chain, the square roots beside
-//     it: depth 28 instead of 36) and forms M = (4x4 Cholesky factor)^-1;
-//   * each lane turns the raw rows it needs into MFMA operands with one 4-term dot product each
-//     (panel L = raw M^T, finished inverse rows = M raw), stores the finished column / inverse-row entries straight
-//     to global memory, issues the MFMAs and publishes the next group's raw columns / rows: ONE barrier per group.
+// rank-4 trailing update of a group is ONE v_mfma_f64_16x16x4 per 16x16 tile.  The serial part is the 4x4 pivot
+// block of each group (LDL^T with Newton reciprocals: ~26 dependent f64 operations, ~13 ns each).  It is taken off
+// the update path by WAVE SPECIALISATION: wave 0 (whose rows are finished after the first four groups) runs the
+// pivot chain of group g+1 while waves 1-3 apply the update of group g (operands, MFMAs, stores).  The chain does
+// not wait for the MFMAs: its 4x4 block is (block of g+1 before the update of g, staged one iteration earlier)
+// - (rows of the panel of g)(rows)^T, recomputed from LDS.  Per group: ONE barrier; LDS holds the four raw pivot
+// columns (64x4), the four raw rows of the running inverse (4x64), the next 4x4 block and the chain's results.
+//   panel          L[:, J]  = T diag(s),   T = raw N^T      (N = unit-lower inverse of the 4x4 LDL^T factor)
+//   update         A       -= T diag(r) T^T                 (r = 1/pivot, s = 1/sqrt(pivot))
+//   inverse rows   Y[J, :]  = diag(s) N rawY,   Y[below] -= T diag(r) (N rawY)
 struct DiagShared {
     double colraw[2][64][4];   // [ping-pong][row][v]  = A[row][j0+v]
     double rowraw[2][64][4];   // [ping-pong][col][v]  = Y[j0+v][col]   (Y = running inverse)
+    double blk[2][4][4];       // [ping-pong][v][u]    = A[j0+4+v][j0+4+u] before the update of the current group
+    double chain[2][16];       // [ping-pong] n10 n20 n30 n21 | n31 n32 r0 r1 | r2 r3 p0 p1 | p2 p3 - -
     double piv[64];
 };
+
+// LDL^T of a 4x4 block (lower part c..): unit-lower inverse N, reciprocal pivots r (0 for inactive pivots), pivots p
+__device__ __forceinline__ void pivot_chain(double c00, double c10, double c11, double c20, double c21, double c22,
+                                            double c30, double c31, double c32, double c33, int nact, int j0, int &bad,
+                                            double *out) {
+    double p0 = c00;
+    if (!(p0 > 0.0)) { if (!bad) bad = j0 + 1; p0 = 1.0; }
+    const double r0 = rcp_f64(p0);
+    const double l10 = c10 * r0, l20 = c20 * r0, l30 = c30 * r0;
+    double p1 = fma(-l10, c10, c11);
+    const double w21 = fma(-l20, c10, c21), w31 = fma(-l30, c10, c31);
+    double q2 = fma(-l20, c20, c22), w32 = fma(-l30, c20, c32), q3 = fma(-l30, c30, c33);
+    if (nact < 2) p1 = 1.0;
+    if (!(p1 > 0.0)) { if (!bad) bad = j0 + 2; p1 = 1.0; }
+    const double r1 = rcp_f64(p1);
+    const double l21 = w21 * r1, l31 = w31 * r1;
+    double p2 = fma(-l21, w21, q2);
+    w32 = fma(-l31, w21, w32);
+    q3 = fma(-l31, w31, q3);
+    if (nact < 3) p2 = 1.0;
+    if (!(p2 > 0.0)) { if (!bad) bad = j0 + 3; p2 = 1.0; }
+    const double r2 = rcp_f64(p2);
+    const double l32 = w32 * r2;
+    double p3 = fma(-l32, w32, q3);
+    if (nact < 4) p3 = 1.0;
+    if (!(p3 > 0.0)) { if (!bad) bad = j0 + 4; p3 = 1.0; }
+    const double r3 = rcp_f64(p3);
+    const double n20 = fma(l21, l10, -l20), n31 = fma(l32, l21, -l31);
+    const double n30 = fma(-l32, n20, fma(l31, l10, -l30));
+    out[0] = -l10; out[1] = n20; out[2] = n30; out[3] = -l21;
+    out[4] = n31; out[5] = -l32; out[6] = r0; out[7] = nact > 1 ? r1 : 0.0;
+    out[8] = nact > 2 ? r2 : 0.0; out[9] = nact > 3 ? r3 : 0.0; out[10] = p0; out[11] = p1;
+    out[12] = p2; out[13] = p3;
+}
 
 // Factor the 64x64 tile held in registers, write the factor to Ab (ld; strictly upper part zeroed) and the inverse
 // of the factor to Wb (64x64), accumulate logdet / info of matrix b.  ncol = pivots in this block (rows/columns
@@ -73,7 +112,7 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[t][r] = (16 * w + lu + 4 * r == 16 * t + lm) ? 1.0 : 0.0;
     if (tid < 64) sh.piv[tid] = 1.0;
-    int bad = 0;
+    int bad = 0;   // wave 0 only
     if ((lm >> 2) == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sh.colraw[0][16 * w + lu + 4 * r][lm & 3] = a[0][r];
@@ -81,6 +120,19 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
     if (w == 0) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) sh.rowraw[0][16 * t + lm][lu] = y[t][0];
+        if ((lm >> 2) == 1) sh.blk[0][lu][lm & 3] = a[0][1];   // A[4+lu][4+(lm&3)]
+    }
+    __syncthreads();
+    if (w == 0) {   // pivot chain of group 0
+        const double2 *cr = reinterpret_cast<const double2 *>(&sh.colraw[0][0][0]);
+        const double2 C0 = cr[0], C1 = cr[2], C2a = cr[4], C2b = cr[5], C3a = cr[6], C3b = cr[7];
+        double o[14];
+        pivot_chain(C0.x, C1.x, C1.y, C2a.x, C2a.y, C2b.x, C3a.x, C3a.y, C3b.x, C3b.y, ncol >= 4 ? 4 : ncol, 0, bad, o);
+        if (l == 0) {
+            double2 *dst = reinterpret_cast<double2 *>(&sh.chain[0][0]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) dst[i] = make_double2(o[2 * i], o[2 * i + 1]);
+        }
     }
     __syncthreads();
 
@@ -89,12 +141,56 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
         const int jb = g >> 2, j0 = 4 * g, buf = g & 1;
         if (j0 >= ncol) break;
         const int nact = ncol - j0 >= 4 ? 4 : ncol - j0;   // active pivots of this group
+        const bool more = (g + 1 < 16) && (j0 + 4 < ncol);  // a further group follows
+        const int jbn = (g + 1) >> 2, jqn = (g + 1) & 3;
+        const double2 *cr = reinterpret_cast<const double2 *>(&sh.colraw[buf][0][0]);
+        const double2 *ck = reinterpret_cast<const double2 *>(&sh.chain[buf][0]);
+        const double2 K0 = ck[0], K1 = ck[1], K2 = ck[2], K3 = ck[3], K4 = ck[4], K5 = ck[5], K6 = ck[6];
+        const double n10 = K0.x, n20 = K0.y, n30 = K1.x, n21 = K1.y, n31 = K2.x, n32 = K2.y;
+        const double r0 = K3.x, r1 = K3.y, r2 = K4.x, r3 = K4.y;
+        // ---- wave 0: pivot chain of the NEXT group (needs no result of this group's MFMAs) ----
+        if (w == 0 && more) {
+            double2 Ra[4], Rb[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Ra[v] = cr[2 * (j0 + 4 + v)];
+                Rb[v] = cr[2 * (j0 + 4 + v) + 1];
+            }
+            const double2 *bk = reinterpret_cast<const double2 *>(&sh.blk[buf][0][0]);
+            const double2 B0 = bk[0], B1 = bk[2], B2a = bk[4], B2b = bk[5], B3a = bk[6], B3b = bk[7];
+            double T0[4], T1[4], T2[4], T3[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                T0[v] = Ra[v].x;
+                T1[v] = fma(Ra[v].x, n10, Ra[v].y);
+                T2[v] = fma(Ra[v].y, n21, fma(Ra[v].x, n20, Rb[v].x));
+                T3[v] = fma(Rb[v].x, n32, fma(Ra[v].y, n31, fma(Ra[v].x, n30, Rb[v].y)));
+            }
+            double c[4][4];
+            c[0][0] = B0.x;
+            c[1][0] = B1.x; c[1][1] = B1.y;
+            c[2][0] = B2a.x; c[2][1] = B2a.y; c[2][2] = B2b.x;
+            c[3][0] = B3a.x; c[3][1] = B3a.y; c[3][2] = B3b.x; c[3][3] = B3b.y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double e0 = T0[i] * r0, e1 = T1[i] * r1, e2 = T2[i] * r2, e3 = T3[i] * r3;
+#pragma unroll
+                for (int j = 0; j <= i; ++j)
+                    c[i][j] = fma(-e3, T3[j], fma(-e2, T2[j], fma(-e1, T1[j], fma(-e0, T0[j], c[i][j]))));
+            }
+            const int nan_ = ncol - (j0 + 4) >= 4 ? 4 : ncol - (j0 + 4);
+            double o[14];
+            pivot_chain(c[0][0], c[1][0], c[1][1], c[2][0], c[2][1], c[2][2], c[3][0], c[3][1], c[3][2], c[3][3], nan_,
+                        j0 + 4, bad, o);
+            if (l == 0) {
+                double2 *dst = reinterpret_cast<double2 *>(&sh.chain[buf ^ 1][0]);
+#pragma unroll
+                for (int i = 0; i < 7; ++i) dst[i] = make_double2(o[2 * i], o[2 * i + 1]);
+            }
+        }
         if (w >= jb) {
-            // ---- operands from LDS (issued ahead of the chain) ----
-            const double2 *cr = reinterpret_cast<const double2 *>(&sh.colraw[buf][0][0]);
+            // ---- update of THIS group ----
             const double2 *rr = reinterpret_cast<const double2 *>(&sh.rowraw[buf][0][0]);
-            const double2 C0 = cr[2 * j0], C1 = cr[2 * (j0 + 1)], C2a = cr[2 * (j0 + 2)], C2b = cr[2 * (j0 + 2) + 1];
-            const double2 C3a = cr[2 * (j0 + 3)], C3b = cr[2 * (j0 + 3) + 1];
             const double2 rAa = cr[2 * myrow], rAb = cr[2 * myrow + 1];
             double2 rBa[4], rBb[4], rYa[4], rYb[4];
 #pragma unroll
@@ -107,75 +203,50 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
                 rYa[t] = rr[2 * (16 * t + lm)];
                 rYb[t] = rr[2 * (16 * t + lm) + 1];
             }
-            // ---- 4x4 pivot block: LDL^T, reciprocals on the chain ----
-            double p0 = C0.x;
-            const double c10 = C1.x, c11 = C1.y, c20 = C2a.x, c21 = C2a.y, c22 = C2b.x;
-            const double c30 = C3a.x, c31 = C3a.y, c32 = C3b.x, c33 = C3b.y;
-            if (!(p0 > 0.0)) { if (!bad) bad = j0 + 1; p0 = 1.0; }
-            const double r0 = rcp_f64(p0);
-            const double l10 = c10 * r0, l20 = c20 * r0, l30 = c30 * r0;
-            double p1 = fma(-l10, c10, c11);
-            const double w21 = fma(-l20, c10, c21), w31 = fma(-l30, c10, c31);
-            double q2 = fma(-l20, c20, c22), w32 = fma(-l30, c20, c32), q3 = fma(-l30, c30, c33);
-            if (nact < 2) p1 = 1.0;
-            if (!(p1 > 0.0)) { if (!bad) bad = j0 + 2; p1 = 1.0; }
-            const double r1 = rcp_f64(p1);
-            const double l21 = w21 * r1, l31 = w31 * r1;
-            double p2 = fma(-l21, w21, q2);
-            w32 = fma(-l31, w21, w32);
-            q3 = fma(-l31, w31, q3);
-            if (nact < 3) p2 = 1.0;
-            if (!(p2 > 0.0)) { if (!bad) bad = j0 + 3; p2 = 1.0; }
-            const double r2 = rcp_f64(p2);
-            const double l32 = w32 * r2;
-            double p3 = fma(-l32, w32, q3);
-            if (nact < 4) p3 = 1.0;
-            if (!(p3 > 0.0)) { if (!bad) bad = j0 + 4; p3 = 1.0; }
-            const double s0 = rsqrt_f64(p0);
-            const double s1 = nact > 1 ? rsqrt_f64(p1) : 0.0;
-            const double s2 = nact > 2 ? rsqrt_f64(p2) : 0.0;
-            const double s3 = nact > 3 ? rsqrt_f64(p3) : 0.0;
+            const double p0 = K5.x, p1 = K5.y, p2 = K6.x, p3 = K6.y;
             if (tid == 192) {
                 sh.piv[j0] = p0;
                 if (nact > 1) sh.piv[j0 + 1] = p1;
                 if (nact > 2) sh.piv[j0 + 2] = p2;
                 if (nact > 3) sh.piv[j0 + 3] = p3;
             }
-            // unit-lower inverse N, then row lu of M = diag(s) N
-            const double n20 = fma(l21, l10, -l20), n31 = fma(l32, l21, -l31);
-            const double n30 = fma(-l32, n20, fma(l31, l10, -l30));
-            const double m0 = lu == 0 ? s0 : (lu == 1 ? -l10 * s1 : (lu == 2 ? n20 * s2 : n30 * s3));
-            const double m1 = lu == 0 ? 0.0 : (lu == 1 ? s1 : (lu == 2 ? -l21 * s2 : n31 * s3));
-            const double m2 = lu < 2 ? 0.0 : (lu == 2 ? s2 : -l32 * s3);
-            const double m3 = lu < 3 ? 0.0 : s3;
-            // ---- MFMA operands: panel value of (row, pivot lu), finished inverse row lu ----
-            const double xA = fma(rAb.y, m3, fma(rAb.x, m2, fma(rAa.y, m1, rAa.x * m0)));
-            const double opA = (myrow >= j0 + nact) ? -xA : 0.0;
-            if (lu < nact) Ab[(int64_t)myrow * ld + j0 + lu] = (myrow >= j0 + lu) ? xA : 0.0;
-            const int tn = (g + 1) >> 2;   // tile of the next group's columns: update it first
+            const double c0 = lu == 0 ? 1.0 : (lu == 1 ? n10 : (lu == 2 ? n20 : n30));
+            const double c1 = lu == 0 ? 0.0 : (lu == 1 ? 1.0 : (lu == 2 ? n21 : n31));
+            const double c2 = lu < 2 ? 0.0 : (lu == 2 ? 1.0 : n32);
+            const double c3 = lu < 3 ? 0.0 : 1.0;
+            const double rl = lu == 0 ? r0 : (lu == 1 ? r1 : (lu == 2 ? r2 : r3));
+            const double pl = lu == 0 ? p0 : (lu == 1 ? p1 : (lu == 2 ? p2 : p3));
+            const double tA = fma(rAb.y, c3, fma(rAb.x, c2, fma(rAa.y, c1, rAa.x * c0)));
+            const double opA = (myrow >= j0 + nact) ? -tA * rl : 0.0;
+            const int tn = jbn < 4 ? jbn : 3;   // tile of the next group's columns: update it first
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                const int t = (tt == 0) ? (tn < 4 ? tn : 3) : ((tt <= (tn < 4 ? tn : 3)) ? tt - 1 : tt);
+                const int t = (tt == 0) ? tn : ((tt <= tn) ? tt - 1 : tt);
                 if (t < jb) continue;
-                const double xB = fma(rBb[t].y, m3, fma(rBb[t].x, m2, fma(rBa[t].y, m1, rBa[t].x * m0)));
-                const double opB = (16 * t + lm >= j0 + nact) ? xB : 0.0;
+                const double tB = fma(rBb[t].y, c3, fma(rBb[t].x, c2, fma(rBa[t].y, c1, rBa[t].x * c0)));
+                const double opB = (16 * t + lm >= j0 + nact) ? tB : 0.0;
                 a[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opB, a[t], 0, 0, 0);
             }
+            double tY[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                double xY = 0.0;
+                tY[t] = 0.0;
                 if (t <= jb) {
-                    xY = fma(rYb[t].y, m3, fma(rYb[t].x, m2, fma(rYa[t].y, m1, rYa[t].x * m0)));
-                    y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, xY, y[t], 0, 0, 0);
+                    tY[t] = fma(rYb[t].y, c3, fma(rYb[t].x, c2, fma(rYa[t].y, c1, rYa[t].x * c0)));
+                    y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, tY[t], y[t], 0, 0, 0);
                 }
-                if (w == 3 && lu < nact) Wb[(j0 + lu) * 64 + 16 * t + lm] = xY;
+            }
+            const double sl = rsqrt_f64(pl);   // off the MFMA path: only the stored values are scaled
+            if (lu < nact) Ab[(int64_t)myrow * ld + j0 + lu] = (myrow >= j0 + lu) ? tA * sl : 0.0;
+            if (w == 3 && lu < nact) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Wb[(j0 + lu) * 64 + 16 * t + lm] = tY[t] * sl;
             }
         } else if (lu < nact) {
             Ab[(int64_t)myrow * ld + j0 + lu] = 0.0;   // rows above the pivots: strictly upper part
         }
-        // ---- raw columns / inverse rows of the next group ----
-        if (g + 1 < 16 && j0 + 4 < ncol) {
-            const int jbn = (g + 1) >> 2, jqn = (g + 1) & 3;
+        // ---- raw columns / inverse rows of the next group, 4x4 block of the one after ----
+        if (more) {
             if (w >= jbn && (lm >> 2) == jqn) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sh.colraw[buf ^ 1][16 * w + lu + 4 * r][lm & 3] = a[jbn < 4 ? jbn : 3][r];
@@ -183,6 +254,10 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
             if (w == jbn) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) sh.rowraw[buf ^ 1][16 * t + lm][lu] = y[t][jqn];
+            }
+            if (g + 2 < 16 && j0 + 8 < ncol) {
+                const int jb2 = (g + 2) >> 2, jq2 = (g + 2) & 3;
+                if (w == jb2 && (lm >> 2) == jq2) sh.blk[buf ^ 1][lu][lm & 3] = a[jb2 < 4 ? jb2 : 3][jq2];
             }
         }
         __syncthreads();
@@ -197,18 +272,14 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
                 if (row >= ncol) Wb[row * 64 + col] = y[t][r];
             }
     }
-    if (tid == 192 && bad) sh.piv[0] = -(double)bad;   // hand the failure to the reducing wave (a pivot is never < 0)
-    __syncthreads();
-    if (tid < 64) {
-        const double p00 = sh.piv[0];
-        const int badw = p00 < 0.0 ? (int)(-p00) : 0;
-        double v = (tid < ncol && !(tid == 0 && badw)) ? log(sh.piv[tid]) : 0.0;
+    if (tid < 64) {   // wave 0 (the chain wave knows about failed pivots); the last barrier made piv visible
+        double v = (tid < ncol && !(tid == 0 && bad)) ? log(sh.piv[tid]) : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (tid == 0) {
             logdet[b] = (k == 0 ? 0.0 : logdet[b]) + v;
             if (k == 0) info[b] = 0;
-            if (badw && info[b] == 0) info[b] = k * 64 + badw;
+            if (bad && info[b] == 0) info[b] = k * 64 + bad;
         }
     }
 }
@@ -458,7 +529,7 @@ __device__ __forceinline__ void wg_wait_acquire(int32_t *flag, int target, int32
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void potrf_step_kernel(StepArgs g) {
+__global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     __shared__ double tiles[2 * 64 * LDM];   // As | Bs
     __shared__ DiagShared sh;
     double *As = tiles, *Bs = tiles + 64 * LDM;
