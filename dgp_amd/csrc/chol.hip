@@ -102,7 +102,7 @@ struct Tile64 {
     d4 v[4];
 };
 __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double *Ab, int64_t ld, double *Wb, int ncol,
-                                            int k, int b, double *logdet, int32_t *info) {
+                                            int k, int b, double *logdet, int32_t *info, long long *trace = nullptr) {
     d4 (&a)[4] = tile.v;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lm = l & 15, lu = l >> 4;
     const int myrow = 16 * w + lm;   // row this lane serves as MFMA A operand / stores as finished column
@@ -143,6 +143,7 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
         const int nact = ncol - j0 >= 4 ? 4 : ncol - j0;   // active pivots of this group
         const bool more = (g + 1 < 16) && (j0 + 4 < ncol);  // a further group follows
         const int jbn = (g + 1) >> 2, jqn = (g + 1) & 3;
+        if (trace && tid == 0) trace[4 * g] = wall_clock64();
         const double2 *cr = reinterpret_cast<const double2 *>(&sh.colraw[buf][0][0]);
         const double2 *ck = reinterpret_cast<const double2 *>(&sh.chain[buf][0]);
         const double2 K0 = ck[0], K1 = ck[1], K2 = ck[2], K3 = ck[3], K4 = ck[4], K5 = ck[5], K6 = ck[6];
@@ -187,6 +188,7 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
 #pragma unroll
                 for (int i = 0; i < 7; ++i) dst[i] = make_double2(o[2 * i], o[2 * i + 1]);
             }
+            if (trace && tid == 0) trace[4 * g + 1] = wall_clock64();
         }
         if (w >= jb) {
             // ---- update of THIS group ----
@@ -245,6 +247,7 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
         } else if (lu < nact) {
             Ab[(int64_t)myrow * ld + j0 + lu] = 0.0;   // rows above the pivots: strictly upper part
         }
+        if (trace && tid == 192) trace[4 * g + 2] = wall_clock64();
         // ---- raw columns / inverse rows of the next group, 4x4 block of the one after ----
         if (more) {
             if (w >= jbn && (lm >> 2) == jqn) {
@@ -260,6 +263,7 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
                 if (w == jb2 && (lm >> 2) == jq2) sh.blk[buf ^ 1][lu][lm & 3] = a[jb2 < 4 ? jb2 : 3][jq2];
             }
         }
+        if (trace && tid == 192) trace[4 * g + 3] = wall_clock64();
         __syncthreads();
     }
     if (ncol < 64) {   // last block: carried right-hand-side rows / columns are still in registers
@@ -370,10 +374,9 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
                 acc[t][r] = C[((int64_t)bi * 64 + crow + 4 * r) * ld + (int64_t)bj * 64 + 16 * t + ccol];
     }
 
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const double *Ag, *Bg;
-        int64_t lda = ld, ldb = ld;
-        int limA = 64, limB = 64;
+    // operands of k-block kb
+    auto operands = [&](int kb, const double *&Ag, const double *&Bg, int64_t &lda, int64_t &ldb, int &lim) {
+        lda = ld; ldb = ld; lim = 64;
         if (MODE == G_TRSM) {
             Ag = A + ((int64_t)bi * 64) * ld + (int64_t)kb * 64;
             Bg = g.ws + (int64_t)blockIdx.z * g.stride_ws + (int64_t)kb * 4096; ldb = 64;
@@ -389,17 +392,29 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
         } else {
             Ag = A + ((int64_t)kb * 64) * ld + (int64_t)bi * 64;
             Bg = A + ((int64_t)kb * 64) * ld + (int64_t)bj * 64;
-            int64_t lim = g.n - (int64_t)kb * 64;   // rows >= n (right-hand sides) do not belong to L^-1
-            limA = limB = lim >= 64 ? 64 : (int)lim;
+            int64_t l = g.n - (int64_t)kb * 64;   // rows >= n (right-hand sides) do not belong to L^-1
+            lim = l >= 64 ? 64 : (int)l;
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            __syncthreads();
-            if (OPA == OP_MK) load_mk(Ag, lda, As, tid, h); else load_km(Ag, lda, As, tid, h, limA);
-            if (OPB == OP_MK) load_mk(Bg, ldb, Bs, tid, h); else load_km(Bg, ldb, Bs, tid, h, limB);
-            __syncthreads();
-            mfma_tile<OPA, OPB>(As, Bs, acc, wave, lane, sign);
-        }
+    };
+    auto fetch = [&](int st, HalfTile &fa, HalfTile &fb) {
+        const double *Ag, *Bg;
+        int64_t lda, ldb;
+        int lim;
+        operands(kb0 + (st >> 1), Ag, Bg, lda, ldb, lim);
+        fa = (OPA == OP_MK) ? fetch_mk(Ag, lda, tid, st & 1) : fetch_km(Ag, lda, tid, st & 1, lim);
+        fb = (OPB == OP_MK) ? fetch_mk(Bg, ldb, tid, st & 1) : fetch_km(Bg, ldb, tid, st & 1, lim);
+    };
+    // software pipeline over the 32-deep stages: the loads of stage st+1 are in flight during the MFMAs of stage st
+    const int nst = 2 * (kb1 - kb0);
+    HalfTile fa, fb;
+    if (nst > 0) fetch(0, fa, fb);
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();
+        if (OPA == OP_MK) commit_mk(fa, As, tid); else commit_km(fa, As, tid);
+        if (OPB == OP_MK) commit_mk(fb, Bs, tid); else commit_km(fb, Bs, tid);
+        if (st + 1 < nst) fetch(st + 1, fa, fb);
+        __syncthreads();
+        mfma_tile<OPA, OPB>(As, Bs, acc, wave, lane, sign);
     }
 
 #pragma unroll
@@ -570,7 +585,8 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     if (ti == 0) {   // the diagonal tile: factor it right away
         STAMP(1);
         const int64_t rem = g.n - (int64_t)k * 64;
-        diag_factor(acc, sh, C, ld, Wk, rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0), k, b, g.logdet, g.info);
+        diag_factor(acc, sh, C, ld, Wk, rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0), k, b, g.logdet, g.info,
+                    (g.trace && b == 0) ? g.trace + 1024 + 64 * k : nullptr);
         STAMP(2);
         wg_release_store(g.flags + b, k + 1, tid);
         STAMP(3);

@@ -38,6 +38,49 @@ __device__ __forceinline__ void load_km(const double *__restrict__ g, int64_t ld
     }
 }
 
+// The same staging split in two, for software pipelining: fetch_* issues the global loads of a half tile into
+// registers (no wait), commit_* writes them to LDS one stage later, while the MFMAs of the stage between run.
+struct HalfTile {
+    double2 v[4];
+};
+__device__ __forceinline__ HalfTile fetch_mk(const double *__restrict__ g, int64_t ldg, int tid, int h) {
+    HalfTile f;
+    const int c2 = (tid & 15) * 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        f.v[it] = *reinterpret_cast<const double2 *>(g + (int64_t)((tid >> 4) + 16 * it) * ldg + 32 * h + c2);
+    return f;
+}
+__device__ __forceinline__ void commit_mk(const HalfTile &f, double *__restrict__ s, int tid) {
+    const int c2 = (tid & 15) * 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (tid >> 4) + 16 * it;
+        s[r * LDM + c2] = f.v[it].x;
+        s[r * LDM + c2 + 1] = f.v[it].y;
+    }
+}
+__device__ __forceinline__ HalfTile fetch_km(const double *__restrict__ g, int64_t ldg, int tid, int h, int row_limit) {
+    HalfTile f;
+    const int c2 = (tid & 31) * 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (tid >> 5) + 8 * it;
+        f.v[it] = make_double2(0.0, 0.0);
+        if (32 * h + r < row_limit) f.v[it] = *reinterpret_cast<const double2 *>(g + (int64_t)(32 * h + r) * ldg + c2);
+    }
+    return f;
+}
+__device__ __forceinline__ void commit_km(const HalfTile &f, double *__restrict__ s, int tid) {
+    const int c2 = (tid & 31) * 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (tid >> 5) + 8 * it;
+        s[r * LDK + c2] = f.v[it].x;
+        s[r * LDK + c2 + 1] = f.v[it].y;
+    }
+}
+
 // acc[t] += sign * A(16w.., :) * B(:, 16t..)   over the KC-deep staged half tiles
 template <int OPA, int OPB>
 __device__ __forceinline__ void mfma_tile(const double *As, const double *Bs, d4 acc[4], int wave, int lane,

@@ -2,15 +2,14 @@
 (dgp.py:71-129 construction, :154-691 wiring, :1364-1412 train, :1517-1541 estimate).
 
 The driver is plain Python like the reference's; what it drives is not: the I-step
-is the device-resident ESS imputer (dgp_amd.imputation) and the M-step optimises
-all GP nodes concurrently, one HIP stream per node, with scipy L-BFGS-B calling
-the device objective (kernel.llik).  Optimising nodes concurrently instead of one
-after another does not change any result: given the imputed latents every node's
-objective involves only its own hyper-parameters (dgp.py:1391-1398).
+is the device-resident ESS imputer (dgp_amd.imputation) and the M-step advances
+the L-BFGS-B runs of all GP nodes in lock-step, their objective evaluations
+(kernel.llik) batched on the device (dgp_amd.mstep).  Optimising the nodes side by
+side instead of one after another does not change any result: given the imputed
+latents every node's objective involves only its own hyper-parameters
+(dgp.py:1391-1398).
 """
 import copy
-from concurrent.futures import ThreadPoolExecutor
-
 import numpy as np
 import torch
 from tqdm import trange, tqdm
@@ -68,7 +67,6 @@ class dgp:
         self.compute_r2()
         self.N = 0
         self.burnin = None
-        self._pool = None
 
     # ------------------------------------------------------------------ wiring
     def _warm_start(self, In, num_kernel):
@@ -161,34 +159,27 @@ class dgp:
 
     # ------------------------------------------------------------------ training
     def _m_step(self):
-        """One L-BFGS-B fit per GP node (dgp.py:1391-1398); the nodes' objective evaluations are batched in
-        lock-step on the device (dgp_amd.mstep.LlikBatcher).  Vecchia nodes evaluate on their own."""
-        from .mstep import LlikBatcher
-        nodes = [(l, nd) for l, layer in enumerate(self.all_layer) for nd in layer if nd.type == 'gp']
-        dense = [nd for _, nd in nodes if not nd.vecch]
-        batcher = LlikBatcher(self.engine, len(dense)) if len(dense) > 1 else None
-        if self._pool is None or self._pool[1] != len(nodes):
-            self._pool = (ThreadPoolExecutor(max_workers=len(nodes)), len(nodes))
+        """One L-BFGS-B fit per GP node (dgp.py:1391-1398).  The dense nodes' optimisers advance in lock-step from this
+        thread, their objective evaluations batched on the device (dgp_amd.mstep); Vecchia nodes (and every node if
+        scipy's L-BFGS-B core is not the expected one) run kernel.maximise() one after another like the reference."""
+        from . import mstep
         eng = self.engine
-
-        def work(args):
-            l, nd = args
-            joined = batcher is not None and not nd.vecch
-            try:
-                with eng.stream():
-                    nd.engine = eng
-                    nd._batcher = batcher if joined else None
-                    if nd.prior_name == 'ref':
-                        nd.compute_cl()
-                    if l != 0:
-                        nd.r2()
+        nodes = [(l, nd) for l, layer in enumerate(self.all_layer) for nd in layer if nd.type == 'gp']
+        with eng.stream():
+            for l, nd in nodes:
+                nd.engine = eng
+                if nd.prior_name == 'ref':
+                    nd.compute_cl()
+                if l != 0:
+                    nd.r2()
+            dense = [nd for _, nd in nodes if not nd.vecch] if mstep._HAVE_CORE else []
+            if dense:
+                self.last_mstep = mstep.maximise_lockstep(eng, dense, self)
+            else:
+                self.last_mstep = None
+            for _, nd in nodes:
+                if not any(nd is d for d in dense):
                     nd.maximise()
-            finally:
-                nd._batcher = None
-                if joined:
-                    batcher.done()
-        list(self._pool[0].map(work, nodes))
-        self.last_mstep = None if batcher is None else (batcher.rounds, batcher.evals)
 
     def train(self, N=500, ess_burn=10, disable=False):
         """N iterations of stochastic EM (dgp.py:1364-1412) with the same restart policy on LinAlgError."""

@@ -65,7 +65,6 @@ class kernel:
         self._engine = engine
         self._stats = None       # device-side prediction statistics (compute_stats)
         self._staged = None
-        self._batcher = None
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -84,7 +83,6 @@ class kernel:
         st['_engine'] = None
         st['_staged'] = None
         st['_stats'] = None
-        st['_batcher'] = None
         return st
 
     def _X(self):
@@ -215,12 +213,7 @@ class kernel:
     def llik(self, x):
         """Negative log-likelihood and gradient wrt log-parameters (kernel_class.py:403-449)."""
         self.update(x)
-        batcher = getattr(self, '_batcher', None)
-        if batcher is not None:      # M-step rendezvous: evaluated together with the other nodes' objectives
-            host = batcher.evaluate(self)
-        else:
-            host = self._llik_device()
-        return self._llik_finish(host)
+        return self._llik_finish(self._llik_device())
 
     def _llik_device(self):
         """K -> Cholesky (y as augmented row) -> inverse -> in-flight derivative reductions for THIS node alone.
@@ -356,9 +349,8 @@ class kernel:
             self.ord_nn()
 
     # --------------------------------------------------------------------- M-step
-    def maximise(self, method='L-BFGS-B'):
-        """One M-step of the node: scipy L-BFGS-B over log-parameters driving the device objective
-        (kernel_class.py:516-579; same bounds, maxiter and maxfun)."""
+    def _opt_setup(self):
+        """Start point, bounds and options of the node's L-BFGS-B run (kernel_class.py:516-560)."""
         x0 = self.log_t()
         p = len(x0)
         nl = p - 1 if self.nugget_est else p
@@ -375,14 +367,21 @@ class kernel:
             lb[-1] = np.log(1e-8)
             bounded = True
         opts = {'maxiter': 100, 'maxfun': int(max(30, 20 + 5 * self.D))}
+        if self.vecch and self.target == 'gp' and len(self.length) != 1:
+            opts = {'maxfun': int(max(50, 20 + 5 * self.D))}
+        return x0, (lb if bounded else None), (ub if bounded else None), opts
+
+    def maximise(self, method='L-BFGS-B'):
+        """One M-step of the node: scipy L-BFGS-B over log-parameters driving the device objective
+        (kernel_class.py:516-579; same bounds, maxiter and maxfun)."""
+        x0, lb, ub, opts = self._opt_setup()
         kw = dict(method=method, jac=True)
-        if bounded:
+        if lb is not None:
             kw['bounds'] = Bounds(lb, ub)
         fun = self.llik
         if self.vecch:
             fun = self.llik_vecch
             if self.target == 'gp' and len(self.length) != 1:
-                opts = {'maxfun': int(max(50, 20 + 5 * self.D))}
                 kw['callback'] = self.callback
         self._stage()
         self._in_maximise = True

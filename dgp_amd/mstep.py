@@ -1,89 +1,162 @@
-"""Lock-step evaluation of the M-step objectives.
+"""Lock-step M-step.
 
-Every GP node runs its own scipy L-BFGS-B (one Python thread each, as the reference runs them one after another,
-dgp.py:1391-1398); each objective evaluation needs K assembly + Cholesky + inverse + reductions on the device.
-Measured on MI355X, independent factorisations on separate HIP streams overlap only ~3x: the ~100 launches of one
-evaluation are serialised on the host side of the runtime.  So the threads rendezvous instead: when every still
-active optimiser has asked for an evaluation, the last one to arrive runs ONE batched pipeline for all of them
+The reference fits its GP nodes one after another, each with scipy's L-BFGS-B (dgp.py:1391-1398,
+kernel_class.py:516-579); every objective evaluation needs K assembly + Cholesky + inverse + reductions on the
+device.  One factorisation is a latency-bound chain that leaves most of an MI355X idle, and independent
+factorisations on separate HIP streams overlap only ~3x (the launches serialise on the host side of the runtime).
+So the optimisers advance in LOCK-STEP from one thread instead: scipy's reverse-communication L-BFGS-B core is
+driven for all nodes at once, and every round the pending objective evaluations run as ONE batched pipeline
 (per-node K assembly with its own hyper-parameters, batched potrf / potri graphs, per-node reductions, a single
-device-to-host copy) and hands the results back.  Results are those of kernel.llik evaluated alone.
+device-to-host copy).  Every node sees exactly the iterates scipy.optimize.minimize would give it.
 """
-import threading
 
 import numpy as np
 import torch
 
+try:   # scipy 1.15's reverse-communication L-BFGS-B core (the routine scipy.optimize.minimize itself drives)
+    import scipy
+    from scipy.optimize import _lbfgsb as _core
+    _HAVE_CORE = tuple(int(v) for v in scipy.__version__.split('.')[:2]) == (1, 15) and \
+        'ln_task' in (_core.setulb.__doc__ or '')
+except Exception:   # pragma: no cover
+    _core, _HAVE_CORE = None, False
 
-class LlikBatcher:
-    def __init__(self, engine, n_active):
-        self.e = engine
-        self.cv = threading.Condition()
-        self.pending = []
-        self.results = {}
-        self.active = int(n_active)
-        self.error = None
-        self.rounds = 0
-        self.evals = 0
 
-    # ---- called from the optimiser threads -------------------------------------------------
-    def evaluate(self, node):
-        with self.cv:
-            self.pending.append(node)
-            if len(self.pending) >= self.active:
-                self._run()
+class _Problem:
+    """State of one L-BFGS-B run, laid out as scipy's _minimize_lbfgsb does (scipy/optimize/_lbfgsb_py.py)."""
+
+    def __init__(self, x0, lb, ub, maxiter, maxfun, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxls=20):
+        n = len(x0)
+        self.m, self.maxls, self.maxiter, self.maxfun = maxcor, maxls, maxiter, maxfun
+        self.factr, self.pgtol = ftol / np.finfo(float).eps, gtol
+        self.nbd = np.zeros(n, np.int32)
+        self.low, self.up = np.zeros(n), np.zeros(n)
+        x0 = np.asarray(x0, dtype=np.float64).ravel()
+        if lb is not None:
+            if (lb > ub).any():
+                raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound.")
+            x0 = np.clip(x0, lb, ub)
+            for i in range(n):
+                lo, hi = np.isfinite(lb[i]), np.isfinite(ub[i])
+                if lo:
+                    self.low[i] = lb[i]
+                if hi:
+                    self.up[i] = ub[i]
+                self.nbd[i] = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}[(lo, hi)]
+        self.x = np.array(x0, dtype=np.float64)
+        self.f = np.array(0.0)
+        self.g = np.zeros(n)
+        self.wa = np.zeros(2 * maxcor * n + 5 * n + 11 * maxcor * maxcor + 8 * maxcor)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task = np.zeros(2, dtype=np.int32)
+        self.ln_task = np.zeros(2, dtype=np.int32)
+        self.lsave = np.zeros(4, dtype=np.int32)
+        self.isave = np.zeros(44, dtype=np.int32)
+        self.dsave = np.zeros(29)
+        self.nit = self.nfev = 0
+        self.finished = False
+
+    def advance(self):
+        """Run the core until it asks for f and g at self.x (returns True) or stops (returns False)."""
+        while True:
+            _core.setulb(self.m, self.x, self.low, self.up, self.nbd, self.f, self.g, self.factr, self.pgtol, self.wa,
+                         self.iwa, self.task, self.lsave, self.isave, self.dsave, self.maxls, self.ln_task)
+            if self.task[0] == 3:
+                return True
+            if self.task[0] == 1:   # new iteration: same stopping tests as scipy
+                self.nit += 1
+                if self.nit >= self.maxiter:
+                    self.task[0], self.task[1] = 5, 504
+                elif self.nfev > self.maxfun:
+                    self.task[0], self.task[1] = 5, 502
             else:
-                while id(node) not in self.results and self.error is None:
-                    self.cv.wait()
-            if self.error is not None:
-                raise self.error
-            return self.results.pop(id(node))
+                self.finished = True
+                return False
 
-    def done(self):
-        """An optimiser finished (or failed): it no longer takes part in the rendezvous."""
-        with self.cv:
-            self.active -= 1
-            if self.pending and len(self.pending) >= self.active:
-                self._run()
 
-    # ---- the batched pipeline (lock held by the thread that completes the rendezvous) --------
-    def _run(self):
-        try:
-            groups = {}
-            for nd in self.pending:
-                groups.setdefault(len(nd.output), []).append(nd)
-            for n, nodes in groups.items():
-                self._run_group(n, nodes)
-            self.rounds += 1
-            self.evals += len(self.pending)
-        except Exception as ex:   # surfaces in every waiting optimiser
-            self.error = ex
-        self.pending = []
-        self.cv.notify_all()
+def minimize_lockstep(problems, evaluate):
+    """Run several independent L-BFGS-B minimisations in lock-step from ONE thread: every round, all runs that want an
+    objective value get it from one call evaluate([(index, x), ...]) -> [(f, g), ...].  Each run sees exactly the
+    sequence of points scipy.optimize.minimize(method='L-BFGS-B') would give it (same core, same options)."""
+    if not _HAVE_CORE:
+        raise RuntimeError('scipy L-BFGS-B core not available')
+    rounds = 0
+    while True:
+        want = [i for i, p in enumerate(problems) if not p.finished and p.advance()]
+        if not want:
+            return rounds
+        out = evaluate([(i, problems[i].x.copy()) for i in want])
+        for i, (f, g) in zip(want, out):
+            p = problems[i]
+            p.f = np.array(float(np.asarray(f).reshape(-1)[0]))
+            p.g = np.asarray(g, dtype=np.float64).copy()
+            p.nfev += 1
+        rounds += 1
 
-    def _run_group(self, n, nodes):
-        e = self.e
-        B = len(nodes)
-        Np = e.padded_dim(n)
-        with e.stream():
-            cap = max(B, getattr(self, '_cap', 0))
-            self._cap = cap
-            A = e.workspace(('mstepA', n), cap * Np * Np * 8).view(torch.float64)[:B * Np * Np].view(B, Np, Np)
-            Ainv = e.workspace(('mstepAinv', n), cap * Np * Np * 8).view(torch.float64)[:B * Np * Np].view(B, Np, Np)
-            for b, nd in enumerate(nodes):
-                s = nd._staged if nd._staged is not None else nd._stage()
-                e.kmatrix(nd.name, s['Xl'], None, s['Xg'], nd.length, nd.nugget[0], W=s['W'], out=A[b], full=False, Y=s['y'])
-            work = e.potrf_workspace(n, B)
-            logdet, info = e.potrf(n, A, batch=B, work=work)
-            quad = e.aug_quad(n, A, B, 1)
-            e.potri(n, A, Ainv, 1, work, batch=B)
-            reds = []
-            for b, nd in enumerate(nodes):
-                s = nd._staged
-                red, P = e.grad_reduce(nd.name, s['Xl'], None, s['Xg'], nd.length, nd.nugget[0], nd.nugget_est, Ainv[b], W=s['W'])
-                reds.append((red, P))
-            packed = torch.cat([logdet, quad.reshape(-1), info.to(torch.float64)] + [r for r, _ in reds]).cpu().numpy()
-        off = 3 * B
-        for b, (nd, (_, P)) in enumerate(zip(nodes, reds)):
-            red = packed[off:off + 2 * P]
-            off += 2 * P
-            self.results[id(nd)] = np.concatenate(([packed[b], packed[B + b]], red, [packed[2 * B + b]]))
+
+
+def batched_llik_device(e, n, nodes, cache):
+    """kernel._llik_device for several nodes of the same size at once: per-node K assembly with its own
+    hyper-parameters, ONE batched potrf / potri, per-node reductions, ONE device-to-host copy."""
+    B = len(nodes)
+    Np = e.padded_dim(n)
+    with e.stream():
+        cap = max(B, getattr(cache, '_cap', 0))
+        cache._cap = cap
+        A = e.workspace(('mstepA', n), cap * Np * Np * 8).view(torch.float64)[:B * Np * Np].view(B, Np, Np)
+        Ainv = e.workspace(('mstepAinv', n), cap * Np * Np * 8).view(torch.float64)[:B * Np * Np].view(B, Np, Np)
+        for b, nd in enumerate(nodes):
+            s = nd._staged if nd._staged is not None else nd._stage()
+            e.kmatrix(nd.name, s['Xl'], None, s['Xg'], nd.length, nd.nugget[0], W=s['W'], out=A[b], full=False, Y=s['y'])
+        work = e.potrf_workspace(n, B)
+        logdet, info = e.potrf(n, A, batch=B, work=work)
+        quad = e.aug_quad(n, A, B, 1)
+        e.potri(n, A, Ainv, 1, work, batch=B)
+        reds = []
+        for b, nd in enumerate(nodes):
+            s = nd._staged
+            red, P = e.grad_reduce(nd.name, s['Xl'], None, s['Xg'], nd.length, nd.nugget[0], nd.nugget_est, Ainv[b], W=s['W'])
+            reds.append((red, P))
+        packed = torch.cat([logdet, quad.reshape(-1), info.to(torch.float64)] + [r for r, _ in reds]).cpu().numpy()
+    off = 3 * B
+    res = []
+    for b, (nd, (_, P)) in enumerate(zip(nodes, reds)):
+        red = packed[off:off + 2 * P]
+        off += 2 * P
+        res.append(np.concatenate(([packed[b], packed[B + b]], red, [packed[2 * B + b]])))
+    return res
+
+
+def maximise_lockstep(engine, nodes, cache):
+    """kernel.maximise() for several dense GP nodes at once (dgp.py:1391-1398 runs them one after another; given
+    the imputed latents their objectives are independent): one L-BFGS-B state per node, every round's objective
+    evaluations batched on the device.  Returns (rounds, evaluations)."""
+    setups = [nd._opt_setup() for nd in nodes]
+    problems = [_Problem(x0, lb, ub, opts.get('maxiter', 15000), opts.get('maxfun', 15000)) for x0, lb, ub, opts in setups]
+    evals = [0]
+
+    def evaluate(req):
+        for i, x in req:
+            nodes[i].update(x)
+        groups = {}
+        for i, _ in req:
+            groups.setdefault(len(nodes[i].output), []).append(i)
+        host = {}
+        for n, idxs in groups.items():
+            for i, res in zip(idxs, batched_llik_device(engine, n, [nodes[i] for i in idxs], cache)):
+                host[i] = res
+        evals[0] += len(req)
+        return [nodes[i]._llik_finish(host[i]) for i, _ in req]
+
+    for nd in nodes:
+        nd._stage()
+        nd._in_maximise = True
+    try:
+        rounds = minimize_lockstep(problems, evaluate)
+    finally:
+        for nd in nodes:
+            nd._in_maximise = False
+            nd.iter_count = 0
+    for nd in nodes:
+        nd.add_to_path()
+    return rounds, evals[0]

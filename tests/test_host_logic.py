@@ -125,3 +125,59 @@ print('rank', dd.rank(), 'ok')
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'ok' in o
+
+
+def test_lockstep_lbfgsb_matches_scipy_minimize():
+    """dgp_amd.mstep.minimize_lockstep drives scipy's L-BFGS-B core for several problems at once; every problem
+    must see exactly the iterates scipy.optimize.minimize(method='L-BFGS-B', jac=True) produces on its own."""
+    from scipy.optimize import minimize, Bounds
+    from dgp_amd import mstep
+    if not mstep._HAVE_CORE:
+        pytest.skip('scipy L-BFGS-B core differs from the one the driver was written for')
+
+    def rosen(x):
+        f = np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2)
+        g = np.zeros_like(x)
+        g[:-1] = -400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+        return np.atleast_1d(f), g
+
+    def quartic(x):
+        return np.atleast_1d(np.sum((x - 0.3) ** 4 + 0.5 * x ** 2)), 4 * (x - 0.3) ** 3 + x
+
+    def logistic(x):
+        e = np.exp(-x)
+        return np.atleast_1d(np.sum(np.log1p(e) + 0.1 * x ** 2)), -e / (1 + e) + 0.2 * x
+
+    cases = [(rosen, np.array([-1.2, 1.0, 0.5]), None, None, dict(maxiter=100, maxfun=35)),
+             (quartic, np.array([2.0, -1.0]), np.array([-np.inf, -0.5]), np.array([1.5, np.inf]), dict(maxiter=100, maxfun=30)),
+             (logistic, np.array([3.0, -2.0, 0.1, 0.7]), np.array([-1.0, -np.inf, -np.inf, 0.2]),
+              np.array([np.inf, np.inf, 13.0, 0.9]), dict(maxiter=3, maxfun=30)),
+             (rosen, np.array([0.0, 0.0]), None, None, dict(maxiter=100, maxfun=5))]
+    ref_pts, ref_last = [], []
+    for fun, x0, lb, ub, opts in cases:
+        pts = []
+
+        def logged(x, fun=fun, pts=pts):
+            pts.append(np.array(x, dtype=float))
+            return fun(x)
+        kw = {} if lb is None else dict(bounds=Bounds(lb, ub))
+        res = minimize(logged, x0, method='L-BFGS-B', jac=True, options=opts, **kw)
+        ref_pts.append(pts)
+        ref_last.append(res.x)
+    got = [[] for _ in cases]
+
+    def evaluate(req):
+        out = []
+        for i, x in req:
+            got[i].append(x.copy())
+            out.append(cases[i][0](x))
+        return out
+    probs = [mstep._Problem(x0, lb, ub, o['maxiter'], o['maxfun']) for _, x0, lb, ub, o in cases]
+    rounds = mstep.minimize_lockstep(probs, evaluate)
+    assert rounds == max(len(p) for p in ref_pts)
+    for i in range(len(cases)):
+        assert len(got[i]) == len(ref_pts[i]), (i, len(got[i]), len(ref_pts[i]))
+        for a, b in zip(got[i], ref_pts[i]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(probs[i].x, ref_last[i])

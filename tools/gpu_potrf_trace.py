@@ -33,3 +33,11 @@ for k in range(1, nbk):
     nxt = t[k + 1][0] - r[0] if k + 1 < nbk else float('nan')
     print('%2d | %5.1f  %5.1f  %5.1f | %5.1f %5.1f | %6.1f' % (k, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[9] - r[8] if r[8] else 0,
                                                         r[10] - r[9] if r[8] else 0, nxt))
+
+d = tr.cpu().numpy()[1024:].reshape(-1, 16, 4).astype(np.float64) / 100.0
+kk = 5
+print('block %d, per group (us from group start): chain done (wave 0) | update done (wave 3) | writes done | next group start' % kk)
+for g in range(16):
+    r = d[kk][g]
+    nxt = d[kk][g + 1][0] - r[0] if g < 15 else float('nan')
+    print('%2d | %5.2f | %5.2f | %5.2f | %5.2f' % (g, r[1] - r[0], r[2] - r[0], r[3] - r[0], nxt))
