@@ -98,7 +98,9 @@ def main():
     ap.add_argument('--imputations', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-predict', action='store_true')
-    ap.add_argument('--prof-kernel', default='syrk', help='kernel class timed with HIP events for the roofline')
+    ap.add_argument('--prof-kernel', default='syrk',
+                    help="kernel class timed with HIP events for the roofline ('syrk' = the fused block-step kernel "
+                         "of the factorisation, the dominant kernel; 'lauum', 'trtri', 'kmatrix', ...)")
     args = ap.parse_args()
 
     import torch
@@ -176,7 +178,7 @@ def main():
                             frac=ach / HBM_PEAK_GBS, traffic=None)
             else:
                 ach = tot_w / (tot_ms * 1e-3) / 1e12
-                roof = dict(bound='mfma', kernel='tile_gemm_kernel<%s>' % args.prof_kernel, achieved=ach,
+                roof = dict(bound='mfma', kernel={'syrk': 'potrf_step_kernel'}.get(args.prof_kernel, 'tile_gemm_kernel<%s>' % args.prof_kernel), achieved=ach,
                             peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None)
             roof.update(launches=tot_n, avg_launch_us=1e3 * tot_ms / tot_n, work_per_launch=tot_w / tot_n,
                         event_pair_overhead_us=ev_us, avg_launch_us_uncorrected=1e3 * raw_ms / tot_n,

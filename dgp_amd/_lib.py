@@ -27,6 +27,14 @@ _l = C.c_int64
 _d = C.c_double
 _z = C.c_size_t
 
+class Node(C.Structure):
+    """dgpamd_node (include/dgp_amd.h)."""
+    _fields_ = [('kind', C.c_int), ('Dl', C.c_int), ('Dg', C.c_int), ('nlen', C.c_int), ('nugget_est', C.c_int),
+                ('reserved', C.c_int), ('ldloc', C.c_int64), ('Xloc', C.c_void_p), ('colmap', C.c_void_p),
+                ('Xglob', C.c_void_p), ('length', C.c_void_p), ('nugget', C.c_double), ('W', C.c_void_p),
+                ('y', C.c_void_p)]
+
+
 SIGNATURES = {
     'dgpamd_create': (_i, [_i, _p, C.POINTER(_p)]),
     'dgpamd_destroy': (_i, [_p]),
@@ -55,6 +63,7 @@ SIGNATURES = {
     'dgpamd_potri_batched': (_i, [_p, _l, _p, _p, _l, _i, _i, _p]),
     'dgpamd_grad_workspace': (_z, [_l, _i]),
     'dgpamd_grad_reduce': (_i, [_p, _i, _l, _p, _l, _p, _i, _p, _i, _p, _i, _d, _p, _i, _p, _p, _p]),
+    'dgpamd_llik_batch': (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _p, _p, _p, _l]),
     'dgpamd_gp_workspace': (_z, [_l, _l]),
     'dgpamd_gp_predict': (_i, [_p, _i, _l, _l, _i, _p, _p, _p, _i, _p, _l, _p, _i, _d, _d, _p, _p, _p]),
     'dgpamd_linkgp_workspace': (_z, [_l, _l, _i]),

@@ -29,6 +29,8 @@ struct dgpamd_ctx {
     int use_graphs;                                   // replay static launch sequences as hipGraphs
     int linkgp_direct;                                // 1: evaluate the Matern J factor in the reference's direct form
     long long *trace;                                 // device buffer for in-kernel timestamps (diagnostics), or null
+    double *pinned;                                   // small pinned staging buffer for result copies (lazy)
+    size_t pinned_bytes;
     std::map<std::array<uint64_t, 10>, hipGraphExec_t> graphs;
 };
 

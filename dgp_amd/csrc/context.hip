@@ -23,6 +23,8 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->use_graphs = 1;
     ctx->linkgp_direct = 0;
     ctx->trace = nullptr;
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
     // NULL = the device's default (null) stream, which is also torch's default current stream
     ctx->stream = (hipStream_t)stream;
     ctx->own_stream = false;
@@ -34,6 +36,7 @@ extern "C" int dgpamd_destroy(dgpamd_ctx *ctx) {
     if (!ctx) return DGPAMD_BAD_ARG;
     for (auto &kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
     return DGPAMD_OK;
 }

@@ -299,3 +299,63 @@ extern "C" int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n, const do
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }
+
+
+// ----------------------------------------------------------------------------
+// lock-step M-step: the device part of kernel.llik for several nodes in one call
+// ----------------------------------------------------------------------------
+__global__ void llik_pack_kernel(const double *logdet, const int32_t *info, const double *A, int64_t ld, int64_t stride_a,
+                                 int64_t n, double *out, int64_t stride_out, int batch) {
+    const int b = threadIdx.x;
+    if (b < batch) {
+        out[b * stride_out] = logdet[b];
+        out[b * stride_out + 1] = -A[(int64_t)b * stride_a + n * ld + n];   // y' K^-1 y sits negated in the corner
+        out[b * stride_out + 2] = (double)info[b];
+    }
+}
+
+extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *Ainv,
+                                 int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
+                                 int64_t stride_out) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || !nodes || !A || !Ainv || !work || !grad_work || !dev_out || !host_out) BAD_ARG(ctx, "null pointer or n <= 0");
+    if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
+    const int64_t Np = padded_dim(n);
+    if (n + 1 > Np) BAD_ARG(ctx, "no room for the augmented row");
+    if (batch > 1 && stride_a < Np * Np) BAD_ARG(ctx, "stride_a < Np*Np");
+    for (int b = 0; b < batch; ++b) {
+        const dgpamd_node &nd = nodes[b];
+        const int P = (nd.nlen == 1 ? 1 : nd.Dl + nd.Dg) + (nd.nugget_est ? 1 : 0);
+        if (3 + 2 * P > stride_out) BAD_ARG(ctx, "stride_out too small");
+        int rc = dgpamd_kmatrix(ctx, nd.kind, n, nd.Xloc, nd.ldloc, 0, nd.colmap, nd.Dl, nd.Xglob, nd.Dg, nd.length, nd.nlen,
+                                nd.nugget, nd.W, A + (int64_t)b * stride_a, Np, 0, 0, nd.y, n, 0, 1, 1);
+        if (rc) return rc;
+    }
+    double *logdet = dev_out + (int64_t)batch * stride_out;
+    int32_t *info = reinterpret_cast<int32_t *>(logdet + batch);
+    int rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work);
+    if (rc) return rc;
+    hipLaunchKernelGGL(llik_pack_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)logdet,
+                       (const int32_t *)info, (const double *)A, Np, stride_a, n, dev_out, stride_out, batch);
+    rc = dgpamd_potri_batched(ctx, n, A, Ainv, stride_a, 1, batch, work);
+    if (rc) return rc;
+    for (int b = 0; b < batch; ++b) {
+        const dgpamd_node &nd = nodes[b];
+        rc = dgpamd_grad_reduce(ctx, nd.kind, n, nd.Xloc, nd.ldloc, nd.colmap, nd.Dl, nd.Xglob, nd.Dg, nd.length, nd.nlen,
+                                nd.nugget, nd.W, nd.nugget_est, Ainv + (int64_t)b * stride_a, dev_out + b * stride_out + 3,
+                                grad_work);
+        if (rc) return rc;
+    }
+    const size_t bytes = (size_t)batch * stride_out * sizeof(double);
+    if (ctx->pinned_bytes < bytes) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->pinned, bytes < 65536 ? 65536 : bytes, hipHostMallocDefault));
+        ctx->pinned_bytes = bytes < 65536 ? 65536 : bytes;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, dev_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host_out, ctx->pinned, bytes);
+    return DGPAMD_OK;
+}

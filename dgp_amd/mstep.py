@@ -11,7 +11,6 @@ device-to-host copy).  Every node sees exactly the iterates scipy.optimize.minim
 """
 
 import numpy as np
-import torch
 
 try:   # scipy 1.15's reverse-communication L-BFGS-B core (the routine scipy.optimize.minimize itself drives)
     import scipy
@@ -95,62 +94,45 @@ def minimize_lockstep(problems, evaluate):
 
 
 
-def batched_llik_device(e, n, nodes, cache):
-    """kernel._llik_device for several nodes of the same size at once: per-node K assembly with its own
-    hyper-parameters, ONE batched potrf / potri, per-node reductions, ONE device-to-host copy."""
-    B = len(nodes)
-    Np = e.padded_dim(n)
-    with e.stream():
-        cap = max(B, getattr(cache, '_cap', 0))
-        cache._cap = cap
-        A = e.workspace(('mstepA', n), cap * Np * Np * 8).view(torch.float64)[:B * Np * Np].view(B, Np, Np)
-        Ainv = e.workspace(('mstepAinv', n), cap * Np * Np * 8).view(torch.float64)[:B * Np * Np].view(B, Np, Np)
-        for b, nd in enumerate(nodes):
-            s = nd._staged if nd._staged is not None else nd._stage()
-            e.kmatrix(nd.name, s['Xl'], None, s['Xg'], nd.length, nd.nugget[0], W=s['W'], out=A[b], full=False, Y=s['y'])
-        work = e.potrf_workspace(n, B)
-        logdet, info = e.potrf(n, A, batch=B, work=work)
-        quad = e.aug_quad(n, A, B, 1)
-        e.potri(n, A, Ainv, 1, work, batch=B)
-        reds = []
-        for b, nd in enumerate(nodes):
-            s = nd._staged
-            red, P = e.grad_reduce(nd.name, s['Xl'], None, s['Xg'], nd.length, nd.nugget[0], nd.nugget_est, Ainv[b], W=s['W'])
-            reds.append((red, P))
-        packed = torch.cat([logdet, quad.reshape(-1), info.to(torch.float64)] + [r for r, _ in reds]).cpu().numpy()
-    off = 3 * B
-    res = []
-    for b, (nd, (_, P)) in enumerate(zip(nodes, reds)):
-        red = packed[off:off + 2 * P]
-        off += 2 * P
-        res.append(np.concatenate(([packed[b], packed[B + b]], red, [packed[2 * B + b]])))
-    return res
-
-
 def maximise_lockstep(engine, nodes, cache):
     """kernel.maximise() for several dense GP nodes at once (dgp.py:1391-1398 runs them one after another; given
     the imputed latents their objectives are independent): one L-BFGS-B state per node, every round's objective
-    evaluations batched on the device.  Returns (rounds, evaluations)."""
+    evaluations batched on the device by ONE C call (dgpamd_llik_batch).  Returns (rounds, evaluations)."""
     setups = [nd._opt_setup() for nd in nodes]
     problems = [_Problem(x0, lb, ub, opts.get('maxiter', 15000), opts.get('maxfun', 15000)) for x0, lb, ub, opts in setups]
     evals = [0]
-
-    def evaluate(req):
-        for i, x in req:
-            nodes[i].update(x)
-        groups = {}
-        for i, _ in req:
-            groups.setdefault(len(nodes[i].output), []).append(i)
-        host = {}
-        for n, idxs in groups.items():
-            for i, res in zip(idxs, batched_llik_device(engine, n, [nodes[i] for i in idxs], cache)):
-                host[i] = res
-        evals[0] += len(req)
-        return [nodes[i]._llik_finish(host[i]) for i, _ in req]
-
     for nd in nodes:
         nd._stage()
         nd._in_maximise = True
+    groups = {}
+    for i, nd in enumerate(nodes):
+        groups.setdefault(len(nd.output), []).append(i)
+    plans, where = {}, {}
+    with engine.stream():
+        for n, idxs in groups.items():
+            plans[n] = engine.llik_plan(n, [dict(kind=nodes[i].name, Xloc=nodes[i]._staged['Xl'], Xglob=nodes[i]._staged['Xg'],
+                                                 nlen=len(nodes[i].length), nugget_est=nodes[i].nugget_est,
+                                                 W=nodes[i]._staged['W'], y=nodes[i]._staged['y']) for i in idxs])
+            for pos, i in enumerate(idxs):
+                where[i] = (n, pos)
+
+    def evaluate(req):
+        todo = {}
+        for i, x in req:
+            nd = nodes[i]
+            nd.update(x)
+            n, pos = where[i]
+            plans[n].set(pos, nd.length, nd.nugget[0])
+            todo.setdefault(n, []).append((pos, i))
+        host = {}
+        with engine.stream():
+            for n, lst in todo.items():
+                res = plans[n].run([pos for pos, _ in lst])
+                for pos, i in lst:
+                    host[i] = res[pos]
+        evals[0] += len(req)
+        return [nodes[i]._llik_finish(host[i]) for i, _ in req]
+
     try:
         rounds = minimize_lockstep(problems, evaluate)
     finally:

@@ -247,6 +247,12 @@ class Engine:
                                          _dp(work)))
         return out, P
 
+    def llik_plan(self, n, specs):
+        """Prepare the static part of dgpamd_llik_batch for a fixed set of GP nodes of size n.  specs: list of dicts
+        kind, Xloc (n x ldloc tensor), Xglob (tensor or None), nlen, nugget_est, W (tensor or None), y (tensor).  Returns a
+        plan whose per-call inputs are only the hyper-parameters (plan.set) -- no allocation, one C call per round."""
+        return _LlikPlan(self, n, specs)
+
     def gp_predict(self, kind, x, Wtr, length, Rinv, ldr, ry, scale, nugget, mean=None, var=None):
         """ry: (n,) -> mean (M,) ; ry: (S, n) -> mean (S, M).  var is (M,) either way."""
         M, D = x.shape
@@ -363,3 +369,58 @@ def default_engine(device=None):
     if device not in _default:
         _default[device] = Engine(device)
     return _default[device]
+
+
+class _LlikPlan:
+    """Arguments of dgpamd_llik_batch kept alive between the rounds of a lock-step M-step."""
+
+    def __init__(self, eng, n, specs):
+        self.e, self.n, self.B = eng, int(n), len(specs)
+        B, Np = self.B, eng.padded_dim(n)
+        self.keep = specs                      # tensors stay referenced
+        self.nodes = (_lib.Node * B)()
+        self.lengths = []
+        self.P = []
+        for b, sp in enumerate(specs):
+            nd = self.nodes[b]
+            Xl, Xg = sp['Xloc'], sp['Xglob']
+            nd.kind = KIND[sp['kind']]
+            nd.Dl, nd.Dg = Xl.shape[1], 0 if Xg is None else Xg.shape[1]
+            nd.nlen, nd.nugget_est, nd.ldloc = int(sp['nlen']), 1 if sp['nugget_est'] else 0, Xl.shape[1]
+            nd.Xloc, nd.colmap, nd.Xglob = Xl.data_ptr(), None, None if Xg is None else Xg.data_ptr()
+            length = np.ones(nd.nlen)
+            self.lengths.append(length)
+            nd.length = length.ctypes.data
+            nd.W = None if sp['W'] is None else sp['W'].data_ptr()
+            nd.y = sp['y'].data_ptr()
+            self.P.append((1 if nd.nlen == 1 else nd.Dl + nd.Dg) + nd.nugget_est)
+        self.stride_out = 3 + 2 * max(self.P)
+        self.A = eng.workspace(('mstepA', n), B * Np * Np * 8)
+        self.Ainv = eng.workspace(('mstepAinv', n), B * Np * Np * 8)
+        self.work = eng.potrf_workspace(n, B)
+        self.gwork = eng.workspace(('grad', n, max(self.P)), lib.dgpamd_grad_workspace(n, max(self.P)))
+        self.dev_out = eng.empty(B * (self.stride_out + 2))
+        self.host = np.zeros((B, self.stride_out))
+        self.stride_a = Np * Np
+
+    def set(self, b, length, nugget):
+        self.lengths[b][:] = length
+        self.nodes[b].nugget = float(nugget)
+
+    def run(self, idx):
+        """Evaluate the nodes listed in idx (positions in the plan); returns {position: host vector
+        [logdet, y'K^-1y, tr.., quad.., info]} in kernel._llik_device's layout."""
+        e = self.e
+        if len(idx) == self.B:
+            nodes, B = self.nodes, self.B
+        else:
+            B = len(idx)
+            nodes = (_lib.Node * B)(*[self.nodes[i] for i in idx])
+        host = self.host[:B]
+        e._chk(lib.dgpamd_llik_batch(e.h, self.n, B, nodes, _dp(self.A), _dp(self.Ainv), self.stride_a, _dp(self.work),
+                                     _dp(self.gwork), _dp(self.dev_out), host.ctypes.data_as(C.c_void_p), self.stride_out))
+        out = {}
+        for r, i in enumerate(idx):
+            P = self.P[i]
+            out[i] = np.concatenate((host[r, :2], host[r, 3:3 + 2 * P], host[r, 2:3]))
+        return out

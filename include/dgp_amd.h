@@ -161,6 +161,32 @@ int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n,
                        const double *Xglob, int Dg,
                        const double *length_h, int nlen, double nugget, const double *W, int nugget_est,
                        const double *Ainv, double *out, void *work);
+
+/* kernel.llik's device part (kernel_class.py:403-449) for `batch` GP nodes of the same size n in ONE call -- the
+ * lock-step M-step (dgp.py:1391-1398 fits the nodes one after another; their objectives are independent): per node
+ * K assembly with its own inputs / hyper-parameters (y as augmented row), ONE batched factorisation and inverse,
+ * per-node derivative reductions, ONE device-to-host copy.  The call returns after the results have landed:
+ *   host_out[b * stride_out + ...] = { logdet K_b, y' K_b^-1 y, info (0 = PD), tr_p (P_b values), quad_p (P_b values) }
+ * with P_b as in dgpamd_grad_reduce; stride_out >= 3 + 2 max P_b.  A, Ainv: batch x Np x Np buffers (stride
+ * stride_a); work: dgpamd_potrf_workspace(n, batch); grad_work: dgpamd_grad_workspace(n, max P_b);
+ * dev_out: device scratch of batch * (stride_out + 2) doubles. */
+typedef struct {
+    int kind;              /* DGPAMD_SEXP / DGPAMD_MATERN25 */
+    int Dl, Dg, nlen;      /* local / global input columns, number of lengthscales */
+    int nugget_est;
+    int reserved;
+    int64_t ldloc;
+    const double *Xloc;    /* device, n x ldloc */
+    const int32_t *colmap; /* host, Dl entries, or NULL */
+    const double *Xglob;   /* device, n x Dg, or NULL */
+    const double *length;  /* host, nlen entries */
+    double nugget;
+    const double *W;       /* device replicate weights or NULL */
+    const double *y;       /* device, n */
+} dgpamd_node;
+int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *Ainv,
+                      int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
+                      int64_t stride_out);
 size_t dgpamd_grad_workspace(int64_t n, int nparam);
 
 /* ---- a11  GP prediction ------------------------------------------------------

@@ -165,6 +165,48 @@ def test_loglik_batched_vs_oracle(eng):
         close(npy(ll)[b], O.log_likelihood(Xb, y, length, 1.3, 1e-5, 'matern2.5'), rtol=1e-10)
 
 
+def test_llik_batch_vs_oracle(eng):
+    """dgpamd_llik_batch (one call per lock-step M-step round): nodes with different kernels, inputs, lengthscale
+    layouts and nugget_est, full batch and a sub-batch, against the oracle's nll/gradient ingredients."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(11)
+    n = 333
+    Xa, Xb, G = rng.uniform(size=(n, 2)), rng.uniform(size=(n, 3)), rng.uniform(size=(n, 2))
+    ys = [rng.normal(size=n) for _ in range(3)]
+    cfg = [dict(kind='sexp', Xl=Xa, Xg=None, length=np.array([0.7]), nugget=1e-4, nugget_est=False, y=ys[0]),
+           dict(kind='matern2.5', Xl=Xb, Xg=G, length=np.array([0.9, 1.3, 0.6, 1.1, 0.8]), nugget=2e-3, nugget_est=True, y=ys[1]),
+           dict(kind='matern2.5', Xl=Xa, Xg=G, length=np.array([1.2]), nugget=1e-5, nugget_est=True, y=ys[2])]
+    plan = eng.llik_plan(n, [dict(kind=c['kind'], Xloc=eng.tensor(c['Xl']), Xglob=None if c['Xg'] is None else eng.tensor(c['Xg']),
+                                  nlen=len(c['length']), nugget_est=c['nugget_est'], W=None, y=eng.tensor(c['y'])) for c in cfg])
+
+    def reference(c):
+        X = c['Xl'] if c['Xg'] is None else np.concatenate((c['Xl'], c['Xg']), 1)
+        K, fod = O.k_matrix_fod(X, c['length'], c['nugget'], c['kind'], c['nugget_est'], None)
+        Kinv = np.linalg.inv(K)
+        a = Kinv @ c['y']
+        return (np.linalg.slogdet(K)[1], c['y'] @ a, np.array([np.sum(Kinv * d) for d in fod]),
+                np.array([a @ d @ a for d in fod]))
+
+    for idx in ([0, 1, 2], [2, 0], [1]):
+        for b in idx:
+            plan.set(b, cfg[b]['length'], cfg[b]['nugget'])
+        out = plan.run(idx)
+        for b in idx:
+            ld, q, tr, qq = reference(cfg[b])
+            P = len(tr)
+            h = out[b]
+            assert len(h) == 3 + 2 * P and h[-1] == 0
+            close(h[0], ld, rtol=1e-10, atol=1e-9)
+            close(h[1], q, rtol=1e-8)
+            close(h[2:2 + P], tr, rtol=1e-7, atol=1e-8 * np.abs(tr).max())
+            close(h[2 + P:2 + 2 * P], qq, rtol=1e-7, atol=1e-8 * np.abs(qq).max())
+    # a non-positive-definite node is reported through its info word, the others are unaffected
+    plan.set(0, cfg[0]['length'], -2.0)
+    out = plan.run([0, 1])
+    assert out[0][-1] > 0 and out[1][-1] == 0
+    close(out[1][0], reference(cfg[1])[0], rtol=1e-10, atol=1e-9)
+
+
 def test_trmv_is_fmvn(eng, golden):
     g = golden('g4_fmvn')
     # cov = scale*K: factor K = cov/scale on device, nu = sqrt(scale) L z  (functions.py:113-121)

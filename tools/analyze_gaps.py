@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""GPU idle time between consecutive kernels of a rocprofv3 --kernel-trace CSV, grouped by (previous -> next) kernel."""
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][-40:]) for r in rows))
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # ignore the first `skip` fraction (warm-up / construction)
+ev = ev[int(len(ev) * skip / 100):]
+busy = sum(e - s for s, e, _ in ev)
+span = ev[-1][1] - ev[0][0]
+gaps = collections.defaultdict(lambda: [0, 0])
+end = ev[0][1]
+prev = ev[0][2]
+for s, e, name in ev[1:]:
+    if s > end:
+        g = gaps[(prev, name)]
+        g[0] += s - end
+        g[1] += 1
+    if e > end:
+        end, prev = e, name
+print('span %.1f ms, kernel busy (sum) %.1f ms, idle %.1f ms' % (span / 1e6, busy / 1e6, sum(g[0] for g in gaps.values()) / 1e6))
+for (a, b), (t, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:18]:
+    print('%8.2f ms  %6d x %7.1f us   %s -> %s' % (t / 1e6, n, t / n / 1e3, a, b))

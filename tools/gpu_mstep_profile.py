@@ -9,11 +9,12 @@ from dgp_amd import mstep
 model, X, Y = build_model(2000, 5, 100, 0)
 for _ in range(2):
     model.imp.sample(burnin=10); model._m_step()
+from dgp_amd import ops
 T = dict(dev=0.0, n=0)
-orig = mstep.batched_llik_device
-def timed(*a, **k):
-    t = time.perf_counter(); r = orig(*a, **k); T['dev'] += time.perf_counter() - t; T['n'] += 1; return r
-mstep.batched_llik_device = timed
+orig = ops._LlikPlan.run
+def timed(self, idx):
+    t = time.perf_counter(); r = orig(self, idx); T['dev'] += time.perf_counter() - t; T['n'] += 1; return r
+ops._LlikPlan.run = timed
 N = 6
 tot = 0.0
 rounds = evals = 0
