@@ -66,6 +66,7 @@ __device__ __forceinline__ void pivot_chain(double c00, double c10, double c11, 
                                             double c30, double c31, double c32, double c33, int nact, int j0, int &bad,
                                             double *out) {
     double p0 = c00;
+    if (nact < 1) p0 = 1.0;
     if (!(p0 > 0.0)) { if (!bad) bad = j0 + 1; p0 = 1.0; }
     const double r0 = rcp_f64(p0);
     const double l10 = c10 * r0, l20 = c20 * r0, l30 = c30 * r0;
@@ -90,7 +91,7 @@ __device__ __forceinline__ void pivot_chain(double c00, double c10, double c11, 
     const double n20 = fma(l21, l10, -l20), n31 = fma(l32, l21, -l31);
     const double n30 = fma(-l32, n20, fma(l31, l10, -l30));
     out[0] = -l10; out[1] = n20; out[2] = n30; out[3] = -l21;
-    out[4] = n31; out[5] = -l32; out[6] = r0; out[7] = nact > 1 ? r1 : 0.0;
+    out[4] = n31; out[5] = -l32; out[6] = nact > 0 ? r0 : 0.0; out[7] = nact > 1 ? r1 : 0.0;
     out[8] = nact > 2 ? r2 : 0.0; out[9] = nact > 3 ? r3 : 0.0; out[10] = p0; out[11] = p1;
     out[12] = p2; out[13] = p3;
 }
@@ -288,30 +289,10 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
     }
 }
 
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t ld, int64_t stride_a, int k, int64_t n,
-                                                         double *ws, int64_t stride_ws, double *logdet,
-                                                         int32_t *info, int32_t *flags) {
-    __shared__ DiagShared sh;
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    double *Ab = A + (int64_t)b * stride_a + ((int64_t)k * 64) * ld + (int64_t)k * 64;
-    double *Wb = ws + (int64_t)b * stride_ws + (int64_t)k * 4096;
-    int64_t rem = n - (int64_t)k * 64;
-    const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-    const int wave = tid >> 6, lane = tid & 63;
-    Tile64 a;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a.v[t][r] = Ab[(int64_t)(16 * wave + (lane >> 4) + 4 * r) * ld + 16 * t + (lane & 15)];
-    diag_factor(a, sh, Ab, ld, Wb, ncol, k, b, logdet, info);
-    if (tid == 0 && flags) flags[b] = k + 1;   // visible to the next launch (kernel boundary)
-}
-
 // ----------------------------------------------------------------------------
 // 64x64x64 tile GEMM engine on f64 MFMA
 // ----------------------------------------------------------------------------
-enum { G_TRSM = 0, G_SYRK = 1, G_TRTRI1 = 2, G_TRTRI2 = 3, G_LAUUM = 4 };
+enum { G_TRTRI1 = 2, G_TRTRI2 = 3, G_LAUUM = 4 };
 
 struct GemmArgs {
     double *A;        // Np x Np buffers
@@ -327,7 +308,7 @@ struct GemmArgs {
 template <int MODE>
 __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
     constexpr int OPA = (MODE == G_LAUUM) ? OP_KM : OP_MK;
-    constexpr int OPB = (MODE == G_TRSM || MODE == G_SYRK) ? OP_MK : OP_KM;
+    constexpr int OPB = OP_KM;
     __shared__ double As[(OPA == OP_MK) ? 64 * LDM : KC * LDK];
     __shared__ double Bs[(OPB == OP_MK) ? 64 * LDM : KC * LDK];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -338,15 +319,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
     int bi, bj, kb0, kb1;          // output tile, k-block range [kb0, kb1)
     double *C;                     // output buffer
     double sign = 1.0;
-    bool accumulate = false;
-    if (MODE == G_TRSM) {
-        bi = g.k + 1 + blockIdx.x; bj = g.k; kb0 = g.k; kb1 = g.k + 1; C = A;
-    } else if (MODE == G_SYRK) {
-        int ti, tj;
-        tri_decode(blockIdx.x, ti, tj);
-        bi = g.k + 1 + ti; bj = g.k + 1 + tj; kb0 = g.k; kb1 = g.k + 1; C = A;
-        sign = -1.0; accumulate = true;
-    } else if (MODE == G_TRTRI1 || MODE == G_TRTRI2) {
+    if (MODE == G_TRTRI1 || MODE == G_TRTRI2) {
         const int s = g.s, per = s * s;
         const int p = blockIdx.x / per, rem = blockIdx.x - p * per;
         const int base = 2 * p * s;
@@ -366,24 +339,10 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
-    if (accumulate) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[t][r] = C[((int64_t)bi * 64 + crow + 4 * r) * ld + (int64_t)bj * 64 + 16 * t + ccol];
-    }
-
     // operands of k-block kb
     auto operands = [&](int kb, const double *&Ag, const double *&Bg, int64_t &lda, int64_t &ldb, int &lim) {
         lda = ld; ldb = ld; lim = 64;
-        if (MODE == G_TRSM) {
-            Ag = A + ((int64_t)bi * 64) * ld + (int64_t)kb * 64;
-            Bg = g.ws + (int64_t)blockIdx.z * g.stride_ws + (int64_t)kb * 4096; ldb = 64;
-        } else if (MODE == G_SYRK) {
-            Ag = A + ((int64_t)bi * 64) * ld + (int64_t)kb * 64;
-            Bg = A + ((int64_t)bj * 64) * ld + (int64_t)kb * 64;
-        } else if (MODE == G_TRTRI1) {
+        if (MODE == G_TRTRI1) {
             Ag = A + ((int64_t)bi * 64) * ld + (int64_t)kb * 64;
             Bg = A + ((int64_t)kb * 64) * ld + (int64_t)bj * 64;
         } else if (MODE == G_TRTRI2) {
@@ -428,24 +387,37 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
 }
 
 // ----------------------------------------------------------------------------
-// One block step of the factorisation as ONE launch (k >= 1).  Roles, in dispatch (= urgency) order:
-//   chain   one workgroup per matrix: brings the diagonal tile (k,k) up to date, factors it (diag_factor) and
-//           publishes the block's inverse with an agent-scope release;
-//   panel   the workgroups of column k (tiles (i,k), i > k) update their tile, wait for that flag and apply
-//           P_i = A_ik Linv_k^T;
-//   bulk    trailing tiles (i,j) of the columns j = k+1, k+3, ...: LAZY update, two panels (k-2, k-1) = 128 pivots at
-//           a time.  A tile of column j is touched by the launches k = j-1, j-3, ... (two panels each) and finally
-//           by launch j (column k above, panel j-1 only), so C is read and written once per 128 pivots instead of
-//           once per 64 while the serial chain still applies a single panel.
-// The serial pivot chain of step k overlaps the bulk update, and a factorisation is nbk+1 launches.
-// Deadlock freedom: only column-k workgroups ever wait, and they wait for the chain workgroup of the SAME launch,
-// which has a lower block index (dispatched first) and never waits itself.  The spin is bounded (info = -1).
+// One block step k of the factorisation as ONE launch, driven by a TASK TABLE built on the host (one task per
+// workgroup and matrix, in urgency = dispatch order).  A task is a 64x64 tile update
+//      C = (first ? 0 : C) +/- sum_{kb0 <= kb < kb0+nkb}  L[li][kb] R[ri][kb]^T          (buffers A / T / S)
+// followed by one of
+//   STORE   (bulk)   store the tile;
+//   CHAIN            factor the diagonal tile (diag_factor) and publish the block's inverse W_k with an agent-scope
+//                    release (MI355X_MICROARCH.md hand-off recipe);
+//   SOLVE   (panel)  wait for that flag (acquire, bounded spin), tile <- tile * W_k^T  -- the explicit inverse of the
+//                    diagonal block turns every triangular solve into an MFMA GEMM;
+//   TDIAG            wait, write W_k^T (the diagonal block of L^-T).
+// Plain factorisation (buffer A): column k = chain + panel tasks applying panel k-1; the bulk is LAZY -- tiles of the
+// columns k+1, k+3, ... take two panels (k-2, k-1) = 128 pivots per visit, so C is read/written once per 128 pivots
+// while the serial chain still applies a single panel.
+// Fused inverse (dgpamd_potrf_inv): the identity rides along as n extra rows (buffer T, only its non-zero tiles
+// exist) with a zero corner (buffer S).  The same right-looking sweep then leaves T = L^-T and the Schur
+// complement of K in [[K, I], [I, 0]], i.e. S = K^-1 (accumulated with a + sign), and column n of T = -K^-1 y:
+// what potri (TRTRI + LAUUM) computes in ~13 more latency-bound launches becomes bulk work in the shadow of the
+// pivot chain.  T tiles follow the same lazy rule as A's; S tile (q, q') is visited by the launches
+// k = q+2, q+4, ... (two panels each) and by two tail launches.
+// Deadlock freedom: only SOLVE / TDIAG workgroups wait, and only for the chain workgroup of the SAME launch, which
+// has a lower block index (dispatched first) and never waits itself.  The spin is bounded (info = -1).
 // ----------------------------------------------------------------------------
+enum { T_STORE = 0, T_SOLVE = 1, T_CHAIN = 2, T_TDIAG = 3 };
+enum { BUF_A = 0, BUF_T = 1, BUF_S = 2 };
+
 struct StepArgs {
-    double *A;
+    double *buf[3];   // A (Np x Np, K with the right-hand sides as extra rows), T (L^-T), S (K^-1)
     double *ws;
     int64_t ld, stride_a, stride_ws, n;
     int nbk, k, batch;
+    const int4 *tasks;   // this launch's tasks
     double *logdet;
     int32_t *info;
     int32_t *flags;
@@ -455,6 +427,16 @@ struct StepArgs {
     do {                                                                                  \
         if (g.trace && b == 0 && tid == 0) g.trace[16 * g.k + (slot)] = wall_clock64();   \
     } while (0)
+
+static inline int4 make_task(int post, int first, int plus, int mask_last, int bufC, int ci, int cj, int bufL, int li,
+                             int bufR, int ri, int kb0, int nkb) {
+    int4 t;
+    t.x = post | (first << 4) | (plus << 5) | (mask_last << 6) | (bufC << 8) | (bufL << 10) | (bufR << 12);
+    t.y = ci | (cj << 16);
+    t.z = li | (ri << 16);
+    t.w = kb0 | (nkb << 16);
+    return t;
+}
 
 __device__ __forceinline__ void load_acc(d4 (&acc)[4], const double *C, int64_t ld, int crow, int ccol) {
 #pragma unroll
@@ -468,38 +450,50 @@ __device__ __forceinline__ void store_acc(const d4 (&acc)[4], double *C, int64_t
 #pragma unroll
         for (int r = 0; r < 4; ++r) C[(int64_t)(crow + 4 * r) * ld + 16 * t + ccol] = acc[t][r];
 }
-// acc -= sum over nkb consecutive 64-blocks  Pi_kb Pj_kb^T.  Software pipelined: the global loads of the next
-// half tile are in flight (registers) while the MFMAs of the current one run.
-__device__ __forceinline__ void rank_update(d4 (&acc)[4], const double *Pi, const double *Pj, int64_t ld, int nkb,
-                                            double *As, double *Bs, int tid, int wave, int lane) {
+// acc = (C ? C : 0) + sign * sum over nkb consecutive 64-blocks  L_kb R_kb^T.  Software pipelined: the global loads of
+// the next half tile are in flight (registers) while the MFMAs of the current one run.  In the 64-block number
+// mask_kb (relative to the first) the columns >= klim of both operands read as zero.
+__device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const double *Lp, const double *Rp, int64_t ld,
+                                            int nkb, double sign, int mask_kb, int klim, double *As, double *Bs, int tid,
+                                            int wave, int lane) {
     const int c2 = (tid & 15) * 2, r0 = tid >> 4;
+    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
     double2 pa[4], pb[4];
     const int nh = 2 * nkb;
-    if (nh > 0) {
+    auto fetch = [&](int hh) {
+        const int64_t off = 32 * hh;   // consecutive half tiles are consecutive 32-column slabs
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            pa[it] = *reinterpret_cast<const double2 *>(Pi + (int64_t)(r0 + 16 * it) * ld + c2);
-            pb[it] = *reinterpret_cast<const double2 *>(Pj + (int64_t)(r0 + 16 * it) * ld + c2);
+            pa[it] = *reinterpret_cast<const double2 *>(Lp + (int64_t)(r0 + 16 * it) * ld + off + c2);
+            pb[it] = *reinterpret_cast<const double2 *>(Rp + (int64_t)(r0 + 16 * it) * ld + off + c2);
         }
+    };
+    if (nh > 0) fetch(0);
+    if (C) {
+        load_acc(acc, C, ld, crow, ccol);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
     }
     for (int hh = 0; hh < nh; ++hh) {
         __syncthreads();
+        if ((hh >> 1) == mask_kb) {
+            const int c = 32 * (hh & 1) + c2;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (c >= klim) pa[it].x = pb[it].x = 0.0;
+                if (c + 1 >= klim) pa[it].y = pb[it].y = 0.0;
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int r = r0 + 16 * it;
             As[r * LDM + c2] = pa[it].x; As[r * LDM + c2 + 1] = pa[it].y;
             Bs[r * LDM + c2] = pb[it].x; Bs[r * LDM + c2 + 1] = pb[it].y;
         }
-        if (hh + 1 < nh) {
-            const int64_t off = 32 * (hh + 1);   // consecutive half tiles are consecutive 32-column slabs
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                pa[it] = *reinterpret_cast<const double2 *>(Pi + (int64_t)(r0 + 16 * it) * ld + off + c2);
-                pb[it] = *reinterpret_cast<const double2 *>(Pj + (int64_t)(r0 + 16 * it) * ld + off + c2);
-            }
-        }
+        if (hh + 1 < nh) fetch(hh + 1);
         __syncthreads();
-        mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, -1.0);
+        mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, sign);
     }
 }
 // out += sign * in * Bg^T   (in: accumulator-layout 64x64 tile, Bg: 64x64 row-major tile in global memory)
@@ -550,39 +544,43 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     double *As = tiles, *Bs = tiles + 64 * LDM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
-    const int k = g.k, m = g.nbk - g.k, batch = g.batch;
-    int b, ti, tj;
-    {
-        const int idx = blockIdx.x;
-        if (idx < batch * m) {                     // column k: chain (ti == 0) and panel workgroups
-            b = idx % batch; ti = idx / batch; tj = 0;
-        } else {                                   // bulk: columns k+1, k+3, ...
-            int bulk = 0;
-            for (int c = 1; c < m; c += 2) bulk += m - c;
-            int r = idx - batch * m;
-            b = r / bulk;
-            r -= b * bulk;
-            tj = 1;
-            while (r >= m - tj) { r -= m - tj; tj += 2; }
-            ti = tj + r;
+    const int k = g.k, batch = g.batch;
+    const int b = blockIdx.x % batch;
+    const int4 tk = g.tasks[blockIdx.x / batch];
+    const int post = tk.x & 15, first = (tk.x >> 4) & 1, plus = (tk.x >> 5) & 1, mask_last = (tk.x >> 6) & 1;
+    const int bufC = (tk.x >> 8) & 3, bufL = (tk.x >> 10) & 3, bufR = (tk.x >> 12) & 3;
+    const int ci = tk.y & 0xffff, cj = tk.y >> 16, li = tk.z & 0xffff, ri = tk.z >> 16;
+    const int kb0 = tk.w & 0xffff, nkb = tk.w >> 16;
+    const int64_t ld = g.ld, mo = (int64_t)b * g.stride_a;
+    const int64_t rem_last = g.n - (int64_t)(g.nbk - 1) * 64;
+    const int ncol_last = rem_last > 0 ? (int)rem_last : 0;   // pivots of the last block (the rest are carried rows)
+    double *C = g.buf[bufC] + mo + ((int64_t)ci * 64) * ld + (int64_t)cj * 64;
+    double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096;
+
+    if (post == T_TDIAG) {   // T[k][k] = W_k^T, rows of the carried right-hand sides zeroed
+        wg_wait_acquire(g.flags + b, k + 1, g.info + b, tid);
+        const int nrow = (k == g.nbk - 1) ? ncol_last : 64;
+        for (int idx = tid; idx < 4096; idx += 256) tiles[(idx >> 6) * 65 + (idx & 63)] = Wk[idx];
+        __syncthreads();
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int r = idx >> 6, c = idx & 63;
+            C[(int64_t)r * ld + c] = r < nrow ? tiles[c * 65 + r] : 0.0;
         }
+        return;
     }
-    const int nprev = (tj == 0 || k < 2) ? 1 : 2;   // panels (k-nprev .. k-1) are applied to this tile
-    const int bi = k + ti, bj = k + tj;
-    const int64_t ld = g.ld;
-    double *A = g.A + (int64_t)b * g.stride_a;
-    double *C = A + ((int64_t)bi * 64) * ld + (int64_t)bj * 64;
-    const int64_t pc = (int64_t)(k - nprev) * 64;
     Tile64 acc;
-    if (tj == 0 && ti == 0) STAMP(0);
-    load_acc(acc.v, C, ld, crow, ccol);
-    rank_update(acc.v, A + ((int64_t)bi * 64) * ld + pc, A + ((int64_t)bj * 64) * ld + pc, ld, nprev, As, Bs, tid, wave, lane);
-    if (tj != 0) {   // plain trailing tile
+    if (post == T_CHAIN) {
+        STAMP(0);
+        __builtin_amdgcn_s_setprio(3);   // the chain shares its CU with a bulk workgroup
+    }
+    tile_update(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
+                g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
+                mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
+    if (post == T_STORE) {
         store_acc(acc.v, C, ld, crow, ccol);
         return;
     }
-    double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096;
-    if (ti == 0) {   // the diagonal tile: factor it right away
+    if (post == T_CHAIN) {
         STAMP(1);
         const int64_t rem = g.n - (int64_t)k * 64;
         diag_factor(acc, sh, C, ld, Wk, rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0), k, b, g.logdet, g.info,
@@ -592,16 +590,26 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
         STAMP(3);
         return;
     }
-    // panel tile (bi, k): wait for Linv_k, then P_i = A_ik * Linv_k^T
-    if (ti == 1) STAMP(8);
+    // T_SOLVE: wait for W_k, then tile <- tile * W_k^T
+    const bool stamp = (bufC == BUF_A && ci == k + 1);
+    if (stamp) STAMP(8);
     wg_wait_acquire(g.flags + b, k + 1, g.info + b, tid);
-    if (ti == 1) STAMP(9);
+    if (stamp) STAMP(9);
     d4 out[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) out[t] = (d4){0.0, 0.0, 0.0, 0.0};
     mul_acc_bt(out, acc.v, Wk, 64, 1.0, As, Bs, tid, wave, lane);
     store_acc(out, C, ld, crow, ccol);
-    if (ti == 1) STAMP(10);
+    if (stamp) STAMP(10);
+}
+
+// column n of T holds -K^-1 y: copy it into row n of S (the layout dgpamd_potri leaves: row n of Ainv = -alpha^T)
+__global__ void copy_alpha_kernel(const double *T, double *S, int64_t ld, int64_t n, int64_t stride_a) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    T += (int64_t)blockIdx.y * stride_a;
+    S += (int64_t)blockIdx.y * stride_a;
+    S[n * ld + j] = T[j * ld + n];
 }
 
 // place the diagonal-block inverses on the diagonal of the (to be inverted) factor
@@ -663,39 +671,103 @@ extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
     return potrf_ws_doubles(n, batch) * sizeof(double) + 2 * DGPAMD_MAXB * sizeof(int32_t);   // + info, step flags
 }
 
-static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet,
-                          int32_t *info, double *ws, int32_t *flags) {
+// Task tables (see potrf_step_kernel): one vector of tasks per launch, cached on the device per (nbk, inverse).
+struct TaskTable {
+    int4 *dev = nullptr;
+    std::vector<int> offset, count;
+    std::vector<double> tile_ops;   // 64^3 multiply-add units per launch and matrix (for the profiler)
+};
+
+static void build_tasks(int nbk, bool inv, std::vector<std::vector<int4>> &L, std::vector<double> &ops) {
+    const int nl = nbk + (inv ? 2 : 0);
+    L.assign(nl, {});
+    ops.assign(nl, 0.0);
+    for (int k = 0; k < nl; ++k) {
+        std::vector<int4> &t = L[k];
+        double &w = ops[k];
+        if (k < nbk) {
+            const int np1 = k >= 1 ? 1 : 0;   // column k takes panel k-1 only
+            t.push_back(make_task(T_CHAIN, 0, 0, 0, BUF_A, k, k, BUF_A, k, BUF_A, k, k - np1, np1));
+            w += np1 + 1;
+            if (inv) t.push_back(make_task(T_TDIAG, 1, 0, 0, BUF_T, k, k, BUF_A, 0, BUF_A, 0, 0, 0));
+            for (int i = k + 1; i < nbk; ++i) {
+                t.push_back(make_task(T_SOLVE, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, k - np1, np1));
+                w += np1 + 1;
+            }
+            if (inv)
+                for (int q = k - 1; q >= 0; --q) {   // T[q][k]: first touched by panel k-1 when q == k-1
+                    t.push_back(make_task(T_SOLVE, q == k - 1, 0, 0, BUF_T, q, k, BUF_T, q, BUF_A, k, k - 1, 1));
+                    w += 2;
+                }
+            // lazy bulk of A: columns k+1, k+3, ... take the panels (k-2, k-1)
+            const int kb0 = k >= 2 ? k - 2 : 0, nkb = k - kb0;
+            if (nkb > 0)
+                for (int j = k + 1; j < nbk; j += 2)
+                    for (int i = j; i < nbk; ++i) {
+                        t.push_back(make_task(T_STORE, 0, 0, 0, BUF_A, i, j, BUF_A, i, BUF_A, j, kb0, nkb));
+                        w += nkb;
+                    }
+            if (inv && nkb > 0)   // same rule for the rows of T that already have a panel: q <= k-1
+                for (int j = k + 1; j < nbk; j += 2)
+                    for (int q = 0; q <= k - 1; ++q) {
+                        const int f0 = q > kb0 ? q : kb0;   // panels >= q only; the first visit starts from zero
+                        t.push_back(make_task(T_STORE, f0 == q, 0, 0, BUF_T, q, j, BUF_T, q, BUF_A, j, f0, k - f0));
+                        w += k - f0;
+                    }
+        }
+        if (inv)   // S[q][q'] += Pt_q Pt_q'^T for the panels (k-2, k-1), rows q = k-2, k-4, ...
+            for (int q = k - 2; q >= 0; q -= 2) {
+                const int nkb = (k - 1 < nbk ? k : nbk) - (k - 2);   // clip to panels < nbk
+                if (nkb <= 0) continue;
+                const int mask = (k - 2 + nkb - 1 == nbk - 1) ? 1 : 0;   // the last block carries right-hand sides
+                for (int q2 = 0; q2 <= q; ++q2) {
+                    t.push_back(make_task(T_STORE, q == k - 2, 1, mask, BUF_S, q, q2, BUF_T, q, BUF_T, q2, k - 2, nkb));
+                    w += nkb;
+                }
+            }
+    }
+}
+
+static int get_tasks(dgpamd_ctx *ctx, int nbk, bool inv, TaskTable *&out) {
+    static std::map<std::pair<dgpamd_ctx *, std::pair<int, int>>, TaskTable> cache;   // contexts are few and long-lived
+    TaskTable &tt = cache[{ctx, {nbk, inv ? 1 : 0}}];
+    if (!tt.dev) {
+        std::vector<std::vector<int4>> L;
+        build_tasks(nbk, inv, L, tt.tile_ops);
+        std::vector<int4> flat;
+        for (auto &v : L) {
+            tt.offset.push_back((int)flat.size());
+            tt.count.push_back((int)v.size());
+            flat.insert(flat.end(), v.begin(), v.end());
+        }
+        HIP_TRY(ctx, hipMalloc((void **)&tt.dev, flat.size() * sizeof(int4)));
+        HIP_TRY(ctx, hipMemcpy(tt.dev, flat.data(), flat.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
+    out = &tt;
+    return DGPAMD_OK;
+}
+
+static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *T, double *S, int64_t stride_a, int batch,
+                          double *logdet, int32_t *info, double *ws, int32_t *flags, const TaskTable *tt) {
     const int64_t Np = padded_dim(n);
     const int nbk = (int)(Np / 64);
-    const int64_t stride_ws = (int64_t)nbk * 4096;
     const double tile_flops = 2.0 * 64.0 * 64.0 * 64.0;
-    // step 0: diagonal block and first panel as two launches
-    PROF_BEGIN(ctx, PROF_POTRF_DIAG, (double)batch * (64.0 * 64.0 * 64.0));
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, ctx->stream, A, Np, stride_a, 0, n, ws, stride_ws,
-                       logdet, info, flags);
-    PROF_END(ctx, PROF_POTRF_DIAG);
-    if (nbk > 1) {
-        GemmArgs g;
-        g.A = A; g.B = nullptr; g.ws = ws; g.ld = Np; g.stride_a = stride_a; g.stride_ws = stride_ws;
-        g.n = n; g.nbk = nbk; g.k = 0; g.s = 0;
-        PROF_BEGIN(ctx, PROF_TRSM, (double)batch * (nbk - 1) * tile_flops);
-        hipLaunchKernelGGL(tile_gemm_kernel<G_TRSM>, dim3(nbk - 1, 1, batch), dim3(256), 0, ctx->stream, g);
-        PROF_END(ctx, PROF_TRSM);
-    }
-    // steps 1..nbk-1: trailing update with panel k-1 + factorisation of block k + panel k, fused
+    HIP_TRY(ctx, hipMemsetAsync(flags, 0, DGPAMD_MAXB * sizeof(int32_t), ctx->stream));
     StepArgs st;
-    st.A = A; st.ws = ws; st.ld = Np; st.stride_a = stride_a; st.stride_ws = stride_ws; st.n = n; st.nbk = nbk;
-    st.logdet = logdet; st.info = info; st.flags = flags; st.batch = batch;
-    st.trace = ctx->trace;
-    for (int k = 1; k < nbk; ++k) {
-        const int m = nbk - k, np = k >= 2 ? 2 : 1;
-        int bulk = 0;
-        for (int c = 1; c < m; c += 2) bulk += m - c;
-        st.k = k;
-        PROF_BEGIN(ctx, PROF_SYRK, (double)batch * (bulk * np + m + (m - 1)) * tile_flops);
-        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(batch * (m + bulk))), dim3(256), 0, ctx->stream, st);
+    st.buf[BUF_A] = A; st.buf[BUF_T] = T; st.buf[BUF_S] = S;
+    st.ws = ws; st.ld = Np; st.stride_a = stride_a; st.stride_ws = (int64_t)nbk * 4096; st.n = n; st.nbk = nbk;
+    st.logdet = logdet; st.info = info; st.flags = flags; st.batch = batch; st.trace = ctx->trace;
+    for (size_t k = 0; k < tt->count.size(); ++k) {
+        if (tt->count[k] == 0) continue;
+        st.k = (int)k;
+        st.tasks = tt->dev + tt->offset[k];
+        PROF_BEGIN(ctx, PROF_SYRK, (double)batch * tt->tile_ops[k] * tile_flops);
+        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(batch * tt->count[k])), dim3(256), 0, ctx->stream, st);
         PROF_END(ctx, PROF_SYRK);
     }
+    if (T)
+        hipLaunchKernelGGL(copy_alpha_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, ctx->stream,
+                           (const double *)T, S, Np, n, stride_a);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }
@@ -709,17 +781,20 @@ __global__ void potrf_copy_out_kernel(const double *ld_ws, const int32_t *info_w
 }
 
 int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
-              double *ws) {
-    // 3 launches per 64-column block step with a static shape: replayed as one hipGraph.  The graph writes
+              double *ws, double *T, double *S) {
+    // One launch per 64-column block step with a static shape: replayed as one hipGraph.  The graph writes
     // logdet/info into the workspace tail (fixed addresses -> the cached graph does not depend on where the
     // caller wants them); a tiny kernel outside the graph copies them out.
     const int64_t nbk = padded_dim(n) / 64;
     double *ld_ws = ws + (size_t)batch * nbk * 4096 + DGPAMD_MAXB;
     int32_t *info_ws = reinterpret_cast<int32_t *>(ws + (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB);
     int32_t *flags = info_ws + DGPAMD_MAXB;
+    TaskTable *tt = nullptr;
+    int rc = get_tasks(ctx, (int)nbk, T != nullptr, tt);   // (uploads the table on first use: outside the capture)
+    if (rc) return rc;
     const std::array<uint64_t, 10> key = {1, (uint64_t)n, (uint64_t)batch, (uint64_t)A, (uint64_t)stride_a, (uint64_t)ws,
-                                          0, 0, 0, 0};
-    int rc = graph_run(ctx, key, [&]() { return potrf_launches(ctx, n, A, stride_a, batch, ld_ws, info_ws, ws, flags); });
+                                          (uint64_t)T, (uint64_t)S, 0, 0};
+    rc = graph_run(ctx, key, [&]() { return potrf_launches(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, flags, tt); });
     if (rc) return rc;
     hipLaunchKernelGGL(potrf_copy_out_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)ld_ws,
                        (const int32_t *)info_ws, logdet, info, batch);
@@ -734,7 +809,18 @@ extern "C" int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t strid
     if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
     const int64_t Np = padded_dim(n);
     if (batch > 1 && stride_a < Np * Np) BAD_ARG(ctx, "stride_a < Np*Np");
-    return run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work);
+    return run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, nullptr, nullptr);
+}
+
+extern "C" int dgpamd_potrf_inv(dgpamd_ctx *ctx, int64_t n, double *A, double *T, double *S, int64_t stride_a, int batch,
+                                double *logdet, int32_t *info, void *work) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || !A || !T || !S || !logdet || !info || !work) BAD_ARG(ctx, "null pointer or n <= 0");
+    if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
+    const int64_t Np = padded_dim(n);
+    if (n + 1 > Np) BAD_ARG(ctx, "no room for the right-hand-side row");
+    if (batch > 1 && stride_a < Np * Np) BAD_ARG(ctx, "stride_a < Np*Np");
+    return run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, T, S);
 }
 
 extern "C" int dgpamd_aug_quad(dgpamd_ctx *ctx, int64_t n, const double *A, int64_t stride_a, int batch, int r,

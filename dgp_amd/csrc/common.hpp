@@ -183,6 +183,6 @@ int build_kmat_args(dgpamd_ctx *ctx, KmatArgs &a, int kind, int64_t n, const dou
                     const double *length_h, int nlen, double nugget, const double *W, double *K, int64_t ldk,
                     int64_t stride_k, int full, const double *Y, int64_t ldy, int64_t stride_y, int r, int batch);
 int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
-              double *ws);
+              double *ws, double *T = nullptr, double *S = nullptr);   // T, S: fused inverse (dgpamd_potrf_inv)
 size_t potrf_ws_doubles(int64_t n, int batch);
 

@@ -314,11 +314,11 @@ __global__ void llik_pack_kernel(const double *logdet, const int32_t *info, cons
     }
 }
 
-extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *Ainv,
-                                 int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
+extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T,
+                                 double *Ainv, int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
                                  int64_t stride_out) {
     if (!ctx) return DGPAMD_BAD_ARG;
-    if (n <= 0 || !nodes || !A || !Ainv || !work || !grad_work || !dev_out || !host_out) BAD_ARG(ctx, "null pointer or n <= 0");
+    if (n <= 0 || !nodes || !A || !T || !Ainv || !work || !grad_work || !dev_out || !host_out) BAD_ARG(ctx, "null pointer or n <= 0");
     if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
     const int64_t Np = padded_dim(n);
     if (n + 1 > Np) BAD_ARG(ctx, "no room for the augmented row");
@@ -333,12 +333,10 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     }
     double *logdet = dev_out + (int64_t)batch * stride_out;
     int32_t *info = reinterpret_cast<int32_t *>(logdet + batch);
-    int rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work);
+    int rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, T, Ainv);   // factor + inverse, one sweep
     if (rc) return rc;
     hipLaunchKernelGGL(llik_pack_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)logdet,
                        (const int32_t *)info, (const double *)A, Np, stride_a, n, dev_out, stride_out, batch);
-    rc = dgpamd_potri_batched(ctx, n, A, Ainv, stride_a, 1, batch, work);
-    if (rc) return rc;
     for (int b = 0; b < batch; ++b) {
         const dgpamd_node &nd = nodes[b];
         rc = dgpamd_grad_reduce(ctx, nd.kind, n, nd.Xloc, nd.ldloc, nd.colmap, nd.Dl, nd.Xglob, nd.Dg, nd.length, nd.nlen,

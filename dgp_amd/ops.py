@@ -182,6 +182,17 @@ class Engine:
         self._chk(lib.dgpamd_potrf(self.h, n, _dp(A), Np * Np, batch, _dp(logdet), _dp(info), _dp(work)))
         return logdet, info
 
+    def potrf_inv(self, n, A, T, S, batch=1, work=None):
+        """Factorisation and inverse in one sweep (dgpamd_potrf_inv): A -> L, T -> L^-T, S -> K^-1 (lower tiles,
+        row n = -alpha^T).  Returns (logdet, info) device tensors."""
+        Np = self.padded_dim(n)
+        if work is None:
+            work = self.potrf_workspace(n, batch)
+        logdet = self.empty(batch)
+        info = self.empty(batch, dtype=torch.int32)
+        self._chk(lib.dgpamd_potrf_inv(self.h, n, _dp(A), _dp(T), _dp(S), Np * Np, batch, _dp(logdet), _dp(info), _dp(work)))
+        return logdet, info
+
     def aug_quad(self, n, A, batch, r):
         Np = self.padded_dim(n)
         out = self.empty(batch, r, r)
@@ -397,6 +408,7 @@ class _LlikPlan:
         self.stride_out = 3 + 2 * max(self.P)
         self.A = eng.workspace(('mstepA', n), B * Np * Np * 8)
         self.Ainv = eng.workspace(('mstepAinv', n), B * Np * Np * 8)
+        self.T = eng.workspace(('mstepT', n), B * Np * Np * 8)
         self.work = eng.potrf_workspace(n, B)
         self.gwork = eng.workspace(('grad', n, max(self.P)), lib.dgpamd_grad_workspace(n, max(self.P)))
         self.dev_out = eng.empty(B * (self.stride_out + 2))
@@ -417,7 +429,7 @@ class _LlikPlan:
             B = len(idx)
             nodes = (_lib.Node * B)(*[self.nodes[i] for i in idx])
         host = self.host[:B]
-        e._chk(lib.dgpamd_llik_batch(e.h, self.n, B, nodes, _dp(self.A), _dp(self.Ainv), self.stride_a, _dp(self.work),
+        e._chk(lib.dgpamd_llik_batch(e.h, self.n, B, nodes, _dp(self.A), _dp(self.T), _dp(self.Ainv), self.stride_a, _dp(self.work),
                                      _dp(self.gwork), _dp(self.dev_out), host.ctypes.data_as(C.c_void_p), self.stride_out))
         out = {}
         for r, i in enumerate(idx):

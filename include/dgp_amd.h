@@ -144,6 +144,15 @@ int dgpamd_ess_propose(dgpamd_ctx *ctx, int64_t n, int M, const double *F, const
  * Ainv (Np x Np buffer) holds K^-1 in BOTH triangles of [0,n)x[0,n) and row n+q
  * of columns [0,n) holds -alpha_q^T = -(K^-1 y_q)^T.  A is overwritten with L^-1. */
 int dgpamd_potri(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int r, void *work);
+/* Factorisation AND inverse in one sweep (replaces potrf + potri where both are wanted, e.g. kernel.llik
+ * kernel_class.py:417-423): the identity rides along as n extra rows, so the right-looking sweep leaves
+ *   A: as dgpamd_potrf;   T (Np x Np): L^-T in its first n rows (block upper triangular; column n = -K^-1 y_0);
+ *   S (Np x Np): K^-1 in the lower 64x64 tiles of its first n rows/columns (diagonal tiles full), row n = -(K^-1 y_0)^T
+ * -- the layout dgpamd_potri leaves in Ainv, minus the strictly upper tiles.  T and S need no initialisation.
+ * The inverse's GEMM work runs in the shadow of the factorisation's pivot chain instead of after it. */
+int dgpamd_potrf_inv(dgpamd_ctx *ctx, int64_t n, double *A, double *T, double *S, int64_t stride_a, int batch,
+                     double *logdet, int32_t *info, void *work);
+
 /* Same on `batch` buffers (A and Ainv share the batch stride stride_a; work = the batched potrf workspace). */
 int dgpamd_potri_batched(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int64_t stride_a, int r, int batch,
                          void *work);
@@ -167,8 +176,8 @@ int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n,
  * K assembly with its own inputs / hyper-parameters (y as augmented row), ONE batched factorisation and inverse,
  * per-node derivative reductions, ONE device-to-host copy.  The call returns after the results have landed:
  *   host_out[b * stride_out + ...] = { logdet K_b, y' K_b^-1 y, info (0 = PD), tr_p (P_b values), quad_p (P_b values) }
- * with P_b as in dgpamd_grad_reduce; stride_out >= 3 + 2 max P_b.  A, Ainv: batch x Np x Np buffers (stride
- * stride_a); work: dgpamd_potrf_workspace(n, batch); grad_work: dgpamd_grad_workspace(n, max P_b);
+ * with P_b as in dgpamd_grad_reduce; stride_out >= 3 + 2 max P_b.  A, T, Ainv: batch x Np x Np buffers (stride
+ * stride_a; see dgpamd_potrf_inv); work: dgpamd_potrf_workspace(n, batch); grad_work: dgpamd_grad_workspace(n, max P_b);
  * dev_out: device scratch of batch * (stride_out + 2) doubles. */
 typedef struct {
     int kind;              /* DGPAMD_SEXP / DGPAMD_MATERN25 */
@@ -184,7 +193,7 @@ typedef struct {
     const double *W;       /* device replicate weights or NULL */
     const double *y;       /* device, n */
 } dgpamd_node;
-int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *Ainv,
+int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T, double *Ainv,
                       int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
                       int64_t stride_out);
 size_t dgpamd_grad_workspace(int64_t n, int nparam);

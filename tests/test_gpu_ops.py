@@ -94,7 +94,7 @@ def test_llik_and_loglik_golden(eng, golden):
 
 
 @pytest.mark.parametrize('name', ['sexp', 'matern2.5'])
-@pytest.mark.parametrize('n', [65, 500, 2000])
+@pytest.mark.parametrize('n', [65, 500, 1984, 2000])
 def test_potrf_potri_sizes(eng, name, n):
     """Factor / inverse / alpha / logdet / quad against LAPACK at sizes around the tile edges and the bench size."""
     from oracle import dgp_oracle as O
@@ -128,6 +128,45 @@ def test_potrf_potri_sizes(eng, name, n):
     close(Ai[:n, :n], Ai[:n, :n].T, rtol=0, atol=0)   # symmetric by construction
     alpha = Kinv @ y
     close(-Ai[n, :n], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
+
+
+@pytest.mark.parametrize('n,B', [(65, 1), (200, 3), (1000, 2), (2000, 1), (1984, 1)])
+def test_potrf_inv_one_sweep(eng, n, B):
+    """dgpamd_potrf_inv: factor, L^-T, K^-1 (lower tiles) and -alpha from ONE sweep, against LAPACK."""
+    import torch
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(n + B)
+    Np = eng.padded_dim(n)
+    A = eng.empty(B, Np, Np)
+    T = torch.full((B, Np, Np), float('nan'), dtype=torch.float64, device=A.device)   # needs no initialisation
+    S = torch.full((B, Np, Np), float('nan'), dtype=torch.float64, device=A.device)
+    Ks, ys = [], []
+    for b in range(B):
+        X = rng.uniform(size=(n, 3))
+        y = rng.normal(size=n)
+        name = 'sexp' if b % 2 else 'matern2.5'
+        Ks.append(O.k_matrix(X, np.array([0.6]), 1e-4, name))
+        ys.append(y)
+        eng.kmatrix(name, eng.tensor(X), None, None, np.array([0.6]), 1e-4, out=A[b], full=False, Y=eng.tensor(y))
+    logdet, info = eng.potrf_inv(n, A, T, S, batch=B)
+    eng.sync()
+    assert not npy(info).any()
+    for b in range(B):
+        Lref = np.linalg.cholesky(Ks[b])
+        Kinv = np.linalg.inv(Ks[b])
+        sc = np.abs(Kinv).max()
+        close(np.tril(npy(A[b])[:n, :n]), Lref, rtol=1e-8, atol=1e-10)
+        close(npy(logdet)[b], 2 * np.log(np.diag(Lref)).sum(), rtol=1e-10, atol=1e-9)
+        Linv = np.linalg.inv(Lref)
+        Tb = npy(T[b])[:n, :n]
+        # T is block upper triangular: compare where it is defined (tile row <= tile column)
+        tr, tc = np.arange(n)[:, None] // 64, np.arange(n)[None, :] // 64
+        close(np.where(tr <= tc, Tb, 0.0), np.where(tr <= tc, Linv.T, 0.0), rtol=1e-7, atol=1e-8 * np.abs(Linv).max())
+        Sb = npy(S[b])
+        close(np.where(tr >= tc, Sb[:n, :n], 0.0), np.where(tr >= tc, Kinv, 0.0), rtol=1e-7, atol=1e-8 * sc)
+        alpha = Kinv @ ys[b]
+        close(-Sb[n, :n], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
+        close(-npy(A[b])[n, n], ys[b] @ alpha, rtol=1e-8)
 
 
 def test_potrf_reports_not_pd(eng):

@@ -12,13 +12,14 @@ Np = eng.padded_dim(n)
 G = eng.tensor(rng.uniform(size=(n, 5)))
 y = eng.tensor(rng.normal(size=n))
 ev0, ev1 = eng.event(), eng.event()
-print('n=%d   B | potrf ms  TF/s | potri ms  TF/s' % n)
-for B in (1, 2, 4, 6, 8, 12, 16):
+print('n=%d   B | potrf ms  TF/s | potri ms  TF/s | potrf_inv (one sweep) ms  TF/s' % n)
+for B in (1, 2, 3, 4, 6, 8, 12):
     X = eng.tensor(rng.uniform(size=(B, n, 5)))
     A = eng.empty(B, Np, Np)
     Ainv = eng.empty(B, Np, Np)
     work = eng.potrf_workspace(n, B)
-    tf, ti = [], []
+    T = eng.empty(B, Np, Np)
+    tf, ti, tv = [], [], []
     for rep in range(6):
         eng.kmatrix('matern2.5', X, None, G, [1.0], 1e-6, out=A, full=False, Y=y, batch=B)
         eng.record(ev0)
@@ -29,4 +30,10 @@ for B in (1, 2, 4, 6, 8, 12, 16):
         eng.potri(n, A, Ainv, 1, work, batch=B)
         eng.record(ev1)
         ti.append(eng.elapsed_ms(ev0, ev1))
-    print('        %2d | %7.3f %6.2f | %7.3f %6.2f' % (B, min(tf), B * n ** 3 / 3 / min(tf) / 1e9, min(ti), B * 2 * n ** 3 / 3 / min(ti) / 1e9))
+        eng.kmatrix('matern2.5', X, None, G, [1.0], 1e-6, out=A, full=False, Y=y, batch=B)
+        eng.record(ev0)
+        eng.potrf_inv(n, A, T, Ainv, batch=B, work=work)
+        eng.record(ev1)
+        tv.append(eng.elapsed_ms(ev0, ev1))
+    print('        %2d | %7.3f %6.2f | %7.3f %6.2f | %7.3f %6.2f' % (B, min(tf), B * n ** 3 / 3 / min(tf) / 1e9, min(ti), B * 2 * n ** 3 / 3 / min(ti) / 1e9,
+                                                             min(tv), B * n ** 3 / min(tv) / 1e9))
