@@ -159,7 +159,8 @@ class imputer:
         """ESS-within-Gibbs over the layers (imputation.py:22-42)."""
         self._attach()
         n_layer = len(self.all_layer)
-        for _ in range(burnin + 1):
+        ahead = self._prior_draws_ahead(burnin + 1) if n_layer > 1 else None
+        for sweep in range(burnin + 1):
             for l in range(n_layer - 1):
                 upper = self.all_layer[l + 1]
                 hetero = any(nd.type == 'likelihood' and nd.exact_post_idx is not None for nd in upper)
@@ -167,11 +168,60 @@ class imputer:
                     raise NotImplementedError('the Hetero exact-posterior step (imputation.py:141-164) is outside the '
                                               'accelerated path')
                 if self.block:
-                    self.one_sample_block(l)
+                    self.one_sample_block(l, nu=ahead[sweep] if (ahead is not None and l == 0) else None)
                 else:
                     for k in range(len(self.all_layer[l])):
                         self.one_sample(l, k)
         self._detach()
+
+    def _layer_factors(self, l, dense):
+        """Cholesky factors of the dense nodes `dense` of layer l in ONE batched buffer (stride Np^2) so that the draws
+        are a single batched triangular product; the buffer is reused while inputs and hyper-parameters are unchanged
+        (first layer: the whole I-step and beyond; deeper layers: their inputs change every sweep)."""
+        e = self.engine
+        layer = self.all_layer[l]
+        n = self.F[l].shape[0]
+        Np = e.padded_dim(n)
+        sigs = tuple((k, layer[k].name, tuple(np.asarray(layer[k].length, float)), float(layer[k].nugget[0]),
+                      id(layer[k].input) if l == 0 else None) for k in dense)
+        hit = self._factor_cache.get(l)
+        if l != 0 or hit is None or hit[0] != sigs:
+            buf = hit[1] if hit is not None and hit[1].shape[0] == len(dense) else e.empty(len(dense), Np, Np)
+            for j, k in enumerate(dense):
+                nd = layer[k]
+                Xl, cm = self._node_input(l, k, nd)
+                e.kmatrix(nd.name, Xl, cm, self._glob[(l, k)], nd.length, nd.nugget[0], out=buf[j], full=False)
+            for c0 in range(0, len(dense), 64):
+                nb = min(64, len(dense) - c0)
+                _, info = e.potrf(n, buf[c0:c0 + nb], batch=nb)
+                info = info.cpu().numpy()
+                if info.any():
+                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[info != 0][0]))
+            self._factor_cache[l] = (sigs, buf)
+        return self._factor_cache[l][1]
+
+    def _prior_draws_ahead(self, sweeps):
+        """Layer 0's prior draws for all `sweeps` sweeps of a sample() call at once: its factors depend only on X and
+        the hyper-parameters, so the normals of every sweep are uploaded in one copy and the triangular products are
+        queued back to back.  Consumes the normal stream in the order the sequential loop would as long as layer 0 is
+        the only hidden layer; with an injected stream and deeper hierarchies it is therefore not used."""
+        layer = self.all_layer[0]
+        if not self.block or any(nd.vecch or nd.type != 'gp' for nd in layer):
+            return None
+        if self.draws._z is not None and len(self.all_layer) > 2:
+            return None
+        e = self.engine
+        n, M = self.F[0].shape
+        if M > 64:
+            return None
+        buf = self._layer_factors(0, list(range(M)))
+        Z = np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)])
+        Zd = e.tensor(Z)
+        scales = [float(nd.scale[0]) for nd in layer]
+        out = e.empty(sweeps, M, n)
+        for s_ in range(sweeps):
+            e.trmv_lower(n, buf, scales, Zd[s_], batch=M, out=out[s_])
+        return out.transpose(1, 2).contiguous()
 
     def _prior_draw(self, l, cols=None):
         """nu[:, k] = chol(scale_k K_k) z_k for the nodes `cols` of layer l (default: all)
@@ -185,26 +235,7 @@ class imputer:
         dense = [k for k in cols if not layer[k].vecch]
         Z = {k: self.draws.normal(n) for k in cols}
         if dense:
-            # Factors of the whole layer live in ONE batched buffer (stride Np^2) so that the draws are a single
-            # batched triangular product; the buffer is reused while inputs and hyper-parameters are unchanged
-            # (first layer: the whole I-step and beyond; deeper layers: their inputs change every sweep).
-            sigs = tuple((k, layer[k].name, tuple(np.asarray(layer[k].length, float)), float(layer[k].nugget[0]),
-                          id(layer[k].input) if l == 0 else None) for k in dense)
-            hit = self._factor_cache.get(l)
-            if l != 0 or hit is None or hit[0] != sigs:
-                buf = hit[1] if hit is not None and hit[1].shape[0] == len(dense) else e.empty(len(dense), Np, Np)
-                for j, k in enumerate(dense):
-                    nd = layer[k]
-                    Xl, cm = self._node_input(l, k, nd)
-                    e.kmatrix(nd.name, Xl, cm, self._glob[(l, k)], nd.length, nd.nugget[0], out=buf[j], full=False)
-                for c0 in range(0, len(dense), 64):
-                    nb = min(64, len(dense) - c0)
-                    _, info = e.potrf(n, buf[c0:c0 + nb], batch=nb)
-                    info = info.cpu().numpy()
-                    if info.any():
-                        raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[info != 0][0]))
-                self._factor_cache[l] = (sigs, buf)
-            buf = self._factor_cache[l][1]
+            buf = self._layer_factors(l, dense)
             Zd = e.tensor(np.stack([Z[k] for k in dense]))
             scales = [float(layer[k].scale[0]) for k in dense]
             for c0 in range(0, len(dense), 64):
@@ -279,11 +310,12 @@ class imputer:
             info = np.zeros(B)
         return host, info
 
-    def one_sample_block(self, l):
-        """Layer-wise ESS update of layer l given layer l+1 (imputation.py:44-119)."""
+    def one_sample_block(self, l, nu=None):
+        """Layer-wise ESS update of layer l given layer l+1 (imputation.py:44-119); nu: prior draw made ahead."""
         e = self.engine
         F = self.F[l]
-        nu = self._prior_draw(l)
+        if nu is None:
+            nu = self._prior_draw(l)
         cur = self._ll_cache.get(l)
         if cur is None:
             ll, info = self._upper_loglik(l, F[None])
