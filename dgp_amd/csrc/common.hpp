@@ -185,4 +185,5 @@ int build_kmat_args(dgpamd_ctx *ctx, KmatArgs &a, int kind, int64_t n, const dou
 int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
               double *ws, double *T = nullptr, double *S = nullptr);   // T, S: fused inverse (dgpamd_potrf_inv)
 size_t potrf_ws_doubles(int64_t n, int batch);
+int ensure_pinned(dgpamd_ctx *ctx, size_t bytes);   // grow the context's pinned staging buffer
 

@@ -49,6 +49,29 @@ extern "C" int dgpamd_sync(dgpamd_ctx *ctx) {
     return DGPAMD_OK;
 }
 
+int ensure_pinned(dgpamd_ctx *ctx, size_t bytes) {
+    if (ctx->pinned_bytes >= bytes) return DGPAMD_OK;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    const size_t want = bytes < 65536 ? 65536 : bytes;
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_fetch(dgpamd_ctx *ctx, const void *device_src, void *host_dst, size_t bytes) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (!device_src || !host_dst) BAD_ARG(ctx, "null pointer");
+    if (bytes == 0) return DGPAMD_OK;
+    int rc = ensure_pinned(ctx, bytes);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host_dst, ctx->pinned, bytes);
+    return DGPAMD_OK;
+}
+
 extern "C" int dgpamd_event_create(dgpamd_ctx *ctx, void **ev) {
     if (!ctx || !ev) return DGPAMD_BAD_ARG;
     hipEvent_t e;

@@ -345,13 +345,8 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
         if (rc) return rc;
     }
     const size_t bytes = (size_t)batch * stride_out * sizeof(double);
-    if (ctx->pinned_bytes < bytes) {
-        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr;
-        ctx->pinned_bytes = 0;
-        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->pinned, bytes < 65536 ? 65536 : bytes, hipHostMallocDefault));
-        ctx->pinned_bytes = bytes < 65536 ? 65536 : bytes;
-    }
+    rc = ensure_pinned(ctx, bytes);
+    if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, dev_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(host_out, ctx->pinned, bytes);

@@ -300,12 +300,17 @@ class imputer:
                     nd.input = FPh[b][nd.rep, :][:, nd.input_dim] if nd.rep is not None else FPh[b][:, nd.input_dim]
                     host[b] += float(np.sum(nd.llik()))
         if dev_terms:
-            packed = torch.stack(dev_terms).sum(0)
+            # results come back through the library's pinned buffer (one sync); a single GP node upstairs -- the usual
+            # case -- needs no device-side packing at all
+            if len(dev_terms) == 1:
+                host = host + e.fetch(dev_terms[0])
+            else:
+                host = host + e.fetch(torch.stack(dev_terms).sum(0))
             if infos:
-                packed = torch.cat((packed, torch.stack(infos).to(torch.float64).amax(0)))
-            packed = packed.cpu().numpy()
-            host = host + packed[:B]
-            info = packed[B:] if infos else np.zeros(B)
+                info = e.fetch(infos[0]).astype(np.float64) if len(infos) == 1 else \
+                    e.fetch(torch.stack(infos).amax(0)).astype(np.float64)
+            else:
+                info = np.zeros(B)
         else:
             info = np.zeros(B)
         return host, info

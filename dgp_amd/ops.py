@@ -258,6 +258,14 @@ class Engine:
                                          _dp(work)))
         return out, P
 
+    def fetch(self, t):
+        """Device tensor -> numpy array through the library's pinned staging buffer (one stream sync; cheaper than
+        torch's .cpu() for the few bytes a sampler / optimiser step returns)."""
+        t = t.contiguous()
+        out = np.empty(tuple(t.shape), dtype={torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64}[t.dtype])
+        self._chk(lib.dgpamd_fetch(self.h, _dp(t), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
     def llik_plan(self, n, specs):
         """Prepare the static part of dgpamd_llik_batch for a fixed set of GP nodes of size n.  specs: list of dicts
         kind, Xloc (n x ldloc tensor), Xglob (tensor or None), nlen, nugget_est, W (tensor or None), y (tensor).  Returns a

@@ -59,6 +59,9 @@ int dgpamd_create(int device, void *stream, dgpamd_ctx **out);
 int dgpamd_destroy(dgpamd_ctx *ctx);
 const char *dgpamd_last_error(const dgpamd_ctx *ctx);
 int dgpamd_sync(dgpamd_ctx *ctx);
+/* Results to the host: copy `bytes` from device memory through the context's pinned staging buffer, ordered after
+ * everything queued on the context's stream, and return when they have landed (one stream synchronisation). */
+int dgpamd_fetch(dgpamd_ctx *ctx, const void *device_src, void *host_dst, size_t bytes);
 const char *dgpamd_version(void);
 int64_t dgpamd_padded_dim(int64_t n); /* Np for an n x n problem (>= n+1, multiple of 64) */
 
