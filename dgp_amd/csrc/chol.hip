@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
 //                    diagonal block turns every triangular solve into an MFMA GEMM;
 //   TDIAG            wait, write W_k^T (the diagonal block of L^-T).
 // Plain factorisation (buffer A): column k = chain + panel tasks applying panel k-1; the bulk is LAZY -- tiles of the
-// columns k+1, k+3, ... take two panels (k-2, k-1) = 128 pivots per visit, so C is read/written once per 128 pivots
+// columns k+1, k+1+LAZY, ... take LAZY = 4 panels (256 pivots) per visit, so C is read/written once per 256 pivots
 // while the serial chain still applies a single panel.
 // Fused inverse (dgpamd_potrf_inv): the identity rides along as n extra rows (buffer T, only its non-zero tiles
 // exist) with a zero corner (buffer S).  The same right-looking sweep then leaves T = L^-T and the Schur
@@ -678,6 +678,9 @@ struct TaskTable {
     std::vector<double> tile_ops;   // 64^3 multiply-add units per launch and matrix (for the profiler)
 };
 
+#ifndef LAZY
+#define LAZY 4   // panels (64-pivot blocks) applied per visit of a bulk tile
+#endif
 static void build_tasks(int nbk, bool inv, std::vector<std::vector<int4>> &L, std::vector<double> &ops) {
     const int nl = nbk + (inv ? 2 : 0);
     L.assign(nl, {});
@@ -699,16 +702,16 @@ static void build_tasks(int nbk, bool inv, std::vector<std::vector<int4>> &L, st
                     t.push_back(make_task(T_SOLVE, q == k - 1, 0, 0, BUF_T, q, k, BUF_T, q, BUF_A, k, k - 1, 1));
                     w += 2;
                 }
-            // lazy bulk of A: columns k+1, k+3, ... take the panels (k-2, k-1)
-            const int kb0 = k >= 2 ? k - 2 : 0, nkb = k - kb0;
+            // lazy bulk of A: columns k+1, k+1+LAZY, ... take the LAZY panels (k-LAZY .. k-1)
+            const int kb0 = k >= LAZY ? k - LAZY : 0, nkb = k - kb0;
             if (nkb > 0)
-                for (int j = k + 1; j < nbk; j += 2)
+                for (int j = k + 1; j < nbk; j += LAZY)
                     for (int i = j; i < nbk; ++i) {
                         t.push_back(make_task(T_STORE, 0, 0, 0, BUF_A, i, j, BUF_A, i, BUF_A, j, kb0, nkb));
                         w += nkb;
                     }
             if (inv && nkb > 0)   // same rule for the rows of T that already have a panel: q <= k-1
-                for (int j = k + 1; j < nbk; j += 2)
+                for (int j = k + 1; j < nbk; j += LAZY)
                     for (int q = 0; q <= k - 1; ++q) {
                         const int f0 = q > kb0 ? q : kb0;   // panels >= q only; the first visit starts from zero
                         t.push_back(make_task(T_STORE, f0 == q, 0, 0, BUF_T, q, j, BUF_T, q, BUF_A, j, f0, k - f0));
