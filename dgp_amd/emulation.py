@@ -46,6 +46,7 @@ class emulator:
         self.N = ddist.share(self.N_total, rank, world)
         ss = np.random.SeedSequence(seed)
         self.imp = imputer(all_layer, block, draws=DrawStream(ss.spawn(world)[rank]), engine=self.engine)
+        self._sample_rng = np.random.default_rng(ss.spawn(world)[rank])   # predict(method='sampling')
         if self.vecch:
             self.imp.update_ord_nn()
             self.imp.sample(burnin=20)
@@ -141,10 +142,10 @@ class emulator:
         per-imputation lists if aggregation=False."""
         if x.ndim == 1:
             raise Exception('The testing input has to be a numpy 2d-array')
-        if method != 'mean_var':
-            raise NotImplementedError("method='sampling' (emulation.py:780-822) is outside the accelerated path")
+        if method not in ('mean_var', 'sampling'):
+            raise Exception("method must be either 'mean_var' or 'sampling'.")
         if self.vecch:
-            return self._predict_vecchia(x, full_layer, m, aggregation)
+            return self._predict_vecchia(x, full_layer, m, aggregation, method, sample_size)
         if self._stats is None:
             self._build_stats()
         e = self.engine
@@ -178,6 +179,9 @@ class emulator:
                         mean[s, :, k] = mk
                         var[s, :, k] = vk
             per_layer.append((mean, var))
+        if method == 'sampling':
+            return self._draw_samples([(mean.cpu().numpy(), var.cpu().numpy()) for mean, var in per_layer], sample_size,
+                                      full_layer)
         if not aggregation and not full_layer:
             mu_s, v_s = per_layer[-1]
             return [t.cpu().numpy() for t in mu_s], [t.cpu().numpy() for t in v_s]
@@ -194,11 +198,26 @@ class emulator:
             return [o[0] for o in outs], [o[1] for o in outs]
         return outs[0]
 
-    def _predict_vecchia(self, x, full_layer, m, aggregation):
+    def _draw_samples(self, per_layer, sample_size, full_layer):
+        """method='sampling' (emulation.py:780-822, GP hierarchies): per imputation and layer the outputs are drawn
+        from N(mu_s, sigma2_s), sample_size times.  per_layer: [(mean (S,M,K), var (S,M,K))] as numpy arrays.
+        Returns, like the reference, a list over the final layer's nodes of (M x S*sample_size) arrays, or with
+        full_layer a list over layers of such lists."""
+        rng = self._sample_rng
+        out = []
+        for mean, var in (per_layer if full_layer else per_layer[-1:]):
+            S, M, K = mean.shape
+            sd = np.sqrt(var)
+            draws = rng.normal(np.repeat(mean, sample_size, axis=0), np.repeat(sd, sample_size, axis=0))   # (S*ss, M, K)
+            out.append(list(draws.transpose(2, 1, 0)))
+        return out if full_layer else out[0]
+
+    def _predict_vecchia(self, x, full_layer, m, aggregation, method='mean_var', sample_size=50):
         """Vecchia mode: no stored statistics; every node conditions on its pred_m nearest neighbours
         (kernel_class.py:603-619,647-664) with the imputation's own latents."""
         M, S = len(x), self.N
         mus, vs = [], []
+        layers = [[] for _ in self.all_layer]
         for s in range(S):
             al = self._structure(s)
             m_in = v_in = None
@@ -213,8 +232,21 @@ class emulator:
                     else:
                         mo[:, k], vo[:, k] = nd.linkgp_prediction(m_in[:, nd.input_dim], v_in[:, nd.input_dim], z)
                 m_in, v_in = mo, vo
+                layers[l].append((mo, vo))
             mus.append(m_in)
             vs.append(v_in)
+        if method == 'sampling':
+            return self._draw_samples([(np.stack([a for a, _ in L]), np.stack([b for _, b in L])) for L in layers],
+                                      sample_size, full_layer)
+        if full_layer:
+            outm, outv = [], []
+            for L in layers:
+                mu_l = np.stack([a for a, _ in L])
+                v_l = np.stack([b for _, b in L])
+                mbar = mu_l.mean(0)
+                outm.append(mbar)
+                outv.append((mu_l ** 2 + v_l).mean(0) - mbar ** 2)
+            return outm, outv
         if not aggregation:
             return mus, vs
         e = self.engine

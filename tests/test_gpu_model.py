@@ -166,6 +166,17 @@ def test_matern_2layer_train_predict_small(eng):
     mu, var = emu.predict(X[:40])
     assert np.sqrt(np.mean((mu - Y[:40]) ** 2)) < 0.3          # interpolates its own training data
     assert np.all(np.isfinite(var))
+    # method='sampling' (emulation.py:780-822): D arrays of M x (N*sample_size) draws whose moments are the
+    # mixture moments that method='mean_var' aggregates (emulation.py:846-847)
+    smp = emu.predict(X[:40], method='sampling', sample_size=400)
+    assert isinstance(smp, list) and len(smp) == 1 and smp[0].shape == (40, 3 * 400)
+    sd = np.sqrt(np.maximum(var[:, 0], 1e-12))
+    assert np.all(np.abs(smp[0].mean(1) - mu[:, 0]) < 6 * sd / np.sqrt(1200) + 1e-6)
+    assert np.all(np.abs(smp[0].var(1) - var[:, 0]) < 0.35 * var[:, 0] + 1e-8)
+    full = emu.predict(X[:10], method='sampling', sample_size=5, full_layer=True)
+    assert len(full) == 2 and len(full[0]) == d and full[0][0].shape == (10, 15) and full[1][0].shape == (10, 15)
+    mu_l, var_l = emu.predict(X[:10], full_layer=True)
+    assert len(mu_l) == 2 and mu_l[0].shape == (10, d) and np.allclose(mu_l[1], mu[:10], rtol=1e-9, atol=1e-12)
 
 
 def test_vecchia_train_predict_end_to_end(eng):
@@ -190,6 +201,10 @@ def test_vecchia_train_predict_end_to_end(eng):
     mu, var = emu.predict(X[:50], m=30)
     assert mu.shape == (50, 1) and np.all(np.isfinite(mu)) and np.all(var > -1e-8)
     assert np.sqrt(np.mean((mu - Y[:50]) ** 2)) < 0.35
+    smp = emu.predict(X[:20], m=30, method='sampling', sample_size=7)
+    assert len(smp) == 1 and smp[0].shape == (20, 14) and np.all(np.isfinite(smp[0]))
+    mu_l, var_l = emu.predict(X[:20], m=30, full_layer=True)
+    assert len(mu_l) == 2 and mu_l[0].shape == (20, d) and np.allclose(mu_l[1], mu[:20], rtol=1e-9, atol=1e-12)
 
 
 def test_vecchia_llik_matches_dense_when_m_is_full(eng):
