@@ -66,6 +66,21 @@ class emulator:
                                     for layer in all_layer])
         self._stats = None
 
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st['engine'] = None       # device context and statistics are rebuilt after unpickling (utils.write / read)
+        st['_stats'] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.engine = default_engine()
+        for layer in self.all_layer:
+            for nd in layer:
+                if nd.type == 'gp':
+                    nd.engine = self.engine
+        self.imp._engine = self.engine
+
     # dgpsi keeps `all_layer_set`: N deep copies of the structure.  Built on demand (arrays only, no R^-1).
     @property
     def all_layer_set(self):

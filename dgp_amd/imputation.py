@@ -107,6 +107,8 @@ class imputer:
         st = dict(self.__dict__)
         st['_engine'] = None
         st['_factor_cache'] = {}
+        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache'):   # device state: rebuilt by the next sample()
+            st.pop(key, None)
         return st
 
     # ------------------------------------------------------------------ device state

@@ -51,3 +51,79 @@ class NystromKPCA:
         scores = Knm_c @ (Kis @ U[:, ::-1][:, :self.n_components])
         flip = (scores.min(0) + scores.max(0)) / 2 < 0
         return scores * (1 - 2 * flip)[None, :]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Persistence.  dgpsi pickles whole emulator objects with dill (utils.py:18-42).  Here a trained hierarchy is stored
+# as plain arrays (.npz, no pickled code), so a structure exported from dgpsi -- save_structure() only touches the
+# node attributes both packages share -- loads into this engine and the other way round.
+# ---------------------------------------------------------------------------------------------------------------
+_NODE_ARRAYS = ('length', 'scale', 'nugget', 'input', 'output', 'global_input', 'input_dim', 'connect', 'prior_coef',
+                'bds', 'rep', 'para_path')
+
+
+def save_structure(all_layer, npz_file):
+    """Write the GP hierarchy `all_layer` (e.g. dgp.estimate()) to `npz_file` (arrays only)."""
+    out = {'n_layer': np.array(len(all_layer))}
+    for l, layer in enumerate(all_layer):
+        out['l%d_n' % l] = np.array(len(layer))
+        for k, nd in enumerate(layer):
+            if getattr(nd, 'type', 'gp') != 'gp':
+                raise NotImplementedError('only GP nodes are stored; likelihood nodes keep their own (host) state')
+            p = 'l%d_k%d_' % (l, k)
+            out[p + 'name'] = np.array(str(nd.name))
+            out[p + 'prior_name'] = np.array('' if nd.prior_name is None else str(nd.prior_name))
+            out[p + 'flags'] = np.array([bool(nd.scale_est), bool(nd.nugget_est), bool(getattr(nd, 'vecch', False))])
+            out[p + 'm'] = np.array(-1 if getattr(nd, 'm', None) is None else int(nd.m))
+            for a in _NODE_ARRAYS:
+                v = getattr(nd, a, None)
+                if v is not None:
+                    out[p + a] = np.asarray(v).copy()
+    np.savez_compressed(npz_file, **out)
+
+
+def load_structure(npz_file, engine=None):
+    """Rebuild the hierarchy written by save_structure as dgp_amd.kernel nodes (usable by emulator / lgp / dgp)."""
+    from .kernel_class import kernel
+    with np.load(npz_file if str(npz_file).endswith('.npz') else str(npz_file) + '.npz', allow_pickle=False) as z:
+        d = {k: z[k] for k in z.files}
+    layers = []
+    for l in range(int(d['n_layer'])):
+        layer = []
+        for k in range(int(d['l%d_n' % l])):
+            p = 'l%d_k%d_' % (l, k)
+            g = lambda a: d[p + a].copy() if p + a in d else None   # noqa: E731
+            flags = d[p + 'flags']
+            prior = str(d[p + 'prior_name']) or None
+            nd = kernel(length=g('length'), scale=g('scale'), nugget=g('nugget'), name=str(d[p + 'name']), prior_name=None,
+                        bds=g('bds'), nugget_est=bool(flags[1]), scale_est=bool(flags[0]), input_dim=g('input_dim'),
+                        connect=g('connect'), engine=engine)
+            nd.prior_name, nd.prior_coef = prior, g('prior_coef')   # stored coefficients are the adjusted ones
+            if prior == 'ref':
+                nd.cl = None
+            nd.input, nd.output, nd.global_input = g('input'), g('output'), g('global_input')
+            nd.para_path, nd.rep = g('para_path'), g('rep')
+            nd.vecch = bool(flags[2])
+            nd.m = None if int(d[p + 'm']) < 0 else int(d[p + 'm'])
+            nd.D = nd.input.shape[1] + (0 if nd.global_input is None else nd.global_input.shape[1])
+            if nd.rep is not None:
+                cnt = np.bincount(nd.rep, minlength=nd.rep.max() + 1)
+                nd.W_diag = 1.0 / cnt
+            layer.append(nd)
+        layers.append(layer)
+    return layers
+
+
+def write(emu, pkl_file):
+    """Pickle an emulator / gp / lgp object to `pkl_file`.pkl (dgpsi utils.write, utils.py:18-27).  Device state is
+    dropped and rebuilt on first use after read()."""
+    import pickle
+    with open(pkl_file + '.pkl', 'wb') as f:
+        pickle.dump(emu, f)
+
+
+def read(pkl_file):
+    """Load an object stored by write() (dgpsi utils.read, utils.py:30-42)."""
+    import pickle
+    with open(pkl_file + '.pkl', 'rb') as f:
+        return pickle.load(f)

@@ -173,6 +173,18 @@ def test_matern_2layer_train_predict_small(eng):
     sd = np.sqrt(np.maximum(var[:, 0], 1e-12))
     assert np.all(np.abs(smp[0].mean(1) - mu[:, 0]) < 6 * sd / np.sqrt(1200) + 1e-6)
     assert np.all(np.abs(smp[0].var(1) - var[:, 0]) < 0.35 * var[:, 0] + 1e-8)
+    # persistence: arrays-only structure file and pickled emulator reproduce the predictions
+    import os, tempfile
+    from dgp_amd import save_structure, load_structure, write, read
+    with tempfile.TemporaryDirectory() as tmp:
+        save_structure(model.estimate(), os.path.join(tmp, 'est'))
+        est2 = load_structure(os.path.join(tmp, 'est'))
+        assert np.array_equal(est2[1][0].length, model.estimate()[1][0].length) and est2[1][0].scale_est
+        mu2, var2 = emulator(est2, N=3, seed=2).predict(X[:40])
+        assert np.allclose(mu2, mu, rtol=1e-9, atol=1e-12) and np.allclose(var2, var, rtol=1e-7, atol=1e-12)
+        write(emu, os.path.join(tmp, 'emu'))
+        mu3, var3 = read(os.path.join(tmp, 'emu')).predict(X[:40])
+        assert np.allclose(mu3, mu, rtol=1e-9, atol=1e-12) and np.allclose(var3, var, rtol=1e-7, atol=1e-12)
     full = emu.predict(X[:10], method='sampling', sample_size=5, full_layer=True)
     assert len(full) == 2 and len(full[0]) == d and full[0][0].shape == (10, 15) and full[1][0].shape == (10, 15)
     mu_l, var_l = emu.predict(X[:10], full_layer=True)
