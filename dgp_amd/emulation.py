@@ -274,3 +274,18 @@ class emulator:
         return s1.cpu().numpy(), s2.cpu().numpy()
 
     ppredict = predict   # test points / imputations already run in parallel on the device (emulation.py:578-629)
+
+    def metric(self, x_cand, method='ALM', obj=None, nugget_s=1., m=50, score_only=False):
+        """Sequential-design criterion at the rows of x_cand (emulation.py:323-420).  ALM (the predictive variance)
+        is computed on the accelerated path; MICE and VIGF are not part of it."""
+        if x_cand.ndim == 1:
+            raise Exception('The candidate design set has to be a numpy 2d-array.')
+        if method != 'ALM':
+            raise NotImplementedError("only method='ALM' is implemented (MICE / VIGF: emulation.py:365-420)")
+        _, sigma2 = self.predict(x=x_cand, m=m)
+        if score_only:
+            return sigma2
+        idx = np.argmax(sigma2, axis=0)
+        return idx, sigma2[idx, np.arange(sigma2.shape[1])]
+
+    pmetric = metric

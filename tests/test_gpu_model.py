@@ -185,6 +185,8 @@ def test_matern_2layer_train_predict_small(eng):
         write(emu, os.path.join(tmp, 'emu'))
         mu3, var3 = read(os.path.join(tmp, 'emu')).predict(X[:40])
         assert np.allclose(mu3, mu, rtol=1e-9, atol=1e-12) and np.allclose(var3, var, rtol=1e-7, atol=1e-12)
+    idx, best = emu.metric(X[:40], method='ALM')
+    assert idx.shape == (1,) and best[0] == var[:, 0].max() and idx[0] == int(np.argmax(var[:, 0]))
     full = emu.predict(X[:10], method='sampling', sample_size=5, full_layer=True)
     assert len(full) == 2 and len(full[0]) == d and full[0][0].shape == (10, 15) and full[1][0].shape == (10, 15)
     mu_l, var_l = emu.predict(X[:10], full_layer=True)
