@@ -57,7 +57,7 @@ struct DiagShared {
     double colraw[2][64][4];   // [ping-pong][row][v]  = A[row][j0+v]
     double rowraw[2][64][4];   // [ping-pong][col][v]  = Y[j0+v][col]   (Y = running inverse)
     double blk[2][4][4];       // [ping-pong][v][u]    = A[j0+4+v][j0+4+u] before the update of the current group
-    double chain[2][16];       // [ping-pong] n10 n20 n30 n21 | n31 n32 r0 r1 | r2 r3 p0 p1 | p2 p3 - -
+    double chain[2][4][6];     // [ping-pong][pivot u] row u of the unit-lower inverse N (c0..c3), 1/pivot, pivot
     double piv[64];
 };
 
@@ -96,6 +96,15 @@ __device__ __forceinline__ void pivot_chain(double c00, double c10, double c11, 
     out[12] = p2; out[13] = p3;
 }
 
+// o[] (pivot_chain) -> LDS rows {N[u][0..3], r_u, p_u}, written by lane 0 of the chain wave
+__device__ __forceinline__ void publish_chain(const double *o, double (*dst)[6]) {
+    double2 *d = reinterpret_cast<double2 *>(&dst[0][0]);
+    d[0] = make_double2(1.0, 0.0);   d[1] = make_double2(0.0, 0.0);   d[2] = make_double2(o[6], o[10]);
+    d[3] = make_double2(o[0], 1.0);  d[4] = make_double2(0.0, 0.0);   d[5] = make_double2(o[7], o[11]);
+    d[6] = make_double2(o[1], o[3]); d[7] = make_double2(1.0, 0.0);   d[8] = make_double2(o[8], o[12]);
+    d[9] = make_double2(o[2], o[4]); d[10] = make_double2(o[5], 1.0); d[11] = make_double2(o[9], o[13]);
+}
+
 // Factor the 64x64 tile held in registers, write the factor to Ab (ld; strictly upper part zeroed) and the inverse
 // of the factor to Wb (64x64), accumulate logdet / info of matrix b.  ncol = pivots in this block (rows/columns
 // beyond are carried right-hand sides).
@@ -114,6 +123,7 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
         for (int r = 0; r < 4; ++r) y[t][r] = (16 * w + lu + 4 * r == 16 * t + lm) ? 1.0 : 0.0;
     if (tid < 64) sh.piv[tid] = 1.0;
     int bad = 0;   // wave 0 only
+    double o[14];  // wave 0: results of the newest pivot chain (kept in registers for the next one)
     if ((lm >> 2) == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sh.colraw[0][16 * w + lu + 4 * r][lm & 3] = a[0][r];
@@ -127,13 +137,8 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
     if (w == 0) {   // pivot chain of group 0
         const double2 *cr = reinterpret_cast<const double2 *>(&sh.colraw[0][0][0]);
         const double2 C0 = cr[0], C1 = cr[2], C2a = cr[4], C2b = cr[5], C3a = cr[6], C3b = cr[7];
-        double o[14];
         pivot_chain(C0.x, C1.x, C1.y, C2a.x, C2a.y, C2b.x, C3a.x, C3a.y, C3b.x, C3b.y, ncol >= 4 ? 4 : ncol, 0, bad, o);
-        if (l == 0) {
-            double2 *dst = reinterpret_cast<double2 *>(&sh.chain[0][0]);
-#pragma unroll
-            for (int i = 0; i < 7; ++i) dst[i] = make_double2(o[2 * i], o[2 * i + 1]);
-        }
+        if (l == 0) publish_chain(o, sh.chain[0]);
     }
     __syncthreads();
 
@@ -146,12 +151,10 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
         const int jbn = (g + 1) >> 2, jqn = (g + 1) & 3;
         if (trace && tid == 0) trace[4 * g] = wall_clock64();
         const double2 *cr = reinterpret_cast<const double2 *>(&sh.colraw[buf][0][0]);
-        const double2 *ck = reinterpret_cast<const double2 *>(&sh.chain[buf][0]);
-        const double2 K0 = ck[0], K1 = ck[1], K2 = ck[2], K3 = ck[3], K4 = ck[4], K5 = ck[5], K6 = ck[6];
-        const double n10 = K0.x, n20 = K0.y, n30 = K1.x, n21 = K1.y, n31 = K2.x, n32 = K2.y;
-        const double r0 = K3.x, r1 = K3.y, r2 = K4.x, r3 = K4.y;
         // ---- wave 0: pivot chain of the NEXT group (needs no result of this group's MFMAs) ----
         if (w == 0 && more) {
+            const double n10 = o[0], n20 = o[1], n30 = o[2], n21 = o[3], n31 = o[4], n32 = o[5];
+            const double r0 = o[6], r1 = o[7], r2 = o[8], r3 = o[9];
             double2 Ra[4], Rb[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -181,14 +184,9 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
                     c[i][j] = fma(-e3, T3[j], fma(-e2, T2[j], fma(-e1, T1[j], fma(-e0, T0[j], c[i][j]))));
             }
             const int nan_ = ncol - (j0 + 4) >= 4 ? 4 : ncol - (j0 + 4);
-            double o[14];
             pivot_chain(c[0][0], c[1][0], c[1][1], c[2][0], c[2][1], c[2][2], c[3][0], c[3][1], c[3][2], c[3][3], nan_,
                         j0 + 4, bad, o);
-            if (l == 0) {
-                double2 *dst = reinterpret_cast<double2 *>(&sh.chain[buf ^ 1][0]);
-#pragma unroll
-                for (int i = 0; i < 7; ++i) dst[i] = make_double2(o[2 * i], o[2 * i + 1]);
-            }
+            if (l == 0) publish_chain(o, sh.chain[buf ^ 1]);
             if (trace && tid == 0) trace[4 * g + 1] = wall_clock64();
         }
         if (w >= jb) {
@@ -197,35 +195,27 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
             const double2 rAa = cr[2 * myrow], rAb = cr[2 * myrow + 1];
             double2 rBa[4], rBb[4], rYa[4], rYb[4];
 #pragma unroll
-            for (int t = jb; t < 4; ++t) {
-                rBa[t] = cr[2 * (16 * t + lm)];
-                rBb[t] = cr[2 * (16 * t + lm) + 1];
-            }
+            for (int t = jb; t < 4; ++t)
+                if (t <= w) {   // tiles right of the wave's own rows are strictly upper: never needed
+                    rBa[t] = cr[2 * (16 * t + lm)];
+                    rBb[t] = cr[2 * (16 * t + lm) + 1];
+                }
 #pragma unroll
             for (int t = 0; t <= jb; ++t) {
                 rYa[t] = rr[2 * (16 * t + lm)];
                 rYb[t] = rr[2 * (16 * t + lm) + 1];
             }
-            const double p0 = K5.x, p1 = K5.y, p2 = K6.x, p3 = K6.y;
-            if (tid == 192) {
-                sh.piv[j0] = p0;
-                if (nact > 1) sh.piv[j0 + 1] = p1;
-                if (nact > 2) sh.piv[j0 + 2] = p2;
-                if (nact > 3) sh.piv[j0 + 3] = p3;
-            }
-            const double c0 = lu == 0 ? 1.0 : (lu == 1 ? n10 : (lu == 2 ? n20 : n30));
-            const double c1 = lu == 0 ? 0.0 : (lu == 1 ? 1.0 : (lu == 2 ? n21 : n31));
-            const double c2 = lu < 2 ? 0.0 : (lu == 2 ? 1.0 : n32);
-            const double c3 = lu < 3 ? 0.0 : 1.0;
-            const double rl = lu == 0 ? r0 : (lu == 1 ? r1 : (lu == 2 ? r2 : r3));
-            const double pl = lu == 0 ? p0 : (lu == 1 ? p1 : (lu == 2 ? p2 : p3));
+            const double2 *ck = reinterpret_cast<const double2 *>(&sh.chain[buf][lu][0]);
+            const double2 K0 = ck[0], K1 = ck[1], K2 = ck[2];
+            const double c0 = K0.x, c1 = K0.y, c2 = K1.x, c3 = K1.y, rl = K2.x, pl = K2.y;
+            if (w == 3 && lm == 0 && lu < nact) sh.piv[j0 + lu] = pl;
             const double tA = fma(rAb.y, c3, fma(rAb.x, c2, fma(rAa.y, c1, rAa.x * c0)));
             const double opA = (myrow >= j0 + nact) ? -tA * rl : 0.0;
             const int tn = jbn < 4 ? jbn : 3;   // tile of the next group's columns: update it first
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int t = (tt == 0) ? tn : ((tt <= tn) ? tt - 1 : tt);
-                if (t < jb) continue;
+                if (t < jb || t > w) continue;
                 const double tB = fma(rBb[t].y, c3, fma(rBb[t].x, c2, fma(rBa[t].y, c1, rBa[t].x * c0)));
                 const double opB = (16 * t + lm >= j0 + nact) ? tB : 0.0;
                 a[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opB, a[t], 0, 0, 0);
