@@ -47,6 +47,7 @@ SIGNATURES = {
     'dgpamd_event_elapsed_ms': (_i, [_p, _p, _p, C.POINTER(C.c_float)]),
     'dgpamd_event_destroy': (_i, [_p, _p]),
     'dgpamd_fetch': (_i, [_p, _p, _p, _z]),
+    'dgpamd_fetch2': (_i, [_p, _p, _z, _p, _z, _p]),
     'dgpamd_set_graphs': (_i, [_p, _i]),
     'dgpamd_set_linkgp_direct': (_i, [_p, _i]),
     'dgpamd_debug_trace': (_i, [_p, _p]),

@@ -72,6 +72,20 @@ extern "C" int dgpamd_fetch(dgpamd_ctx *ctx, const void *device_src, void *host_
     return DGPAMD_OK;
 }
 
+extern "C" int dgpamd_fetch2(dgpamd_ctx *ctx, const void *src_a, size_t bytes_a, const void *src_b, size_t bytes_b,
+                             void *host_dst) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (!src_a || !src_b || !host_dst) BAD_ARG(ctx, "null pointer");
+    int rc = ensure_pinned(ctx, bytes_a + bytes_b);
+    if (rc) return rc;
+    char *pin = reinterpret_cast<char *>(ctx->pinned);
+    HIP_TRY(ctx, hipMemcpyAsync(pin, src_a, bytes_a, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(pin + bytes_a, src_b, bytes_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host_dst, pin, bytes_a + bytes_b);
+    return DGPAMD_OK;
+}
+
 extern "C" int dgpamd_event_create(dgpamd_ctx *ctx, void **ev) {
     if (!ctx || !ev) return DGPAMD_BAD_ARG;
     hipEvent_t e;

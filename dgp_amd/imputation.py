@@ -40,13 +40,60 @@ class DrawStream:
         self._z = None if z is None else [np.asarray(v, dtype=float) for v in z]
         self._ubuf = [] if u is None else [float(v) for v in u]
         self._injected_u = u is not None
+        self._zbuf, self._zpos, self._thread = None, 0, None
 
     def normal(self, n):
         if self._z is not None:
             v = self._z.pop(0)
             assert len(v) == n, 'injected normal draw has the wrong length'
             return v
-        return self._gz.standard_normal(n)
+        return self.normals(n)
+
+    def normals(self, count):
+        """The next `count` standard normals of the stream.  They come from a buffer that prefetch() may have filled
+        on a background thread; the sequence is the one the generator yields either way."""
+        self._join()
+        buf = self._zbuf
+        if buf is not None and len(buf) - self._zpos >= count:
+            out = buf[self._zpos:self._zpos + count]
+            self._zpos += count
+            return out
+        rest = None if buf is None else buf[self._zpos:]
+        self._zbuf, self._zpos = None, 0
+        fresh = self._gz.standard_normal(count - (0 if rest is None else len(rest)))
+        return fresh if rest is None or len(rest) == 0 else np.concatenate((rest, fresh))
+
+    def prefetch(self, count):
+        """Generate the next `count` normals on a background thread (numpy releases the GIL while filling), e.g. while
+        the device is busy with the M-step; normals() then hands them out in order."""
+        if self._z is not None or count <= 0:
+            return
+        self._join()
+        have = 0 if self._zbuf is None else len(self._zbuf) - self._zpos
+        if have >= count:
+            return
+        import threading
+        rest = None if have == 0 else self._zbuf[self._zpos:].copy()
+
+        def work():
+            fresh = self._gz.standard_normal(count - have)
+            self._zbuf = fresh if rest is None else np.concatenate((rest, fresh))
+            self._zpos = 0
+        self._zbuf, self._zpos = None, 0
+        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def __getstate__(self):
+        self._join()
+        st = dict(self.__dict__)
+        st['_thread'] = None
+        return st
+
+    def _join(self):
+        t = self._thread
+        if t is not None:
+            t.join()
+            self._thread = None
 
     def uniform_peek(self, k):
         """Up to k upcoming uniforms WITHOUT consuming them (an injected stream may hold fewer)."""
@@ -217,12 +264,16 @@ class imputer:
         if M > 64:
             return None
         buf = self._layer_factors(0, list(range(M)))
-        Z = np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)])
+        if self.draws._z is None:
+            Z = self.draws.normals(sweeps * M * n).reshape(sweeps, M, n)
+        else:
+            Z = np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)])
         Zd = e.tensor(Z)
         scales = [float(nd.scale[0]) for nd in layer]
         out = e.empty(sweeps, M, n)
         for s_ in range(sweeps):
             e.trmv_lower(n, buf, scales, Zd[s_], batch=M, out=out[s_])
+        self.draws.prefetch(sweeps * M * n)   # the next call's normals, generated while the device works
         return out.transpose(1, 2).contiguous()
 
     def _prior_draw(self, l, cols=None):
@@ -304,15 +355,16 @@ class imputer:
         if dev_terms:
             # results come back through the library's pinned buffer (one sync); a single GP node upstairs -- the usual
             # case -- needs no device-side packing at all
-            if len(dev_terms) == 1:
-                host = host + e.fetch(dev_terms[0])
+            if len(dev_terms) == 1 and len(infos) == 1:
+                ll_h, info_h = e.fetch_ll_info(dev_terms[0], infos[0])
+                host, info = host + ll_h, info_h.astype(np.float64)
             else:
-                host = host + e.fetch(torch.stack(dev_terms).sum(0))
-            if infos:
-                info = e.fetch(infos[0]).astype(np.float64) if len(infos) == 1 else \
-                    e.fetch(torch.stack(infos).amax(0)).astype(np.float64)
-            else:
-                info = np.zeros(B)
+                host = host + e.fetch(dev_terms[0] if len(dev_terms) == 1 else torch.stack(dev_terms).sum(0))
+                if infos:
+                    info = e.fetch(infos[0]).astype(np.float64) if len(infos) == 1 else \
+                        e.fetch(torch.stack(infos).amax(0)).astype(np.float64)
+                else:
+                    info = np.zeros(B)
         else:
             info = np.zeros(B)
         return host, info

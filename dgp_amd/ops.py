@@ -266,6 +266,13 @@ class Engine:
         self._chk(lib.dgpamd_fetch(self.h, _dp(t), out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
+    def fetch_ll_info(self, ll, info):
+        """(ll float64 (B,), info int32 (B,)) device tensors -> two numpy arrays with ONE synchronisation."""
+        B = ll.numel()
+        buf = np.empty(12 * B, dtype=np.uint8)
+        self._chk(lib.dgpamd_fetch2(self.h, _dp(ll), 8 * B, _dp(info), 4 * B, buf.ctypes.data_as(C.c_void_p)))
+        return buf[:8 * B].view(np.float64), buf[8 * B:].view(np.int32)
+
     def llik_plan(self, n, specs):
         """Prepare the static part of dgpamd_llik_batch for a fixed set of GP nodes of size n.  specs: list of dicts
         kind, Xloc (n x ldloc tensor), Xglob (tensor or None), nlen, nugget_est, W (tensor or None), y (tensor).  Returns a

@@ -62,6 +62,8 @@ int dgpamd_sync(dgpamd_ctx *ctx);
 /* Results to the host: copy `bytes` from device memory through the context's pinned staging buffer, ordered after
  * everything queued on the context's stream, and return when they have landed (one stream synchronisation). */
 int dgpamd_fetch(dgpamd_ctx *ctx, const void *device_src, void *host_dst, size_t bytes);
+/* Two device regions (e.g. log-likelihoods and their info words) into one host buffer, back to back, one sync. */
+int dgpamd_fetch2(dgpamd_ctx *ctx, const void *src_a, size_t bytes_a, const void *src_b, size_t bytes_b, void *host_dst);
 const char *dgpamd_version(void);
 int64_t dgpamd_padded_dim(int64_t n); /* Np for an n x n problem (>= n+1, multiple of 64) */
 

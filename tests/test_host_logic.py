@@ -181,3 +181,23 @@ def test_lockstep_lbfgsb_matches_scipy_minimize():
         for a, b in zip(got[i], ref_pts[i]):
             assert np.array_equal(a, b)
         assert np.array_equal(probs[i].x, ref_last[i])
+
+
+def test_drawstream_prefetch_keeps_the_sequence():
+    """Normals pre-generated on the background thread are the ones the generator would have produced in place."""
+    from dgp_amd.imputation import DrawStream
+    a, b = DrawStream(123), DrawStream(123)
+    ref = np.concatenate([a.normal(7), a.normals(50), a.normal(13), a.normals(100), a.normal(5)])
+    out = [b.normal(7)]
+    b.prefetch(40)            # fewer than the next request: topped up in place
+    out.append(b.normals(50))
+    b.prefetch(200)           # more than needed: the rest is kept for later requests
+    out.append(b.normal(13))
+    out.append(b.normals(100))
+    b.prefetch(3)
+    out.append(b.normal(5))
+    assert np.array_equal(np.concatenate(out), ref)
+    import pickle
+    b.prefetch(10)
+    c = pickle.loads(pickle.dumps(b))
+    assert np.array_equal(c.normals(10), a.normals(10))
