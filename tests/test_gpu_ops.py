@@ -130,7 +130,7 @@ def test_potrf_potri_sizes(eng, name, n):
     close(-Ai[n, :n], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
 
 
-@pytest.mark.parametrize('n,B', [(65, 1), (200, 3), (1000, 2), (2000, 1), (1984, 1)])
+@pytest.mark.parametrize('n,B', [(10, 2), (64, 1), (65, 1), (200, 3), (333, 5), (1000, 2), (2000, 1), (1984, 1)])
 def test_potrf_inv_one_sweep(eng, n, B):
     """dgpamd_potrf_inv: factor, L^-T, K^-1 (lower tiles) and -alpha from ONE sweep, against LAPACK."""
     import torch
