@@ -216,7 +216,7 @@ class kernel:
         return self._llik_finish(self._llik_device())
 
     def _llik_device(self):
-        """K -> Cholesky (y as augmented row) -> inverse -> in-flight derivative reductions for THIS node alone.
+        """K -> Cholesky + inverse in one sweep (y as augmented row) -> in-flight derivative reductions for THIS node.
         Returns the host vector [logdet, y'K^-1y, tr_p.., quad_p.., info]."""
         e = self.engine
         s = self._staged if getattr(self, '_in_maximise', False) and self._staged is not None else self._stage()
@@ -224,11 +224,10 @@ class kernel:
         Np = e.padded_dim(n)
         A = e.workspace(('llikA', n), Np * Np * 8)
         Ainv = e.workspace(('llikAinv', n), Np * Np * 8)
+        T = e.workspace(('llikT', n), Np * Np * 8)
         e.kmatrix(self.name, s['Xl'], None, s['Xg'], self.length, self.nugget[0], W=s['W'], out=A, full=False, Y=s['y'])
-        work = e.potrf_workspace(n, 1)
-        logdet, info = e.potrf(n, A, work=work)
+        logdet, info = e.potrf_inv(n, A, T, Ainv)   # factor, K^-1 (lower tiles) and -alpha in one sweep
         quad = e.aug_quad(n, A, 1, 1)
-        e.potri(n, A, Ainv, 1, work)
         red, P = e.grad_reduce(self.name, s['Xl'], None, s['Xg'], self.length, self.nugget[0], self.nugget_est, Ainv, W=s['W'])
         import torch
         return torch.cat((logdet, quad.reshape(-1), red, info.to(torch.float64))).cpu().numpy()
