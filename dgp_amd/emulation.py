@@ -150,23 +150,15 @@ class emulator:
                     stats[(l, k)] = dict(shared=False, per=per, ld=Np, n=n, Wg=Xg)
         self._stats = stats
 
-    # ------------------------------------------------------------------ prediction
-    def predict(self, x, method='mean_var', full_layer=False, sample_size=50, m=50, aggregation=True):
-        """Mean and variance at the rows of x (emulation.py:631-854, method='mean_var').
-        Returns (mu, sigma2) as numpy arrays (M x D_out), or per-layer lists if full_layer, or the
-        per-imputation lists if aggregation=False."""
-        if x.ndim == 1:
-            raise Exception('The testing input has to be a numpy 2d-array')
-        if method not in ('mean_var', 'sampling'):
-            raise Exception("method must be either 'mean_var' or 'sampling'.")
-        if self.vecch:
-            return self._predict_vecchia(x, full_layer, m, aggregation, method, sample_size)
+    def _layer_moments(self, x):
+        """Per layer the (mean, variance) of every node at the rows of x for every imputation held by this rank, as
+        device tensors (S, M, K) -- the layer walk of emulation.py:701-779 (dense mode)."""
         if self._stats is None:
             self._build_stats()
         e = self.engine
         M, S = len(x), self.N
         xd = e.tensor(x)
-        per_layer = []   # per layer: (mean (S,M,K), var (S,M,K)) device tensors
+        per_layer = []
         for l, layer in enumerate(self.all_layer):
             K = len(layer)
             mean = e.empty(S, M, K)
@@ -194,6 +186,44 @@ class emulator:
                         mean[s, :, k] = mk
                         var[s, :, k] = vk
             per_layer.append((mean, var))
+        return per_layer
+
+    def _layer_moments_vecchia(self, x, m):
+        """The same layer walk in Vecchia mode (no stored statistics; every node conditions on its pred_m nearest
+        neighbours, kernel_class.py:603-619,647-664).  Returns numpy (S, M, K) pairs per layer."""
+        M, S = len(x), self.N
+        layers = [[] for _ in self.all_layer]
+        for s in range(S):
+            al = self._structure(s)
+            m_in = v_in = None
+            for l, layer in enumerate(al):
+                mo, vo = np.empty((M, len(layer))), np.empty((M, len(layer)))
+                for k, nd in enumerate(layer):
+                    nd.engine = self.engine
+                    nd.pred_m = m
+                    z = None if nd.connect is None else x[:, nd.connect]
+                    if l == 0:
+                        mo[:, k], vo[:, k] = nd.gp_prediction(x[:, nd.input_dim], z)
+                    else:
+                        mo[:, k], vo[:, k] = nd.linkgp_prediction(m_in[:, nd.input_dim], v_in[:, nd.input_dim], z)
+                m_in, v_in = mo, vo
+                layers[l].append((mo, vo))
+        return [(np.stack([a for a, _ in L]), np.stack([b for _, b in L])) for L in layers]
+
+    # ------------------------------------------------------------------ prediction
+    def predict(self, x, method='mean_var', full_layer=False, sample_size=50, m=50, aggregation=True):
+        """Mean and variance at the rows of x (emulation.py:631-854, method='mean_var').
+        Returns (mu, sigma2) as numpy arrays (M x D_out), or per-layer lists if full_layer, or the
+        per-imputation lists if aggregation=False."""
+        if x.ndim == 1:
+            raise Exception('The testing input has to be a numpy 2d-array')
+        if method not in ('mean_var', 'sampling'):
+            raise Exception("method must be either 'mean_var' or 'sampling'.")
+        if self.vecch:
+            return self._predict_vecchia(x, full_layer, m, aggregation, method, sample_size)
+        e = self.engine
+        M, S = len(x), self.N
+        per_layer = self._layer_moments(x)
         if method == 'sampling':
             return self._draw_samples([(mean.cpu().numpy(), var.cpu().numpy()) for mean, var in per_layer], sample_size,
                                       full_layer)
@@ -231,33 +261,13 @@ class emulator:
         """Vecchia mode: no stored statistics; every node conditions on its pred_m nearest neighbours
         (kernel_class.py:603-619,647-664) with the imputation's own latents."""
         M, S = len(x), self.N
-        mus, vs = [], []
-        layers = [[] for _ in self.all_layer]
-        for s in range(S):
-            al = self._structure(s)
-            m_in = v_in = None
-            for l, layer in enumerate(al):
-                mo, vo = np.empty((M, len(layer))), np.empty((M, len(layer)))
-                for k, nd in enumerate(layer):
-                    nd.engine = self.engine
-                    nd.pred_m = m
-                    z = None if nd.connect is None else x[:, nd.connect]
-                    if l == 0:
-                        mo[:, k], vo[:, k] = nd.gp_prediction(x[:, nd.input_dim], z)
-                    else:
-                        mo[:, k], vo[:, k] = nd.linkgp_prediction(m_in[:, nd.input_dim], v_in[:, nd.input_dim], z)
-                m_in, v_in = mo, vo
-                layers[l].append((mo, vo))
-            mus.append(m_in)
-            vs.append(v_in)
+        per_layer = self._layer_moments_vecchia(x, m)
+        mus, vs = list(per_layer[-1][0]), list(per_layer[-1][1])
         if method == 'sampling':
-            return self._draw_samples([(np.stack([a for a, _ in L]), np.stack([b for _, b in L])) for L in layers],
-                                      sample_size, full_layer)
+            return self._draw_samples(per_layer, sample_size, full_layer)
         if full_layer:
             outm, outv = [], []
-            for L in layers:
-                mu_l = np.stack([a for a, _ in L])
-                v_l = np.stack([b for _, b in L])
+            for mu_l, v_l in per_layer:
                 mbar = mu_l.mean(0)
                 outm.append(mbar)
                 outv.append((mu_l ** 2 + v_l).mean(0) - mbar ** 2)
@@ -277,15 +287,59 @@ class emulator:
 
     def metric(self, x_cand, method='ALM', obj=None, nugget_s=1., m=50, score_only=False):
         """Sequential-design criterion at the rows of x_cand (emulation.py:323-420).  ALM (the predictive variance)
-        is computed on the accelerated path; MICE and VIGF are not part of it."""
+        and MICE are computed on the accelerated path; VIGF is not implemented."""
         if x_cand.ndim == 1:
             raise Exception('The candidate design set has to be a numpy 2d-array.')
-        if method != 'ALM':
-            raise NotImplementedError("only method='ALM' is implemented (MICE / VIGF: emulation.py:365-420)")
-        _, sigma2 = self.predict(x=x_cand, m=m)
+        if method == 'ALM':
+            _, sigma2 = self.predict(x=x_cand, m=m)
+            if score_only:
+                return sigma2
+            idx = np.argmax(sigma2, axis=0)
+            return idx, sigma2[idx, np.arange(sigma2.shape[1])]
+        if method != 'MICE':
+            raise NotImplementedError("method='VIGF' (emulation.py:396-420) is not implemented")
+        if self.shard:
+            raise NotImplementedError('MICE is evaluated on one rank (emulator(..., shard=False))')
+        # MICE (emulation.py:377-394): mean over imputations of log(predictive variance / smoothed variance of a GP whose
+        # design is the candidate set itself, functions.mice_var :244-256)
+        if self.vecch:
+            per_layer = self._layer_moments_vecchia(x_cand, m)
+        else:
+            per_layer = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in self._layer_moments(x_cand)]
+        sigma2 = per_layer[-1][1]
+        pred_in = per_layer[-2][0] if self.n_layer > 1 else None
+        M, D, S = len(x_cand), len(self.all_layer[-1]), self.N
+        mice = np.zeros((M, D))
+        for i in range(S):
+            s_i = np.empty((M, D))
+            for k, nd in enumerate(self.all_layer[-1]):
+                s_i[:, k] = self._mice_var(x_cand if pred_in is None else pred_in[i], x_cand, nd, nugget_s)
+            with np.errstate(divide='ignore'):
+                mice += np.log(sigma2[i] / s_i)
+        avg = mice / S
         if score_only:
-            return sigma2
-        idx = np.argmax(sigma2, axis=0)
-        return idx, sigma2[idx, np.arange(sigma2.shape[1])]
+            return avg
+        idx = np.argmax(avg, axis=0)
+        return idx, avg[idx, np.arange(avg.shape[1])]
+
+    def _mice_var(self, x, x_extra, nd, nugget_s):
+        """functions.mice_var (functions.py:244-256) on the device: scale / diag(R^-1) of the correlation matrix of
+        the candidate set (smoothing nugget max(nugget_s, nugget)).  pinvh in the reference; a Cholesky-based
+        inverse here (R is positive definite for any positive nugget)."""
+        e = self.engine
+        Xin = x[:, nd.input_dim]
+        if nd.connect is not None:
+            Xin = np.concatenate((Xin, x_extra[:, nd.connect]), 1)
+        n = len(Xin)
+        Np = e.padded_dim(n)
+        A, Ainv = e.empty(Np, Np), e.empty(Np, Np)
+        e.kmatrix(nd.name, e.tensor(Xin), None, None, nd.length, max(nugget_s, nd.nugget[0]), out=A, full=False)
+        work = e.potrf_workspace(n, 1)
+        _, info = e.potrf(n, A, work=work)
+        e.potri(n, A, Ainv, 0, work)
+        if int(e.fetch(info)[0]):
+            raise np.linalg.LinAlgError('candidate-set correlation matrix is not positive definite')
+        d = torch.diagonal(Ainv)[:n]
+        return (float(nd.scale[0]) / d).cpu().numpy()
 
     pmetric = metric

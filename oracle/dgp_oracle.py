@@ -722,3 +722,15 @@ def link_gp_vecch(m, v, z, w1, global_w1, NNarray, y, scale, length, nugget, nug
         mo[i] = mu
         vo[i] = np.abs(Ry @ J @ Ry - mu**2 + scale * (1 + nugget - tr))
     return mo, vo
+
+
+def mice_var(x, x_extra, input_dim, connect, name, length, scale, nugget, nugget_s):
+    """functions.mice_var (functions.py:244-256): smoothed predictive variance of a GP whose design is the candidate
+    set itself, scale / diag(pinvh(R)) with R built on [x[:, input_dim] | x_extra[:, connect]] and the nugget
+    max(nugget_s, nugget)."""
+    from scipy.linalg import pinvh
+    Xin = x[:, input_dim]
+    if connect is not None:
+        Xin = np.concatenate((Xin, x_extra[:, connect]), 1)
+    R = k_matrix(Xin, np.asarray(length, float), max(nugget_s, nugget), name)
+    return (float(np.asarray(scale).reshape(-1)[0]) / np.diag(pinvh(R, check_finite=False))).reshape(-1, 1)

@@ -187,6 +187,19 @@ def test_matern_2layer_train_predict_small(eng):
         assert np.allclose(mu3, mu, rtol=1e-9, atol=1e-12) and np.allclose(var3, var, rtol=1e-7, atol=1e-12)
     idx, best = emu.metric(X[:40], method='ALM')
     assert idx.shape == (1,) and best[0] == var[:, 0].max() and idx[0] == int(np.argmax(var[:, 0]))
+    # MICE (emulation.py:377-394) against the oracle's mice_var on this emulator's own per-imputation moments
+    from oracle import dgp_oracle as O
+    xc = X[:40]
+    score = emu.metric(xc, method='MICE', nugget_s=1.0, score_only=True)
+    pl = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in emu._layer_moments(xc)]
+    nd = emu.all_layer[-1][0]
+    ref = np.zeros((40, 1))
+    for i in range(emu.N):
+        ref += np.log(pl[-1][1][i] / O.mice_var(pl[-2][0][i], xc, nd.input_dim, nd.connect, nd.name, nd.length, nd.scale,
+                                                 nd.nugget[0], 1.0))
+    assert np.allclose(score, ref / emu.N, rtol=1e-8, atol=1e-10)
+    idx2, best2 = emu.metric(xc, method='MICE')
+    assert idx2[0] == int(np.argmax(score[:, 0])) and best2[0] == score[:, 0].max()
     full = emu.predict(X[:10], method='sampling', sample_size=5, full_layer=True)
     assert len(full) == 2 and len(full[0]) == d and full[0][0].shape == (10, 15) and full[1][0].shape == (10, 15)
     mu_l, var_l = emu.predict(X[:10], full_layer=True)
