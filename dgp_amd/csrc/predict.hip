@@ -515,35 +515,37 @@ __global__ __launch_bounds__(256) void linkgp_Jsep_kernel(LinkArgs a) {
             pre[u] = *reinterpret_cast<const double2 *>(base + pt * REC + 2 * w);
         }
     };
-    auto stash = [&](int k) {
+    auto stash = [&](int k, double *P) {
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const int e = tid + 256 * u;
             const int half = e >= 896, r = (e - half * 896) / 14, w = (e - half * 896) - r * 14;
-            double *d = PT + (half * 64 + r) * PST + 2 * w;
+            double *d = P + (half * 64 + r) * PST + 2 * w;
             d[0] = pre[u].x;
             d[1] = pre[u].y;
         }
-        if (tid < 128) PT[tid * PST + 28] = tid < 64 ? WiT[k * 64 + tid] : WjT[k * 64 + tid - 64];
+        if (tid < 128) P[tid * PST + 28] = tid < 64 ? WiT[k * 64 + tid] : WjT[k * 64 + tid - 64];
     };
     __syncthreads();
-    if (nt > 0) fetch(0, 0);
-
-    const double *Arow = PT + (16 * wave + mi) * PST;   // this lane's row record as an MFMA A operand (i = lane&15)
+    // The records of step (t, k) are double buffered in LDS and their loads run two steps ahead: ONE barrier per step,
+    // and a wave that is done with a step stages the next one while the others still compute.
+    double *PT1 = PT + 128 * PST;
+    const int nstep = nt * Dw;
+    if (nstep > 0) {
+        fetch(0, 0);
+        stash(0, PT);
+        if (nstep > 1) fetch(1 / Dw, 1 % Dw);
+    }
+    int step = 0;
     for (int t = 0; t < nt; ++t) {
         d4 prod[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) prod[tt] = (d4){1.0, 1.0, 1.0, 1.0};
 #pragma unroll 1
-        for (int k = 0; k < Dw; ++k) {
-            __syncthreads();   // the previous pair phase has finished reading PT
-            stash(k);
-            __syncthreads();
-            {   // issue the loads of the next step before computing on this one
-                int k2 = k + 1, t2 = t;
-                if (k2 == Dw) { k2 = 0; ++t2; }
-                if (t2 < nt) fetch(t2, k2);
-            }
+        for (int k = 0; k < Dw; ++k, ++step) {
+            double *P = (step & 1) ? PT1 : PT;
+            __syncthreads();   // records of this step staged; every wave is done with the other buffer
+            const double *Arow = P + (16 * wave + mi) * PST;   // this lane's row record as an MFMA A operand (i = lane&15)
             // A fragments (rows): S[0..11] and T[0..11] in three k-steps each, the erf-difference pair in one (k=3 padded with 0)
             double aS[3], aT[3];
 #pragma unroll
@@ -555,27 +557,39 @@ __global__ __launch_bounds__(256) void linkgp_Jsep_kernel(LinkArgs a) {
             double f2r[4], xr[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                f2r[r] = PT[(mrow + 4 * r) * PST + 27];
-                xr[r] = PT[(mrow + 4 * r) * PST + 28];
+                f2r[r] = P[(mrow + 4 * r) * PST + 27];
+                xr[r] = P[(mrow + 4 * r) * PST + 28];
             }
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const double *Bcol = PT + (64 + 16 * tt + mi) * PST;   // column record as an MFMA B operand (j = lane&15)
-                d4 o1 = {0.0, 0.0, 0.0, 0.0}, o2 = o1, e1 = o1, e2 = o1;
+            // column tiles software pipelined by hand: the MFMAs of tile tt+1 are issued before the (VALU) epilogue of
+            // tile tt, so the matrix pipe stays busy while the J factors are selected and multiplied in
+            d4 o1[2], o2[2], e1[2], e2[2];
+            auto mm = [&](int tt, int slot) {
+                const double *Bcol = P + (64 + 16 * tt + mi) * PST;   // column record as an MFMA B operand (j = lane&15)
+                d4 a1 = {0.0, 0.0, 0.0, 0.0}, a2 = a1, b1 = a1, b2 = a1;
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) {
-                    o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[ks], Bcol[12 + 4 * ks + kq], o1, 0, 0, 0);   // S_row . T_col
-                    o2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[ks], Bcol[4 * ks + kq], o2, 0, 0, 0);        // T_row . S_col
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[ks], Bcol[12 + 4 * ks + kq], a1, 0, 0, 0);   // S_row . T_col
+                    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[ks], Bcol[4 * ks + kq], a2, 0, 0, 0);        // T_row . S_col
                 }
-                e1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aSd, kq < 3 ? Bcol[24 + kq] : 0.0, e1, 0, 0, 0);
-                e2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aTd, kq < 3 ? Bcol[6 + kq] : 0.0, e2, 0, 0, 0);
-                const double f2c = PT[(64 + 16 * tt + mcol) * PST + 27], xc = PT[(64 + 16 * tt + mcol) * PST + 28];
+                b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aSd, kq < 3 ? Bcol[24 + kq] : 0.0, b1, 0, 0, 0);
+                b2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aTd, kq < 3 ? Bcol[6 + kq] : 0.0, b2, 0, 0, 0);
+                o1[slot] = a1; o2[slot] = a2; e1[slot] = b1; e2[slot] = b2;
+            };
+            mm(0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int sl = tt & 1;
+                if (tt < 3) mm(tt + 1, sl ^ 1);
+                const double f2c = P[(64 + 16 * tt + mcol) * PST + 27], xc = P[(64 + 16 * tt + mcol) * PST + 28];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double jd = (xr[r] <= xc) ? fma(f2c - f2r[r], e1[r], o1[r]) : fma(f2r[r] - f2c, e2[r], o2[r]);
+                    const double jd = (xr[r] <= xc) ? fma(f2c - f2r[r], e1[sl][r], o1[sl][r]) : fma(f2r[r] - f2c, e2[sl][r], o2[sl][r]);
                     prod[tt][r] *= jd;
                 }
-                __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: keeps the accumulators to 16 registers
+            }
+            if (step + 1 < nstep) {   // stage the next step into the other buffer (its readers passed this step's barrier)
+                stash((step + 1) % Dw, (step & 1) ? PT : PT1);
+                if (step + 2 < nstep) fetch((step + 2) / Dw, (step + 2) % Dw);
             }
         }
         // deterministic global inputs: separable Matern factor (functions.py:413-420)
@@ -671,7 +685,7 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
             if (ctx->linkgp_direct) {
                 hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_MATERN25>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else {
-                const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)TCH * Dz + TCH * 4 + 128 * PST) * sizeof(double);
+                const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)TCH * Dz + TCH * 4 + 2 * 128 * PST) * sizeof(double);
                 if (shm_sep > 48 * 1024)
                     HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_sep));
                 hipLaunchKernelGGL(matern_records_kernel, dim3((unsigned)((a.npad + 127) / 128), Dw, (unsigned)mc), dim3(256), 0, ctx->stream, a);
