@@ -106,13 +106,13 @@ __device__ __forceinline__ void publish_chain(const double *o, double (*dst)[6])
 }
 
 // Factor the 64x64 tile held in registers, write the factor to Ab (ld; strictly upper part zeroed) and the inverse
-// of the factor to Wb (64x64), accumulate logdet / info of matrix b.  ncol = pivots in this block (rows/columns
-// beyond are carried right-hand sides).
+// of the factor to Wb (64x64); the pivots stay in sh.piv for diag_logdet.  ncol = pivots in this block (rows/columns
+// beyond are carried right-hand sides).  Returns (in wave 0) 1 + the index of the first non-positive pivot, or 0.
 struct Tile64 {
     d4 v[4];
 };
-__device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double *Ab, int64_t ld, double *Wb, int ncol,
-                                            int k, int b, double *logdet, int32_t *info, long long *trace = nullptr) {
+__device__ __forceinline__ int diag_factor(Tile64 &tile, DiagShared &sh, double *Ab, int64_t ld, double *Wb, int ncol,
+                                           long long *trace = nullptr) {
     d4 (&a)[4] = tile.v;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lm = l & 15, lu = l >> 4;
     const int myrow = 16 * w + lm;   // row this lane serves as MFMA A operand / stores as finished column
@@ -267,7 +267,14 @@ __device__ __forceinline__ void diag_factor(Tile64 &tile, DiagShared &sh, double
                 if (row >= ncol) Wb[row * 64 + col] = y[t][r];
             }
     }
-    if (tid < 64) {   // wave 0 (the chain wave knows about failed pivots); the last barrier made piv visible
+    return bad;
+}
+
+// logdet / info of the block just factored (wave 0 knows about failed pivots; the factor's last barrier made the
+// pivots visible).  Kept out of diag_factor so that the chain publishes its block BEFORE this reduction.
+__device__ __forceinline__ void diag_logdet(DiagShared &sh, int ncol, int k, int b, int bad, double *logdet, int32_t *info) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
         double v = (tid < ncol && !(tid == 0 && bad)) ? log(sh.piv[tid]) : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -573,11 +580,12 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     if (post == T_CHAIN) {
         STAMP(1);
         const int64_t rem = g.n - (int64_t)k * 64;
-        diag_factor(acc, sh, C, ld, Wk, rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0), k, b, g.logdet, g.info,
-                    (g.trace && b == 0) ? g.trace + 1024 + 64 * k : nullptr);
+        const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+        const int bad = diag_factor(acc, sh, C, ld, Wk, ncol, (g.trace && b == 0) ? g.trace + 1024 + 64 * k : nullptr);
         STAMP(2);
-        wg_release_store(g.flags + b, k + 1, tid);
+        wg_release_store(g.flags + b, k + 1, tid);   // the panel can start; the log-determinant is nobody's input
         STAMP(3);
+        diag_logdet(sh, ncol, k, b, bad, g.logdet, g.info);
         return;
     }
     // T_SOLVE: wait for W_k, then tile <- tile * W_k^T
