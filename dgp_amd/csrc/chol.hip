@@ -493,10 +493,12 @@ __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const
         mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, sign);
     }
 }
-// out += sign * in * Bg^T   (in: accumulator-layout 64x64 tile, Bg: 64x64 row-major tile in global memory)
+// out += sign * in * Bg^T   (in: accumulator-layout 64x64 tile, Bg: 64x64 row-major tile in global memory).  Both
+// halves of Bg are requested up front: one exposed load latency instead of two on the panel's critical path.
 __device__ __forceinline__ void mul_acc_bt(d4 (&out)[4], const d4 (&in)[4], const double *Bg, int64_t ldb, double sign,
                                            double *As, double *Bs, int tid, int wave, int lane) {
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
+    const HalfTile b0 = fetch_mk(Bg, ldb, tid, 0), b1 = fetch_mk(Bg, ldb, tid, 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
@@ -504,7 +506,7 @@ __device__ __forceinline__ void mul_acc_bt(d4 (&out)[4], const d4 (&in)[4], cons
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) As[(crow + 4 * r) * LDM + 16 * t + ccol] = in[2 * h + t][r];
-        load_mk(Bg, ldb, Bs, tid, h);
+        commit_mk(h == 0 ? b0 : b1, Bs, tid);
         __syncthreads();
         mfma_tile<OP_MK, OP_MK>(As, Bs, out, wave, lane, sign);
     }
