@@ -141,6 +141,8 @@ class imputer:
         self.draws = draws if draws is not None else DrawStream()
         self._engine = engine
         self.batch = int(batch)
+        self.batch_next = 4      # size of the 2nd, 3rd, ... speculative batch of an update: after a rejected batch the
+                                 # bracket is narrow and acceptance is near (measured: I-step -7% against 12 throughout)
         self._factor_cache = {}
         self.stats = dict(proposals=0, updates=0, batches=0)
 
@@ -390,6 +392,8 @@ class imputer:
             us = self.draws.uniform_peek(B - 1)
             thetas, brackets = speculative_angles(theta, lo, hi, us)
             nb = len(thetas)
+            if self.batch_next:
+                B = min(self.batch, int(self.batch_next))   # after a rejected batch the bracket is narrow
             FP = e.ess_propose(F, nu, thetas)
             ll, info = self._upper_loglik(l, FP)
             self.stats['batches'] += 1
@@ -423,10 +427,13 @@ class imputer:
         lo, hi = theta - TWO_PI, theta
         fk, nk = F[:, k:k + 1].contiguous(), nu[:, k:k + 1].contiguous()
         self.stats['updates'] += 1
+        B = self.batch
         while True:
-            us = self.draws.uniform_peek(self.batch - 1)
+            us = self.draws.uniform_peek(B - 1)
             thetas, brackets = speculative_angles(theta, lo, hi, us)
             nb = len(thetas)
+            if self.batch_next:
+                B = min(self.batch, int(self.batch_next))
             col = e.ess_propose(fk, nk, thetas)            # (nb, n, 1)
             FP = F.unsqueeze(0).repeat(nb, 1, 1)
             FP[:, :, k] = col[:, :, 0]

@@ -8,7 +8,8 @@ from dgp_amd import kernel_class
 
 model, X, Y = build_model(2000, 5, 100, 0)
 imp = model.imp
-imp.batch = int(os.environ.get("ESS_BATCH", "8"))
+imp.batch = int(os.environ.get("ESS_BATCH", "12"))
+imp.batch_next = int(os.environ.get("ESS_BATCH_NEXT", "0")) or None
 for _ in range(2):
     imp.sample(burnin=10); model._m_step()
 T = dict(i=0.0, m=0.0, prior=0.0, upper=0.0, attach=0.0, detach=0.0)
