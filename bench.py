@@ -180,6 +180,11 @@ def main():
                 ach = tot_w / (tot_ms * 1e-3) / 1e12
                 roof = dict(bound='mfma', kernel={'syrk': 'potrf_step_kernel'}.get(args.prof_kernel, 'tile_gemm_kernel<%s>' % args.prof_kernel), achieved=ach,
                             peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None)
+            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_bench_step_kernel.json')
+            if args.prof_kernel == 'syrk' and os.path.exists(pmc):   # HBM bytes per launch, measured offline with rocprofv3 --pmc
+                with open(pmc) as f:
+                    roof['traffic'] = json.load(f)['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/r01_pmc_bench_step_kernel.json (FETCH_SIZE x2 + WRITE_SIZE, same command)'
             roof.update(launches=tot_n, avg_launch_us=1e3 * tot_ms / tot_n, work_per_launch=tot_w / tot_n,
                         event_pair_overhead_us=ev_us, avg_launch_us_uncorrected=1e3 * raw_ms / tot_n,
                         sustained_f64_mfma_tflops_measured=47.5)
