@@ -352,3 +352,82 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     memcpy(host_out, ctx->pinned, bytes);
     return DGPAMD_OK;
 }
+
+
+// ----------------------------------------------------------------------------
+// a7  one elliptical-slice update, loop and all (imputation.py:81-119)
+// ----------------------------------------------------------------------------
+extern "C" int dgpamd_ess_update(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double *NU, const dgpamd_node *node,
+                                 double scale, double log_y, double *state, const double *uniforms, int nuni, int batch_first,
+                                 int batch_next, double *FP, double *A, void *work, double *ll_dev, int32_t *info_dev,
+                                 double *out) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || M <= 0 || !F || !NU || !node || !state || !FP || !A || !work || !ll_dev || !info_dev || !out)
+        BAD_ARG(ctx, "null pointer or empty block");
+    if (nuni < 0 || (nuni > 0 && !uniforms)) BAD_ARG(ctx, "bad uniform stream");
+    if (batch_first <= 0 || batch_first > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch_first <= DGPAMD_MAXB");
+    if (batch_next <= 0 || batch_next > batch_first) batch_next = batch_first;
+    const int64_t Np = padded_dim(n);
+    double theta = state[0], lo = state[1], hi = state[2];
+    bool pending = state[3] != 0.0;
+    int used = 0, proposals = 0, batches = 0;
+    auto shrink = [&](double u) {   // imputation.py:115-119; numpy's uniform(lo, hi) = lo + (hi - lo) u
+        if (theta < 0.0) lo = theta; else hi = theta;
+        theta = lo + (hi - lo) * u;
+    };
+    auto finish = [&](int status, double ll, int info) {
+        state[0] = theta; state[1] = lo; state[2] = hi; state[3] = pending ? 1.0 : 0.0;
+        out[0] = status; out[1] = used; out[2] = proposals; out[3] = batches; out[4] = ll; out[5] = info;
+        return DGPAMD_OK;
+    };
+    double th[DGPAMD_MAXB], blo[DGPAMD_MAXB], bhi[DGPAMD_MAXB], llh[DGPAMD_MAXB + DGPAMD_MAXB / 2 + 1];
+    int B = batch_first;
+    for (;;) {
+        if (pending) {   // closing shrink of the previous, fully rejected batch
+            if (used >= nuni) return finish(1, 0.0, 0);
+            shrink(uniforms[used++]);
+            pending = false;
+            B = batch_next;
+        }
+        // speculative angles: theta followed by what the next rejections would produce
+        int nb = 1;
+        th[0] = theta; blo[0] = lo; bhi[0] = hi;
+        {
+            double t_ = theta, l_ = lo, h_ = hi;
+            while (nb < B && used + nb - 1 < nuni) {
+                if (t_ < 0.0) l_ = t_; else h_ = t_;
+                t_ = l_ + (h_ - l_) * uniforms[used + nb - 1];
+                th[nb] = t_; blo[nb] = l_; bhi[nb] = h_;
+                ++nb;
+            }
+        }
+        int rc = dgpamd_ess_propose(ctx, n, M, F, NU, th, nb, FP);
+        if (rc) return rc;
+        rc = dgpamd_loglik(ctx, node->kind, n, FP, M, n * (int64_t)M, (const int32_t *)node->colmap, node->Dl, node->Xglob,
+                           node->Dg, node->length, node->nlen, node->nugget, node->W, scale, node->y, A, Np * Np, nb, ll_dev,
+                           info_dev, work);
+        if (rc) return rc;
+        rc = dgpamd_fetch2(ctx, ll_dev, sizeof(double) * nb, info_dev, sizeof(int32_t) * nb, llh);
+        if (rc) return rc;
+        const int32_t *infoh = reinterpret_cast<const int32_t *>(llh + nb);
+        ++batches;
+        for (int b = 0; b < nb; ++b) {
+            if (infoh[b] != 0) {
+                proposals += b + 1;
+                return finish(2, 0.0, infoh[b]);
+            }
+            if (llh[b] > log_y) {
+                used += b;
+                proposals += b + 1;
+                theta = th[b]; lo = blo[b]; hi = bhi[b];
+                HIP_TRY(ctx, hipMemcpyAsync(F, FP + (int64_t)b * n * M, sizeof(double) * n * M, hipMemcpyDeviceToDevice,
+                                            ctx->stream));
+                return finish(0, llh[b], 0);
+            }
+        }
+        used += nb - 1;
+        proposals += nb;
+        theta = th[nb - 1]; lo = blo[nb - 1]; hi = bhi[nb - 1];
+        pending = true;
+    }
+}

@@ -144,6 +144,7 @@ class imputer:
         self.batch_next = 4      # size of the 2nd, 3rd, ... speculative batch of an update: after a rejected batch the
                                  # bracket is narrow and acceptance is near (measured: I-step -7% against 12 throughout)
         self._factor_cache = {}
+        self._ess_plans = {}
         self.stats = dict(proposals=0, updates=0, batches=0)
 
     @property
@@ -156,6 +157,7 @@ class imputer:
         st = dict(self.__dict__)
         st['_engine'] = None
         st['_factor_cache'] = {}
+        st['_ess_plans'] = {}
         for key in ('F', '_glob', '_yy', '_x0', '_ll_cache'):   # device state: rebuilt by the next sample()
             st.pop(key, None)
         return st
@@ -371,6 +373,28 @@ class imputer:
             info = np.zeros(B)
         return host, info
 
+    def _ess_plan(self, l):
+        """dgpamd_ess_update arguments for layer l when the layer above is ONE dense GP node without a reference prior
+        (else None: the general loop below handles several / Vecchia / likelihood nodes).  Rebuilt when the node's
+        hyper-parameters, the batch size or the device state change."""
+        upper = self.all_layer[l + 1]
+        if len(upper) != 1 or l + 1 != len(self.all_layer) - 1:   # (a hidden layer's output is itself being sampled)
+            return None
+        nd = upper[0]
+        if nd.type != 'gp' or nd.vecch or nd.prior_name == 'ref':
+            return None
+        n, M = self.F[l].shape
+        y = self._node_y(l + 1, 0)
+        key = (tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), self.batch, y.data_ptr(),
+               None if self._glob[(l + 1, 0)] is None else self._glob[(l + 1, 0)].data_ptr())
+        hit = self._ess_plans.get(l)
+        if hit is None or hit[0] != key:
+            W = None if nd.rep is None else self.engine.tensor(nd.W_diag)
+            plan = self.engine.ess_plan(n, M, nd.name, np.asarray(nd.input_dim, dtype=np.int32), self._glob[(l + 1, 0)],
+                                        nd.length, nd.nugget[0], W, y, self.batch)
+            self._ess_plans[l] = hit = (key, plan)
+        return hit[1]
+
     def one_sample_block(self, l, nu=None):
         """Layer-wise ESS update of layer l given layer l+1 (imputation.py:44-119); nu: prior draw made ahead."""
         e = self.engine
@@ -388,6 +412,25 @@ class imputer:
         lo, hi = theta - TWO_PI, theta
         B = self.batch
         self.stats['updates'] += 1
+        plan = self._ess_plan(l)
+        if plan is not None:   # one dense GP node upstairs: the whole shrinking-bracket loop is one library call
+            nd = self.all_layer[l + 1][0]
+            pending = False
+            while True:
+                us = self.draws.uniform_peek(64)
+                status, used, props, nbat, ll_acc, info, theta, lo, hi, pending = plan.run(
+                    F, nu, nd.scale[0], log_y, theta, lo, hi, pending, us, self.batch_next)
+                self.draws.uniform_take(used)
+                self.stats['proposals'] += props
+                self.stats['batches'] += nbat
+                if status == 2:
+                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % info)
+                if status == 0:
+                    self._ll_cache[l] = ll_acc
+                    self._ll_cache.pop(l - 1, None)
+                    return
+                if len(us) == used and self.draws._injected_u:
+                    raise RuntimeError('injected uniform stream exhausted')
         while True:
             us = self.draws.uniform_peek(B - 1)
             thetas, brackets = speculative_angles(theta, lo, hi, us)

@@ -273,6 +273,10 @@ class Engine:
         self._chk(lib.dgpamd_fetch2(self.h, _dp(ll), 8 * B, _dp(info), 4 * B, buf.ctypes.data_as(C.c_void_p)))
         return buf[:8 * B].view(np.float64), buf[8 * B:].view(np.int32)
 
+    def ess_plan(self, n, M, kind, colmap, Xglob, length, nugget, W, y, batch):
+        """Static arguments of dgpamd_ess_update for one upper GP node (see _EssPlan.run)."""
+        return _EssPlan(self, n, M, kind, colmap, Xglob, length, nugget, W, y, batch)
+
     def llik_plan(self, n, specs):
         """Prepare the static part of dgpamd_llik_batch for a fixed set of GP nodes of size n.  specs: list of dicts
         kind, Xloc (n x ldloc tensor), Xglob (tensor or None), nlen, nugget_est, W (tensor or None), y (tensor).  Returns a
@@ -451,3 +455,41 @@ class _LlikPlan:
             P = self.P[i]
             out[i] = np.concatenate((host[r, :2], host[r, 3:3 + 2 * P], host[r, 2:3]))
         return out
+
+
+class _EssPlan:
+    """One elliptical-slice update per call: dgpamd_ess_update with its scratch buffers kept alive."""
+
+    def __init__(self, eng, n, M, kind, colmap, Xglob, length, nugget, W, y, batch):
+        self.e, self.n, self.M, self.batch = eng, int(n), int(M), int(batch)
+        Np = eng.padded_dim(n)
+        self.keep = (Xglob, W, y)
+        self.colmap = np.ascontiguousarray(np.asarray(colmap, dtype=np.int32))
+        self.length = np.ascontiguousarray(np.asarray(length, dtype=np.float64))
+        nd = self.node = _lib.Node()
+        nd.kind, nd.Dl, nd.Dg = KIND[kind], len(self.colmap), 0 if Xglob is None else Xglob.shape[1]
+        nd.nlen, nd.nugget_est, nd.ldloc = len(self.length), 0, M
+        nd.Xloc, nd.colmap = None, self.colmap.ctypes.data
+        nd.Xglob = None if Xglob is None else Xglob.data_ptr()
+        nd.length, nd.nugget = self.length.ctypes.data, float(nugget)
+        nd.W = None if W is None else W.data_ptr()
+        nd.y = y.data_ptr()
+        self.FP = eng.workspace(('essFP', n, M, batch), batch * n * M * 8)
+        self.A = eng.workspace(('essA', n, batch), batch * Np * Np * 8)
+        self.work = eng.potrf_workspace(n, batch)
+        self.ll = eng.empty(batch)
+        self.info = eng.empty(batch, dtype=torch.int32)
+        self.state = np.zeros(4)
+        self.out = np.zeros(6)
+
+    def run(self, F, NU, scale, log_y, theta, lo, hi, pending, uniforms, batch_next):
+        """Returns (status, consumed, proposals, batches, ll, info, theta, lo, hi, pending)."""
+        e = self.e
+        us = np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64))
+        self.state[:] = (theta, lo, hi, 1.0 if pending else 0.0)
+        e._chk(lib.dgpamd_ess_update(e.h, self.n, self.M, _dp(F), _dp(NU), C.byref(self.node), float(scale), float(log_y),
+                                     self.state.ctypes.data_as(C.c_void_p), us.ctypes.data_as(C.c_void_p), len(us),
+                                     self.batch, int(batch_next) if batch_next else self.batch, _dp(self.FP), _dp(self.A),
+                                     _dp(self.work), _dp(self.ll), _dp(self.info), self.out.ctypes.data_as(C.c_void_p)))
+        o, st = self.out, self.state
+        return int(o[0]), int(o[1]), int(o[2]), int(o[3]), float(o[4]), int(o[5]), st[0], st[1], st[2], bool(st[3])

@@ -162,6 +162,41 @@ int dgpamd_potrf_inv(dgpamd_ctx *ctx, int64_t n, double *A, double *T, double *S
 int dgpamd_potri_batched(dgpamd_ctx *ctx, int64_t n, double *A, double *Ainv, int64_t stride_a, int r, int batch,
                          void *work);
 
+/* A GP node as the batched entry points take it (host struct; pointers as commented). */
+typedef struct {
+    int kind;              /* DGPAMD_SEXP / DGPAMD_MATERN25 */
+    int Dl, Dg, nlen;      /* local / global input columns, number of lengthscales */
+    int nugget_est;
+    int reserved;
+    int64_t ldloc;
+    const double *Xloc;    /* device, n x ldloc */
+    const int32_t *colmap; /* host, Dl entries, or NULL */
+    const double *Xglob;   /* device, n x Dg, or NULL */
+    const double *length;  /* host, nlen entries */
+    double nugget;
+    const double *W;       /* device replicate weights or NULL */
+    const double *y;       /* device, n */
+} dgpamd_node;
+
+/* ---- a7  one elliptical-slice update of a latent block, loop and all ------------
+ * imputation.one_sample_block imputation.py:81-119 for the common case of ONE dense GP node upstairs: the
+ * shrinking-bracket loop runs here (speculative batches: propose -> batched log-likelihood -> one result copy per
+ * batch), so an update costs one library call instead of several host round trips per batch.
+ *   F (n x M, device): current latent block, overwritten by the accepted proposal; NU: the prior draw;
+ *   node: the upper node (its Xloc / ldloc are ignored: the proposals are its local input through node->colmap);
+ *   scale: its variance; log_y: the slice threshold; state[4] = {theta, lo, hi, pending}: the current angle and
+ *   bracket (pending != 0: the last batch was rejected and its closing shrink still needs a uniform);
+ *   uniforms[nuni]: the next draws of the sampler's uniform stream, consumed exactly as the sequential loop
+ *   (imputation.py:115-119) would; batch_first / batch_next: speculative proposals per batch;
+ *   FP (batch_first x n x M), A (batch_first x Np x Np), work (dgpamd_potrf_workspace(n, batch_first)),
+ *   ll_dev (batch_first doubles), info_dev (batch_first int32): device scratch.
+ * out[6] = {status, uniforms consumed, proposals evaluated, batches, accepted log-likelihood, info}: status 0 =
+ * accepted, 1 = uniforms used up (call again with more; state is updated), 2 = a proposal's matrix is not positive
+ * definite (info = the LAPACK-style index). */
+int dgpamd_ess_update(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double *NU, const dgpamd_node *node, double scale,
+                      double log_y, double *state, const double *uniforms, int nuni, int batch_first, int batch_next,
+                      double *FP, double *A, void *work, double *ll_dev, int32_t *info_dev, double *out);
+
 /* ---- a8  M-step objective pieces -------------------------------------------
  * kernel.llik  kernel_class.py:403-449 restructured:
  *   tr_p   = sum_ij Kinv_ij dK_p,ij          (= trace(K^-1 dK_p))
@@ -184,20 +219,6 @@ int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n,
  * with P_b as in dgpamd_grad_reduce; stride_out >= 3 + 2 max P_b.  A, T, Ainv: batch x Np x Np buffers (stride
  * stride_a; see dgpamd_potrf_inv); work: dgpamd_potrf_workspace(n, batch); grad_work: dgpamd_grad_workspace(n, max P_b);
  * dev_out: device scratch of batch * (stride_out + 2) doubles. */
-typedef struct {
-    int kind;              /* DGPAMD_SEXP / DGPAMD_MATERN25 */
-    int Dl, Dg, nlen;      /* local / global input columns, number of lengthscales */
-    int nugget_est;
-    int reserved;
-    int64_t ldloc;
-    const double *Xloc;    /* device, n x ldloc */
-    const int32_t *colmap; /* host, Dl entries, or NULL */
-    const double *Xglob;   /* device, n x Dg, or NULL */
-    const double *length;  /* host, nlen entries */
-    double nugget;
-    const double *W;       /* device replicate weights or NULL */
-    const double *y;       /* device, n */
-} dgpamd_node;
 int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T, double *Ainv,
                       int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
                       int64_t stride_out);
