@@ -46,6 +46,7 @@ SIGNATURES = {
     'dgpamd_event_record': (_i, [_p, _p]),
     'dgpamd_event_elapsed_ms': (_i, [_p, _p, _p, C.POINTER(C.c_float)]),
     'dgpamd_event_destroy': (_i, [_p, _p]),
+    'dgpamd_gemv': (_i, [_p, _l, _l, _p, _l, _p, _p]),
     'dgpamd_fetch': (_i, [_p, _p, _p, _z]),
     'dgpamd_fetch2': (_i, [_p, _p, _z, _p, _z, _p]),
     'dgpamd_set_graphs': (_i, [_p, _i]),

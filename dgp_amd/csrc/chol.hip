@@ -835,6 +835,29 @@ extern "C" int dgpamd_aug_quad(dgpamd_ctx *ctx, int64_t n, const double *A, int6
     return DGPAMD_OK;
 }
 
+// out[i] = sum_j A[i][j] x[j]; one wave per row
+__global__ __launch_bounds__(256) void gemv_kernel(const double *A, int64_t ld, int64_t rows, int64_t cols, const double *x,
+                                                   double *out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= rows) return;
+    const double *row = A + i * ld;
+    double s = 0.0;
+    for (int64_t j = lane; j < cols; j += 64) s = fma(row[j], x[j], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) out[i] = s;
+}
+
+extern "C" int dgpamd_gemv(dgpamd_ctx *ctx, int64_t rows, int64_t cols, const double *A, int64_t ld, const double *x,
+                           double *out) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (rows <= 0 || cols <= 0 || !A || !x || !out || ld < cols) BAD_ARG(ctx, "bad arguments");
+    hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, A, ld, rows, cols, x, out);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
 extern "C" int dgpamd_trmv_lower(dgpamd_ctx *ctx, int64_t n, const double *L, int64_t stride_a, const double *scale_h,
                                  const double *z, double *out, int batch) {
     if (!ctx) return DGPAMD_BAD_ARG;

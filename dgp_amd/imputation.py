@@ -216,11 +216,8 @@ class imputer:
         for sweep in range(burnin + 1):
             for l in range(n_layer - 1):
                 upper = self.all_layer[l + 1]
-                hetero = any(nd.type == 'likelihood' and nd.exact_post_idx is not None for nd in upper)
-                if hetero:
-                    raise NotImplementedError('the Hetero exact-posterior step (imputation.py:141-164) is outside the '
-                                              'accelerated path')
-                if self.block:
+                hetero = any(nd.type == 'likelihood' and getattr(nd, 'exact_post_idx', None) is not None for nd in upper)
+                if self.block and not hetero:   # (imputation.py:35-42: an exact-posterior likelihood forces node-wise updates)
                     self.one_sample_block(l, nu=ahead[sweep] if (ahead is not None and l == 0) else None)
                 else:
                     for k in range(len(self.all_layer[l])):
@@ -261,6 +258,8 @@ class imputer:
         layer = self.all_layer[0]
         if not self.block or any(nd.vecch or nd.type != 'gp' for nd in layer):
             return None
+        if any(nd.type == 'likelihood' and getattr(nd, 'exact_post_idx', None) is not None for nd in self.all_layer[1]):
+            return None   # node-wise updates (sample())
         if self.draws._z is not None and len(self.all_layer) > 2:
             return None
         e = self.engine
@@ -455,12 +454,39 @@ class imputer:
             theta, (lo, hi) = thetas[-1], brackets[-1]
             theta, lo, hi = shrink(theta, lo, hi, self.draws.uniform_take(1)[0])
 
+    def _exact_posterior(self, l, k, lik):
+        """Latent column k of layer l drawn from its exact conditional posterior under the likelihood node `lik`
+        (imputation.py:141-164 -> Hetero.posterior, likelihood_class.py:134-243; dense mode)."""
+        e = self.engine
+        nd = self.all_layer[l][k]
+        if nd.vecch:
+            raise NotImplementedError('the Vecchia form of the exact-posterior step (vecchia.py:426-476) is not implemented')
+        F = self.F[l]
+        n = F.shape[0]
+        Xl, cm = self._node_input(l, k, nd)
+        K = e.kmatrix(nd.name, Xl, cm, self._glob[(l, k)], nd.length, nd.nugget[0])   # full n x n, device
+        Fh = F.cpu().numpy()
+        lik.input = Fh[lik.rep, :][:, lik.input_dim] if lik.rep is not None else Fh[:, lik.input_dim]
+        g, y = lik.posterior_terms(n)
+        sd = self.draws.normal(2 * n).reshape(n, 2)
+        f = e.post_het(K, nd.scale[0], e.tensor(g), e.tensor(y), e.tensor(sd))
+        F[:, k] = f
+        self._ll_cache.pop(l, None)
+        self._ll_cache.pop(l - 1, None)
+
     def one_sample(self, l, k):
         """Node-wise ESS update of latent column k of layer l given the nodes of layer l+1 it feeds
         (imputation.py:121-221, the non-Hetero branch): same speculative batches, one column rotated."""
         e = self.engine
         F = self.F[l]
         linked = [j for j, nd in enumerate(self.all_layer[l + 1]) if k in np.asarray(nd.input_dim)]
+        if len(linked) == 1:
+            lik = self.all_layer[l + 1][linked[0]]
+            if lik.type == 'likelihood' and getattr(lik, 'exact_post_idx', None) is not None:
+                idx = int(np.where(np.asarray(lik.input_dim) == k)[0][0])
+                if idx in np.asarray(lik.exact_post_idx):
+                    self._exact_posterior(l, k, lik)
+                    return
         nu = self._prior_draw(l, [k])
         ll, info = self._upper_loglik(l, F[None], only=linked)
         if info[0] != 0:

@@ -258,6 +258,43 @@ class Engine:
                                          _dp(work)))
         return out, P
 
+    def gemv(self, A, x, out=None):
+        rows, cols = A.shape
+        if out is None:
+            out = self.empty(rows)
+        self._chk(lib.dgpamd_gemv(self.h, rows, cols, _dp(A), A.stride(0), _dp(x), _dp(out)))
+        return out
+
+    def post_het(self, K, scale, gamma_eff, y_eff, sd):
+        """One draw of the mean latent of a heteroskedastic Gaussian likelihood from its exact conditional posterior
+        (Hetero.post_het1 / post_het2, likelihood_class.py:184-243) with v = scale K:
+            f = K alpha + u,   (K + diag(gamma_eff / scale)) alpha = y_eff - u - w,
+            u = chol(v) sd[:, 0],   w = sqrt(gamma_eff) sd[:, 1].
+        K: (n, n) full kernel matrix (device); gamma_eff, y_eff: (n,) device; sd: (n, 2) device.  Two factorisations:
+        one for u, one (with the right-hand side riding along, inverse in the same sweep) for alpha."""
+        n = K.shape[0]
+        Np = self.padded_dim(n)
+        A = self.workspace(('hetA', n), Np * Np * 8).view(torch.float64).view(Np, Np)
+        T = self.workspace(('hetT', n), Np * Np * 8).view(torch.float64).view(Np, Np)
+        S = self.workspace(('hetS', n), Np * Np * 8).view(torch.float64).view(Np, Np)
+        work = self.potrf_workspace(n, 1)
+        A.zero_()
+        A[:n, :n] = K
+        _, info1 = self.potrf(n, A, work=work)
+        u = self.trmv_lower(n, A, [float(scale)], sd[:, 0].contiguous())[0]
+        w = torch.sqrt(gamma_eff) * sd[:, 1]
+        A.zero_()
+        A[:n, :n] = K
+        A.diagonal()[:n] += gamma_eff / float(scale)
+        A[n, :n] = y_eff - u - w
+        _, info2 = self.potrf_inv(n, A, T, S, work=work)
+        alpha = -S[n, :n]
+        f = self.gemv(K, alpha.contiguous()) + u
+        bad = int(self.fetch(info1)[0]) or int(self.fetch(info2)[0])
+        if bad:
+            raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite' % bad)
+        return f
+
     def fetch(self, t):
         """Device tensor -> numpy array through the library's pinned staging buffer (one stream sync; cheaper than
         torch's .cpu() for the few bytes a sampler / optimiser step returns)."""

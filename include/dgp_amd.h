@@ -121,6 +121,10 @@ int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int ba
  * y_q^T K^-1 y_q'  (= -corner).                                               */
 int dgpamd_aug_quad(dgpamd_ctx *ctx, int64_t n, const double *A, int64_t stride_a, int batch, int r, double *quad);
 
+/* Dense row-major matrix-vector product out = A x (rows x cols, leading dimension ld): the K alpha + u step of the
+ * heteroskedastic exact-posterior draw (likelihood_class.py:184-243), where K is a full kernel matrix. */
+int dgpamd_gemv(dgpamd_ctx *ctx, int64_t rows, int64_t cols, const double *A, int64_t ld, const double *x, double *out);
+
 /* ---- a5  ESS target log-likelihood, batched over speculative proposals -----
  * kernel.log_likelihood_func  kernel_class.py:481-492:
  *   ll[b] = -0.5 ( n log(scale) + logdet(K_b) + y^T K_b^-1 y / scale )

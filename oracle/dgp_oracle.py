@@ -15,7 +15,7 @@ one entry (shared) or one per column of X; kernel names are the reference's
 strings 'sexp' / 'matern2.5'.
 """
 import numpy as np
-from scipy.linalg import cholesky, cho_solve, solve_triangular
+from scipy.linalg import cholesky, cho_factor, cho_solve, solve_triangular
 from scipy.special import erf
 
 SQ5 = np.sqrt(5.0)
@@ -734,3 +734,46 @@ def mice_var(x, x_extra, input_dim, connect, name, length, scale, nugget, nugget
         Xin = np.concatenate((Xin, x_extra[:, connect]), 1)
     R = k_matrix(Xin, np.asarray(length, float), max(nugget_s, nugget), name)
     return (float(np.asarray(scale).reshape(-1)[0]) / np.diag(pinvh(R, check_finite=False))).reshape(-1, 1)
+
+
+# ------------------------------------------------------------------ heteroskedastic Gaussian likelihood
+def hetero_llik(inp, out):
+    """Hetero.llik (likelihood_class.py:108-113): sum_i -0.5 (log 2pi + logvar_i + (y_i - mu_i)^2 / exp(logvar_i)),
+    the ratio formed as exp(log r2 - logvar) like the reference."""
+    mu, log_var = inp[:, 0], inp[:, 1]
+    r2 = (np.asarray(out).flatten() - mu) ** 2
+    with np.errstate(divide='ignore'):
+        return float(np.sum(-0.5 * (np.log(2 * np.pi) + log_var + np.exp(np.log(r2) - log_var))))
+
+
+def hetero_prediction(m, v):
+    """Hetero.prediction (likelihood_class.py:123-127): mean m_0, variance exp(m_1 + v_1 / 2) + v_0."""
+    return m[:, 0].flatten(), (np.exp(m[:, 1] + v[:, 1] / 2) + v[:, 0]).flatten()
+
+
+def post_het1(v, Gamma, y, sd):
+    """Hetero.post_het1 (likelihood_class.py:184-207) with the normals sd (n x 2) injected: a draw of the mean latent
+    from its exact conditional posterior, f = mu + u - v (v + diag Gamma)^-1 (u + w), mu = v (v + diag Gamma)^-1 y,
+    u = chol(v) sd[:,0], w = sqrt(Gamma) sd[:,1]."""
+    vG = v + np.diag(Gamma)
+    c = cho_factor(vG, lower=True, check_finite=False)
+    L1 = np.linalg.cholesky(v)
+    mu = v @ cho_solve(c, np.asarray(y).flatten(), check_finite=False)
+    u = L1 @ sd[:, 0]
+    w = np.sqrt(Gamma) * sd[:, 1]
+    return -v @ cho_solve(c, u + w, check_finite=False) + mu + u
+
+
+def post_het2(v, Gamma, mask, y, sd):
+    """Hetero.post_het2 (likelihood_class.py:209-243): the same with replicates -- observation i belongs to site
+    mask[i]; per site the precision-weighted sums M Gamma^-1 y and M Gamma^-1 M replace y and Gamma."""
+    N = v.shape[0]
+    Gi = 1.0 / Gamma
+    MGy = np.bincount(mask, weights=Gi * np.asarray(y).flatten(), minlength=N)
+    iMGM = 1.0 / np.bincount(mask, weights=Gi, minlength=N)
+    c = cho_factor(v + np.diag(iMGM), lower=True, check_finite=False)
+    L1 = np.linalg.cholesky(v)
+    mu = v @ cho_solve(c, iMGM * MGy, check_finite=False)
+    u = L1 @ sd[:, 0]
+    w = np.sqrt(iMGM) * sd[:, 1]
+    return -v @ cho_solve(c, u + w, check_finite=False) + mu + u

@@ -439,8 +439,94 @@ def gen_lgp():
         save('g10_lgp_' + tag, **out)
 
 
+
+# ---------------------------------------------------------------- G13  heteroskedastic Gaussian likelihood
+def dump_lik(nd, pre):
+    out = {pre + 'input': nd.input.copy(), pre + 'output': nd.output.copy(),
+           pre + 'input_dim': np.asarray(nd.input_dim, np.int64).copy(), pre + 'has_rep': np.array(nd.rep is not None)}
+    if nd.rep is not None:
+        out[pre + 'rep'] = np.asarray(nd.rep, np.int64).copy()
+    return out
+
+
+def gen_hetero():
+    """Hetero likelihood (likelihood_class.py:94-243): llik / prediction, the exact conditional posterior draws
+    post_het1 / post_het2 with logged normals, and imputer.sample(burnin=2) trajectories of a 2-layer
+    (2 GP nodes -> Hetero) hierarchy, without and with replicates (imputation.py:121-221)."""
+    import dgpsi.likelihood_class as RL
+    from dgpsi import Hetero
+    rng = np.random.default_rng(77)
+    out = {}
+    # (a) exact posterior draws
+    n = 15
+    X = rng.uniform(size=(n, 2))
+    k = kernel(length=np.array([0.6]), scale=1.7, nugget=1e-4, name='matern2.5')
+    k.input = X
+    v = k.scale * k.k_matrix()
+    Gamma = np.exp(rng.normal(size=n))
+    y = rng.normal(size=(n, 1))
+    log = DrawLog(8)
+    old = np.random.randn
+    np.random.randn = log.randn
+    try:
+        f1 = RL.Hetero.post_het1(v, Gamma, y)
+        counts = rng.integers(1, 4, size=n)
+        mask = np.repeat(np.arange(n), counts)
+        Gamma2 = np.exp(rng.normal(size=len(mask)))
+        y2 = rng.normal(size=(len(mask), 1))
+        f2 = RL.Hetero.post_het2(v, Gamma2, mask, y2)
+    finally:
+        np.random.randn = old
+    out.update(a_X=X, a_length=k.length.copy(), a_scale=k.scale.copy(), a_nugget=k.nugget.copy(), a_v=v, a_Gamma=Gamma, a_y=y,
+               a_z1=log.z[0].reshape(n, 2), a_f1=f1, a_mask=mask, a_Gamma2=Gamma2, a_y2=y2, a_z2=log.z[1].reshape(n, 2), a_f2=f2)
+    # (b) llik / prediction / pllik
+    h = Hetero()
+    h.input = rng.normal(size=(n, 2))
+    h.output = rng.normal(size=(n, 1))
+    m, vv = rng.normal(size=(9, 2)), rng.uniform(0.1, 1.0, size=(9, 2))
+    pm, pv = h.prediction(m, vv)
+    out.update(b_input=h.input, b_output=h.output, b_llik=np.array(h.llik()), b_m=m, b_v=vv, b_pm=pm, b_pv=pv,
+               )
+    # (c) sampler trajectories
+    for tag, rep in (('norep', False), ('rep', True)):
+        np.random.seed(31)
+        n = 16
+        X = rng.uniform(size=(n, 2))
+        if rep:
+            X = np.concatenate((X, X[:5], X[2:4]))
+        f = np.sin(4 * X[:, 0]) + X[:, 1]
+        Y = (f + np.exp(0.5 * (X[:, 0] - 1.0)) * rng.normal(size=len(X)))[:, None]
+        layers = combine([kernel(length=np.array([1.0]), name='matern2.5'), kernel(length=np.array([1.0]), name='sexp')],
+                         [Hetero()])
+        model = dgp(X, Y, layers)
+        logz, logh = DrawLog(9), DrawLog(10)
+        oldr, oldu, oldn = RF.randn, RI.uniform, np.random.randn
+        RI.fmvn.__globals__['randn'] = logz.randn
+        RI.uniform = logz.uniform
+        np.random.randn = logh.randn
+        try:
+            pre = dump_structure(model.all_layer[:1], 'c_%s_pre_' % tag)
+            pre.update(dump_lik(model.all_layer[1][0], 'c_%s_pre_lik_' % tag))
+            model.imp.sample(burnin=2)
+            post = dump_structure(model.all_layer[:1], 'c_%s_post_' % tag)
+            post.update(dump_lik(model.all_layer[1][0], 'c_%s_post_lik_' % tag))
+        finally:
+            RI.fmvn.__globals__['randn'] = oldr
+            RI.uniform = oldu
+            np.random.randn = oldn
+        out.update(pre)
+        out.update(post)
+        out['c_%s_z' % tag] = np.stack(logz.z) if logz.z else np.zeros((0, 1))
+        out['c_%s_u' % tag] = np.array(logz.u)
+        out['c_%s_zh' % tag] = np.stack([z.reshape(-1) for z in logh.z])
+        out['c_%s_X' % tag] = X
+        out['c_%s_Y' % tag] = Y
+        print('   hetero', tag, 'fmvn draws', len(logz.z), 'posterior draws', len(logh.z), 'uniforms', len(logz.u))
+    save('g13_hetero', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp']
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero']
     if 'kernel' in which:
         gen_kernel_cases()
     if 'fmvn' in which:
@@ -455,3 +541,5 @@ if __name__ == '__main__':
         gen_emulator()
     if 'lgp' in which:
         gen_lgp()
+    if 'hetero' in which:
+        gen_hetero()

@@ -18,6 +18,10 @@ def eng():
     return Engine(0)
 
 
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
 def close(a, b, rtol=1e-9, atol=1e-12):
     np.testing.assert_allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol)
 
@@ -302,3 +306,50 @@ def test_gp_class_predict_matches_reference(eng, golden):
     assert len(m2.export()) == 1
     smp = m2.predict(d['xt'], method='sampling', sample_size=7)
     assert smp.shape == (len(d['xt']), 7)
+
+
+def test_hetero_exact_posterior_draw(eng, golden):
+    """Engine.post_het (the device form of Hetero.post_het1 / post_het2) against the reference's draws (g13_hetero)."""
+    from oracle import dgp_oracle as O
+    from dgp_amd import Hetero
+    g = golden('g13_hetero')
+    v = g['a_v']
+    f1 = eng.post_het(eng.tensor(v), 1.0, eng.tensor(g['a_Gamma']), eng.tensor(g['a_y'].flatten()), eng.tensor(g['a_z1']))
+    close(npy(f1), g['a_f1'], rtol=1e-8, atol=1e-10)
+    h = Hetero()
+    h.rep = g['a_mask']
+    h.input = np.stack((np.zeros(len(g['a_mask'])), np.log(g['a_Gamma2'])), 1)
+    h.output = g['a_y2']
+    f2 = h.posterior(np.array([0]), v, sd=g['a_z2'], engine=eng)
+    close(f2, g['a_f2'], rtol=1e-8, atol=1e-10)
+    # the same through scale * K with the kernel matrix assembled on the device
+    K = eng.kmatrix('matern2.5', eng.tensor(g['a_X']), None, None, g['a_length'], g['a_nugget'][0])
+    f1b = eng.post_het(K, g['a_scale'][0], eng.tensor(g['a_Gamma']), eng.tensor(g['a_y'].flatten()), eng.tensor(g['a_z1']))
+    close(npy(f1b), g['a_f1'], rtol=1e-8, atol=1e-10)
+    close(h.llik(), O.hetero_llik(h.input, h.output), rtol=1e-13)
+
+
+@pytest.mark.parametrize('tag', ['norep', 'rep'])
+def test_hetero_sampler_matches_reference(eng, golden, tag):
+    """imputer.sample(burnin=2) of a (2 GP nodes -> Hetero) hierarchy with the reference's own draws: the mean latent
+    from its exact conditional posterior, the log-variance latent by ESS against the likelihood (imputation.py:121-221)."""
+    from dgp_amd import Hetero
+    from dgp_amd.imputation import imputer, DrawStream
+    g = golden('g13_hetero')
+    pre = 'c_%s_' % tag
+    layer1 = build_structure(g, pre + 'pre_', eng)[0]
+    lik = Hetero(input_dim=g[pre + 'pre_lik_input_dim'].copy())
+    lik.input, lik.output = g[pre + 'pre_lik_input'].copy(), g[pre + 'pre_lik_output'].copy()
+    lik.rep = g[pre + 'pre_lik_rep'].copy() if bool(g[pre + 'pre_lik_has_rep']) else None
+    z, zh = g[pre + 'z'], g[pre + 'zh']
+    zs = []
+    for i in range(len(zh)):     # per sweep: posterior normals of node 0, then the prior draw of node 1
+        zs.append(zh[i])
+        zs.append(z[i])
+    imp = imputer([layer1, [lik]], block=True, draws=DrawStream(z=zs, u=list(g[pre + 'u'])), engine=eng, batch=3)
+    imp.sample(burnin=2)
+    assert imp.draws.exhausted()
+    post = build_structure(g, pre + 'post_', eng)[0]
+    for a, b in zip(layer1, post):
+        close(a.output, b.output, rtol=1e-7, atol=1e-9)
+    close(lik.input, g[pre + 'post_lik_input'], rtol=1e-7, atol=1e-9)

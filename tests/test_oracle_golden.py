@@ -238,3 +238,14 @@ def test_emulator_predict(golden, tag):
             close(nd['scale'], pe[0])
             close(nd['length'], pe[1:-1])
             close(nd['nugget'], pe[-1])
+
+
+def test_hetero_pieces(golden):
+    """Hetero likelihood restatement against the reference's outputs (g13_hetero: likelihood_class.py:94-243)."""
+    g = golden('g13_hetero')
+    close(O.hetero_llik(g['b_input'], g['b_output']), float(g['b_llik']), rtol=1e-12)
+    pm, pv = O.hetero_prediction(g['b_m'], g['b_v'])
+    close(pm, g['b_pm'], rtol=1e-14)
+    close(pv, g['b_pv'], rtol=1e-14)
+    close(O.post_het1(g['a_v'], g['a_Gamma'], g['a_y'], g['a_z1']), g['a_f1'], rtol=1e-9, atol=1e-11)
+    close(O.post_het2(g['a_v'], g['a_Gamma2'], g['a_mask'], g['a_y2'], g['a_z2']), g['a_f2'], rtol=1e-9, atol=1e-11)
