@@ -54,11 +54,11 @@ class dgp:
                                 [ker(length=np.array([1.]), scale_est=True, connect=np.arange(D)) for _ in range(q)])
         self.all_layer = all_layer
         self.n_layer = len(all_layer)
-        for layer in all_layer:
+        for l, layer in enumerate(all_layer):
             for nd in layer:
-                if nd.type == 'likelihood' and nd.name in ('Categorical', 'Hetero', 'ZIP', 'ZINB', 'NegBin', 'Poisson'):
-                    raise NotImplementedError('likelihood-specific warm starts (dgp.py:163-564) are outside the '
-                                              'accelerated path; GP-only hierarchies are supported')
+                if nd.type == 'likelihood' and (nd.name != 'Hetero' or l != self.n_layer - 1):
+                    raise NotImplementedError('of the likelihood nodes only Hetero (final layer) is supported; the other '
+                                              'likelihood-specific warm starts (dgp.py:263-564) are outside the path')
         self.initialize()
         self.block = block
         self.draws = DrawStream(seed)
@@ -81,20 +81,71 @@ class dgp:
             return KernelPCA(n_components=num_kernel, kernel='sigmoid').fit_transform(In)
         return np.concatenate((In, In[:, np.random.choice(d, num_kernel - d)]), 1)
 
+    def _is_hetero_pair(self, l):
+        """Layer l feeds a lone Hetero likelihood with exactly two GP nodes (dgp.py:163)."""
+        return (l == self.n_layer - 2 and len(self.all_layer[l]) == 2 and len(self.all_layer[l + 1]) == 1
+                and getattr(self.all_layer[l + 1][0], 'name', None) == 'Hetero')
+
+    def _hetero_warm_start(self):
+        """Initial (mean, log-variance) latents under a Hetero likelihood (dgp.py:163-246).  Without replicates: a
+        reference-prior GP is fitted to y, its leave-one-out residuals give log-variance targets, a second GP fitted to
+        those is sampled (clipped to +-2.576 sd).  With replicates: site means and bias-corrected log sample
+        variances (singletons take the median variance)."""
+        from .gp import gp as single_gp
+        from scipy.special import psi
+        G, D = self.X.shape
+        y = self.Y.flatten()
+        Out = np.empty((G, 2))
+        if self.indices is None:
+            Out[:, 0] = y
+            fit = single_gp(self.X, y.reshape(-1, 1),
+                            ker(length=np.ones(D), name=self.all_layer[-2][0].name, scale_est=True, nugget_est=True,
+                                prior_name='ref', nugget=1e-2), vecchia=self.vecch, m=self.m, ord_fun=self.ord_fun)
+            fit.train()
+            m_mu = fit.loo()[0].flatten()
+            z = np.log(np.maximum((y - m_mu) ** 2, 1e-12) + 1e-12)
+            fit = single_gp(self.X, z.reshape(-1, 1),
+                            ker(length=np.ones(D), name=self.all_layer[-2][1].name, scale_est=True, nugget_est=True,
+                                prior_name='ref', nugget=1e-2), vecchia=self.vecch, m=self.m, ord_fun=self.ord_fun)
+            fit.train()
+            m_lv, v_lv = fit.loo()
+            m_lv = m_lv.flatten()
+            sd = np.sqrt(np.maximum((v_lv - fit.kernel.nugget * fit.kernel.scale).flatten(), 1e-12))
+            Out[:, 1] = np.clip(np.random.normal(loc=m_lv, scale=sd), m_lv - 2.576 * sd, m_lv + 2.576 * sd)
+        else:
+            counts = np.bincount(self.indices, minlength=G).astype(float)
+            s1 = np.bincount(self.indices, weights=y, minlength=G)
+            s2sum = np.bincount(self.indices, weights=y * y, minlength=G)
+            Out[:, 0] = s1 / counts
+            valid = counts > 1.0
+            s2 = np.full(G, np.nan)
+            s2[valid] = np.maximum((s2sum - s1 ** 2 / np.maximum(counts, 1.0))[valid] / (counts[valid] - 1.0), 0.0)
+            s2 = np.where(valid, s2, np.nanmedian(s2[valid]))
+            nu = (counts - 1.0) / 2.0
+            with np.errstate(divide='ignore', invalid='ignore'):
+                bias = np.where(valid, psi(nu) - np.log(np.maximum(nu, 1e-12)), 0.0)
+            Out[:, 1] = np.log(s2 + 1e-12) - bias
+        return Out
+
     def initialize(self):
-        """Assign input / global_input / output / D / para_path to every node (dgp.py:154-691, GP nodes)."""
+        """Assign input / global_input / output / D / para_path to every node (dgp.py:154-691; GP nodes and a Hetero
+        likelihood in the final layer)."""
         global_in = In = self.X
         for l, layer in enumerate(self.all_layer):
             last = l == self.n_layer - 1
-            Out = None if last else self._warm_start(In, len(layer))
+            Out = None if last else (self._hetero_warm_start() if self._is_hetero_pair(l) else self._warm_start(In, len(layer)))
             for k, nd in enumerate(layer):
                 if last and self.indices is not None:
                     nd.rep = self.indices
                 if nd.input_dim is None:
                     nd.input_dim = np.arange(In.shape[1])
-                    nd.input = copy.copy(In)
-                else:
-                    nd.input = In[:, nd.input_dim]
+                if nd.type == 'likelihood':
+                    if len(nd.input_dim) != 2:
+                        raise Exception('You need two and only two GP nodes to feed the ' + nd.name + ' likelihood node.')
+                    nd.input = In[nd.rep, :][:, nd.input_dim] if nd.rep is not None else In[:, nd.input_dim]
+                    nd.output = self.Y[:, [k]]
+                    continue
+                nd.input = In[:, nd.input_dim]
                 if nd.type == 'gp':
                     if nd.connect is not None:
                         if l == 0 and len(np.intersect1d(nd.connect, nd.input_dim)) != 0:
@@ -215,8 +266,11 @@ class dgp:
         In = self.X
         for l, layer in enumerate(self.all_layer):
             last = l == self.n_layer - 1
-            Out = None if last else self._warm_start(In, len(layer))
+            Out = None if last else (self._hetero_warm_start() if self._is_hetero_pair(l) else self._warm_start(In, len(layer)))
             for k, nd in enumerate(layer):
+                if nd.type == 'likelihood':
+                    nd.input = In[nd.rep, :][:, nd.input_dim] if nd.rep is not None else In[:, nd.input_dim]
+                    continue
                 nd.input = In[:, nd.input_dim]
                 if not last:
                     nd.output = Out[:, [k]].copy()

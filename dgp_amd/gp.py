@@ -102,3 +102,26 @@ class gp:
         raise Exception("method must be 'mean_var' or 'sampling'.")
 
     ppredict = predict
+
+    def loo(self, method='mean_var', sample_size=50, m=30):
+        """Leave-one-out predictions at the training inputs (gp.py:326-371).  Dense mode: the closed form on the
+        stored statistics, sigma2_i = scale / (R^-1)_ii, mu_i = y_i - (R^-1 y)_i / (R^-1)_ii."""
+        if self.vecch:
+            raise NotImplementedError('leave-one-out in Vecchia mode (vecchia.py:656-694) is not implemented')
+        k = self.kernel
+        st = k._stats
+        n = st['n']
+        import torch
+        d = torch.diagonal(st['Rinv'])[:n]
+        s2 = (1.0 / d).cpu().numpy().reshape(-1, 1)
+        mu = self.Y - k.Rinv_y[:, None] * s2
+        s2 = k.scale * s2
+        if self.indices is not None:
+            mu, s2 = mu[self.indices, :], s2[self.indices, :]
+        if method == 'mean_var':
+            return mu, s2
+        if method == 'sampling':
+            return np.random.normal(mu.flatten(), np.sqrt(s2.flatten()), size=(sample_size, len(mu))).T
+        raise Exception("method must be 'mean_var' or 'sampling'.")
+
+    ploo = loo

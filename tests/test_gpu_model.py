@@ -353,3 +353,30 @@ def test_hetero_sampler_matches_reference(eng, golden, tag):
     for a, b in zip(layer1, post):
         close(a.output, b.output, rtol=1e-7, atol=1e-9)
     close(lik.input, g[pre + 'post_lik_input'], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize('rep', [False, True])
+def test_hetero_dgp_end_to_end(eng, rep):
+    """A heteroskedastic DGP through the public API (dgp.py:163-246 warm start, node-wise sampler with the exact
+    posterior step, M-step over the two GP nodes): the learnt noise level must follow the truth."""
+    from dgp_amd import dgp, kernel, combine, Hetero
+    rng = np.random.default_rng(4)
+    np.random.seed(4)
+    x = np.sort(rng.uniform(size=45 if rep else 90))
+    if rep:
+        x = np.repeat(x, 2)
+    X = x[:, None]
+    sd = 0.05 + 0.5 * x ** 2
+    Y = (np.sin(6 * x) + sd * rng.normal(size=len(x)))[:, None]
+    layers = combine([kernel(length=np.array([0.5]), name='sexp', scale_est=True),
+                      kernel(length=np.array([0.5]), name='sexp', scale_est=True)], [Hetero()])   # as in the reference's demo
+    model = dgp(X, Y, layers, seed=2)
+    lik = model.all_layer[1][0]
+    assert (lik.rep is not None) == rep and lik.input.shape == (len(x), 2)
+    model.train(N=40, ess_burn=5, disable=True)
+    assert model.all_layer[0][0].para_path.shape[0] == 41 and np.all(np.isfinite(model.all_layer[0][1].para_path))
+    mean_lat, logvar_lat = model.all_layer[0][0].output[:, 0], model.all_layer[0][1].output[:, 0]
+    xs = model.X[:, 0]
+    assert np.sqrt(np.mean((mean_lat - np.sin(6 * xs)) ** 2)) < 0.25
+    lo, hi = xs < 0.3, xs > 0.75
+    assert np.mean(logvar_lat[hi]) > np.mean(logvar_lat[lo]) + 1.0      # noise grows with x (log-variance gap ~4)
