@@ -164,8 +164,13 @@ class emulator:
             mean = e.empty(S, M, K)
             var = e.empty(S, M, K)
             for k, nd in enumerate(layer):
-                if nd.type != 'gp':
-                    raise NotImplementedError('likelihood-node prediction is outside the accelerated path')
+                if nd.type != 'gp':   # likelihood node: closed-form moments of y from the feeding latents' (host protocol)
+                    pm, pv = (t.cpu().numpy() for t in per_layer[-1])
+                    for s in range(S):
+                        mk, vk = nd.prediction(m=pm[s][:, nd.input_dim], v=pv[s][:, nd.input_dim])
+                        mean[s, :, k] = e.tensor(mk)
+                        var[s, :, k] = e.tensor(vk)
+                    continue
                 st = self._stats[(l, k)]
                 z = None if nd.connect is None else xd[:, torch.as_tensor(nd.connect, device=xd.device)].contiguous()
                 if l == 0:
@@ -199,8 +204,12 @@ class emulator:
             for l, layer in enumerate(al):
                 mo, vo = np.empty((M, len(layer))), np.empty((M, len(layer)))
                 for k, nd in enumerate(layer):
-                    nd.engine = self.engine
-                    nd.pred_m = m
+                    if nd.type == 'gp':
+                        nd.engine = self.engine
+                        nd.pred_m = m
+                    if nd.type != 'gp':
+                        mo[:, k], vo[:, k] = nd.prediction(m=m_in[:, nd.input_dim], v=v_in[:, nd.input_dim])
+                        continue
                     z = None if nd.connect is None else x[:, nd.connect]
                     if l == 0:
                         mo[:, k], vo[:, k] = nd.gp_prediction(x[:, nd.input_dim], z)
@@ -249,13 +258,47 @@ class emulator:
         Returns, like the reference, a list over the final layer's nodes of (M x S*sample_size) arrays, or with
         full_layer a list over layers of such lists."""
         rng = self._sample_rng
-        out = []
-        for mean, var in (per_layer if full_layer else per_layer[-1:]):
+        lik = any(nd.type == 'likelihood' for nd in self.all_layer[-1])
+        out, prev = [], None
+        for li, (mean, var) in enumerate(per_layer):
+            last = li == len(per_layer) - 1
+            if not (full_layer or last or (lik and li == len(per_layer) - 2)):
+                continue
             S, M, K = mean.shape
-            sd = np.sqrt(var)
-            draws = rng.normal(np.repeat(mean, sample_size, axis=0), np.repeat(sd, sample_size, axis=0))   # (S*ss, M, K)
-            out.append(list(draws.transpose(2, 1, 0)))
+            mu_r, sd_r = np.repeat(mean, sample_size, axis=0), np.repeat(np.sqrt(var), sample_size, axis=0)
+            draws = rng.normal(mu_r, sd_r)                       # (S*ss, M, K)
+            if last and lik:   # likelihood nodes sample y from draws of their feeding latents (emulation.py:785-822)
+                for k, nd in enumerate(self.all_layer[-1]):
+                    if nd.type == 'likelihood':
+                        for j in range(draws.shape[0]):
+                            draws[j, :, k] = nd.sampling(prev[j][:, nd.input_dim])
+            prev = draws
+            if full_layer or last:
+                out.append(list(draws.transpose(2, 1, 0)))
         return out if full_layer else out[0]
+
+    def nllik(self, x, y, m=50):
+        """Negative predicted log-likelihood of test data under a DGP with ONE likelihood node on top
+        (emulation.py:856-914): per imputation the latents' moments at x, the likelihood integrated by
+        Gauss-Hermite quadrature (ghdiag), averaged over imputations.  Returns (mean, per-point values)."""
+        from .likelihood_class import ghdiag
+        if len(self.all_layer[-1]) != 1 or self.all_layer[-1][0].type != 'likelihood':
+            raise Exception('The method is only applicable to a DGP with the final layer formed by only ONE node, which '
+                            'must be a likelihood node.')
+        if self.shard:
+            raise NotImplementedError('nllik is evaluated on one rank (emulator(..., shard=False))')
+        X0, indices = np.unique(x, return_inverse=True, axis=0)
+        indices = np.asarray(indices).reshape(-1)
+        if len(X0) != len(x):
+            x = X0
+        if self.vecch:
+            per_layer = self._layer_moments_vecchia(x, m)
+        else:
+            per_layer = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in self._layer_moments(x)]
+        pm, pv = per_layer[-2]
+        lik = [ghdiag(self.all_layer[-1][0].pllik, pm[s][indices, :], pv[s][indices, :], y) for s in range(self.N)]
+        nl = -np.log(np.mean(lik, axis=0)).flatten()
+        return np.mean(nl), nl
 
     def _predict_vecchia(self, x, full_layer, m, aggregation, method='mean_var', sample_size=50):
         """Vecchia mode: no stored statistics; every node conditions on its pred_m nearest neighbours

@@ -4,7 +4,20 @@ input_dim, exact_post_idx, rep (likelihood_class.py:30-90) -- except for the one
 the exact conditional posterior draw of the heteroskedastic Gaussian likelihood's mean latent (two n x n
 factorisations per draw, likelihood_class.py:184-243), which runs on the device (Engine.post_het).
 """
+import itertools
+
 import numpy as np
+
+
+def ghdiag(fct, mu, var, y):
+    """E[exp(fct(y, f))] under f ~ N(mu, diag(var)) by the tensor-product 10-point Gauss-Hermite rule
+    (functions.ghdiag, functions.py:233-241).  mu, var: (M, N) latent moments per test point; returns (M, 1)."""
+    x, w = np.polynomial.hermite.hermgauss(10)
+    N = mu.shape[1]
+    nodes = np.array(list(itertools.product(*(x,) * N)))
+    weights = np.prod(np.array(list(itertools.product(*(w,) * N))), 1)[:, None] * np.pi ** (-0.5 * N)
+    fn = np.sqrt(2.0) * (np.sqrt(var[:, None]) * nodes) + mu[:, None]
+    return np.sum(np.exp(np.log(weights[None, :]) + fct(y[:, None], fn)), axis=1)
 
 
 class Hetero:

@@ -777,3 +777,23 @@ def post_het2(v, Gamma, mask, y, sd):
     u = L1 @ sd[:, 0]
     w = np.sqrt(iMGM) * sd[:, 1]
     return -v @ cho_solve(c, u + w, check_finite=False) + mu + u
+
+
+def hetero_pllik(y, f):
+    """Hetero.pllik (likelihood_class.py:115-121): pointwise Gaussian log-density with mean f[..., 0] and
+    log-variance f[..., 1]; y (M, 1, 1)-broadcastable, f (M, Q, 2) -> (M, Q, 1)."""
+    mu, var = f[:, :, [0]], np.exp(f[:, :, [1]])
+    return -0.5 * (np.log(2 * np.pi * var) + (y - mu) ** 2 / var)
+
+
+def ghdiag(fct, mu, var, y):
+    """functions.ghdiag (functions.py:233-241): E[exp(fct(y, f))] under f ~ N(mu, diag(var)) by the tensor-product
+    10-point Gauss-Hermite rule (mu, var: M x N latents per test point) -> (M, 1)."""
+    import itertools
+    x, w = np.polynomial.hermite.hermgauss(10)
+    N = mu.shape[1]
+    xn = np.array(list(itertools.product(*(x,) * N)))
+    wn = np.prod(np.array(list(itertools.product(*(w,) * N))), 1)[:, None]
+    fn = np.sqrt(2.0) * (np.sqrt(var[:, None]) * xn) + mu[:, None]
+    ll = fct(y[:, None], fn)
+    return np.sum(np.exp(np.log((wn * np.pi ** (-0.5 * N))[None, :]) + ll), axis=1)

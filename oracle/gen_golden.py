@@ -485,8 +485,9 @@ def gen_hetero():
     h.output = rng.normal(size=(n, 1))
     m, vv = rng.normal(size=(9, 2)), rng.uniform(0.1, 1.0, size=(9, 2))
     pm, pv = h.prediction(m, vv)
+    yq = rng.normal(size=(9, 1))
     out.update(b_input=h.input, b_output=h.output, b_llik=np.array(h.llik()), b_m=m, b_v=vv, b_pm=pm, b_pv=pv,
-               )
+               b_yq=yq, b_gh=RF.ghdiag(h.pllik, m, vv, yq))
     # (c) sampler trajectories
     for tag, rep in (('norep', False), ('rep', True)):
         np.random.seed(31)

@@ -380,3 +380,24 @@ def test_hetero_dgp_end_to_end(eng, rep):
     assert np.sqrt(np.mean((mean_lat - np.sin(6 * xs)) ** 2)) < 0.25
     lo, hi = xs < 0.3, xs > 0.75
     assert np.mean(logvar_lat[hi]) > np.mean(logvar_lat[lo]) + 1.0      # noise grows with x (log-variance gap ~4)
+    if not rep:
+        # emulator with the likelihood on top: predictive moments of y (Hetero.prediction), sampling, nllik
+        from dgp_amd import emulator
+        from dgp_amd.likelihood_class import ghdiag
+        from oracle import dgp_oracle as O
+        emu = emulator(model.estimate(), N=4, seed=5)
+        xt = np.linspace(0.05, 0.95, 19)[:, None]
+        mu, var = emu.predict(xt)
+        assert mu.shape == (19, 1) and np.sqrt(np.mean((mu[:, 0] - np.sin(6 * xt[:, 0])) ** 2)) < 0.3
+        assert var[xt[:, 0] > 0.75].mean() > 4 * var[xt[:, 0] < 0.3].mean()       # sd 0.33-0.5 against 0.05-0.1
+        mu_l, var_l = emu.predict(xt, full_layer=True)
+        assert len(mu_l) == 2 and mu_l[0].shape == (19, 2) and np.allclose(mu_l[1], mu)
+        smp = emu.predict(xt, method='sampling', sample_size=300)
+        assert len(smp) == 1 and smp[0].shape == (19, 1200)
+        assert np.all(np.abs(smp[0].mean(1) - mu[:, 0]) < 6 * np.sqrt(var[:, 0] / 1200) + 1e-3)
+        yt = (np.sin(6 * xt[:, 0]) + (0.05 + 0.5 * xt[:, 0] ** 2) * rng.normal(size=19))[:, None]
+        avg, per = emu.nllik(xt, yt)
+        assert per.shape == (19,) and np.isfinite(avg) and avg < 1.0
+        m_, v_ = rng.normal(size=(6, 2)), rng.uniform(0.1, 1.0, size=(6, 2))
+        y_ = rng.normal(size=(6, 1))
+        assert np.allclose(ghdiag(Hetero.pllik, m_, v_, y_), O.ghdiag(O.hetero_pllik, m_, v_, y_), rtol=1e-13)

@@ -247,5 +247,6 @@ def test_hetero_pieces(golden):
     pm, pv = O.hetero_prediction(g['b_m'], g['b_v'])
     close(pm, g['b_pm'], rtol=1e-14)
     close(pv, g['b_pv'], rtol=1e-14)
+    close(O.ghdiag(O.hetero_pllik, g['b_m'], g['b_v'], g['b_yq']), g['b_gh'], rtol=1e-12)
     close(O.post_het1(g['a_v'], g['a_Gamma'], g['a_y'], g['a_z1']), g['a_f1'], rtol=1e-9, atol=1e-11)
     close(O.post_het2(g['a_v'], g['a_Gamma2'], g['a_mask'], g['a_y2'], g['a_z2']), g['a_f2'], rtol=1e-9, atol=1e-11)
