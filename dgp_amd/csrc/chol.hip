@@ -403,7 +403,12 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
 // what potri (TRTRI + LAUUM) computes in ~13 more latency-bound launches becomes bulk work in the shadow of the
 // pivot chain.  T tiles follow the same lazy rule as A's; S tile (q, q') is visited by the launches
 // k = q+2, q+4, ... (two panels each) and by two tail launches.
-// Deadlock freedom: only SOLVE / TDIAG workgroups wait, and only for the chain workgroup of the SAME launch, which
+// CU guard: with two workgroups per CU, workgroups i and i + 256 of a launch share a CU (measured, tools/ubench/
+// hwid.hip).  The pivot chain is issue- and LDS-bound and a bulk workgroup beside it slows it by ~40 %, so workgroups
+// 256 .. 256+batch-1 are placeholders that sleep until "their" chain has published its block (potrf_inv at B = 3:
+// 1.21 -> 1.00 ms).  They hold no task, check through HW_ID / XCC_ID that they really are on the chain's CU, and
+// leave at once otherwise.
+// Deadlock freedom: only SOLVE / TDIAG workgroups and the placeholders wait, and only for the chain workgroup of the SAME launch, which
 // has a lower block index (dispatched first) and never waits itself.  The spin is bounded (info = -1).
 // ----------------------------------------------------------------------------
 enum { T_STORE = 0, T_SOLVE = 1, T_CHAIN = 2, T_TDIAG = 3 };
@@ -415,6 +420,7 @@ struct StepArgs {
     int64_t ld, stride_a, stride_ws, n;
     int nbk, k, batch;
     const int4 *tasks;   // this launch's tasks
+    int guard;           // 1: workgroups 256 .. 256+batch-1 are placeholders that keep the chain workgroups' CUs to themselves
     double *logdet;
     int32_t *info;
     int32_t *flags;
@@ -537,6 +543,14 @@ __device__ __forceinline__ void wg_wait_acquire(int32_t *flag, int target, int32
     __syncthreads();
 }
 
+// The CU this workgroup runs on: XCC_ID[2:0] and HW_ID[15:8] (SE / SH / CU ids) -- measured on MI355X
+// (tools/ubench/hwid.hip): 256 distinct keys, and workgroups i and i + 256 of a launch share one.
+__device__ __forceinline__ int cu_key() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    return (int)(((xcc & 7u) << 8) | ((hw >> 8) & 0xffu)) + 1;
+}
+
 __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     __shared__ double tiles[2 * 64 * LDM];   // As | Bs
     __shared__ DiagShared sh;
@@ -544,8 +558,32 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
     const int k = g.k, batch = g.batch;
-    const int b = blockIdx.x % batch;
-    const int4 tk = g.tasks[blockIdx.x / batch];
+    int32_t *cukey = g.flags + DGPAMD_MAXB;   // per matrix: (launch + 1) << 16 | CU key of its chain workgroup
+    int bidx = blockIdx.x;
+    if (g.guard && bidx >= 256) {
+        // The pivot chain is issue- and LDS-bound: a bulk workgroup on the same CU slows it by ~40 % (measured).  With two
+        // workgroups per CU, workgroup 256 + b lands beside chain workgroup b: it is a placeholder that sleeps until
+        // that chain has published its block, so the slot is taken and the chain has the CU to itself.  (If the
+        // hardware placed it elsewhere it leaves at once.)
+        if (bidx < 256 + batch) {
+            if (tid == 0) {
+                const int c = bidx - 256, tag = (k + 1) << 16;
+                int key = 0, spins = 0;
+                while (((key = __hip_atomic_load(&cukey[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 16) != k + 1 &&
+                       ++spins < 64)
+                    __builtin_amdgcn_s_sleep(2);
+                if (key == (tag | cu_key())) {
+                    spins = 0;
+                    while (__hip_atomic_load(&g.flags[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 1 && ++spins < (1 << 20))
+                        __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            return;
+        }
+        bidx -= batch;
+    }
+    const int b = bidx % batch;
+    const int4 tk = g.tasks[bidx / batch];
     const int post = tk.x & 15, first = (tk.x >> 4) & 1, plus = (tk.x >> 5) & 1, mask_last = (tk.x >> 6) & 1;
     const int bufC = (tk.x >> 8) & 3, bufL = (tk.x >> 10) & 3, bufR = (tk.x >> 12) & 3;
     const int ci = tk.y & 0xffff, cj = tk.y >> 16, li = tk.z & 0xffff, ri = tk.z >> 16;
@@ -570,7 +608,9 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     Tile64 acc;
     if (post == T_CHAIN) {
         STAMP(0);
-        __builtin_amdgcn_s_setprio(3);   // the chain shares its CU with a bulk workgroup
+        __builtin_amdgcn_s_setprio(3);
+        if (g.guard && tid == 0)
+            __hip_atomic_store(&cukey[b], ((k + 1) << 16) | cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     tile_update(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
                 g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
@@ -668,7 +708,7 @@ size_t potrf_ws_doubles(int64_t n, int batch) {
 }
 
 extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
-    return potrf_ws_doubles(n, batch) * sizeof(double) + 2 * DGPAMD_MAXB * sizeof(int32_t);   // + info, step flags
+    return potrf_ws_doubles(n, batch) * sizeof(double) + 3 * DGPAMD_MAXB * sizeof(int32_t);   // + info, step flags, chain CU keys
 }
 
 // Task tables (see potrf_step_kernel): one vector of tasks per launch, cached on the device per (nbk, inverse).
@@ -755,7 +795,7 @@ static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *T, doub
     const int64_t Np = padded_dim(n);
     const int nbk = (int)(Np / 64);
     const double tile_flops = 2.0 * 64.0 * 64.0 * 64.0;
-    HIP_TRY(ctx, hipMemsetAsync(flags, 0, DGPAMD_MAXB * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(flags, 0, 2 * DGPAMD_MAXB * sizeof(int32_t), ctx->stream));
     StepArgs st;
     st.buf[BUF_A] = A; st.buf[BUF_T] = T; st.buf[BUF_S] = S;
     st.ws = ws; st.ld = Np; st.stride_a = stride_a; st.stride_ws = (int64_t)nbk * 4096; st.n = n; st.nbk = nbk;
@@ -764,8 +804,10 @@ static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *T, doub
         if (tt->count[k] == 0) continue;
         st.k = (int)k;
         st.tasks = tt->dev + tt->offset[k];
+        const int64_t nwg = (int64_t)batch * tt->count[k];
+        st.guard = (k < (size_t)nbk && nwg > 256) ? 1 : 0;   // (tail launches have no chain; small launches no neighbours)
         PROF_BEGIN(ctx, PROF_SYRK, (double)batch * tt->tile_ops[k] * tile_flops);
-        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(batch * tt->count[k])), dim3(256), 0, ctx->stream, st);
+        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(nwg + (st.guard ? batch : 0))), dim3(256), 0, ctx->stream, st);
         PROF_END(ctx, PROF_SYRK);
     }
     if (T)

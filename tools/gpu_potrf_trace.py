@@ -16,13 +16,17 @@ G = eng.tensor(rng.uniform(size=(n, 5)))
 y = eng.tensor(rng.normal(size=n))
 A = eng.empty(B, Np, Np)
 work = eng.potrf_workspace(n, B)
+T, S = eng.empty(B, Np, Np), eng.empty(B, Np, Np)
 tr = torch.zeros(4096, dtype=torch.int64, device=A.device)
 for rep in range(3):
     eng.kmatrix('matern2.5', X, None, G, [1.0], 1e-6, out=A, full=False, Y=y, batch=B)
     if rep == 2:
         lib.dgpamd_debug_trace(eng.h, C.c_void_p(tr.data_ptr()))
         eng.set_graphs(False)
-    eng.potrf(n, A, batch=B, work=work)
+    if os.environ.get('INV'):
+        eng.potrf_inv(n, A, T, S, batch=B, work=work)
+    else:
+        eng.potrf(n, A, batch=B, work=work)
 torch.cuda.synchronize()
 lib.dgpamd_debug_trace(eng.h, None)
 t = tr.cpu().numpy().reshape(-1, 16).astype(np.float64) / 100.0   # us
