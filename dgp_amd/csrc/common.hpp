@@ -30,6 +30,8 @@ struct dgpamd_ctx {
     int linkgp_direct;                                // 1: evaluate the Matern J factor in the reference's direct form
     long long *trace;                                 // device buffer for in-kernel timestamps (diagnostics), or null
     double *pinned;                                   // small pinned staging buffer for result copies (lazy)
+    char *devargs, *hostargs;                         // argument arrays of the multi-node launches (device / pinned host)
+    size_t devargs_bytes;
     size_t pinned_bytes;
     std::map<std::array<uint64_t, 10>, hipGraphExec_t> graphs;
 };
@@ -178,6 +180,7 @@ struct KmatArgs {
     int r;
 };
 int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch);
+int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatArgs *host_args, int count);   // same n / mode
 int build_kmat_args(dgpamd_ctx *ctx, KmatArgs &a, int kind, int64_t n, const double *Xloc, int64_t ldloc,
                     int64_t stride_loc, const int32_t *colmap_h, int Dl, const double *Xglob, int Dg,
                     const double *length_h, int nlen, double nugget, const double *W, double *K, int64_t ldk,
@@ -186,4 +189,5 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
               double *ws, double *T = nullptr, double *S = nullptr);   // T, S: fused inverse (dgpamd_potrf_inv)
 size_t potrf_ws_doubles(int64_t n, int batch);
 int ensure_pinned(dgpamd_ctx *ctx, size_t bytes);   // grow the context's pinned staging buffer
+int ensure_devargs(dgpamd_ctx *ctx, size_t bytes);  // grow the device / pinned argument arrays
 

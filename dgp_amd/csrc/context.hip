@@ -25,6 +25,8 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->trace = nullptr;
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;
+    ctx->devargs = ctx->hostargs = nullptr;
+    ctx->devargs_bytes = 0;
     // NULL = the device's default (null) stream, which is also torch's default current stream
     ctx->stream = (hipStream_t)stream;
     ctx->own_stream = false;
@@ -37,6 +39,8 @@ extern "C" int dgpamd_destroy(dgpamd_ctx *ctx) {
     for (auto &kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->devargs) (void)hipFree(ctx->devargs);
+    if (ctx->hostargs) (void)hipHostFree(ctx->hostargs);
     delete ctx;
     return DGPAMD_OK;
 }
@@ -57,6 +61,20 @@ int ensure_pinned(dgpamd_ctx *ctx, size_t bytes) {
     const size_t want = bytes < 65536 ? 65536 : bytes;
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->pinned, want, hipHostMallocDefault));
     ctx->pinned_bytes = want;
+    return DGPAMD_OK;
+}
+
+int ensure_devargs(dgpamd_ctx *ctx, size_t bytes) {
+    if (ctx->devargs_bytes >= bytes) return DGPAMD_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing may still read the old arrays
+    if (ctx->devargs) (void)hipFree(ctx->devargs);
+    if (ctx->hostargs) (void)hipHostFree(ctx->hostargs);
+    ctx->devargs = ctx->hostargs = nullptr;
+    ctx->devargs_bytes = 0;
+    const size_t want = bytes < 65536 ? 65536 : bytes;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->devargs, want));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->hostargs, want, hipHostMallocDefault));
+    ctx->devargs_bytes = want;
     return DGPAMD_OK;
 }
 

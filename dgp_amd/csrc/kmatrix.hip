@@ -8,10 +8,11 @@
 // (rows ty+16a, cols tx+16b) so that every store instruction of a wave writes
 // four full 128-byte lines.  The kernel is f64-VALU + HBM-write bound.
 #include "common.hpp"
+#include <algorithm>
 
 
 template <int KIND>
-__global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
+__device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     extern __shared__ double lds[];
     const int D = a.kp.Dl + a.kp.Dg;
     double *XiT = lds;            // [D][64]
@@ -19,7 +20,6 @@ __global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
     double *TT = lds + 2 * D * 64;   // [64][65] transposition buffer for the mirrored tile (full mode only)
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
-    const int b = blockIdx.z;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64;
@@ -143,6 +143,35 @@ __global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
                 if (interior || i0 + tx + 16 * q < a.n) row[16 * q] = TT[(tx + 16 * q) * 65 + ty + 16 * p];
         }
     }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
+    kmatrix_body<KIND>(a, blockIdx.z);
+}
+
+// Several nodes in one launch (grid.z = node): every node brings its own inputs, kernel family and hyper-parameters,
+// read from an argument array in device memory (uniform addresses: scalar loads).
+__global__ __launch_bounds__(256) void kmatrix_multi_kernel(const KmatArgs *args) {
+    const KmatArgs &a = args[blockIdx.z];
+    if (a.kp.kind == DGPAMD_SEXP)
+        kmatrix_body<DGPAMD_SEXP>(a, 0);
+    else
+        kmatrix_body<DGPAMD_MATERN25>(a, 0);
+}
+
+int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatArgs *host_args, int count) {
+    int Dmax = 0, full = 0;
+    for (int c = 0; c < count; ++c) {
+        Dmax = std::max(Dmax, host_args[c].kp.Dl + host_args[c].kp.Dg);
+        full |= host_args[c].full;
+    }
+    int64_t rows = host_args[0].full ? host_args[0].n : padded_dim(host_args[0].n);
+    int nbk = (int)((rows + 63) / 64);
+    size_t shm = ((size_t)2 * Dmax * 64 + (full ? 64 * 65 : 0)) * sizeof(double);
+    hipLaunchKernelGGL(kmatrix_multi_kernel, dim3(nbk * (nbk + 1) / 2, 1, count), dim3(256), shm, ctx->stream, dev_args);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
 }
 
 int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch) {

@@ -110,7 +110,7 @@ __device__ __forceinline__ double dcoef(double df) {
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs a) {
+__device__ __forceinline__ void grad_reduce_body(const GradArgs &a) {
     extern __shared__ double lds[];
     const int D = a.kp.Dl + a.kp.Dg;
     double *XiT = lds, *XjT = lds + D * 64;
@@ -257,6 +257,24 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs a) {
     if (tid < P2) a.partial[(int64_t)blockIdx.x * P2 + tid] = red[tid] + red[P2 + tid] + red[2 * P2 + tid] + red[3 * P2 + tid];
 }
 
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs a) {
+    grad_reduce_body<KIND>(a);
+}
+
+// Several nodes in one launch (grid.z = node), arguments from a device array; `out` of node c follows its GradArgs.
+struct GradMulti {
+    GradArgs a;
+    double *out;
+};
+__global__ __launch_bounds__(256) void grad_reduce_multi_kernel(const GradMulti *args) {
+    const GradArgs &a = args[blockIdx.z].a;
+    if (a.kp.kind == DGPAMD_SEXP)
+        grad_reduce_body<DGPAMD_SEXP>(a);
+    else
+        grad_reduce_body<DGPAMD_MATERN25>(a);
+}
+
 __global__ __launch_bounds__(256) void grad_final_kernel(const double *partial, int ntiles, int P2, double *out) {
     __shared__ double sm[4];
     const int idx = blockIdx.x, tid = threadIdx.x;
@@ -266,6 +284,19 @@ __global__ __launch_bounds__(256) void grad_final_kernel(const double *partial, 
     if ((tid & 63) == 0) sm[tid >> 6] = v;
     __syncthreads();
     if (tid == 0) out[idx] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void grad_final_multi_kernel(const GradMulti *args, int ntiles) {
+    __shared__ double sm[4];
+    const GradMulti &g = args[blockIdx.y];
+    const int idx = blockIdx.x, tid = threadIdx.x, P2 = 2 * g.a.P;
+    if (idx >= P2) return;
+    double v = 0.0;
+    for (int t = tid; t < ntiles; t += 256) v += g.a.partial[(int64_t)t * P2 + idx];
+    v = wave_sum(v);
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) g.out[idx] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
 extern "C" size_t dgpamd_grad_workspace(int64_t n, int nparam) {
@@ -323,26 +354,54 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     const int64_t Np = padded_dim(n);
     if (n + 1 > Np) BAD_ARG(ctx, "no room for the augmented row");
     if (batch > 1 && stride_a < Np * Np) BAD_ARG(ctx, "stride_a < Np*Np");
+    // argument arrays of the two multi-node launches: [KmatArgs x batch | GradMulti x batch], staged in pinned memory
+    const size_t need = (size_t)batch * (sizeof(KmatArgs) + sizeof(GradMulti));
+    int rc = ensure_devargs(ctx, need);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the previous call's argument copy has been consumed
+    KmatArgs *ka = reinterpret_cast<KmatArgs *>(ctx->hostargs);
+    GradMulti *ga = reinterpret_cast<GradMulti *>(ctx->hostargs + (size_t)batch * sizeof(KmatArgs));
+    const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
+    int Pmax = 0, Dmax = 0;
     for (int b = 0; b < batch; ++b) {
         const dgpamd_node &nd = nodes[b];
-        const int P = (nd.nlen == 1 ? 1 : nd.Dl + nd.Dg) + (nd.nugget_est ? 1 : 0);
+        const int D = nd.Dl + nd.Dg;
+        const int P = (nd.nlen == 1 ? 1 : D) + (nd.nugget_est ? 1 : 0);
         if (3 + 2 * P > stride_out) BAD_ARG(ctx, "stride_out too small");
-        int rc = dgpamd_kmatrix(ctx, nd.kind, n, nd.Xloc, nd.ldloc, 0, nd.colmap, nd.Dl, nd.Xglob, nd.Dg, nd.length, nd.nlen,
-                                nd.nugget, nd.W, A + (int64_t)b * stride_a, Np, 0, 0, nd.y, n, 0, 1, 1);
+        Pmax = P > Pmax ? P : Pmax;
+        Dmax = D > Dmax ? D : Dmax;
+        rc = build_kmat_args(ctx, ka[b], nd.kind, n, nd.Xloc, nd.ldloc, 0, (const int32_t *)nd.colmap, nd.Dl, nd.Xglob, nd.Dg,
+                             nd.length, nd.nlen, nd.nugget, nd.W, A + (int64_t)b * stride_a, Np, 0, 0, nd.y, n, 0, 1, 1);
         if (rc) return rc;
     }
+    const size_t gw = dgpamd_grad_workspace(n, Pmax);   // per node (the caller provides batch of them)
+    for (int b = 0; b < batch; ++b) {
+        const dgpamd_node &nd = nodes[b];
+        GradArgs &g = ga[b].a;
+        g.kp = ka[b].kp;
+        g.n = n; g.Xloc = nd.Xloc; g.ldloc = nd.ldloc; g.Xglob = nd.Xglob; g.W = nd.W;
+        g.Ainv = Ainv + (int64_t)b * stride_a; g.ld = Np;
+        g.shared_len = (nd.nlen == 1); g.nugget_est = nd.nugget_est ? 1 : 0;
+        g.P = (nd.nlen == 1 ? 1 : nd.Dl + nd.Dg) + g.nugget_est;
+        g.partial = reinterpret_cast<double *>(reinterpret_cast<char *>(grad_work) + (size_t)b * gw);
+        ga[b].out = dev_out + b * stride_out + 3;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->devargs, ctx->hostargs, need, hipMemcpyHostToDevice, ctx->stream));
+    const KmatArgs *kd = reinterpret_cast<const KmatArgs *>(ctx->devargs);
+    const GradMulti *gd = reinterpret_cast<const GradMulti *>(ctx->devargs + (size_t)batch * sizeof(KmatArgs));
+    rc = launch_kmatrix_multi(ctx, kd, ka, batch);
+    if (rc) return rc;
     double *logdet = dev_out + (int64_t)batch * stride_out;
     int32_t *info = reinterpret_cast<int32_t *>(logdet + batch);
-    int rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, T, Ainv);   // factor + inverse, one sweep
+    rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, T, Ainv);   // factor + inverse, one sweep
     if (rc) return rc;
     hipLaunchKernelGGL(llik_pack_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)logdet,
                        (const int32_t *)info, (const double *)A, Np, stride_a, n, dev_out, stride_out, batch);
-    for (int b = 0; b < batch; ++b) {
-        const dgpamd_node &nd = nodes[b];
-        rc = dgpamd_grad_reduce(ctx, nd.kind, n, nd.Xloc, nd.ldloc, nd.colmap, nd.Dl, nd.Xglob, nd.Dg, nd.length, nd.nlen,
-                                nd.nugget, nd.W, nd.nugget_est, Ainv + (int64_t)b * stride_a, dev_out + b * stride_out + 3,
-                                grad_work);
-        if (rc) return rc;
+    {
+        const size_t shm = ((size_t)2 * Dmax * 64 + 4 * 2 * Pmax) * sizeof(double);
+        hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(ntiles, 1, batch), dim3(256), shm, ctx->stream, gd);
+        hipLaunchKernelGGL(grad_final_multi_kernel, dim3(2 * Pmax, batch), dim3(256), 0, ctx->stream, gd, ntiles);
+        LAUNCH_CHECK(ctx);
     }
     const size_t bytes = (size_t)batch * stride_out * sizeof(double);
     rc = ensure_pinned(ctx, bytes);

@@ -466,7 +466,7 @@ class _LlikPlan:
         self.Ainv = eng.workspace(('mstepAinv', n), B * Np * Np * 8)
         self.T = eng.workspace(('mstepT', n), B * Np * Np * 8)
         self.work = eng.potrf_workspace(n, B)
-        self.gwork = eng.workspace(('grad', n, max(self.P)), lib.dgpamd_grad_workspace(n, max(self.P)))
+        self.gwork = eng.workspace(('gradB', n, max(self.P), B), B * lib.dgpamd_grad_workspace(n, max(self.P)))
         self.dev_out = eng.empty(B * (self.stride_out + 2))
         self.host = np.zeros((B, self.stride_out))
         self.stride_a = Np * Np

@@ -221,7 +221,8 @@ int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n,
  * per-node derivative reductions, ONE device-to-host copy.  The call returns after the results have landed:
  *   host_out[b * stride_out + ...] = { logdet K_b, y' K_b^-1 y, info (0 = PD), tr_p (P_b values), quad_p (P_b values) }
  * with P_b as in dgpamd_grad_reduce; stride_out >= 3 + 2 max P_b.  A, T, Ainv: batch x Np x Np buffers (stride
- * stride_a; see dgpamd_potrf_inv); work: dgpamd_potrf_workspace(n, batch); grad_work: dgpamd_grad_workspace(n, max P_b);
+ * stride_a; see dgpamd_potrf_inv); work: dgpamd_potrf_workspace(n, batch); grad_work: batch x dgpamd_grad_workspace(n, max P_b)
+ * (the nodes' reductions run side by side in one launch, like their K assemblies);
  * dev_out: device scratch of batch * (stride_out + 2) doubles. */
 int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T, double *Ainv,
                       int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
