@@ -330,7 +330,7 @@ class emulator:
 
     def metric(self, x_cand, method='ALM', obj=None, nugget_s=1., m=50, score_only=False):
         """Sequential-design criterion at the rows of x_cand (emulation.py:323-420).  ALM (the predictive variance)
-        and MICE are computed on the accelerated path; VIGF is not implemented."""
+        MICE and VIGF (GP hierarchies) are computed from the device layer walk."""
         if x_cand.ndim == 1:
             raise Exception('The candidate design set has to be a numpy 2d-array.')
         if method == 'ALM':
@@ -339,10 +339,12 @@ class emulator:
                 return sigma2
             idx = np.argmax(sigma2, axis=0)
             return idx, sigma2[idx, np.arange(sigma2.shape[1])]
-        if method != 'MICE':
-            raise NotImplementedError("method='VIGF' (emulation.py:396-420) is not implemented")
+        if method not in ('MICE', 'VIGF'):
+            raise Exception("method must be 'ALM', 'MICE' or 'VIGF'.")
         if self.shard:
-            raise NotImplementedError('MICE is evaluated on one rank (emulator(..., shard=False))')
+            raise NotImplementedError('MICE / VIGF are evaluated on one rank (emulator(..., shard=False))')
+        if method == 'VIGF':
+            return self._vigf(x_cand, obj, m, score_only)
         # MICE (emulation.py:377-394): mean over imputations of log(predictive variance / smoothed variance of a GP whose
         # design is the candidate set itself, functions.mice_var :244-256)
         if self.vecch:
@@ -364,6 +366,39 @@ class emulator:
             return avg
         idx = np.argmax(avg, axis=0)
         return idx, avg[idx, np.arange(avg.shape[1])]
+
+    def _vigf(self, x_cand, obj, m, score_only):
+        """VIGF criterion (emulation.py:396-420, predict_vigf :526-576) for GP hierarchies: with b the squared
+        difference between the imputation's predictive mean and the output at the nearest training input, and s2 its
+        predictive variance, E[b^2 + 6 b s2 + 3 s2^2] - (E[b + s2])^2 over the imputations."""
+        if obj is None:
+            raise Exception('The dgp object that is used to build the emulator must be supplied to the argument `obj` '
+                            'when VIGF criterion is chosen.')
+        if obj.indices is not None:
+            raise Exception('VIGF criterion is currently not applicable to DGP emulators whose training data contain '
+                            'replicates but without a likelihood node.')
+        if any(nd.type != 'gp' for nd in self.all_layer[-1]):
+            raise NotImplementedError('VIGF with a likelihood layer (predict_vigf_2layer_likelihood) is not implemented')
+        X = obj.X
+        e = self.engine
+        if len(x_cand) * len(X) <= 20_000_000:
+            d2 = (x_cand ** 2).sum(1)[:, None] - 2.0 * x_cand @ X.T + (X ** 2).sum(1)[None, :]
+            index = np.argmin(d2, axis=1)
+        else:
+            index = e.nn_query(e.tensor(x_cand), e.tensor(X), 1).cpu().numpy().reshape(-1)
+        if self.vecch:
+            mean, var = self._layer_moments_vecchia(x_cand, m)[-1]
+        else:
+            mean, var = (t.cpu().numpy() for t in self._layer_moments(x_cand)[-1])
+        Ytr = np.stack([np.asarray(nd.output, float).reshape(-1)[index] for nd in self.all_layer[-1]], 1)   # (M, D)
+        bias = (mean - Ytr[None]) ** 2
+        E1 = np.mean(bias ** 2 + 6 * bias * var + 3 * var ** 2, axis=0)
+        E2 = np.mean(bias + var, axis=0)
+        vigf = E1 - E2 ** 2
+        if score_only:
+            return vigf
+        idx = np.argmax(vigf, axis=0)
+        return idx, vigf[idx, np.arange(vigf.shape[1])]
 
     def _mice_var(self, x, x_extra, nd, nugget_s):
         """functions.mice_var (functions.py:244-256) on the device: scale / diag(R^-1) of the correlation matrix of

@@ -202,6 +202,12 @@ def test_matern_2layer_train_predict_small(eng):
         ref += np.log(pl[-1][1][i] / O.mice_var(pl[-2][0][i], xc, nd.input_dim, nd.connect, nd.name, nd.length, nd.scale,
                                                  nd.nugget[0], 1.0))
     assert np.allclose(score, ref / emu.N, rtol=1e-8, atol=1e-10)
+    # VIGF (emulation.py:396-420) from the same per-imputation moments
+    vig = emu.metric(xc, method='VIGF', obj=model, score_only=True)
+    nearest = np.argmin(((xc[:, None, :] - model.X[None]) ** 2).sum(-1), 1)
+    b = (pl[-1][0] - model.all_layer[-1][0].output[nearest][None, :, :]) ** 2
+    ref_v = np.mean(b ** 2 + 6 * b * pl[-1][1] + 3 * pl[-1][1] ** 2, 0) - np.mean(b + pl[-1][1], 0) ** 2
+    assert vig.shape == (40, 1) and np.allclose(vig, ref_v, rtol=1e-10, atol=1e-14)
     idx2, best2 = emu.metric(xc, method='MICE')
     assert idx2[0] == int(np.argmax(score[:, 0])) and best2[0] == score[:, 0].max()
     full = emu.predict(X[:10], method='sampling', sample_size=5, full_layer=True)
