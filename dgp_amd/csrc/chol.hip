@@ -420,7 +420,8 @@ struct StepArgs {
     int64_t ld, stride_a, stride_ws, n;
     int nbk, k, batch;
     const int4 *tasks;   // this launch's tasks
-    int guard;           // 1: workgroups 256 .. 256+batch-1 are placeholders that keep the chain workgroups' CUs to themselves
+    int guard;           // > 0: workgroups guard .. guard+batch-1 (guard = number of CUs) are placeholders that keep the
+                         // chain workgroups' CUs to themselves
     double *logdet;
     int32_t *info;
     int32_t *flags;
@@ -560,14 +561,14 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     const int k = g.k, batch = g.batch;
     int32_t *cukey = g.flags + DGPAMD_MAXB;   // per matrix: (launch + 1) << 16 | CU key of its chain workgroup
     int bidx = blockIdx.x;
-    if (g.guard && bidx >= 256) {
+    if (g.guard && bidx >= g.guard) {
         // The pivot chain is issue- and LDS-bound: a bulk workgroup on the same CU slows it by ~40 % (measured).  With two
-        // workgroups per CU, workgroup 256 + b lands beside chain workgroup b: it is a placeholder that sleeps until
+        // workgroups per CU, workgroup (number of CUs) + b lands beside chain workgroup b: it is a placeholder that sleeps until
         // that chain has published its block, so the slot is taken and the chain has the CU to itself.  (If the
         // hardware placed it elsewhere it leaves at once.)
-        if (bidx < 256 + batch) {
+        if (bidx < g.guard + batch) {
             if (tid == 0) {
-                const int c = bidx - 256, tag = (k + 1) << 16;
+                const int c = bidx - g.guard, tag = (k + 1) << 16;
                 int key = 0, spins = 0;
                 while (((key = __hip_atomic_load(&cukey[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 16) != k + 1 &&
                        ++spins < 64)
@@ -805,7 +806,7 @@ static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *T, doub
         st.k = (int)k;
         st.tasks = tt->dev + tt->offset[k];
         const int64_t nwg = (int64_t)batch * tt->count[k];
-        st.guard = (k < (size_t)nbk && nwg > 256) ? 1 : 0;   // (tail launches have no chain; small launches no neighbours)
+        st.guard = (k < (size_t)nbk && nwg > ctx->num_cu) ? ctx->num_cu : 0;   // (tail launches: no chain; small ones: no neighbours)
         PROF_BEGIN(ctx, PROF_SYRK, (double)batch * tt->tile_ops[k] * tile_flops);
         hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(nwg + (st.guard ? batch : 0))), dim3(256), 0, ctx->stream, st);
         PROF_END(ctx, PROF_SYRK);

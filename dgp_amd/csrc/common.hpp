@@ -20,6 +20,7 @@ enum { PROF_NONE = 0, PROF_KMATRIX = 1, PROF_POTRF_DIAG = 2, PROF_TRSM = 3, PROF
 
 struct dgpamd_ctx {
     int device;
+    int num_cu;                                       // compute units of the device (workgroups i and i + num_cu share one)
     hipStream_t stream;
     bool own_stream;
     char err[512];

@@ -23,6 +23,11 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->use_graphs = 1;
     ctx->linkgp_direct = 0;
     ctx->trace = nullptr;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+        ctx->num_cu = ncu;
+    }
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;
     ctx->devargs = ctx->hostargs = nullptr;
