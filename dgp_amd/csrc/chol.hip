@@ -420,6 +420,8 @@ struct StepArgs {
     int64_t ld, stride_a, stride_ws, n;
     int nbk, k, batch;
     const int4 *tasks;   // this launch's tasks
+    int nhead, npanel, lead;   // task order in the table: head (chain, tdiag), panel (solve), bulk; the panel workgroups
+                               // are dispatched after the first `lead` bulk tasks (they only wait: no slot hogging)
     int guard;           // > 0: workgroups guard .. guard+batch-1 (guard = number of CUs) are placeholders that keep the
                          // chain workgroups' CUs to themselves
     double *logdet;
@@ -584,7 +586,12 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
         bidx -= batch;
     }
     const int b = bidx % batch;
-    const int4 tk = g.tasks[bidx / batch];
+    int slot = bidx / batch;
+    if (slot >= g.nhead) {
+        if (slot < g.nhead + g.lead) slot += g.npanel;                      // one of the first bulk tasks
+        else if (slot < g.nhead + g.lead + g.npanel) slot -= g.lead;        // a panel task
+    }
+    const int4 tk = g.tasks[slot];
     const int post = tk.x & 15, first = (tk.x >> 4) & 1, plus = (tk.x >> 5) & 1, mask_last = (tk.x >> 6) & 1;
     const int bufC = (tk.x >> 8) & 3, bufL = (tk.x >> 10) & 3, bufR = (tk.x >> 12) & 3;
     const int ci = tk.y & 0xffff, cj = tk.y >> 16, li = tk.z & 0xffff, ri = tk.z >> 16;
@@ -715,10 +722,13 @@ extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
 // Task tables (see potrf_step_kernel): one vector of tasks per launch, cached on the device per (nbk, inverse).
 struct TaskTable {
     int4 *dev = nullptr;
-    std::vector<int> offset, count;
+    std::vector<int> offset, count, nhead, npanel;
     std::vector<double> tile_ops;   // 64^3 multiply-add units per launch and matrix (for the profiler)
 };
 
+#ifndef PANEL_LEAD
+#define PANEL_LEAD 1024   // bulk workgroups dispatched before the (waiting) panel workgroups of a launch
+#endif
 #ifndef LAZY
 #define LAZY 4   // panels (64-pivot blocks) applied per visit of a bulk tile
 #endif
@@ -782,6 +792,14 @@ static int get_tasks(dgpamd_ctx *ctx, int nbk, bool inv, TaskTable *&out) {
         for (auto &v : L) {
             tt.offset.push_back((int)flat.size());
             tt.count.push_back((int)v.size());
+            int nh = 0, np_ = 0;
+            for (auto &t4 : v) {
+                const int post = t4.x & 15;
+                nh += (post == T_CHAIN || post == T_TDIAG);
+                np_ += (post == T_SOLVE);
+            }
+            tt.nhead.push_back(nh);
+            tt.npanel.push_back(np_);
             flat.insert(flat.end(), v.begin(), v.end());
         }
         HIP_TRY(ctx, hipMalloc((void **)&tt.dev, flat.size() * sizeof(int4)));
@@ -805,6 +823,12 @@ static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *T, doub
         if (tt->count[k] == 0) continue;
         st.k = (int)k;
         st.tasks = tt->dev + tt->offset[k];
+        st.nhead = tt->nhead[k];
+        st.npanel = tt->npanel[k];
+        {
+            const int nbulk = tt->count[k] - st.nhead - st.npanel, lead = (PANEL_LEAD + batch - 1) / batch;
+            st.lead = lead < nbulk ? lead : nbulk;
+        }
         const int64_t nwg = (int64_t)batch * tt->count[k];
         st.guard = (k < (size_t)nbk && nwg > ctx->num_cu) ? ctx->num_cu : 0;   // (tail launches: no chain; small ones: no neighbours)
         PROF_BEGIN(ctx, PROF_SYRK, (double)batch * tt->tile_ops[k] * tile_flops);
