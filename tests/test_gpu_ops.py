@@ -429,3 +429,45 @@ def test_vecchia_spsolve_long_chain(eng):
     ref = O.forward_solve_sp(L, NN, b)
     out = eng.vecchia_spsolve(eng.tensor(L), eng.tensor(NN, dtype=torch.int64), 1.0, eng.tensor(b))
     close(npy(out), ref, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 63, 64, 127, 128, 129, 192, 257, 320, 449, 511])
+def test_potrf_and_inv_edge_sizes(eng, n):
+    """Sizes around the 64-wide block edges (also n = 64 j: a last block that carries only the right-hand side), three
+    matrices per call, both entry points, against LAPACK."""
+    import torch
+    rng = np.random.default_rng(1000 + n)
+    B = 3
+    Np = eng.padded_dim(n)
+    A1, A2 = eng.empty(B, Np, Np), eng.empty(B, Np, Np)
+    T = torch.full((B, Np, Np), float('nan'), dtype=torch.float64, device=A1.device)
+    S = torch.full((B, Np, Np), float('nan'), dtype=torch.float64, device=A1.device)
+    Ks, ys = [], []
+    for b in range(B):
+        X = rng.uniform(size=(n, 2))
+        G = rng.normal(size=(n, n + 3))
+        K = G @ G.T / (n + 3) + 0.5 * np.eye(n)          # well conditioned, not a kernel matrix
+        y = rng.normal(size=n)
+        Ks.append(K)
+        ys.append(y)
+        M = np.zeros((Np, Np))
+        M[:n, :n] = K
+        M[n, :n] = y
+        A1[b] = eng.tensor(M)
+        A2[b] = eng.tensor(M)
+    ld1, info1 = eng.potrf(n, A1, batch=B)
+    ld2, info2 = eng.potrf_inv(n, A2, T, S, batch=B)
+    eng.sync()
+    assert not npy(info1).any() and not npy(info2).any()
+    tr, tc = np.arange(n)[:, None] // 64, np.arange(n)[None, :] // 64
+    for b in range(B):
+        L = np.linalg.cholesky(Ks[b])
+        Kinv = np.linalg.inv(Ks[b])
+        alpha = Kinv @ ys[b]
+        for A, ld in ((A1, ld1), (A2, ld2)):
+            close(np.tril(npy(A[b])[:n, :n]), L, rtol=1e-9, atol=1e-11)
+            close(npy(ld)[b], 2 * np.log(np.diag(L)).sum(), rtol=1e-11, atol=1e-10)
+            close(-npy(A[b])[n, n], ys[b] @ alpha, rtol=1e-9)
+        close(np.where(tr >= tc, npy(S[b])[:n, :n], 0.0), np.where(tr >= tc, Kinv, 0.0), rtol=1e-8, atol=1e-10)
+        close(-npy(S[b])[n, :n], alpha, rtol=1e-8, atol=1e-10)
+        close(np.where(tr <= tc, npy(T[b])[:n, :n], 0.0), np.where(tr <= tc, np.linalg.inv(L).T, 0.0), rtol=1e-8, atol=1e-10)
