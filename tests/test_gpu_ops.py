@@ -471,3 +471,64 @@ def test_potrf_and_inv_edge_sizes(eng, n):
         close(np.where(tr >= tc, npy(S[b])[:n, :n], 0.0), np.where(tr >= tc, Kinv, 0.0), rtol=1e-8, atol=1e-10)
         close(-npy(S[b])[n, :n], alpha, rtol=1e-8, atol=1e-10)
         close(np.where(tr <= tc, npy(T[b])[:n, :n], 0.0), np.where(tr <= tc, np.linalg.inv(L).T, 0.0), rtol=1e-8, atol=1e-10)
+
+
+def test_ess_update_resumes_when_uniforms_run_out(eng):
+    """dgpamd_ess_update hands back (status 1) when the supplied uniforms are used up; continuing with the next
+    uniforms must reach the accepted proposal, log-likelihood and uniform count of a single call that had them all,
+    and of the sequential loop (imputation.py:81-119) done by hand with the oracle."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(5)
+    n, M = 150, 2
+    F0, NU = rng.normal(size=(n, M)), rng.normal(size=(n, M))
+    G = rng.uniform(size=(n, 1))
+    length, nugget, scale = np.array([1.1, 0.8, 0.9]), 1e-4, 1.4
+    # y drawn from the GP at the current latent: the current state is a good one, most proposals are rejected
+    y = O.fmvn(scale * O.k_matrix(np.concatenate((F0, G), 1), length, nugget, 'sexp'), rng.standard_normal(n))
+    us = rng.uniform(size=40)
+
+    def ll_of(Fp):
+        return O.log_likelihood(np.concatenate((Fp, G), 1), y, length, scale, nugget, 'sexp')
+    cur = ll_of(F0)
+    theta0 = 2 * np.pi * 0.37
+
+    def sequential(log_y):
+        theta, lo, hi, used = theta0, theta0 - 2 * np.pi, theta0, 0
+        while True:
+            Fp = O.update_f(F0, NU, theta)
+            l = ll_of(Fp)
+            if l > log_y:
+                return Fp, l, used
+            if theta < 0:
+                lo = theta
+            else:
+                hi = theta
+            theta = lo + (hi - lo) * us[used]
+            used += 1
+    for frac in (0.999, 0.99, 0.9, 0.5):     # a slice demanding enough for several shrinks before acceptance
+        log_y = cur + np.log(frac)
+        Fp, l, used = sequential(log_y)
+        if used >= 3:
+            break
+    assert 3 <= used < 30
+
+    def run(chunks):
+        plan = eng.ess_plan(n, M, 'sexp', np.arange(M, dtype=np.int32), eng.tensor(G), length, nugget, None, eng.tensor(y), 3)
+        Fd, NUd = eng.tensor(F0.copy()), eng.tensor(NU)
+        th, l_, h_, pend, pos, props = theta0, theta0 - 2 * np.pi, theta0, False, 0, 0
+        while True:
+            status, u, p, nb, ll_acc, info, th, l_, h_, pend = plan.run(Fd, NUd, scale, log_y, th, l_, h_, pend,
+                                                                      us[pos:pos + chunks], 2)
+            pos += u
+            props += p
+            assert status in (0, 1) and info == 0
+            if status == 0:
+                eng.sync()
+                return npy(Fd), ll_acc, pos, props
+    Fa, lla, useda, propsa = run(40)
+    Fb, llb, usedb, propsb = run(1)       # one uniform per call: resumes after every shrink
+    assert useda == usedb == used and propsa >= used + 1
+    close(Fa, Fp, rtol=1e-12, atol=1e-13)
+    close(Fb, Fp, rtol=1e-12, atol=1e-13)
+    close(lla, l, rtol=1e-9)
+    close(llb, l, rtol=1e-9)
