@@ -157,7 +157,7 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events around each of its launches, same steps ----
     roof = None
-    if rank == 0:
+    if rank == 0 and args.prof_kernel != 'none':
         engines = [eng]
         for e in engines:
             e.prof_enable(args.prof_kernel)

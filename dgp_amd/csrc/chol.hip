@@ -592,6 +592,12 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
         else if (slot < g.nhead + g.lead + g.npanel) slot -= g.lead;        // a panel task
     }
     const int4 tk = g.tasks[slot];
+    // debug (dgpamd_debug_trace): per-workgroup start / end / (task kind, panels, CU) of the launch named in trace[4095]
+    long long *wtr = (g.trace && tid == 0 && g.trace[4095] == k) ? g.trace + 4096 + 4 * (int64_t)blockIdx.x : nullptr;
+    if (wtr) {
+        wtr[0] = wall_clock64();
+        wtr[2] = (tk.x & 15) | ((tk.w >> 16) << 8) | ((long long)cu_key() << 16);
+    }
     const int post = tk.x & 15, first = (tk.x >> 4) & 1, plus = (tk.x >> 5) & 1, mask_last = (tk.x >> 6) & 1;
     const int bufC = (tk.x >> 8) & 3, bufL = (tk.x >> 10) & 3, bufR = (tk.x >> 12) & 3;
     const int ci = tk.y & 0xffff, cj = tk.y >> 16, li = tk.z & 0xffff, ri = tk.z >> 16;
@@ -625,6 +631,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
                 mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
     if (post == T_STORE) {
         store_acc(acc.v, C, ld, crow, ccol);
+        if (wtr) wtr[1] = wall_clock64();
         return;
     }
     if (post == T_CHAIN) {
@@ -636,6 +643,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
         wg_release_store(g.flags + b, k + 1, tid);   // the panel can start; the log-determinant is nobody's input
         STAMP(3);
         diag_logdet(sh, ncol, k, b, bad, g.logdet, g.info);
+        if (wtr) wtr[1] = wall_clock64();
         return;
     }
     // T_SOLVE: wait for W_k, then tile <- tile * W_k^T
@@ -649,6 +657,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     mul_acc_bt(out, acc.v, Wk, 64, 1.0, As, Bs, tid, wave, lane);
     store_acc(out, C, ld, crow, ccol);
     if (stamp) STAMP(10);
+    if (wtr) wtr[1] = wall_clock64();
 }
 
 // column n of T holds -K^-1 y: copy it into row n of S (the layout dgpamd_potri leaves: row n of Ainv = -alpha^T)

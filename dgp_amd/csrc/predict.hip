@@ -205,6 +205,7 @@ struct LinkArgs {
     double scale, nugget;
     double *partial;   // [ntiles][Mc]
     double *recs;      // [Mc][Dw][npad][REC] separable Matern records (linkgp_Jsep)
+    double *gfac;      // [Mc][npad] Matern factor of the deterministic global inputs (linkgp_Jsep)
     int64_t npad;
     double *mean, *var;
 };
@@ -459,7 +460,20 @@ __global__ __launch_bounds__(256) void matern_records_kernel(LinkArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void linkgp_Jsep_kernel(LinkArgs a) {
+// Deterministic global inputs: the separable Matern factor k(Wg_i, z_t) of (training point, test point)
+// (functions.py:413-420), once per pair of points instead of once per tile pair in the J kernel.
+__global__ __launch_bounds__(256) void global_factor_kernel(LinkArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tt = blockIdx.y, t = a.t0 + tt;
+    if (i >= a.npad || t >= a.M) return;
+    double pr = 1.0, sm = 0.0;
+    if (i < a.n)
+        for (int g = 0; g < a.Dz; ++g)
+            corr_accum_matern((a.Wg[i * a.Dz + g] - a.z[t * a.Dz + g]) / a.len[a.Dw + g], pr, sm);
+    a.gfac[tt * a.npad + i] = pr * exp(-SQRT5 * sm);
+}
+
+__global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
     extern __shared__ double lds[];
     const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
     double *WiT = lds;                    // [DT][64]
@@ -524,8 +538,13 @@ __global__ __launch_bounds__(256) void linkgp_Jsep_kernel(LinkArgs a) {
             d[0] = pre[u].x;
             d[1] = pre[u].y;
         }
-        if (tid < 128) P[tid * PST + 28] = tid < 64 ? WiT[k * 64 + tid] : WjT[k * 64 + tid - 64];
+        {   // (all 256 threads: the upper half repeats the lower half's stores -- no branch in the pair loop)
+            const int q = tid & 127;
+            P[q * PST + 28] = q < 64 ? WiT[k * 64 + q] : WjT[k * 64 + q - 64];
+            P[q * PST + 29] = 0.0;   // the zero that pads the 3-term erf-difference products to an MFMA k-step of 4
+        }
     };
+    const int iSd = kq < 3 ? 6 + kq : 29, iTd = kq < 3 ? 24 + kq : 29;   // (unconditional loads: no exec-masked branches in the pair loop)
     __syncthreads();
     // The records of step (t, k) are double buffered in LDS and their loads run two steps ahead: ONE barrier per step,
     // and a wave that is done with a step stages the next one while the others still compute.
@@ -553,64 +572,81 @@ __global__ __launch_bounds__(256) void linkgp_Jsep_kernel(LinkArgs a) {
                 aS[ks] = Arow[4 * ks + kq];
                 aT[ks] = Arow[12 + 4 * ks + kq];
             }
-            const double aSd = kq < 3 ? Arow[6 + kq] : 0.0, aTd = kq < 3 ? Arow[24 + kq] : 0.0;
+            const double aSd = Arow[iSd], aTd = Arow[iTd];
             double f2r[4], xr[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 f2r[r] = P[(mrow + 4 * r) * PST + 27];
                 xr[r] = P[(mrow + 4 * r) * PST + 28];
             }
-            // column tiles software pipelined by hand: the MFMAs of tile tt+1 are issued before the (VALU) epilogue of
-            // tile tt, so the matrix pipe stays busy while the J factors are selected and multiplied in
+            // Column tiles software pipelined by hand: the 8 MFMAs of tile tt+1 are issued in pairs between the four
+            // row groups of tile tt's (VALU) epilogue -- an MFMA occupies the matrix pipe for 64 cycles while the wave
+            // is free to issue VALU work, so the J-factor selects/multiplies ride in its shadow.  The sched_barrier()
+            // fences pin that order (on its own the compiler issues all 32 MFMAs first and all epilogues afterwards).
             d4 o1[2], o2[2], e1[2], e2[2];
-            auto mm = [&](int tt, int slot) {
-                const double *Bcol = P + (64 + 16 * tt + mi) * PST;   // column record as an MFMA B operand (j = lane&15)
-                d4 a1 = {0.0, 0.0, 0.0, 0.0}, a2 = a1, b1 = a1, b2 = a1;
+            double bf[8];
+            auto loadB = [&](int tt) {   // column records as MFMA B operands (j = lane&15)
+                const double *Bcol = P + (64 + 16 * tt + mi) * PST;
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) {
-                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[ks], Bcol[12 + 4 * ks + kq], a1, 0, 0, 0);   // S_row . T_col
-                    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[ks], Bcol[4 * ks + kq], a2, 0, 0, 0);        // T_row . S_col
+                    bf[ks] = Bcol[12 + 4 * ks + kq];
+                    bf[3 + ks] = Bcol[4 * ks + kq];
                 }
-                b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aSd, kq < 3 ? Bcol[24 + kq] : 0.0, b1, 0, 0, 0);
-                b2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aTd, kq < 3 ? Bcol[6 + kq] : 0.0, b2, 0, 0, 0);
-                o1[slot] = a1; o2[slot] = a2; e1[slot] = b1; e2[slot] = b2;
+                bf[6] = Bcol[iTd];
+                bf[7] = Bcol[iSd];
             };
-            mm(0, 0);
+            auto mm2 = [&](int c, int slot) {   // MFMA pair c of a tile: S_row . T_col and T_row . S_col, then the erf pair
+                const d4 z = {0.0, 0.0, 0.0, 0.0};
+                if (c < 3) {
+                    o1[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[c], bf[c], c ? o1[slot] : z, 0, 0, 0);
+                    o2[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[c], bf[3 + c], c ? o2[slot] : z, 0, 0, 0);
+                } else {
+                    e1[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aSd, bf[6], z, 0, 0, 0);
+                    e2[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aTd, bf[7], z, 0, 0, 0);
+                }
+            };
+            loadB(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mm2(c, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int sl = tt & 1;
-                if (tt < 3) mm(tt + 1, sl ^ 1);
                 const double f2c = P[(64 + 16 * tt + mcol) * PST + 27], xc = P[(64 + 16 * tt + mcol) * PST + 28];
+                if (tt < 3) loadB(tt + 1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double jd = (xr[r] <= xc) ? fma(f2c - f2r[r], e1[sl][r], o1[sl][r]) : fma(f2r[r] - f2c, e2[sl][r], o2[sl][r]);
-                    prod[tt][r] *= jd;
+                    if (tt < 3) mm2(r, sl ^ 1);
+                    const double d = f2c - f2r[r];
+                    const double j1 = fma(d, e1[sl][r], o1[sl][r]), j2 = fma(-d, e2[sl][r], o2[sl][r]);
+                    prod[tt][r] *= (xr[r] <= xc) ? j1 : j2;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (step + 1 < nstep) {   // stage the next step into the other buffer (its readers passed this step's barrier)
-                stash((step + 1) % Dw, (step & 1) ? PT : PT1);
-                if (step + 2 < nstep) fetch((step + 2) / Dw, (step + 2) % Dw);
+            {   // stage the next step into the other buffer (its readers passed this step's barrier).  Past the end the
+                // last step is staged / fetched again (harmless) so that the loop body stays one basic block.
+                const int s1 = step + 1 < nstep ? step + 1 : nstep - 1, s2 = step + 2 < nstep ? step + 2 : nstep - 1;
+                stash(s1 % Dw, (step & 1) ? PT : PT1);
+                fetch(s2 / Dw, s2 % Dw);
             }
         }
-        // deterministic global inputs: separable Matern factor (functions.py:413-420)
-        double gr[4];
+        // deterministic global inputs: separable Matern factor (functions.py:413-420), precomputed per point
+        double gr[4], gc[4];
+        if (Dz) {
+            const double *gf = a.gfac + ((tbase - a.t0) + t) * a.npad;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double pi_ = 1.0, si = 0.0;
-            for (int g = 0; g < Dz; ++g)
-                corr_accum_matern((WiT[(Dw + g) * 64 + mrow + 4 * r] - tz[t * Dz + g]) / a.len[Dw + g], pi_, si);
-            gr[r] = Dz ? pi_ * exp(-SQRT5 * si) : 1.0;
+            for (int r = 0; r < 4; ++r) gr[r] = gf[i0 + mrow + 4 * r];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) gc[tt] = gf[j0 + 16 * tt + mcol];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gr[r] = gc[r] = 1.0;
         }
         double acc = 0.0;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            double pj = 1.0, sj = 0.0;
-            for (int g = 0; g < Dz; ++g)
-                corr_accum_matern((WjT[(Dw + g) * 64 + 16 * tt + mcol] - tz[t * Dz + g]) / a.len[Dw + g], pj, sj);
-            const double gc = Dz ? pj * exp(-SQRT5 * sj) : 1.0;
+        for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = fma(Cr[tt][r], prod[tt][r] * gr[r] * gc, acc);
-        }
+            for (int r = 0; r < 4; ++r) acc = fma(Cr[tt][r], prod[tt][r] * gr[r] * gc[tt], acc);
         acc = wave_sum_p(acc);
         if (lane == 0) red[t * 4 + wave] = acc;
     }
@@ -640,7 +676,7 @@ extern "C" size_t dgpamd_linkgp_workspace(int64_t n, int64_t M, int Dw) {
     int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
     if (Mc > MC_MAX) Mc = MC_MAX;
     int64_t Ms = Mc > MC_SEP ? MC_SEP : Mc;
-    return (size_t)(nb * (nb + 1) / 2 * Mc + Ms * (int64_t)Dw * nb * 64 * REC) * sizeof(double);
+    return (size_t)(nb * (nb + 1) / 2 * Mc + Ms * (int64_t)Dw * nb * 64 * REC + Ms * nb * 64) * sizeof(double);
 }
 
 extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz, const double *m,
@@ -669,6 +705,7 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
     a.npad = (int64_t)nb * 64;
     if (sep && Mc > MC_SEP) Mc = MC_SEP;   // records of one chunk: Mc*Dw*npad*224 B
     a.Mc = Mc;
+    a.gfac = a.recs + Mc * (int64_t)Dw * a.npad * REC;
     const int DT = Dw + Dz;
     size_t shm = ((size_t)2 * DT * 64 + (size_t)TCH * (2 * Dw + Dz) + TCH * 4) * sizeof(double);
     if (kind == DGPAMD_MATERN25) shm += 64 * 65 * sizeof(double);
@@ -689,6 +726,8 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
                 if (shm_sep > 48 * 1024)
                     HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_sep));
                 hipLaunchKernelGGL(matern_records_kernel, dim3((unsigned)((a.npad + 127) / 128), Dw, (unsigned)mc), dim3(256), 0, ctx->stream, a);
+                if (Dz)
+                    hipLaunchKernelGGL(global_factor_kernel, dim3((unsigned)((a.npad + 255) / 256), (unsigned)mc), dim3(256), 0, ctx->stream, a);
                 PROF_BEGIN(ctx, PROF_LINKGP_J, (double)mc * (double)n * (double)n * 0.5 * Dw * 30.0 * 2.0);
                 hipLaunchKernelGGL(linkgp_Jsep_kernel, dim3(ntiles, tb), dim3(256), shm_sep, ctx->stream, a);
                 PROF_END(ctx, PROF_LINKGP_J);

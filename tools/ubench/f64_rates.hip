@@ -1,6 +1,7 @@
 // Microbenchmark: sustained f64 MFMA (v_mfma_f64_16x16x4_f64) and f64 FMA (v_fma_f64) rates on gfx950.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <int NACC>
@@ -45,10 +46,10 @@ float timeit(F f) {
     return ms;
 }
 
-int main() {
+int main(int argc, char **argv) {
     double *out;
     (void)hipMalloc(&out, 256 * 4096 * 256 * sizeof(double));
-    const int iters = 20000;
+    const int iters = argc > 1 ? atoi(argv[1]) : 20000;
     for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu *= 2) {
         int grid = 256 * wg_per_cu;
         float ms = timeit([&] { hipLaunchKernelGGL(mfma_loop<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0, 1e-3); });
