@@ -131,18 +131,28 @@ __global__ __launch_bounds__(256) void gp_quad_kernel(GpQuadArgs a) {
 __global__ __launch_bounds__(256) void gp_finalize_kernel(const double *R, const double *partial, const double *ry,
                                                           int nry, int64_t n, int nb, int64_t Mc, int64_t t0, int64_t M,
                                                           double scale, double nugget, double *mean, double *var) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= Mc || t0 + t >= M) return;
+    // 64 test points per workgroup (coalesced over t), the training points in 4 interleaved slices (one per wave)
+    __shared__ double part[4][64];
+    const int slice = threadIdx.x >> 6, tl = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 64 + tl;
+    const bool live = t < Mc && t0 + t < M;
     for (int s = blockIdx.y; s < nry; s += gridDim.y) {
         const double *rys = ry + (int64_t)s * n;
         double m = 0.0;
-        for (int64_t i = 0; i < n; ++i) m = fma(rys[i], R[i * Mc + t], m);
-        mean[(int64_t)s * M + t0 + t] = m;
+        if (live)
+            for (int64_t i = slice; i < n; i += 4) m = fma(rys[i], R[i * Mc + t], m);
+        part[slice][tl] = m;
+        __syncthreads();
+        if (slice == 0 && live) mean[(int64_t)s * M + t0 + t] = (part[0][tl] + part[1][tl]) + (part[2][tl] + part[3][tl]);
+        __syncthreads();
     }
     if (blockIdx.y == 0) {
         double q = 0.0;
-        for (int b = 0; b < nb; ++b) q += partial[(int64_t)b * Mc + t];
-        var[t0 + t] = fabs(scale * (1.0 + nugget - q));
+        if (live)
+            for (int b = slice; b < nb; b += 4) q += partial[(int64_t)b * Mc + t];
+        part[slice][tl] = q;
+        __syncthreads();
+        if (slice == 0 && live) var[t0 + t] = fabs(scale * (1.0 + nugget - ((part[0][tl] + part[1][tl]) + (part[2][tl] + part[3][tl]))));
     }
 }
 
@@ -182,7 +192,7 @@ extern "C" int dgpamd_gp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M
         else
             hipLaunchKernelGGL(cross_corr_kernel<DGPAMD_MATERN25>, dim3(nb, tb), dim3(256), shm, ctx->stream, c);
         hipLaunchKernelGGL(gp_quad_kernel, dim3(nb, tb), dim3(256), 0, ctx->stream, q);
-        hipLaunchKernelGGL(gp_finalize_kernel, dim3((unsigned)((mc + 255) / 256), (unsigned)(nry < 64 ? nry : 64)),
+        hipLaunchKernelGGL(gp_finalize_kernel, dim3((unsigned)((mc + 63) / 64), (unsigned)(nry < 64 ? nry : 64)),
                            dim3(256), 0, ctx->stream, (const double *)R, (const double *)partial, ry, nry, n, nb, Mc,
                            t0, M, scale, nugget, mean, var);
     }
@@ -210,16 +220,17 @@ struct LinkArgs {
     double *mean, *var;
 };
 
-// mean_t = sum_i I_i(t) ry_i : one wave per test point
+// mean_t = sum_i I_i(t) ry_i : one workgroup per test point (the training points strided over its 256 threads)
 template <int KIND>
 __global__ __launch_bounds__(256) void linkgp_mean_kernel(LinkArgs a) {
+    __shared__ double part[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t t = a.t0 + (int64_t)blockIdx.x * 4 + wave;
+    const int64_t t = a.t0 + (int64_t)blockIdx.x;
     if (t >= a.M || t >= a.t0 + a.Mc) return;
     const double *mt = a.m + t * a.Dw, *vt = a.v + t * a.Dw;
     const double *zt = a.Dz ? a.z + t * a.Dz : nullptr;
     double acc = 0.0;
-    for (int64_t i = lane; i < a.n; i += 64) {
+    for (int64_t i = threadIdx.x; i < a.n; i += 256) {
         double I;
         if (KIND == DGPAMD_SEXP) {
             double e = 0.0;
@@ -242,7 +253,10 @@ __global__ __launch_bounds__(256) void linkgp_mean_kernel(LinkArgs a) {
         acc = fma(I, a.ry[i], acc);
     }
     acc = wave_sum_p(acc);
-    if (lane == 0) {
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc = (part[0] + part[1]) + (part[2] + part[3]);
         if (KIND == DGPAMD_SEXP) {
             double c = 1.0;
             for (int k = 0; k < a.Dw; ++k) c *= 1.0 + 2.0 * vt[k] / (a.len[k] * a.len[k]);
@@ -416,6 +430,8 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
 //                           ahead of the pair phase; every pair costs 30 FMAs (both orientations) and a select
 //                           instead of 3 erf + 5 exp + ~300 flops.  The grid runs tiles fastest so that a
 //                           test-chunk's records (TCH*Dw*n*224 B) are re-read from the Infinity Cache.
+// LDS-qualified volatile view: fragment reads stay single ds_read_b64 (see the pair loop)
+typedef volatile double __attribute__((address_space(3))) vlds_double;
 #define REC 28
 #define PST 30   // LDS stride of a record (+x at [28]); stride 30 doubles -> conflict-free column reads
 #define MC_SEP 256
@@ -564,7 +580,9 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
         for (int k = 0; k < Dw; ++k, ++step) {
             double *P = (step & 1) ? PT1 : PT;
             __syncthreads();   // records of this step staged; every wave is done with the other buffer
-            const double *Arow = P + (16 * wave + mi) * PST;   // this lane's row record as an MFMA A operand (i = lane&15)
+            // volatile: keeps these fragment reads as ds_read_b64 (2 LDS cycles, 64 banks: conflict-free with PST = 30); merged
+            // into ds_read2_b64 by the compiler they take 8 cycles and bank modulo 32 (2-way conflicts here)
+            const vlds_double *Arow = (const vlds_double *)(P + (16 * wave + mi) * PST);   // this lane's row record as an MFMA A operand (i = lane&15)
             // A fragments (rows): S[0..11] and T[0..11] in three k-steps each, the erf-difference pair in one (k=3 padded with 0)
             double aS[3], aT[3];
 #pragma unroll
@@ -586,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
             d4 o1[2], o2[2], e1[2], e2[2];
             double bf[8];
             auto loadB = [&](int tt) {   // column records as MFMA B operands (j = lane&15)
-                const double *Bcol = P + (64 + 16 * tt + mi) * PST;
+                const vlds_double *Bcol = (const vlds_double *)(P + (64 + 16 * tt + mi) * PST);
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) {
                     bf[ks] = Bcol[12 + 4 * ks + kq];
@@ -656,12 +674,15 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void linkgp_finalize_kernel(LinkArgs a, int ntiles) {
-    const int64_t tt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void linkgp_finalize_kernel(LinkArgs a, int ntiles) {   // one wave per test point
+    const int lane = threadIdx.x & 63;
+    const int64_t tt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t t = a.t0 + tt;
     if (tt >= a.Mc || t >= a.M) return;
     double s = 0.0;
-    for (int b = 0; b < ntiles; ++b) s += a.partial[(int64_t)b * a.Mc + tt];
+    for (int b = lane; b < ntiles; b += 64) s += a.partial[(int64_t)b * a.Mc + tt];
+    s = wave_sum_p(s);
+    if (lane) return;
     if (KIND == DGPAMD_SEXP) {
         double c = 1.0;
         for (int k = 0; k < a.Dw; ++k) c *= 1.0 + 4.0 * a.v[t * a.Dw + k] / (a.len[k] * a.len[k]);
@@ -714,11 +735,11 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
         const int64_t mc = M - t0 < Mc ? M - t0 : Mc;
         const unsigned tb = (unsigned)((mc + TCH - 1) / TCH);
         if (kind == DGPAMD_SEXP) {
-            hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_SEXP>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_SEXP>, dim3((unsigned)mc), dim3(256), 0, ctx->stream, a);
             hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_SEXP>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
-            hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_SEXP>, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, a, ntiles);
+            hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_SEXP>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a, ntiles);
         } else {
-            hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_MATERN25>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_MATERN25>, dim3((unsigned)mc), dim3(256), 0, ctx->stream, a);
             if (ctx->linkgp_direct) {
                 hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_MATERN25>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else {
@@ -732,7 +753,7 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
                 hipLaunchKernelGGL(linkgp_Jsep_kernel, dim3(ntiles, tb), dim3(256), shm_sep, ctx->stream, a);
                 PROF_END(ctx, PROF_LINKGP_J);
             }
-            hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_MATERN25>, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, ctx->stream, a, ntiles);
+            hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_MATERN25>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a, ntiles);
         }
     }
     LAUNCH_CHECK(ctx);
