@@ -290,22 +290,24 @@ def test_gp_and_linkgp_golden(eng, golden, direct):
     eng.set_linkgp_direct(False)
 
 
-def test_linkgp_separable_equals_direct(eng):
-    """Same inputs through both evaluations of the Matern J factor, incl. tiny and zero input variances."""
+@pytest.mark.parametrize('n,M,Dw,Dz', [(130, 40, 4, 1), (200, 37, 2, 0), (64, 5, 5, 3), (257, 19, 1, 2)])
+def test_linkgp_separable_equals_direct(eng, n, M, Dw, Dz):
+    """Same inputs through both evaluations of the Matern J factor, incl. tiny and zero input variances, with and
+    without deterministic global inputs, sizes on and off the 64-point tile edge."""
     from oracle import dgp_oracle as O
     rng = np.random.default_rng(21)
-    n, M, Dw, Dz = 130, 40, 4, 1
     X = rng.uniform(size=(n, Dw + Dz))
     y = rng.normal(size=n)
     length = rng.uniform(0.3, 1.5, size=Dw + Dz)
-    st = O.compute_stats(X, y, length, 1e-4, 'matern2.5', Dw)
+    nug = 1e-4 if Dw + Dz >= 5 else 1e-2   # (few input dimensions: keep R well conditioned, the two forms differ by rounding x cond)
+    st = O.compute_stats(X, y, length, nug, 'matern2.5', Dw)
     mm = rng.uniform(-0.2, 1.2, size=(M, Dw))
     vv = 10.0 ** rng.uniform(-6, 0, size=(M, Dw))
     vv[0] = 0.0
-    vv[1, 2] = 0.0
-    z = rng.uniform(size=(M, Dz))
-    args = (eng.tensor(mm), eng.tensor(vv), eng.tensor(z), eng.tensor(X[:, :Dw]), eng.tensor(X[:, Dw:]), length,
-            eng.tensor(st['Rinv']), n, eng.tensor(st['Rinv_y']), 1.3, 1e-4)
+    vv[1, Dw - 1] = 0.0
+    z = rng.uniform(size=(M, Dz)) if Dz else None
+    args = (eng.tensor(mm), eng.tensor(vv), eng.tensor(z) if Dz else None, eng.tensor(X[:, :Dw]),
+            eng.tensor(X[:, Dw:]) if Dz else None, length, eng.tensor(st['Rinv']), n, eng.tensor(st['Rinv_y']), 1.3, nug)
     eng.set_linkgp_direct(True)
     m1, v1 = eng.linkgp_predict('matern2.5', *args)
     m1, v1 = npy(m1), npy(v1)
@@ -313,7 +315,7 @@ def test_linkgp_separable_equals_direct(eng):
     m2, v2 = eng.linkgp_predict('matern2.5', *args)
     close(npy(m2), m1, rtol=1e-12, atol=1e-14)
     close(npy(v2), v1, rtol=1e-6, atol=1e-8)
-    lmr, lvr = O.link_gp_predict(mm, vv, z, X[:, :Dw], X[:, Dw:], st['Rinv'], st['Rinv_y'], 1.3, length, 1e-4, 'matern2.5')
+    lmr, lvr = O.link_gp_predict(mm, vv, z, X[:, :Dw], X[:, Dw:] if Dz else None, st['Rinv'], st['Rinv_y'], 1.3, length, nug, 'matern2.5')
     close(m1, lmr, rtol=1e-8, atol=1e-10)
     close(v1, lvr, rtol=1e-6, atol=1e-8)
     close(npy(v2), lvr, rtol=1e-6, atol=1e-8)
