@@ -187,7 +187,8 @@ def main():
                 roof['traffic_source'] = 'profiles/r01_pmc_bench_step_kernel.json (FETCH_SIZE x2 + WRITE_SIZE, same command)'
             roof.update(launches=tot_n, avg_launch_us=1e3 * tot_ms / tot_n, work_per_launch=tot_w / tot_n,
                         event_pair_overhead_us=ev_us, avg_launch_us_uncorrected=1e3 * raw_ms / tot_n,
-                        sustained_f64_mfma_tflops_measured=47.5)
+                        f64_mfma_tflops_measured={'register_only_loop': 47.5, 'tile_engine_standalone_4_panels': 42.0,
+                                                      'tile_engine_standalone_16_panels': 64.0})
     kernel_class.kernel._llik_finish = orig_finish
 
     # ---- prediction leg: emulator with the imputations sharded over the ranks --------------------
