@@ -261,30 +261,168 @@ class dgp:
 
     ptrain = train   # nodes are already optimised concurrently (dgp.py:1414-1472 used a process pool)
 
-    def reinit_all_layer(self, reset_lengthscale, row=0):
-        """Fresh latent warm start, hyper-parameters back to para_path[row] (dgp.py:1097-1362, GP nodes)."""
-        In = self.X
+    def _set_final_output(self, nd, k):
+        """Observed output of final-layer node k from self.Y (site means / weights with replicates, dgp.py:1344-1356)."""
+        if nd.type == 'likelihood' or nd.rep is None:
+            nd.output = self.Y[:, [k]].copy()
+            return
+        G = nd.rep.max() + 1
+        nd.W_diag = 1.0 / np.bincount(nd.rep, minlength=G)
+        nd.output = (np.bincount(nd.rep, weights=self.Y[:, k], minlength=G) * nd.W_diag).reshape(-1, 1)
+        res = self.Y[:, [k]] - nd.output[nd.rep, :]
+        nd.sum_residual = (res.T @ res).flatten()
+
+    def reinit_all_layer(self, reset_lengthscale, row=0, truncate=True):
+        """Fresh latent warm start from the current (X, Y), hyper-parameters back to para_path[row] if asked
+        (dgp.py:1097-1362, GP nodes and Hetero).  truncate: drop the path after `row` (a restarted train() call must not
+        leave the failed attempt's iterations in para_path; update_xy keeps the history like the reference)."""
+        global_in = In = self.X
         for l, layer in enumerate(self.all_layer):
             last = l == self.n_layer - 1
             Out = None if last else (self._hetero_warm_start() if self._is_hetero_pair(l) else self._warm_start(In, len(layer)))
             for k, nd in enumerate(layer):
+                if last:
+                    nd.rep = self.indices
                 if nd.type == 'likelihood':
                     nd.input = In[nd.rep, :][:, nd.input_dim] if nd.rep is not None else In[:, nd.input_dim]
+                    nd.output = self.Y[:, [k]].copy()
                     continue
                 nd.input = In[:, nd.input_dim]
-                if not last:
-                    nd.output = Out[:, [k]].copy()
                 if nd.type == 'gp':
+                    if nd.connect is not None:
+                        nd.global_input = global_in[:, nd.connect]
+                    nd.m = self.m
                     if reset_lengthscale:
                         est = nd.para_path[row]
                         nd.scale, nd.length, nd.nugget = np.atleast_1d(est[0]), np.atleast_1d(est[1:-1]), np.atleast_1d(est[-1])
-                        nd.para_path = nd.para_path[:row + 1]
-                    if nd.prior_name == 'ref':
-                        nd.compute_cl()
+                        if truncate:
+                            nd.para_path = nd.para_path[:row + 1]
+                if last:
+                    self._set_final_output(nd, k)
+                else:
+                    nd.output = Out[:, [k]].copy()
+                if nd.type == 'gp' and nd.prior_name == 'ref':
+                    nd.compute_cl()
+            if self.vecch:
+                self._layer_ord_nn(layer)
             if not last:
                 In = copy.copy(Out)
+        stats = self.imp.stats
+        self.imp = imputer(self.all_layer, self.block, draws=self.draws, engine=self.engine)   # (the data may have changed size)
+        self.imp.stats = stats
         self.imp.sample(burnin=10)
         self.compute_r2()
+
+    # ------------------------------------------------------------------ new data (sequential design)
+    def update_xy(self, X, Y, reset=False):
+        """Replace the training data of a trained DGP (dgp.py:824-888).  reset=True: latents and hyper-parameters start
+        over.  Otherwise the structure is warm started: if the new inputs are a subset of the old ones the latents are
+        subsetted; if they are a superset the latents at the new sites are the nodes' conditional means given the
+        current latents, layer by layer; else a fresh warm start with the current hyper-parameters."""
+        if isinstance(Y, list):
+            if len(Y) != 1:
+                raise Exception('Y has to be a numpy 2d-array rather than a list. The list version of Y (for linked '
+                                'emulation) has been reduced. Please use the dedicated lgp class for linked emulation.')
+            Y = Y[0]
+        if Y.ndim == 1 or X.ndim == 1:
+            raise Exception('The input and output data have to be numpy 2d-arrays.')
+        self.Y = Y
+        self.indices = self.counts = None
+        origin_X = self.X.copy()
+        self.X = X
+        if self.check_rep:
+            X0, inv, counts = np.unique(X, return_inverse=True, return_counts=True, axis=0)
+            if len(X0) != len(X):
+                self.X, self.indices, self.counts = X0, np.asarray(inv).reshape(-1), counts
+        self.n_data = self.X.shape[0]
+        self.m = min(self.m, self.n_data - 1)
+        if reset:
+            self.reinit_all_layer(reset_lengthscale=True, truncate=False)
+        else:
+            new_in_old = (self.X[:, None] == origin_X).all(-1)
+            if new_in_old.any(-1).all():
+                self._update_all_layer_smaller(np.where(new_in_old)[1])
+                burn = 50
+            elif new_in_old.any(0).all():
+                self._update_all_layer_larger(np.where((self.X == origin_X[:, None]).all(-1))[1])
+                burn = 50
+            else:
+                self.reinit_all_layer(reset_lengthscale=False)
+                burn = 190      # (reinit_all_layer already ran 10 sweeps: 200 in total as the reference)
+            self.imp = imputer(self.all_layer, self.block, draws=self.draws, engine=self.engine)
+            self.imp.sample(burnin=burn)
+            self.compute_r2()
+
+    def _update_all_layer_larger(self, sub_idx):
+        """The old inputs are rows sub_idx of the new ones (dgp.py:890-1012): hidden latents at the new sites = each
+        node's GP conditional mean given its current input/output pairs, propagated layer by layer."""
+        global_in = In = self.X
+        mask = np.zeros(len(self.X), dtype=bool)
+        mask[sub_idx] = True
+        for l, layer in enumerate(self.all_layer):
+            last = l == self.n_layer - 1
+            Out = None if last else np.empty((len(In), len(layer)))
+            for k, nd in enumerate(layer):
+                if nd.type == 'gp':
+                    nd.m = self.m
+                if not last:
+                    zz = None if nd.connect is None else global_in[~mask, :][:, nd.connect]
+                    if nd.vecch:
+                        nd.pred_m = 50
+                    else:
+                        nd.compute_stats()
+                    mu = nd.gp_prediction(In[~mask, :][:, nd.input_dim], zz)[0]
+                    Out[sub_idx, k] = nd.output.flatten()
+                    Out[~mask, k] = np.asarray(mu).flatten()
+                    nd.input = In[:, nd.input_dim].copy()
+                    nd.output = Out[:, [k]].copy()
+                    if nd.connect is not None:
+                        nd.global_input = global_in[:, nd.connect].copy()
+                    nd._stats = None
+                else:
+                    nd.rep = self.indices
+                    if nd.type == 'likelihood' and nd.rep is not None:
+                        nd.input = In[nd.rep, :][:, nd.input_dim].copy()
+                    else:
+                        nd.input = In[:, nd.input_dim].copy()
+                    if nd.type == 'gp' and nd.connect is not None:
+                        nd.global_input = global_in[:, nd.connect].copy()
+                    self._set_final_output(nd, k)
+                if nd.type == 'gp' and nd.prior_name == 'ref':
+                    nd.compute_cl()
+            if self.vecch:
+                self._layer_ord_nn(layer)
+            if not last:
+                In = Out.copy()
+
+    def _update_all_layer_smaller(self, sub_idx):
+        """The new inputs are rows sub_idx of the old ones (dgp.py:1014-1095): latents are subsetted."""
+        for l, layer in enumerate(self.all_layer):
+            last = l == self.n_layer - 1
+            for k, nd in enumerate(layer):
+                if last and nd.type == 'likelihood':
+                    if nd.rep is not None:    # back to one row per distinct site first
+                        nd.input = np.concatenate([np.unique(nd.input[nd.rep == i, :], axis=0) for i in range(np.max(nd.rep) + 1)], axis=0)
+                    nd.input = nd.input[sub_idx, :]
+                    if self.indices is not None:
+                        nd.input = nd.input[self.indices, :]
+                else:
+                    nd.input = nd.input[sub_idx, :]
+                if last:
+                    nd.rep = self.indices
+                if nd.type == 'gp':
+                    if nd.connect is not None:
+                        nd.global_input = self.X[:, nd.connect].copy()
+                    nd.m = self.m
+                    nd._stats = None
+                if last:
+                    self._set_final_output(nd, k)
+                else:
+                    nd.output = nd.output[sub_idx, :].copy()
+                if nd.type == 'gp' and nd.prior_name == 'ref':
+                    nd.compute_cl()
+            if self.vecch:
+                self._layer_ord_nn(layer)
 
     def estimate(self, burnin=None):
         """Point estimates = mean of para_path[burnin:], burnin default int(0.75 N) (dgp.py:1517-1541)."""

@@ -407,3 +407,71 @@ def test_hetero_dgp_end_to_end(eng, rep):
         m_, v_ = rng.normal(size=(6, 2)), rng.uniform(0.1, 1.0, size=(6, 2))
         y_ = rng.normal(size=(6, 1))
         assert np.allclose(ghdiag(Hetero.pllik, m_, v_, y_), O.ghdiag(O.hetero_pllik, m_, v_, y_), rtol=1e-13)
+
+
+def test_update_xy_warm_starts(eng):
+    """dgp.update_xy (dgp.py:824-1095), the sequential-design entry point: superset -> hidden latents kept at the
+    old sites and set to the nodes' GP conditional means at the new ones (checked against the oracle's gp_predict),
+    subset -> latents subsetted, unrelated design -> fresh warm start, reset=True -> hyper-parameters back to the
+    initial ones; training and prediction keep working afterwards."""
+    from dgp_amd import dgp, kernel, combine, emulator
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(77)
+    d = 2
+    fun = lambda X: np.sin(5.0 * X[:, [0]]) * np.cos(3.0 * X[:, [1]])
+    X = rng.uniform(size=(48, d))
+    Y = fun(X)
+    layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                     [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(d))])
+    model = dgp(X[:40], Y[:40], layers, seed=3)
+    model.train(N=4, ess_burn=3, disable=True)
+    # --- superset: the warm start itself (before any sampling), node by node
+    old_out = [nd.output.copy() for nd in model.all_layer[0]]
+    old_in = [nd.input.copy() for nd in model.all_layer[0]]
+    hyp = [(nd.length.copy(), nd.nugget[0], nd.scale[0]) for nd in model.all_layer[0]]
+    model.Y, model.X, model.indices = Y, X, None
+    model.n_data = len(X)
+    sub = np.arange(40)
+    model._update_all_layer_larger(sub)
+    for k, nd in enumerate(model.all_layer[0]):
+        assert nd.input.shape == (48, d) and nd.output.shape == (48, 1)
+        assert np.array_equal(nd.output[:40], old_out[k])
+        st = O.compute_stats(old_in[k], old_out[k].ravel(), hyp[k][0], hyp[k][1], 'matern2.5', d)
+        mref, _ = O.gp_predict(X[40:, nd.input_dim], old_in[k], st['Rinv'], st['Rinv_y'], hyp[k][2], hyp[k][0], hyp[k][1], 'matern2.5')
+        close(nd.output[40:, 0], mref, rtol=1e-7, atol=1e-9)
+    top = model.all_layer[1][0]
+    assert top.input.shape == (48, d) and top.global_input.shape == (48, d) and np.array_equal(top.output, Y)
+    assert np.array_equal(top.input, np.concatenate([nd.output for nd in model.all_layer[0]], 1))
+    # --- the public call: superset, subset, unrelated, reset
+    model = dgp(X[:40], Y[:40], combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                                        [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(d))]), seed=3)
+    model.train(N=4, ess_burn=3, disable=True)
+    len_before = model.all_layer[1][0].length.copy()
+    model.update_xy(X, Y)
+    assert model.n_data == 48 and model.all_layer[0][0].output.shape == (48, 1) and model.N == 4
+    assert np.array_equal(model.all_layer[1][0].length, len_before)          # hyper-parameters carried over
+    model.train(N=2, ess_burn=3, disable=True)
+    assert model.all_layer[1][0].para_path.shape[0] == 1 + 6
+    keep = np.array([3, 0, 17, 45, 21, 9, 30, 41, 12, 5, 28, 33])
+    model.update_xy(X[keep], Y[keep])
+    assert model.n_data == 12 and model.all_layer[1][0].input.shape == (12, d)
+    assert np.array_equal(model.X, X[keep]) and model.all_layer[0][1].output.shape == (12, 1)
+    assert np.array_equal(model.all_layer[1][0].global_input, X[keep]) and np.array_equal(model.all_layer[1][0].output, Y[keep])
+    # the subsetting itself (before any sampling)
+    m2 = dgp(X, Y, combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                           [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(d))]), seed=4)
+    lat2 = [nd.output.copy() for nd in m2.all_layer[0]]
+    m2.X, m2.Y, m2.n_data = X[keep], Y[keep], 12
+    m2._update_all_layer_smaller(keep)
+    for k, nd in enumerate(m2.all_layer[0]):
+        assert np.array_equal(nd.output, lat2[k][keep]) and np.array_equal(nd.input, X[keep])
+    assert np.array_equal(m2.all_layer[1][0].input, np.concatenate([a[keep] for a in lat2], 1))
+    Xn = rng.uniform(size=(30, d))
+    model.update_xy(Xn, fun(Xn))
+    assert model.n_data == 30 and np.all(np.isfinite(model.all_layer[0][0].output))
+    model.train(N=2, ess_burn=3, disable=True)
+    model.update_xy(Xn, fun(Xn), reset=True)
+    assert np.array_equal(model.all_layer[1][0].length, np.array([1.0])) and model.all_layer[1][0].para_path.shape[0] == 1 + model.N
+    model.train(N=3, ess_burn=3, disable=True)
+    mu, var = emulator(model.estimate(), N=2, seed=1).predict(Xn[:10])
+    assert mu.shape == (10, 1) and np.all(np.isfinite(mu)) and np.all(var > 0)
