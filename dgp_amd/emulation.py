@@ -328,6 +328,40 @@ class emulator:
 
     ppredict = predict   # test points / imputations already run in parallel on the device (emulation.py:578-629)
 
+    def loo(self, X, method=None, sample_size=50, m=30):
+        """Leave-one-out cross validation at the training inputs X (emulation.py:109-143).  As in the reference the
+        walk goes through the Vecchia prediction branches with `loo_state` set: every GP node conditions on its
+        nearest training points with the nearest one (the point itself) dropped -- all other n-1 points for a dense
+        emulator, m for a Vecchia one.  Conditioning sets live in LDS, so a dense emulator is limited to n of roughly
+        140 (larger ones: `to_vecchia()` first, as the reference's own cost of n factorisations of size n suggests)."""
+        if method is None:
+            method = 'mean_var'
+        n_train = len(self.all_layer[0][0].input)
+        isrep = len(X) != n_train
+        if isrep:
+            X, indices = np.unique(X, return_inverse=True, axis=0)
+        m_pred = m + 1 if self.vecch else X.shape[0]
+        gps = [nd for layer in self.all_layer for nd in layer if nd.type == 'gp']
+        was = [nd.vecch for nd in gps]
+        for nd in gps:
+            nd.loo_state, nd.vecch = True, True     # (emulation.py:90-108: the Vecchia branches also serve a dense emulator)
+        try:
+            res = self._predict_vecchia(X, False, m_pred, True, method, sample_size)
+        except RuntimeError as err:
+            if 'too large for LDS' in str(err) and not self.vecch:
+                raise NotImplementedError('loo() of a dense emulator conditions every prediction on all other %d training '
+                                          'points; beyond ~140 points convert the emulator with to_vecchia() first (%s)'
+                                          % (X.shape[0] - 1, err))
+            raise
+        finally:
+            for nd, v in zip(gps, was):
+                nd.loo_state, nd.vecch = False, v
+        if isrep:
+            res = type(res)(item[np.asarray(indices).reshape(-1), :] for item in res)
+        return res
+
+    ploo = loo
+
     def metric(self, x_cand, method='ALM', obj=None, nugget_s=1., m=50, score_only=False):
         """Sequential-design criterion at the rows of x_cand (emulation.py:323-420).  ALM (the predictive variance)
         MICE and VIGF (GP hierarchies) are computed from the device layer walk."""

@@ -105,17 +105,30 @@ class gp:
 
     def loo(self, method='mean_var', sample_size=50, m=30):
         """Leave-one-out predictions at the training inputs (gp.py:326-371).  Dense mode: the closed form on the
-        stored statistics, sigma2_i = scale / (R^-1)_ii, mu_i = y_i - (R^-1 y)_i / (R^-1)_ii."""
-        if self.vecch:
-            raise NotImplementedError('leave-one-out in Vecchia mode (vecchia.py:656-694) is not implemented')
+        stored statistics, sigma2_i = scale / (R^-1)_ii, mu_i = y_i - (R^-1 y)_i / (R^-1)_ii.  Vecchia mode: every point
+        from its m nearest other points."""
         k = self.kernel
-        st = k._stats
-        n = st['n']
-        import torch
-        d = torch.diagonal(st['Rinv'])[:n]
-        s2 = (1.0 / d).cpu().numpy().reshape(-1, 1)
-        mu = self.Y - k.Rinv_y[:, None] * s2
-        s2 = k.scale * s2
+        if self.vecch:
+            # vecchia.py:656-674: each point from its m nearest other points.  That is the Vecchia prediction at the
+            # point with itself struck from its neighbour list; only the point's own nugget differs (it carries the
+            # replicate weight here, not in a prediction), which shifts the variance by scale*nugget*(W_ii - 1).
+            e = k.engine
+            Xs = e.tensor(self.X / k.length)
+            NN = e.nn_query(Xs, Xs, m + 1)[:, 1:].contiguous()
+            wd = np.ones(len(self.Y)) if self.indices is None else self.W_diag
+            Xd = e.tensor(self.X)
+            mu, s2 = e.vecchia_gp(k.name, Xd, Xd, NN, e.tensor(self.Y.reshape(-1)), k.scale[0], k.length, k.nugget[0],
+                                  e.tensor(wd))
+            mu = mu.cpu().numpy().reshape(-1, 1)
+            s2 = s2.cpu().numpy().reshape(-1, 1) + k.scale[0] * k.nugget[0] * (wd.reshape(-1, 1) - 1.0)
+        else:
+            st = k._stats
+            n = st['n']
+            import torch
+            d = torch.diagonal(st['Rinv'])[:n]
+            s2 = (1.0 / d).cpu().numpy().reshape(-1, 1)
+            mu = self.Y - k.Rinv_y[:, None] * s2
+            s2 = k.scale * s2
         if self.indices is not None:
             mu, s2 = mu[self.indices, :], s2[self.indices, :]
         if method == 'mean_var':

@@ -688,6 +688,26 @@ def gp_vecch(x, w, NNarray, y, scale, length, nugget, nugget_diag, name):
     return mo, vo
 
 
+def loo_gp_vecch(x, NNarray, y, scale, length, nugget, nugget_diag, name):
+    """vecchia.loo_gp_vecch (vecchia.py:656-674): row i of NNarray = the point itself followed by its nearest
+    neighbours; the block is ordered self-last and the point is predicted from the others.  Unlike gp_vecch the
+    point's own nugget carries its replicate weight."""
+    x = np.asarray(x, float)
+    y = np.asarray(y, float).reshape(-1)
+    n = x.shape[0]
+    mo, vo = np.zeros(n), np.zeros(n)
+    for i in range(n):
+        idx = NNarray[i]
+        idx = idx[idx >= 0][::-1]
+        Ki = corr_matrix(x[idx], length, name)
+        b = len(idx)
+        Ki[np.arange(b), np.arange(b)] = 1.0 + nugget * nugget_diag[idx]
+        Li = np.linalg.cholesky(Ki)
+        mo[i] = Li[-1, :-1] @ solve_triangular(Li[:-1, :-1], y[idx][:-1], lower=True)
+        vo[i] = scale * Li[-1, -1]**2
+    return mo, vo
+
+
 def link_gp_vecch(m, v, z, w1, global_w1, NNarray, y, scale, length, nugget, nugget_diag, name):
     m = np.asarray(m, float)
     v = np.asarray(v, float)

@@ -388,6 +388,42 @@ def gen_emulator():
         save('g9_emulator_' + tag, **out)
 
 
+def gen_loo():
+    """G14: emulator.loo (emulation.py:109-143) -- the leave-one-out walk through the Vecchia prediction branches with
+    loo_state (kernel_class.py:603-619,647-664): dense emulator (every node conditions on all but the nearest training
+    point) and Vecchia emulator (m = 5)."""
+    for tag, names in (('sexp', ('sexp', 'sexp')), ('matern', ('matern2.5', 'matern2.5'))):
+        X, Y, layers = build_small_dgp(11, 18, 2, names, n_out=2)
+        model = dgp(X, Y, layers)
+        model.train(N=5, ess_burn=2, disable=True)
+        emu = emulator(model.estimate(), N=3)
+        out = {'n_imp': np.array(len(emu.all_layer_set)), 'X': X, 'Y': Y}
+        for s_, al in enumerate(emu.all_layer_set):
+            out.update(dump_structure(al, 's%d_' % s_))
+        mu, var = emu.loo(X)
+        out.update(loo_mu=mu, loo_var=var)
+        emu.to_vecchia()
+        mu, var = emu.loo(X, m=5)
+        out.update(loo_mu_vecch=mu, loo_var_vecch=var)
+        save('g14_loo_' + tag, **out)
+    # gp.loo in Vecchia mode (gp.py:345-353, vecchia.py:656-674), without and with replicated inputs
+    from dgpsi import gp as rgp
+    out = {}
+    for c, rep in enumerate((False, True)):
+        rng = np.random.default_rng(31 + c)
+        X = rng.uniform(size=(26, 2))
+        if rep:
+            X = np.concatenate((X, X[:9], X[:4]), 0)
+        Y = np.sin(4 * X[:, :1]) + X[:, 1:] ** 2 + 0.05 * rng.normal(size=(len(X), 1))
+        np.random.seed(5)
+        g = rgp(X, Y, kernel(length=np.array([0.7, 1.1]), name='matern2.5' if c else 'sexp', scale_est=True, nugget_est=True,
+                             nugget=1e-2), vecchia=True, m=8)
+        mu, s2 = g.loo(m=6)
+        out.update({'c%d_X' % c: X, 'c%d_Y' % c: Y, 'c%d_mu' % c: mu, 'c%d_s2' % c: s2, 'c%d_scale' % c: g.kernel.scale,
+                    'c%d_length' % c: g.kernel.length, 'c%d_nugget' % c: g.kernel.nugget, 'c%d_name' % c: np.array(g.kernel.name)})
+    save('g14_loo_gp', **out)
+
+
 def gen_lgp():
     """G10: feed-forward chain GP -> DGP -> GP (+ one external input on the last emulator), lgp.predict
     (linkgp.py:285-501) from the reference's own imputations (dumped)."""
@@ -527,7 +563,7 @@ def gen_hetero():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero']
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo']
     if 'kernel' in which:
         gen_kernel_cases()
     if 'fmvn' in which:
@@ -544,3 +580,5 @@ if __name__ == '__main__':
         gen_lgp()
     if 'hetero' in which:
         gen_hetero()
+    if 'loo' in which:
+        gen_loo()

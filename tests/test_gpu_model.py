@@ -111,6 +111,37 @@ def test_emulator_predict_matches_reference(eng, golden, tag):
     close(ml[-1], d['mu'], rtol=1e-6, atol=1e-8)
 
 
+@pytest.mark.parametrize('tag', ['sexp', 'matern'])
+def test_emulator_loo_matches_reference(eng, golden, tag):
+    """emulator.loo (emulation.py:109-143) from the reference's own imputations: dense emulator (all other points)
+    and Vecchia emulator (m = 5)."""
+    from dgp_amd.emulation import emulator
+    d = golden('g14_loo_' + tag)
+    S = int(d['n_imp'])
+    emu = emulator.__new__(emulator)
+    est = build_structure(d, 's0_', eng)
+    emu.all_layer, emu.n_layer, emu.vecch, emu.engine = est, len(est), False, eng
+    emu.N = emu.N_total = S
+    emu.shard = False
+    emu.latents = []
+    for s in range(S):
+        ls = build_structure(d, 's%d_' % s, eng)
+        emu.latents.append([np.stack([nd.output[:, 0] for nd in layer], 1) for layer in ls[:-1]])
+    emu.orders = []
+    emu._stats = None
+    mu, var = emu.loo(d['X'])
+    close(mu, d['loo_mu'], rtol=1e-6, atol=1e-8)
+    close(var, d['loo_var'], rtol=1e-5, atol=1e-7)
+    assert not any(nd.loo_state for layer in emu.all_layer for nd in layer)
+    emu.vecch = True
+    for layer in emu.all_layer:
+        for nd in layer:
+            nd.vecch = True
+    mu, var = emu.loo(d['X'], m=5)
+    close(mu, d['loo_mu_vecch'], rtol=1e-6, atol=1e-8)
+    close(var, d['loo_var_vecch'], rtol=1e-5, atol=1e-7)
+
+
 def test_estimate_is_path_mean(eng, golden):
     """dgp.estimate (dgp.py:1529-1540)."""
     from dgp_amd.dgp import dgp
@@ -312,6 +343,20 @@ def test_gp_class_predict_matches_reference(eng, golden):
     assert len(m2.export()) == 1
     smp = m2.predict(d['xt'], method='sampling', sample_size=7)
     assert smp.shape == (len(d['xt']), 7)
+
+
+def test_gp_loo_vecchia_matches_reference(eng, golden):
+    """gp.loo under Vecchia (gp.py:345-353, vecchia.py:656-674) without and with replicated inputs."""
+    from dgp_amd import gp, kernel
+    g = golden('g14_loo_gp')
+    for c in range(2):
+        k = kernel(length=g['c%d_length' % c].copy(), scale=g['c%d_scale' % c][0], nugget=g['c%d_nugget' % c][0],
+                   name=str(g['c%d_name' % c]), scale_est=True, nugget_est=True)
+        model = gp(g['c%d_X' % c], g['c%d_Y' % c], k, vecchia=True, m=8)
+        mu, s2 = model.loo(m=6)
+        close(mu, g['c%d_mu' % c], rtol=1e-8, atol=1e-10)
+        close(s2, g['c%d_s2' % c], rtol=1e-7, atol=1e-10)
+        assert model.loo(method='sampling', sample_size=4, m=6).shape == (len(g['c%d_X' % c]), 4)
 
 
 def test_hetero_exact_posterior_draw(eng, golden):

@@ -250,3 +250,22 @@ def test_hetero_pieces(golden):
     close(O.ghdiag(O.hetero_pllik, g['b_m'], g['b_v'], g['b_yq']), g['b_gh'], rtol=1e-12)
     close(O.post_het1(g['a_v'], g['a_Gamma'], g['a_y'], g['a_z1']), g['a_f1'], rtol=1e-9, atol=1e-11)
     close(O.post_het2(g['a_v'], g['a_Gamma2'], g['a_mask'], g['a_y2'], g['a_z2']), g['a_f2'], rtol=1e-9, atol=1e-11)
+
+
+def test_loo_gp_vecch(golden):
+    """gp.loo in Vecchia mode (gp.py:345-353 -> vecchia.py:656-674) without and with replicated inputs (g14_loo_gp)."""
+    g = golden('g14_loo_gp')
+    for c in range(2):
+        X, Y = g['c%d_X' % c], g['c%d_Y' % c]
+        X0, inv = np.unique(X, return_inverse=True, axis=0)
+        inv = np.asarray(inv).reshape(-1)
+        if len(X0) != len(X):
+            wd = 1.0 / np.bincount(inv)
+            y = np.bincount(inv, weights=Y.ravel()) * wd
+        else:
+            X0, inv, wd, y = X, np.arange(len(X)), np.ones(len(X)), Y.ravel()
+        length = g['c%d_length' % c]
+        NN = O.pred_nn(X0 / length, X0 / length, 7)
+        mu, s2 = O.loo_gp_vecch(X0, NN, y, g['c%d_scale' % c][0], length, g['c%d_nugget' % c][0], wd, str(g['c%d_name' % c]))
+        close(mu[inv], g['c%d_mu' % c].ravel(), rtol=1e-10, atol=1e-12)
+        close(s2[inv], g['c%d_s2' % c].ravel(), rtol=1e-10, atol=1e-12)
