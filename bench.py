@@ -167,10 +167,11 @@ def main():
         for e in engines:
             k, ms, w = e.prof_collect()
             tot_n, tot_ms, tot_w = tot_n + k, tot_ms + ms, tot_w + w
-        # an EMPTY event pair already reports a few microseconds: calibrate that fixed cost and take it out
+        # An EMPTY event pair reports a few microseconds by itself, but that cost does not add to a bracketed kernel: the
+        # raw event average agrees with rocprofv3's per-kernel average of the same command (32.5 vs 33.7 us in
+        # profiles/r01_bench_train_predict_kernel_stats.txt), the "overhead removed" figure does not -- the raw one is reported.
         ev_us = float(np.median([eng.prof_event_overhead_us() for _ in range(5)]))
-        raw_ms = tot_ms
-        tot_ms = max(tot_ms - tot_n * ev_us * 1e-3, 0.25 * tot_ms)
+        corrected_ms = max(tot_ms - tot_n * ev_us * 1e-3, 0.25 * tot_ms)
         if tot_n:
             if args.prof_kernel == 'kmatrix':
                 ach = tot_w / (tot_ms * 1e-3) / 1e9
@@ -186,7 +187,7 @@ def main():
                     roof['traffic'] = json.load(f)['hbm_bytes_per_launch']
                 roof['traffic_source'] = 'profiles/r01_pmc_bench_step_kernel.json (FETCH_SIZE x2 + WRITE_SIZE, same command)'
             roof.update(launches=tot_n, avg_launch_us=1e3 * tot_ms / tot_n, work_per_launch=tot_w / tot_n,
-                        event_pair_overhead_us=ev_us, avg_launch_us_uncorrected=1e3 * raw_ms / tot_n,
+                        event_pair_overhead_us=ev_us, avg_launch_us_if_event_overhead_removed=1e3 * corrected_ms / tot_n,
                         f64_mfma_tflops_measured={'register_only_loop': 47.5, 'tile_engine_standalone_4_panels': 42.0,
                                                       'tile_engine_standalone_16_panels': 64.0})
     kernel_class.kernel._llik_finish = orig_finish
