@@ -426,6 +426,109 @@ extern "C" int dgpamd_vecchia_lmatrix(dgpamd_ctx *ctx, int kind, int64_t n, int 
 }
 
 // ---------------------------------------------------------------------------
+// Hetero likelihood, exact conditional posterior of the mean latent under Vecchia (imputation.py:143-160,
+// vecchia.U_matrix :426-446, U_matrix_sp :599-610, Hetero.post_het_vecch likelihood_class.py:166-182).
+// Row i of impNN (kernel_class.py:268-274) conditions the LATENT of ordered point i on, in the stacked vector
+// [observations 0..n-1 ; latents n..2n-1], its own latent (n+i), its own observation (i) and its nearest other
+// points (latent if earlier in the ordering, observation otherwise).  u_i = L_i^-T e_last of the block
+// scale*corr + diag(gamma on observation entries + 1e-10) is column i of the sparse factor U; the reference
+// assembles U (2n x n) with scipy.sparse and solves with U_l^T.  Here every row is emitted directly in the layout
+// dgpamd_vecchia_spsolve consumes: Lrows[i] = [diagonal, latent-neighbour entries, 0..], NNl[i] = [i, their
+// columns, 0..], and t_i = sum over the observation entries of u * y  (= (U_ol^T y)_i).
+// ---------------------------------------------------------------------------
+struct VHetArgs {
+    VParams vp;
+    int64_t n;
+    int m;
+    const double *X, *gamma, *y;
+    const int64_t *NN;
+    double scale;
+    double *Lrows, *t;
+    int64_t *NNl;
+    int32_t *info;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(VW) void vecchia_het_rows_kernel(VHetArgs a) {
+    extern __shared__ double lds[];
+    const int mp1 = a.m + 1, D = a.vp.D, lda = mp1 + 2;
+    double *A = lds;                         // [(mp1+1)][lda]
+    double *xs = A + (mp1 + 1) * lda;        // [mp1][D] scaled inputs
+    double *V = xs + mp1 * D;                // [2][lda]  u = L^-T e_last
+    int *idx = reinterpret_cast<int *>(V + 2 * lda);
+    const int lane = threadIdx.x;
+    const int64_t i = blockIdx.x, n = a.n;
+    const int b = gather_block(a.NN + i * mp1, mp1, idx, lane);   // reversed: own observation, own latent last
+    __syncthreads();
+    for (int e = lane; e < b * D; e += VW) {
+        const int r = e / D, d = e - r * D;
+        const int64_t p = idx[r] >= n ? idx[r] - n : idx[r];
+        xs[e] = a.X[p * D + d] * a.vp.inv_len[d];
+    }
+    __syncthreads();
+    for (int e = lane; e < b * b; e += VW) {
+        const int r = e / b, c = e - r * b;
+        if (c > r) continue;
+        double v;
+        if (r == c)
+            v = a.scale + (idx[r] >= n ? 0.0 : a.gamma[idx[r]]) + 1e-10;
+        else
+            v = a.scale * corr_pts<KIND>(xs + r * D, xs + c * D, D);
+        A[r * lda + c] = v;
+    }
+    const int bad = lds_chol(A, lda, b, b, lane);
+    for (int c = lane; c < b; c += VW) V[c] = (c == b - 1) ? 1.0 : 0.0;
+    lds_backsolve_T(A, lda, b, V, lda, 1, lane);
+    if (lane == 0) {
+        if (bad) atomicCAS(a.info, 0, (int)(i + 1));   // a block that is not positive definite (numpy raises LinAlgError)
+        double *Lr = a.Lrows + i * mp1;
+        int64_t *Nr = a.NNl + i * mp1;
+        Lr[0] = V[b - 1];
+        Nr[0] = i;
+        int slot = 1;
+        double t = 0.0;
+        for (int c = 0; c < b - 1; ++c) {
+            if (idx[c] >= n) {
+                Lr[slot] = V[c];
+                Nr[slot] = idx[c] - n;
+                ++slot;
+            } else {
+                t = fma(V[c], a.y[idx[c]], t);
+            }
+        }
+        for (; slot < mp1; ++slot) {
+            Lr[slot] = 0.0;
+            Nr[slot] = 0;
+        }
+        a.t[i] = t;
+    }
+}
+
+extern "C" int dgpamd_vecchia_het_rows(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X,
+                                       const int64_t *impNN, const double *length_h, int nlen, double scale,
+                                       const double *gamma, const double *y, double *Lrows, int64_t *NNl, double *t,
+                                       int32_t *info) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || m < 1 || !X || !impNN || !gamma || !y || !Lrows || !NNl || !t || !info) BAD_ARG(ctx, "bad arguments");
+    HIP_TRY(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
+    VHetArgs a;
+    int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, 0.0);
+    if (rc) return rc;
+    a.n = n; a.m = m; a.X = X; a.gamma = gamma; a.y = y; a.NN = impNN; a.scale = scale; a.Lrows = Lrows; a.NNl = NNl; a.t = t; a.info = info;
+    const size_t shm = vrow_lds(m, D);
+    const void *fn = kind == DGPAMD_SEXP ? (const void *)vecchia_het_rows_kernel<DGPAMD_SEXP>
+                                         : (const void *)vecchia_het_rows_kernel<DGPAMD_MATERN25>;
+    rc = set_lds(ctx, fn, shm);
+    if (rc) return rc;
+    if (kind == DGPAMD_SEXP)
+        hipLaunchKernelGGL(vecchia_het_rows_kernel<DGPAMD_SEXP>, dim3((unsigned)n), dim3(VW), shm, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(vecchia_het_rows_kernel<DGPAMD_MATERN25>, dim3((unsigned)n), dim3(VW), shm, ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
 // forward_solve_sp (vecchia.py:111-120): x_i = (b_i - sum_j L[i,j] x[NN[i,j]]) / L[i,0], rows in order.
 // One persistent 1024-thread workgroup walks the rows in windows; inside a window every row whose
 // in-window dependencies are published computes in the same sweep (wavefront over the dependency DAG).

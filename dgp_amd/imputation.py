@@ -459,10 +459,35 @@ class imputer:
         (imputation.py:141-164 -> Hetero.posterior, likelihood_class.py:134-243; dense mode)."""
         e = self.engine
         nd = self.all_layer[l][k]
-        if nd.vecch:
-            raise NotImplementedError('the Vecchia form of the exact-posterior step (vecchia.py:426-476) is not implemented')
         F = self.F[l]
         n = F.shape[0]
+        if nd.vecch:
+            # Vecchia form (imputation.py:143-160, likelihood_class.py:153-182): sparse factor of the stacked
+            # [observations ; latents] vector, rows built and solved on the device in ordered coordinates
+            import torch
+            if getattr(nd, 'imp_NNarray', None) is None:
+                nd.ord_nn(ord=nd.ord, NNarray=nd.NNarray, pointer=True)
+            Fh = F.cpu().numpy()
+            lik.input = Fh[lik.rep, :][:, lik.input_dim] if lik.rep is not None else Fh[:, lik.input_dim]
+            yv = np.asarray(lik.output, float).reshape(-1)
+            if lik.rep is not None:
+                invg = 1.0 / np.exp(lik.input[:, 1])
+                gam = 1.0 / np.bincount(lik.rep, weights=invg, minlength=n)
+                yeff = np.bincount(lik.rep, weights=invg * yv, minlength=n) * gam
+            else:
+                gam, yeff = np.exp(lik.input[:, 1]), yv
+            Xl, cm = self._node_input(l, k, nd)
+            Xc = Xl if cm is None else Xl[:, torch.as_tensor(cm, device=Xl.device, dtype=torch.long)]
+            if self._glob[(l, k)] is not None:
+                Xc = torch.cat((Xc, self._glob[(l, k)]), 1)
+            Xo = Xc[torch.as_tensor(nd.ord, device=Xc.device, dtype=torch.long)].contiguous()
+            z = self.draws.normal(n)
+            f = e.vecchia_post_het(nd.name, Xo, e.tensor(nd.imp_NNarray, dtype=torch.int64), nd.scale[0], nd.length,
+                                   e.tensor(gam[nd.ord]), e.tensor(yeff[nd.ord]), e.tensor(z))
+            F[:, k] = f[e.tensor(nd.rev_ord, dtype=torch.int64)]
+            self._ll_cache.pop(l, None)
+            self._ll_cache.pop(l - 1, None)
+            return
         Xl, cm = self._node_input(l, k, nd)
         K = e.kmatrix(nd.name, Xl, cm, self._glob[(l, k)], nd.length, nd.nugget[0])   # full n x n, device
         Fh = F.cpu().numpy()

@@ -281,7 +281,18 @@ class kernel:
         else:
             self.NNarray = NNarray
         if pointer:
-            raise NotImplementedError('Hetero exact-posterior pointers (imp_pointers) are outside the accelerated path')
+            # conditioning sets of the LATENT values for a Hetero likelihood's exact-posterior step (kernel_class.py:268-274):
+            # in the stacked vector [observations 0..n-1 ; latents n..2n-1] row i = own latent, own observation, the m-1
+            # nearest other points (latent if earlier in the ordering, observation otherwise)
+            e = self.engine
+            Xs = e.tensor((self._X() / self.length)[self.ord])
+            n = Xs.shape[0]
+            NNs = e.nn_query(Xs, Xs, self.m)[:, 1:].cpu().numpy().copy()
+            prev = NNs < np.arange(n)[:, None]
+            NNs[prev] += n
+            self.imp_NNarray = np.hstack((np.arange(n).reshape(-1, 1) + n, np.arange(n).reshape(-1, 1), NNs)).astype(np.int64)
+        else:
+            self.imp_NNarray = None
 
     def _vecch_stage(self):
         e = self.engine

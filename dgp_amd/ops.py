@@ -398,6 +398,24 @@ class Engine:
                                              len(length), float(nugget), _dp(out)))
         return out
 
+    def vecchia_post_het(self, kind, X_ord, impNN, scale, length, gamma, y, z):
+        """Draw of the mean latent from its exact conditional posterior under a Hetero likelihood, Vecchia form
+        (likelihood_class.py:153-182 on vecchia.U_matrix_sp :599-610), in ORDERED coordinates:
+        f = -U_l^-T U_ol^T y + U_l^-T z.  X_ord (n x D), impNN (n x (m+1)) int64, gamma / y / z (n), all on the device."""
+        import torch
+        n, D = X_ord.shape
+        mp1 = impNN.shape[1]
+        length = _f64(length)
+        Lrows, t = self.empty(n, mp1), self.empty(n)
+        NNl = torch.empty((n, mp1), dtype=torch.int64, device=X_ord.device)
+        info = torch.empty(1, dtype=torch.int32, device=X_ord.device)
+        self._chk(lib.dgpamd_vecchia_het_rows(self.h, KIND[kind], n, D, mp1 - 1, _dp(X_ord), _dp(impNN), _hp(length), len(length),
+                                              float(scale), _dp(gamma), _dp(y), _dp(Lrows), _dp(NNl), _dp(t), _dp(info)))
+        bad = int(info.item())
+        if bad:
+            raise np.linalg.LinAlgError('Vecchia block of row %d is not positive definite' % (bad - 1))
+        return self.vecchia_spsolve(Lrows, NNl, 1.0, z) - self.vecchia_spsolve(Lrows, NNl, 1.0, t)
+
     def vecchia_spsolve(self, Lmat, NN, inv_sqrt_scale, b):
         n = Lmat.shape[0]
         out = self.empty(n)

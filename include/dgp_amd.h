@@ -297,6 +297,16 @@ int dgpamd_vecchia_lmatrix(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, c
                            const int64_t *NNarray, const double *length_h, int nlen, double nugget, double *Lmat);
 int dgpamd_vecchia_spsolve(dgpamd_ctx *ctx, int64_t n, int m, const double *Lmat, const int64_t *NNarray,
                            double inv_sqrt_scale, const double *b, double *x);
+/* Hetero likelihood under Vecchia: rows of the sparse factor of the latent mean's conditional posterior
+ * (vecchia.U_matrix :426-446 / U_matrix_sp :599-610 through kernel.ord_nn(pointer=True) kernel_class.py:268-275;
+ * consumer Hetero.post_het_vecch likelihood_class.py:166-182).  X: (n x D) ORDERED inputs; impNN: (n x (m+1))
+ * imp_NNarray; gamma, y: (n) ordered noise variances and observations (site-pooled with replicates).
+ * Out, in dgpamd_vecchia_spsolve's layout: Lrows (n x (m+1)), NNl (n x (m+1)), and t = U_ol^T y (n):
+ * f = -solve(t) + solve(z) is the draw in ordered coordinates.  info (device int32): 0, or 1 + the first row whose
+ * block is not positive definite (the reference's np.linalg.cholesky raises LinAlgError there).             */
+int dgpamd_vecchia_het_rows(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X,
+                            const int64_t *impNN, const double *length_h, int nlen, double scale,
+                            const double *gamma, const double *y, double *Lrows, int64_t *NNl, double *t, int32_t *info);
 
 /* ---- a22/a23  Vecchia prediction -------------------------------------------------
  * gp_vecch vecchia.py:635-654 ; link_gp_vecch :758-796 (IJ_nb :838-907).          */

@@ -708,6 +708,59 @@ def loo_gp_vecch(x, NNarray, y, scale, length, nugget, nugget_diag, name):
     return mo, vo
 
 
+def imp_nn_array(Xs_ord, m):
+    """kernel.ord_nn(pointer=True) (kernel_class.py:268-274): per ordered point i the conditioning set of its LATENT
+    value in the stacked vector [observations (0..n-1) ; latents (n..2n-1)]: its own latent (n+i), its own
+    observation (i) and its m-1 nearest other points -- as latents if they come earlier in the ordering, as
+    observations otherwise."""
+    Xs_ord = np.asarray(Xs_ord, float)
+    n = Xs_ord.shape[0]
+    NNs = pred_nn(Xs_ord, Xs_ord, m)[:, 1:].copy()
+    prev = NNs < np.arange(n)[:, None]
+    NNs[prev] += n
+    return np.hstack((np.arange(n).reshape(-1, 1) + n, np.arange(n).reshape(-1, 1), NNs)).astype(np.int64)
+
+
+def U_matrix_rows(X_ord, impNN, scale, length, name, gamma2):
+    """vecchia.U_matrix through U_matrix_sp's argument conventions (vecchia.py:426-446,599-610): row i = last column of
+    L_i^-T for the block [.., own observation, own latent] of scale*corr + diag(gamma on observation entries + 1e-10)."""
+    X_ord = np.asarray(X_ord, float)
+    n = X_ord.shape[0]
+    X2 = np.vstack((X_ord, X_ord))
+    rev = impNN[:, ::-1]
+    U = np.zeros(rev.shape)
+    for i in range(n):
+        idx = rev[i]
+        idx = idx[idx >= 0]
+        cond = idx > n - 1
+        b = len(idx)
+        Ki = scale * corr_matrix(X2[idx], length, name)
+        Ki[np.arange(b), np.arange(b)] = scale * 1.0 + gamma2[idx] * ~cond + 1e-10
+        Li = np.linalg.cholesky(Ki)
+        e = np.zeros(b)
+        e[-1] = 1.0
+        U[i, :b] = solve_triangular(Li.T, e, lower=False)
+    return U
+
+
+def post_het_vecch(X_ord, impNN, scale, length, name, gamma2, y_ord, z):
+    """Hetero.post_het_vecch on U_matrix_sp's output (likelihood_class.py:166-182, vecchia.py:599-610): with U (2n x n)
+    assembled from the rows, U_l its latent block and U_ol its observation block,
+    f = -U_l^-T U_ol^T y + U_l^-T z   (ordered coordinates)."""
+    n = len(y_ord)
+    rows = U_matrix_rows(X_ord, impNN, scale, length, name, gamma2)
+    rev = impNN[:, ::-1]
+    U = np.zeros((2 * n, n))
+    for i in range(n):
+        idx = rev[i]
+        keep = idx >= 0
+        U[idx[keep], i] = rows[i, :keep.sum()]
+    U_l, U_ol = U[n:], U[:n]
+    L = U_l.T
+    mu = -solve_triangular(L, U_ol.T @ np.asarray(y_ord, float).reshape(-1), lower=True)
+    return mu + solve_triangular(L, np.asarray(z, float).reshape(-1), lower=True)
+
+
 def link_gp_vecch(m, v, z, w1, global_w1, NNarray, y, scale, length, nugget, nugget_diag, name):
     m = np.asarray(m, float)
     v = np.asarray(v, float)

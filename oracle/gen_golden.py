@@ -424,6 +424,58 @@ def gen_loo():
     save('g14_loo_gp', **out)
 
 
+def gen_hetero_vecchia():
+    """G15: the Vecchia form of Hetero's exact conditional-posterior draw (imputation.py:143-160 ->
+    kernel.ord_nn(pointer=True) kernel_class.py:268-275, vecchia.U_matrix_sp :599-610, Hetero.posterior_vecch /
+    post_het_vecch likelihood_class.py:153-182), without and with replicates, normals logged."""
+    import dgpsi.likelihood_class as RL
+    from dgpsi import Hetero
+    out = {}
+    for c, (name, rep) in enumerate((('matern2.5', False), ('sexp', True))):
+        rng = np.random.default_rng(91 + c)
+        np.random.seed(12 + c)
+        n, m = 40, 7
+        X = rng.uniform(size=(n, 2))
+        k = kernel(length=np.array([0.5, 0.8]), scale=1.3, nugget=1e-6, name=name)
+        k.input, k.global_input = X, None
+        k.vecch, k.m, k.nn_method = True, m, 'exact'
+        k.ord_nn(pointer=True)
+        h = Hetero()
+        if rep:
+            counts = rng.integers(1, 4, size=n)
+            h.rep = np.repeat(np.arange(n), counts)
+        else:
+            h.rep = None
+        N = n if h.rep is None else len(h.rep)
+        h.input = np.stack((rng.normal(size=N), rng.normal(size=N) * 0.7 - 1.0), 1)
+        h.output = rng.normal(size=(N, 1))
+        log = DrawLog(20 + c)
+        old = np.random.randn
+        np.random.randn = log.randn
+        try:
+            if rep:
+                invG = 1.0 / np.exp(h.input[:, 1])
+                invd = 1 / (np.bincount(h.rep, weights=invG, minlength=n)[k.ord])
+                U_l, U_ol = RV.U_matrix_sp(X[k.ord], k.imp_NNarray, k.scale[0], k.length, 0.0, k.name, np.concatenate((invd, invd)),
+                                           k.imp_pointer_row, k.imp_pointer_col)
+                f = h.posterior_vecch(idx=0, U_sp_l=U_l, U_sp_ol=U_ol, ord=k.ord, rev_ord=k.rev_ord, invd=invd, invg=invG)
+            else:
+                Gamma = np.exp(h.input[:, 1])[k.ord]
+                U_l, U_ol = RV.U_matrix_sp(X[k.ord], k.imp_NNarray, k.scale[0], k.length, 0.0, k.name, np.concatenate((Gamma, Gamma)),
+                                           k.imp_pointer_row, k.imp_pointer_col)
+                f = h.posterior_vecch(idx=0, U_sp_l=U_l, U_sp_ol=U_ol, ord=k.ord, rev_ord=k.rev_ord)
+        finally:
+            np.random.randn = old
+        pre = 'c%d_' % c
+        out.update({pre + 'X': X, pre + 'ord': k.ord.astype(np.int64), pre + 'm': np.array(m), pre + 'impNN': k.imp_NNarray.astype(np.int64),
+                    pre + 'length': k.length.copy(), pre + 'scale': k.scale.copy(), pre + 'name': np.array(name),
+                    pre + 'lik_input': h.input.copy(), pre + 'lik_output': h.output.copy(), pre + 'z': log.z[0].reshape(-1),
+                    pre + 'f': f, pre + 'has_rep': np.array(rep)})
+        if rep:
+            out[pre + 'rep'] = h.rep.astype(np.int64)
+    save('g15_hetero_vecchia', **out)
+
+
 def gen_lgp():
     """G10: feed-forward chain GP -> DGP -> GP (+ one external input on the last emulator), lgp.predict
     (linkgp.py:285-501) from the reference's own imputations (dumped)."""
@@ -563,7 +615,7 @@ def gen_hetero():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo']
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch']
     if 'kernel' in which:
         gen_kernel_cases()
     if 'fmvn' in which:
@@ -582,3 +634,5 @@ if __name__ == '__main__':
         gen_hetero()
     if 'loo' in which:
         gen_loo()
+    if 'hetvecch' in which:
+        gen_hetero_vecchia()

@@ -269,3 +269,28 @@ def test_loo_gp_vecch(golden):
         mu, s2 = O.loo_gp_vecch(X0, NN, y, g['c%d_scale' % c][0], length, g['c%d_nugget' % c][0], wd, str(g['c%d_name' % c]))
         close(mu[inv], g['c%d_mu' % c].ravel(), rtol=1e-10, atol=1e-12)
         close(s2[inv], g['c%d_s2' % c].ravel(), rtol=1e-10, atol=1e-12)
+
+
+def test_hetero_vecchia_posterior(golden):
+    """Vecchia form of Hetero's exact conditional-posterior draw (g15_hetero_vecchia: kernel_class.py:268-275,
+    vecchia.py:426-446,599-610, likelihood_class.py:153-182), without and with replicates."""
+    g = golden('g15_hetero_vecchia')
+    for c in range(2):
+        d = case(g, 'c%d_' % c)
+        X, ord_, m = d['X'], d['ord'], int(d['m'])
+        n = len(X)
+        length, scale, name = d['length'], d['scale'][0], str(d['name'])
+        imp = O.imp_nn_array((X / length)[ord_], m)
+        assert np.array_equal(imp, d['impNN'])
+        lik_in, y = d['lik_input'], d['lik_output'].ravel()
+        if bool(d['has_rep']):
+            rep = d['rep']
+            invG = 1.0 / np.exp(lik_in[:, 1])
+            invd = 1.0 / np.bincount(rep, weights=invG, minlength=n)[ord_]
+            y_ord = np.bincount(rep, weights=invG * y, minlength=n)[ord_] * invd
+            gamma = invd
+        else:
+            gamma = np.exp(lik_in[:, 1])[ord_]
+            y_ord = y[ord_]
+        f_ord = O.post_het_vecch(X[ord_], imp, scale, length, name, np.concatenate((gamma, gamma)), y_ord, d['z'])
+        close(f_ord[np.argsort(ord_)], d['f'], rtol=1e-9, atol=1e-11)
