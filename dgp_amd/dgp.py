@@ -90,7 +90,8 @@ class dgp:
         """Initial (mean, log-variance) latents under a Hetero likelihood (dgp.py:163-246).  Without replicates: a
         reference-prior GP is fitted to y, its leave-one-out residuals give log-variance targets, a second GP fitted to
         those is sampled (clipped to +-2.576 sd).  With replicates: site means and bias-corrected log sample
-        variances (singletons take the median variance)."""
+        variances; sites observed once take the median variance first and are then redrawn from a GP fitted to the
+        log-variance targets."""
         from .gp import gp as single_gp
         from scipy.special import psi
         G, D = self.X.shape
@@ -124,7 +125,24 @@ class dgp:
             nu = (counts - 1.0) / 2.0
             with np.errstate(divide='ignore', invalid='ignore'):
                 bias = np.where(valid, psi(nu) - np.log(np.maximum(nu, 1e-12)), 0.0)
-            Out[:, 1] = np.log(s2 + 1e-12) - bias
+            z_init = np.log(s2 + 1e-12) - bias
+            if np.any(~valid):
+                # sites observed once: a (slightly relaxed) GP on the log-variance targets fills them in from their
+                # leave-one-out predictive distributions, clipped to +-2 sd (dgp.py:246-258)
+                fit = single_gp(self.X, z_init.reshape(-1, 1),
+                                ker(length=np.ones(D) * 2., name=self.all_layer[-2][1].name, scale_est=True, nugget_est=True,
+                                    prior_name='ref', nugget=1e-1), vecchia=self.vecch, m=self.m, ord_fun=self.ord_fun)
+                fit.train()
+                m_lv, v_lv = fit.loo()
+                sing = ~valid
+                m_s = m_lv[sing].flatten()
+                sd_s = np.sqrt(np.maximum((v_lv[sing] - fit.kernel.nugget * fit.kernel.scale).flatten(), 1e-12))
+                z_init = z_init.copy()
+                z_init[sing] = np.clip(np.random.normal(loc=m_s, scale=sd_s), m_s - 2 * sd_s, m_s + 2 * sd_s)
+            Out[:, 1] = z_init
+        lik_dim = self.all_layer[-1][0].input_dim
+        if lik_dim is not None:
+            Out = Out[:, lik_dim]
         return Out
 
     def initialize(self):

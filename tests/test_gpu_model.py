@@ -415,7 +415,7 @@ def test_hetero_dgp_end_to_end(eng, rep):
     np.random.seed(4)
     x = np.sort(rng.uniform(size=45 if rep else 90))
     if rep:
-        x = np.repeat(x, 2)
+        x = np.repeat(x, np.tile([1, 2, 3], 15))     # (sites observed once exercise the singleton branch of the warm start)
     X = x[:, None]
     sd = 0.05 + 0.5 * x ** 2
     Y = (np.sin(6 * x) + sd * rng.normal(size=len(x)))[:, None]
