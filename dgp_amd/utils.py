@@ -68,9 +68,16 @@ def save_structure(all_layer, npz_file):
     for l, layer in enumerate(all_layer):
         out['l%d_n' % l] = np.array(len(layer))
         for k, nd in enumerate(layer):
-            if getattr(nd, 'type', 'gp') != 'gp':
-                raise NotImplementedError('only GP nodes are stored; likelihood nodes keep their own (host) state')
             p = 'l%d_k%d_' % (l, k)
+            if getattr(nd, 'type', 'gp') != 'gp':
+                if getattr(nd, 'name', None) != 'Hetero':
+                    raise NotImplementedError('of the likelihood nodes only Hetero is stored')
+                out[p + 'likelihood'] = np.array('Hetero')
+                for a in ('input', 'output', 'input_dim', 'rep'):
+                    v = getattr(nd, a, None)
+                    if v is not None:
+                        out[p + a] = np.asarray(v).copy()
+                continue
             out[p + 'name'] = np.array(str(nd.name))
             out[p + 'prior_name'] = np.array('' if nd.prior_name is None else str(nd.prior_name))
             out[p + 'flags'] = np.array([bool(nd.scale_est), bool(nd.nugget_est), bool(getattr(nd, 'vecch', False))])
@@ -93,6 +100,12 @@ def load_structure(npz_file, engine=None):
         for k in range(int(d['l%d_n' % l])):
             p = 'l%d_k%d_' % (l, k)
             g = lambda a: d[p + a].copy() if p + a in d else None   # noqa: E731
+            if p + 'likelihood' in d:
+                from .likelihood_class import Hetero
+                nd = Hetero(input_dim=g('input_dim'))
+                nd.input, nd.output, nd.rep = g('input'), g('output'), g('rep')
+                layer.append(nd)
+                continue
             flags = d[p + 'flags']
             prior = str(d[p + 'prior_name']) or None
             nd = kernel(length=g('length'), scale=g('scale'), nugget=g('nugget'), name=str(d[p + 'name']), prior_name=None,

@@ -476,6 +476,20 @@ def gen_hetero_vecchia():
     save('g15_hetero_vecchia', **out)
 
 
+def gen_export():
+    """G16: a structure trained by the REFERENCE written with tools/export_dgpsi_structure.py (the arrays-only file
+    dgp_amd.load_structure reads), together with the reference's own predictions from it."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from export_dgpsi_structure import export
+    X, Y, layers = build_small_dgp(23, 14, 2, ('matern2.5', 'sexp'), n_out=1)
+    model = dgp(X, Y, layers)
+    model.train(N=4, ess_burn=2, disable=True)
+    est = model.estimate()
+    export(est, os.path.join(OUT, 'g16_dgpsi_export_structure.npz'))
+    out = dump_structure(est, 'est_')
+    save('g16_dgpsi_export_check', **out)
+
+
 def gen_lgp():
     """G10: feed-forward chain GP -> DGP -> GP (+ one external input on the last emulator), lgp.predict
     (linkgp.py:285-501) from the reference's own imputations (dumped)."""
@@ -615,7 +629,7 @@ def gen_hetero():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch']
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch', 'export']
     if 'kernel' in which:
         gen_kernel_cases()
     if 'fmvn' in which:
@@ -636,3 +650,5 @@ if __name__ == '__main__':
         gen_loo()
     if 'hetvecch' in which:
         gen_hetero_vecchia()
+    if 'export' in which:
+        gen_export()

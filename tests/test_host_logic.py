@@ -201,3 +201,38 @@ def test_drawstream_prefetch_keeps_the_sequence():
     b.prefetch(10)
     c = pickle.loads(pickle.dumps(b))
     assert np.array_equal(c.normals(10), a.normals(10))
+
+
+def test_structure_exported_from_dgpsi_loads(golden, tmp_path):
+    """tools/export_dgpsi_structure.py run on a structure trained by the reference (oracle/gen_golden.py:gen_export)
+    -> dgp_amd.load_structure: same hyper-parameters, latents, wiring; and a Hetero likelihood node survives
+    save_structure / load_structure."""
+    from conftest import case, GOLDEN
+    from dgp_amd.utils import load_structure, save_structure
+    from dgp_amd import kernel, Hetero
+    chk = golden('g16_dgpsi_export_check')
+    layers = load_structure(os.path.join(GOLDEN, 'g16_dgpsi_export_structure'))
+    assert len(layers) == int(chk['est_n_layer'])
+    for l, layer in enumerate(layers):
+        assert len(layer) == int(chk['est_l%d_n' % l])
+        for k, nd in enumerate(layer):
+            c = case(chk, 'est_l%d_k%d_' % (l, k))
+            assert nd.name == str(c['name']) and nd.scale_est == bool(c['scale_est']) and nd.nugget_est == bool(c['nugget_est'])
+            for a in ('length', 'scale', 'nugget', 'input', 'output', 'input_dim'):
+                assert np.array_equal(getattr(nd, a), c[a]), a
+            assert (nd.global_input is not None) == bool(c['has_global'])
+            if nd.global_input is not None:
+                assert np.array_equal(nd.global_input, c['global_input']) and np.array_equal(nd.connect, c['connect'])
+            assert nd.D == nd.input.shape[1] + (0 if nd.global_input is None else nd.global_input.shape[1])
+    rng = np.random.default_rng(0)
+    g1, g2, h = kernel(length=np.array([0.7])), kernel(length=np.array([1.2]), name='matern2.5'), Hetero()
+    for g in (g1, g2):
+        g.input, g.output, g.input_dim = rng.uniform(size=(6, 1)), rng.normal(size=(6, 1)), np.array([0])
+        g.para_path = np.atleast_2d(np.concatenate((g.scale, g.length, g.nugget)))
+    h.rep = np.array([0, 0, 1, 2, 3, 4, 5, 5])
+    h.input, h.output, h.input_dim = rng.normal(size=(8, 2)), rng.normal(size=(8, 1)), np.array([0, 1])
+    save_structure([[g1, g2], [h]], str(tmp_path / 'het'))
+    back = load_structure(str(tmp_path / 'het'))
+    assert back[1][0].name == 'Hetero' and back[1][0].type == 'likelihood' and np.array_equal(back[1][0].rep, h.rep)
+    assert np.array_equal(back[1][0].input, h.input) and np.array_equal(back[1][0].output, h.output)
+    assert back[0][1].name == 'matern2.5' and np.array_equal(back[0][1].output, g2.output)
