@@ -42,7 +42,7 @@ for kq in ks:
     t0 = w[:, 0].min()
     st, en = (w[:, 0] - t0) / 100.0, (w[:, 1] - t0) / 100.0
     kind, nkb, cu = w[:, 2] & 15, (w[:, 2] >> 8) & 255, w[:, 2] >> 16
-    names = {0: 'store', 1: 'solve', 2: 'chain', 3: 'tdiag'}
+    names = {0: 'store', 1: 'solve', 2: 'chain', 3: 'tdiag', 4: 'store2'}
     print('launch k=%d, B=%d%s: %d workgroups with a task, span %.1f us, %d distinct CUs' % (kq, B, ' (inverse)' if inv else '', len(w), en.max(), len(set(cu))))
     for kd in sorted(set(kind)):
         for nk in sorted(set(nkb[kind == kd])):
@@ -54,5 +54,5 @@ for kq in ks:
     edges = np.arange(0, en.max() + 5, 5.0)
     occ = [(np.minimum(en, b1) - np.maximum(st, b0)).clip(0).sum() / 5.0 for b0, b1 in zip(edges[:-1], edges[1:])]
     print('  running workgroups per 5-us bin:', ' '.join('%d' % round(o) for o in occ))
-    busy = (en - st)[kind == 0].sum()
+    busy = (en - st)[(kind == 0) | (kind == 4)].sum()
     print('  bulk workgroup-time %.0f us = %.1f us x 512 slots' % (busy, busy / 512))
