@@ -81,6 +81,7 @@ SIGNATURES = {
     'dgpamd_vecchia_nllik': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _i, _d, _p, _i, _p]),
     'dgpamd_vecchia_lmatrix': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _i, _d, _p]),
     'dgpamd_vecchia_spsolve': (_i, [_p, _l, _i, _p, _p, _d, _p, _p]),
+    'dgpamd_vecchia_spsolve_batch': (_i, [_p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
     'dgpamd_vecchia_het_rows': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _i, _d, _p, _p, _p, _p, _p, _p]),
     'dgpamd_vecchia_gp': (_i, [_p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _d, _p, _i, _d, _p, _p, _p]),
     'dgpamd_vecchia_linkgp': (_i, [_p, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _d, _p, _i, _d, _p, _p, _p]),

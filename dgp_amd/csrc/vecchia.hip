@@ -534,11 +534,22 @@ extern "C" int dgpamd_vecchia_het_rows(dgpamd_ctx *ctx, int kind, int64_t n, int
 // in-window dependencies are published computes in the same sweep (wavefront over the dependency DAG).
 // ---------------------------------------------------------------------------
 #define SPW 1024
+// Batched form: workgroup p solves with matrix p / nrhs and right-hand side p (independent chains run side by side:
+// the prior draws of all Vecchia nodes of a layer, for all sweeps of a sample() call, are ONE launch).
 __global__ __launch_bounds__(SPW) void spsolve_kernel(int64_t n, int mp1, const double *L, const int64_t *NN,
-                                                      double lscale, const double *b, double *x) {
+                                                      double lscale, const double *lscales, int nrhs, const double *b,
+                                                      double *x) {
     __shared__ double xs[SPW];
     __shared__ int rdy[SPW];
     const int tid = threadIdx.x;
+    {
+        const int64_t p = blockIdx.x, mat = p / nrhs;
+        L += mat * n * mp1;
+        NN += mat * n * mp1;
+        b += p * n;
+        x += p * n;
+        if (lscales) lscale = lscales[mat];
+    }
     for (int64_t base = 0; base < n; base += SPW) {
         const int64_t i = base + tid;
         const bool active = i < n;
@@ -593,7 +604,19 @@ extern "C" int dgpamd_vecchia_spsolve(dgpamd_ctx *ctx, int64_t n, int m, const d
                                       double inv_sqrt_scale, const double *b, double *x) {
     if (!ctx) return DGPAMD_BAD_ARG;
     if (n <= 0 || m < 0 || !Lmat || !NNarray || !b || !x) BAD_ARG(ctx, "bad arguments");
-    hipLaunchKernelGGL(spsolve_kernel, dim3(1), dim3(SPW), 0, ctx->stream, n, m + 1, Lmat, NNarray, inv_sqrt_scale, b, x);
+    hipLaunchKernelGGL(spsolve_kernel, dim3(1), dim3(SPW), 0, ctx->stream, n, m + 1, Lmat, NNarray, inv_sqrt_scale,
+                       (const double *)nullptr, 1, b, x);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_vecchia_spsolve_batch(dgpamd_ctx *ctx, int64_t n, int m, int nmat, int nrhs, const double *Lmat,
+                                            const int64_t *NNarray, const double *inv_sqrt_scale, const double *b,
+                                            double *x) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || m < 0 || nmat <= 0 || nrhs <= 0 || !Lmat || !NNarray || !inv_sqrt_scale || !b || !x) BAD_ARG(ctx, "bad arguments");
+    hipLaunchKernelGGL(spsolve_kernel, dim3((unsigned)(nmat * nrhs)), dim3(SPW), 0, ctx->stream, n, m + 1, Lmat, NNarray, 1.0,
+                       inv_sqrt_scale, nrhs, b, x);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }

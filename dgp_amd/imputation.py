@@ -256,7 +256,10 @@ class imputer:
         queued back to back.  Consumes the normal stream in the order the sequential loop would as long as layer 0 is
         the only hidden layer; with an injected stream and deeper hierarchies it is therefore not used."""
         layer = self.all_layer[0]
-        if not self.block or any(nd.vecch or nd.type != 'gp' for nd in layer):
+        if not self.block or any(nd.type != 'gp' for nd in layer):
+            return None
+        all_vecch = all(nd.vecch for nd in layer)
+        if any(nd.vecch for nd in layer) and not all_vecch:
             return None
         if any(nd.type == 'likelihood' and getattr(nd, 'exact_post_idx', None) is not None for nd in self.all_layer[1]):
             return None   # node-wise updates (sample())
@@ -266,6 +269,15 @@ class imputer:
         n, M = self.F[0].shape
         if M > 64:
             return None
+        if all_vecch:
+            # Vecchia: M x sweeps independent sparse forward substitutions, all in one launch
+            if self.draws._z is None:
+                Z = self.draws.normals(sweeps * M * n).reshape(sweeps, M, n)
+            else:
+                Z = np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)])
+            xs = self._vecchia_draws(0, list(range(M)), e.tensor(np.ascontiguousarray(Z.transpose(1, 0, 2))))   # (M, sweeps, n)
+            self.draws.prefetch(sweeps * M * n)
+            return xs.permute(1, 2, 0).contiguous()
         buf = self._layer_factors(0, list(range(M)))
         if self.draws._z is None:
             Z = self.draws.normals(sweeps * M * n).reshape(sweeps, M, n)
@@ -298,19 +310,37 @@ class imputer:
                 nb = min(64, len(dense) - c0)
                 out = e.trmv_lower(n, buf[c0:c0 + nb], scales[c0:c0 + nb], Zd[c0:c0 + nb], batch=nb)
                 nu[:, torch.as_tensor(dense[c0:c0 + nb], device=nu.device)] = out.t()
-        for k in cols:
-            nd = layer[k]
-            if nd.vecch:
-                Xl, cm = self._node_input(l, k, nd)
-                X = Xl if cm is None else Xl[:, torch.as_tensor(cm, device=Xl.device, dtype=torch.long)]
-                if self._glob[(l, k)] is not None:
-                    X = torch.cat((X, self._glob[(l, k)]), 1)
-                od = torch.as_tensor(nd.ord, device=X.device, dtype=torch.long)
-                NN = e.tensor(nd.NNarray, dtype=torch.int64)
-                Lm = e.vecchia_lmatrix(nd.name, X[od].contiguous(), NN, nd.length, nd.nugget[0])
-                xs = e.vecchia_spsolve(Lm, NN, 1.0 / np.sqrt(nd.scale[0]), e.tensor(Z[k]))
-                nu[:, k] = xs[torch.as_tensor(nd.rev_ord, device=X.device, dtype=torch.long)]
+        vec = [k for k in cols if layer[k].vecch]
+        if vec:
+            xs = self._vecchia_draws(l, vec, e.tensor(np.stack([Z[k] for k in vec])[:, None, :]))   # (nodes, 1, n)
+            for j, k in enumerate(vec):
+                nu[:, k] = xs[j, 0]
         return nu
+
+    def _vecchia_draws(self, l, nodes, Zd):
+        """fmvn_sp (vecchia.py:133-140) for the Vecchia nodes `nodes` of layer l and Zd.shape[1] normal vectors each
+        (Zd: (nodes, draws, n) on the device): the rows of the sparse inverse factors (one launch per node), then ALL
+        forward substitutions -- independent serial chains -- side by side in one launch.  Returns (nodes, draws, n) in
+        the original point order."""
+        e = self.engine
+        layer = self.all_layer[l]
+        if len({layer[k].NNarray.shape[1] for k in nodes}) != 1:     # different conditioning sizes: one by one
+            return torch.stack([self._vecchia_draws(l, [k], Zd[j:j + 1])[0] for j, k in enumerate(nodes)])
+        Lms, NNs, sc, rev = [], [], [], []
+        for k in nodes:
+            nd = layer[k]
+            Xl, cm = self._node_input(l, k, nd)
+            X = Xl if cm is None else Xl[:, torch.as_tensor(cm, device=Xl.device, dtype=torch.long)]
+            if self._glob[(l, k)] is not None:
+                X = torch.cat((X, self._glob[(l, k)]), 1)
+            od = torch.as_tensor(nd.ord, device=X.device, dtype=torch.long)
+            NN = e.tensor(nd.NNarray, dtype=torch.int64)
+            Lms.append(e.vecchia_lmatrix(nd.name, X[od].contiguous(), NN, nd.length, nd.nugget[0]))
+            NNs.append(NN)
+            sc.append(1.0 / np.sqrt(nd.scale[0]))
+            rev.append(torch.as_tensor(nd.rev_ord, device=X.device, dtype=torch.long))
+        xs = e.vecchia_spsolve_batch(torch.stack(Lms), torch.stack(NNs), sc, Zd.contiguous())
+        return torch.stack([xs[j][:, rev[j]] for j in range(len(nodes))])
 
     def _upper_loglik(self, l, FP, only=None):
         """sum over the nodes of layer l+1 (or those listed in `only`) of their log-likelihood for each candidate

@@ -423,6 +423,15 @@ class Engine:
                                              _dp(out)))
         return out
 
+    def vecchia_spsolve_batch(self, Lmat, NN, inv_sqrt_scale, b):
+        """Lmat, NN: (nmat, n, m+1); inv_sqrt_scale: nmat floats; b: (nmat, nrhs, n) -> x of the same shape."""
+        nmat, n, mp1 = Lmat.shape
+        nrhs = b.shape[1]
+        out = self.empty(nmat, nrhs, n)
+        sc = self.tensor(np.asarray(inv_sqrt_scale, dtype=np.float64))
+        self._chk(lib.dgpamd_vecchia_spsolve_batch(self.h, n, mp1 - 1, nmat, nrhs, _dp(Lmat), _dp(NN), _dp(sc), _dp(b), _dp(out)))
+        return out
+
     def vecchia_gp(self, kind, x, w, NN, y, scale, length, nugget, nugget_diag):
         M, D = x.shape
         length = _f64(length)

@@ -297,6 +297,11 @@ int dgpamd_vecchia_lmatrix(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, c
                            const int64_t *NNarray, const double *length_h, int nlen, double nugget, double *Lmat);
 int dgpamd_vecchia_spsolve(dgpamd_ctx *ctx, int64_t n, int m, const double *Lmat, const int64_t *NNarray,
                            double inv_sqrt_scale, const double *b, double *x);
+/* The same for nmat matrices (Lmat, NNarray: nmat x n x (m+1); inv_sqrt_scale: nmat, device) with nrhs right-hand
+ * sides each (b, x: nmat x nrhs x n): one workgroup per chain -- fmvn_sp (vecchia.py:133-140) for all nodes of a
+ * layer and all sweeps of imputer.sample (imputation.py:54-63) in one launch.                                   */
+int dgpamd_vecchia_spsolve_batch(dgpamd_ctx *ctx, int64_t n, int m, int nmat, int nrhs, const double *Lmat,
+                                 const int64_t *NNarray, const double *inv_sqrt_scale, const double *b, double *x);
 /* Hetero likelihood under Vecchia: rows of the sparse factor of the latent mean's conditional posterior
  * (vecchia.U_matrix :426-446 / U_matrix_sp :599-610 through kernel.ord_nn(pointer=True) kernel_class.py:268-275;
  * consumer Hetero.post_het_vecch likelihood_class.py:166-182).  X: (n x D) ORDERED inputs; impNN: (n x (m+1))

@@ -34,6 +34,25 @@ if which == 'cfg3':
     t = time.perf_counter(); mu, var = emu.predict(xt); sync(); dt = time.perf_counter() - t
     print('cfg3: predict %d pts x %d imputations %.2f s -> %.0f pts/s (x%d imputations = %.0f pt-imputations/s); finite=%s; mem %.1f GB'
           % (M, S, dt, M / dt, S, M * S / dt, np.all(np.isfinite(mu)) and np.all(np.isfinite(var)), torch.cuda.max_memory_allocated() / 2**30))
+elif which == 'cfg4train':
+    # BASELINE config 4 through the public API: Vecchia DGP (default 2-layer structure), a few SI iterations + prediction
+    n, d, m = int(os.environ.get('N', '50000')), 8, 25
+    rng = np.random.default_rng(7)
+    X = rng.uniform(size=(n, d))
+    f = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + X[:, 2] ** 2 + 0.3 * X[:, 3:].sum(1)
+    Y = ((f - f.mean()) / f.std())[:, None]
+    t = time.perf_counter(); model = dgp(X, Y, vecchia=True, m=m, seed=1); sync()
+    print('cfg4train n=%d: construct (warm start + NN + 11 sweeps) %.1f s' % (n, time.perf_counter() - t), flush=True)
+    its = int(os.environ.get('ITERS', '3'))
+    t = time.perf_counter(); model.train(N=its, ess_burn=10, disable=True); sync(); dt = time.perf_counter() - t
+    print('cfg4train: %d SI iterations %.1f s -> %.3f it/s; stats %s' % (its, dt, its / dt, model.imp.stats), flush=True)
+    t = time.perf_counter(); emu = emulator(model.estimate(burnin=0), N=2, seed=3); sync()
+    print('cfg4train: emulator(N=2) %.1f s' % (time.perf_counter() - t), flush=True)
+    xt = rng.uniform(size=(2000, d))
+    ft = np.sin(3 * xt[:, 0]) * np.cos(2 * xt[:, 1]) + xt[:, 2] ** 2 + 0.3 * xt[:, 3:].sum(1)
+    t = time.perf_counter(); mu, var = emu.predict(xt, m=50); sync(); dt = time.perf_counter() - t
+    print('cfg4train: predict 2000 pts x 2 imputations %.2f s (%.0f pts/s), rmse %.3f, mem %.1f GB' % (
+        dt, 2000 / dt, np.sqrt(np.mean((mu[:, 0] - (ft - f.mean()) / f.std()) ** 2)), torch.cuda.max_memory_allocated() / 2**30))
 else:
     n, d, m = int(os.environ.get('N', '50000')), 8, 25
     rng = np.random.default_rng(7)
