@@ -179,12 +179,214 @@ __global__ __launch_bounds__(256) void nn_select_kernel(int64_t nq, int64_t nx, 
     }
 }
 
+// Large candidate sets: the m_out selection passes above recompute every distance every pass.  Here a workgroup writes
+// the distances of its query ONCE (global scratch row), narrows them with a 1024-bin histogram (zooming into the bin
+// that holds the k-th smallest until at most NN_CMAX candidates are left), gathers those into LDS and runs the same
+// (distance, index)-ordered selection passes on that short list -- identical output, ~m_out times less arithmetic.
+// Workgroups are persistent over the queries (grid-stride), one scratch row each.
+#define NN_NB 1024
+#define NN_CMAX 2048
+__global__ __launch_bounds__(256) void nn_select_big_kernel(int64_t nq, int64_t nx, int D, const double *q, const double *x,
+                                                            int m_out, int ordered, int64_t *out, double *scratch) {
+    extern __shared__ double lds[];
+    double *qs = lds;                                   // [D]
+    double *rd = qs + D;                                // [8] wave partials
+    double *cd = rd + 8;                                // [NN_CMAX] candidate distances
+    int64_t *ci = reinterpret_cast<int64_t *>(cd + NN_CMAX);   // [NN_CMAX] candidate indices
+    int64_t *ri = ci + NN_CMAX;                         // [4]
+    int64_t *sel = ri + 4;                              // [m_out]
+    int *hist = reinterpret_cast<int *>(sel + m_out);   // [NN_NB]
+    int *part = hist + NN_NB;                           // [256]
+    int *ctrl = part + 256;                             // [4]: bin*, count below bin*, candidate counter
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double *dist = scratch + (int64_t)blockIdx.x * nx;
+    for (int64_t iq = blockIdx.x; iq < nq; iq += gridDim.x) {
+        const int64_t ncand = ordered ? iq + 1 : nx;
+        const int k = (int)(ncand < m_out ? ncand : m_out);
+        __syncthreads();
+        for (int d = tid; d < D; d += 256) qs[d] = q[iq * D + d];
+        __syncthreads();
+        // ---- distances, once
+        double lo = INFINITY, hi = -INFINITY;
+        for (int64_t j = tid; j < ncand; j += 256) {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) {
+                double df = x[j * D + d] - qs[d];
+                s = fma(df, df, s);
+            }
+            dist[j] = s;
+            lo = fmin(lo, s);
+            hi = fmax(hi, s);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fmin(lo, __shfl_down(lo, off, 64));
+            hi = fmax(hi, __shfl_down(hi, off, 64));
+        }
+        if (lane == 0) {
+            rd[wave] = lo;
+            rd[4 + wave] = hi;
+        }
+        __syncthreads();
+        lo = fmin(fmin(rd[0], rd[1]), fmin(rd[2], rd[3]));
+        hi = fmax(fmax(rd[4], rd[5]), fmax(rd[6], rd[7]));
+        // ---- zoom: histogram of the values <= hi, find the bin of the k-th smallest
+        int ncollect = 0;
+        bool listed = false;
+        for (int zoom = 0; zoom < 6; ++zoom) {
+            const double scale = hi > lo ? (double)NN_NB / (hi - lo) : 0.0;
+            __syncthreads();
+            for (int b = tid; b < NN_NB; b += 256) hist[b] = 0;
+            __syncthreads();
+            for (int64_t j = tid; j < ncand; j += 256) {
+                const double s = dist[j];
+                if (s <= hi) {
+                    int b = (int)((s - lo) * scale);
+                    atomicAdd(&hist[b < NN_NB ? b : NN_NB - 1], 1);
+                }
+            }
+            __syncthreads();
+            part[tid] = hist[4 * tid] + hist[4 * tid + 1] + hist[4 * tid + 2] + hist[4 * tid + 3];
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, c = 0;
+                while (c < 255 && cum + part[c] < k) cum += part[c++];
+                int b = 4 * c;
+                while (b < 4 * c + 3 && cum + hist[b] < k) cum += hist[b++];
+                ctrl[0] = b;
+                ctrl[1] = cum + hist[b];   // everything in the bins <= b
+                ctrl[2] = 0;
+            }
+            __syncthreads();
+            const int bstar = ctrl[0];
+            ncollect = ctrl[1];
+            if (ncollect <= NN_CMAX) {
+                for (int64_t j = tid; j < ncand; j += 256) {
+                    const double s = dist[j];
+                    if (s <= hi) {
+                        int b = (int)((s - lo) * scale);
+                        b = b < NN_NB ? b : NN_NB - 1;
+                        if (b <= bstar) {
+                            const int pos = atomicAdd(&ctrl[2], 1);
+                            cd[pos] = s;
+                            ci[pos] = j;
+                        }
+                    }
+                }
+                listed = true;
+                break;
+            }
+            // too many: keep only the bins <= b* and spread them over the histogram again.  The new upper end is the
+            // largest VALUE kept (an exact, monotone filter: s <= nhi <=> bin(s) <= b*), not a recomputed bin edge.
+            double nhi = -INFINITY;
+            for (int64_t j = tid; j < ncand; j += 256) {
+                const double s = dist[j];
+                if (s <= hi) {
+                    int b = (int)((s - lo) * scale);
+                    b = b < NN_NB ? b : NN_NB - 1;
+                    if (b <= bstar) nhi = fmax(nhi, s);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nhi = fmax(nhi, __shfl_down(nhi, off, 64));
+            __syncthreads();
+            if (lane == 0) rd[wave] = nhi;
+            __syncthreads();
+            nhi = fmax(fmax(rd[0], rd[1]), fmax(rd[2], rd[3]));
+            if (!(nhi < hi) && bstar == NN_NB - 1) break;   // nothing was cut off
+            if (!(nhi > lo)) break;                          // all remaining values equal: ties, stored-distance passes
+            hi = nhi;
+        }
+        __syncthreads();
+        // ---- selection passes in (distance, index) order, over the short list or (ties) over the stored distances
+        double pd = -1.0;
+        int64_t pi = -1;
+        for (int pass = 0; pass < k; ++pass) {
+            double bd = INFINITY;
+            int64_t bidx = INT64_MAX;
+            if (listed) {
+                for (int c = tid; c < ncollect; c += 256)
+                    if (pair_less(pd, pi, cd[c], ci[c]) && pair_less(cd[c], ci[c], bd, bidx)) {
+                        bd = cd[c];
+                        bidx = ci[c];
+                    }
+            } else {
+                for (int64_t j = tid; j < ncand; j += 256) {
+                    const double s = dist[j];
+                    if (pair_less(pd, pi, s, j) && pair_less(s, j, bd, bidx)) {
+                        bd = s;
+                        bidx = j;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                double od = __shfl_down(bd, off, 64);
+                int64_t oi = __shfl_down(bidx, off, 64);
+                if (pair_less(od, oi, bd, bidx)) {
+                    bd = od;
+                    bidx = oi;
+                }
+            }
+            if (lane == 0) {
+                rd[wave] = bd;
+                ri[wave] = bidx;
+            }
+            __syncthreads();
+            bd = rd[0];
+            bidx = ri[0];
+            for (int w = 1; w < 4; ++w)
+                if (pair_less(rd[w], ri[w], bd, bidx)) {
+                    bd = rd[w];
+                    bidx = ri[w];
+                }
+            pd = bd;
+            pi = bidx;
+            if (tid == 0) sel[pass] = bidx;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (ordered) {
+                for (int a = 1; a < k; ++a) {
+                    int64_t v = sel[a];
+                    int b = a - 1;
+                    while (b >= 0 && sel[b] < v) {
+                        sel[b + 1] = sel[b];
+                        --b;
+                    }
+                    sel[b + 1] = v;
+                }
+            }
+            for (int a = 0; a < m_out; ++a) out[iq * m_out + a] = a < k ? sel[a] : -1;
+        }
+    }
+}
+
+#define NN_BIG_MIN 4096   // candidate sets from this size on take the store-once path
+static int launch_nn(dgpamd_ctx *ctx, int64_t nq, int64_t nx, int D, const double *q, const double *x, int m_out, int ordered,
+                     int64_t *out) {
+    if (nx < NN_BIG_MIN) {
+        size_t shm = (D + 4) * sizeof(double) + (4 + (size_t)m_out) * sizeof(int64_t);
+        hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)nq), dim3(256), shm, ctx->stream, nq, nx, D, q, x, m_out, ordered, out);
+        return DGPAMD_OK;
+    }
+    const unsigned grid = (unsigned)(nq < 2 * (int64_t)ctx->num_cu * 2 ? nq : 2 * (int64_t)ctx->num_cu * 2);
+    double *scratch = nullptr;
+    HIP_TRY(ctx, hipMallocAsync((void **)&scratch, (size_t)grid * nx * sizeof(double), ctx->stream));
+    size_t shm = (D + 8 + NN_CMAX) * sizeof(double) + (NN_CMAX + 4 + (size_t)m_out) * sizeof(int64_t) + (NN_NB + 256 + 4) * sizeof(int);
+    if (shm > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)nn_select_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(nn_select_big_kernel, dim3(grid), dim3(256), shm, ctx->stream, nq, nx, D, q, x, m_out, ordered, out, scratch);
+    HIP_TRY(ctx, hipFreeAsync(scratch, ctx->stream));
+    return DGPAMD_OK;
+}
+
 extern "C" int dgpamd_nn_ordered(dgpamd_ctx *ctx, int64_t n, int D, const double *x, int m, int64_t *NNarray) {
     if (!ctx) return DGPAMD_BAD_ARG;
     if (n <= 0 || D <= 0 || !x || !NNarray || m < 0) BAD_ARG(ctx, "bad arguments");
     if (m > n - 1) m = (int)(n - 1);
-    size_t shm = (D + 4) * sizeof(double) + (4 + (size_t)m + 1) * sizeof(int64_t);
-    hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)n), dim3(256), shm, ctx->stream, n, n, D, x, x, m + 1, 1, NNarray);
+    int rc = launch_nn(ctx, n, n, D, x, x, m + 1, 1, NNarray);
+    if (rc) return rc;
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }
@@ -202,8 +404,8 @@ extern "C" int dgpamd_nn_query(dgpamd_ctx *ctx, int64_t M, int64_t n, int D, con
         m = (int)n;
         hipLaunchKernelGGL(nn_cyclic_kernel, dim3((unsigned)((M * m + 255) / 256)), dim3(256), 0, ctx->stream, M, m, NN);
     } else {
-        size_t shm = (D + 4) * sizeof(double) + (4 + (size_t)m) * sizeof(int64_t);
-        hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)M), dim3(256), shm, ctx->stream, M, n, D, q, x, m, 0, NN);
+        int rc = launch_nn(ctx, M, n, D, q, x, m, 0, NN);
+        if (rc) return rc;
     }
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
