@@ -534,3 +534,30 @@ def test_ess_update_resumes_when_uniforms_run_out(eng):
     close(Fb, Fp, rtol=1e-12, atol=1e-13)
     close(lla, l, rtol=1e-9)
     close(llb, l, rtol=1e-9)
+
+
+def test_nn_large_candidate_sets(eng):
+    """The store-once neighbour search (>= 4096 candidates) against numpy: bit-exact in (distance, index) order on integer
+    coordinates (all distances exact, many ties), set-equal with equal neighbour distances on clustered real data,
+    all-equal points, ordered (Vecchia) variant."""
+    rng = np.random.default_rng(11)
+    grid = np.stack(np.meshgrid(np.arange(90.), np.arange(70.)), -1).reshape(-1, 2)[rng.permutation(6300)]
+    q = grid[rng.integers(0, len(grid), 50)] + np.array([0.0, 0.5])
+    got = npy(eng.nn_query(eng.tensor(q), eng.tensor(grid), 40))
+    d = ((q[:, None, :] - grid[None]) ** 2).sum(-1)
+    want = np.lexsort((np.broadcast_to(np.arange(len(grid)), d.shape), d), axis=1)[:, :40]
+    assert np.array_equal(got, want)
+    od = npy(eng.nn_ordered(eng.tensor(grid), 15))
+    for i in (0, 3, 15, 16, 4095, 4096, 5000, 6299):
+        di = ((grid[:i + 1] - grid[i]) ** 2).sum(1)
+        w = np.sort(np.lexsort((np.arange(i + 1), di))[:16])[::-1]
+        assert np.array_equal(od[i][:len(w)], w) and np.all(od[i][len(w):] == -1)
+    x = np.concatenate([rng.normal(size=(3000, 3)) * 1e-3, rng.uniform(size=(3000, 3)) * 100.0])
+    q = x[rng.integers(0, len(x), 30)] + 1e-4
+    got = npy(eng.nn_query(eng.tensor(q), eng.tensor(x), 25))
+    d = ((q[:, None, :] - x[None]) ** 2).sum(-1)
+    want = np.argsort(d, 1)[:, :25]
+    for a, b, dq in zip(got, want, d):
+        assert np.allclose(np.sort(dq[a]), np.sort(dq[b]), rtol=1e-12, atol=0)
+    same = np.ones((5000, 2))
+    assert np.array_equal(npy(eng.nn_query(eng.tensor(same[:3]), eng.tensor(same), 7)), np.tile(np.arange(7), (3, 1)))
