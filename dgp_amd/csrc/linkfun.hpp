@@ -148,7 +148,7 @@ static __device__ __forceinline__ void matern_dim_const(double m, double v, doub
     const double b4 = (mu) * (mu) * (mu) + (x) * (x) * (x) + (x) * (mu) * (mu) + (mu) * (x) * (x) + 3.0 * (v) * (x) + 5.0 * (v) * (mu)
 
 // S-role (the point is the SMALLER one): out[0..11], f2
-static __device__ __noinline__ void matern_role_S(double x, const MaternDimConst &k, double *out, double &f2) {
+static __device__ __forceinline__ void matern_role_S(double x, const MaternDimConst &k, double *out, double &f2) {
     const double l = k.l, l2 = l * l, l3 = l2 * l, l4 = l2 * l2, v = k.v, dx = x - k.m;
     const double hA = exp(k.c5 + k.q5 * dx), hB = exp(k.c5 - k.q5 * dx), eP = exp(k.q5 * dx);
     f2 = erf(dx * k.is2);
@@ -182,7 +182,7 @@ static __device__ __noinline__ void matern_role_S(double x, const MaternDimConst
 }
 
 // T-role (the point is the LARGER one): out[0..14]
-static __device__ __noinline__ void matern_role_T(double x, const MaternDimConst &k, double *out) {
+static __device__ __forceinline__ void matern_role_T(double x, const MaternDimConst &k, double *out) {
     const double l = k.l, l2 = l * l, l3 = l2 * l, l4 = l2 * l2, v = k.v, dx = x - k.m;
     const double hA = exp(k.c5 + k.q5 * dx), hB = exp(k.c5 - k.q5 * dx), eM = exp(-k.q5 * dx);
     const double g2 = exp(-0.5 * dx * dx / v);

@@ -437,14 +437,17 @@ typedef volatile double __attribute__((address_space(3))) vlds_double;
 #define MC_SEP 256
 
 __global__ __launch_bounds__(256) void matern_records_kernel(LinkArgs a) {
+    // 128 points x (S role | T role) per workgroup; the 128 records are staged in LDS and leave as one contiguous
+    // 28.7 KB block (a thread writing its own 224-byte record touched 64 cache lines per store instruction)
+    __shared__ double stage[128 * (REC + 1)];
     const int tid = threadIdx.x, pp = tid & 127, role = tid >> 7;
-    const int64_t i = (int64_t)blockIdx.x * 128 + pp;
+    const int64_t i0 = (int64_t)blockIdx.x * 128, i = i0 + pp;
     const int k = blockIdx.y;
     const int64_t tt = blockIdx.z, t = a.t0 + tt;
-    if (i >= a.npad || t >= a.M) return;
-    const double x = i < a.n ? a.W[i * a.Dw + k] : 0.0;
+    if (t >= a.M) return;
+    const double x = (i < a.n) ? a.W[i * a.Dw + k] : 0.0;
     const double l = a.len[k], zm = a.m[t * a.Dw + k], zv = a.v[t * a.Dw + k];
-    double *rec = a.recs + ((tt * a.Dw + k) * a.npad + i) * REC;
+    double *rec = stage + pp * (REC + 1);
     if (zv != 0.0) {
         MaternDimConst kc;
         matern_dim_const(zm, zv, l, kc);
@@ -474,6 +477,10 @@ __global__ __launch_bounds__(256) void matern_records_kernel(LinkArgs a) {
             for (int c = 13; c < 27; ++c) rec[c] = 0.0;
         }
     }
+    __syncthreads();
+    const int64_t npts = a.npad - i0 < 128 ? a.npad - i0 : 128;
+    double *dst = a.recs + ((tt * a.Dw + k) * a.npad + i0) * REC;
+    for (int e = tid; e < (int)npts * REC; e += 256) dst[e] = stage[(e / REC) * (REC + 1) + e % REC];
 }
 
 // Deterministic global inputs: the separable Matern factor k(Wg_i, z_t) of (training point, test point)
