@@ -423,6 +423,152 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
         a.partial[(int64_t)blockIdx.x * a.Mc + (tbase - a.t0) + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
 }
 
+// SExp J with the pair loop on MFMA (functions.py:432-451 restated).  For test point t the exponent of pair (i, j) is
+//   base_ij + ei_i(t) + ej_j(t) + sum_k c1_k(t) (w_ik - 2 m_k(t) + w_jk)^2,    c1_k = 1 / (8 v_k + 2 l_k^2),
+// and the square expands into a row term, a column term and the dot product sum_k [2 c1_k (w_ik - 2 m_k)] w_jk: per
+// test point the 64 x 64 x Dw products of a tile are a handful of v_mfma_f64_16x16x4 (accumulated on top of base_ij,
+// which sits in the accumulator layout), and the VALU work per pair drops from 3 Dw + exp to 2 adds + exp.  The row /
+// column terms and the A operand of test point t+1 are staged (double buffered in LDS) while t is evaluated.
+__global__ __launch_bounds__(256, 3) void linkgp_Jsexp_kernel(LinkArgs a) {
+    extern __shared__ double lds[];
+    const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
+    const int KP = (Dw + 3) & ~3, LDU = KP + 2;   // row stride = 2 (mod 4) doubles: conflict-free ds_read_b64 A fragments
+    double *WiT = lds;                    // [DT][64]
+    double *WjT = WiT + DT * 64;          // [DT][64]
+    double *WjB = WjT + DT * 64;          // [KP][LDK]   B operand: w_jk, k-major, zero padded
+    double *tm = WjB + KP * LDK;          // [TCH][Dw]
+    double *tv = tm + TCH * Dw;           // [TCH][Dw]
+    double *tz = tv + TCH * Dw;           // [TCH][Dz]
+    double *red = tz + TCH * Dz;          // [TCH][4]
+    double *U = red + TCH * 4;            // [2][64][LDU]  A operand of a test point: 2 c1_k (w_ik - 2 m_k)
+    double *R = U + 2 * 64 * LDU;         // [2][64] row terms
+    double *S = R + 2 * 64;               // [2][64] column terms
+    double *ilg = S + 2 * 64;             // [Dz] reciprocal lengthscales of the global dimensions
+    int bi, bj;
+    tri_decode(blockIdx.x, bi, bj);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
+    const int64_t tbase = a.t0 + (int64_t)blockIdx.y * TCH;
+    int nt = TCH;
+    if (tbase + nt > a.M) nt = (int)(a.M - tbase);
+    if (tbase + nt > a.t0 + a.Mc) nt = (int)(a.t0 + a.Mc - tbase);
+
+    for (int idx = tid; idx < 64 * DT; idx += 256) {
+        int row = idx / DT, d = idx - row * DT;
+        int64_t gi = i0 + row, gj = j0 + row;
+        double vi = 0.0, vj = 0.0;
+        if (d < Dw) {
+            if (gi < n) vi = a.W[gi * Dw + d];
+            if (gj < n) vj = a.W[gj * Dw + d];
+        } else {
+            if (gi < n) vi = a.Wg[gi * Dz + d - Dw];
+            if (gj < n) vj = a.Wg[gj * Dz + d - Dw];
+        }
+        WiT[d * 64 + row] = vi;
+        WjT[d * 64 + row] = vj;
+    }
+    for (int idx = tid; idx < nt * Dw; idx += 256) {
+        tm[idx] = a.m[tbase * Dw + idx];
+        tv[idx] = a.v[tbase * Dw + idx];
+    }
+    for (int idx = tid; idx < nt * Dz; idx += 256) tz[idx] = a.z[tbase * Dz + idx];
+    for (int g = tid; g < Dz; g += 256) ilg[g] = 1.0 / a.len[Dw + g];
+    __syncthreads();
+    for (int idx = tid; idx < KP * 64; idx += 256) {
+        const int k = idx >> 6, j = idx & 63;
+        WjB[k * LDK + j] = k < Dw ? WjT[k * 64 + j] : 0.0;
+    }
+    // accumulator layout: wave w owns rows 16w..16w+15; element (tile tt, reg r) of a lane = row 16w + (lane>>4) + 4r,
+    // column 16tt + (lane&15)
+    const int mrow = 16 * wave + (lane >> 4), mcol = lane & 15, kq = lane >> 4, mi = lane & 15;
+    const double wt = (bi == bj) ? 1.0 : 2.0;
+    d4 Cr[4], base[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = i0 + mrow + 4 * r, gj = j0 + 16 * tt + mcol;
+            Cr[tt][r] = (gi < n && gj < n) ? wt * (a.ry[gi] * a.ry[gj] - a.scale * a.Rinv[gi * a.ldr + gj]) : 0.0;
+            double b = 0.0;   // t-independent part: sum_k (w_ik - w_jk)^2 / (2 l_k^2)  (= -log R2sexp, kernel_class.py:761-763)
+            for (int k = 0; k < Dw; ++k) {
+                const double d = WiT[k * 64 + mrow + 4 * r] - WjT[k * 64 + 16 * tt + mcol];
+                b = fma(d * d, 1.0 / (2.0 * a.len[k] * a.len[k]), b);
+            }
+            base[tt][r] = b;
+        }
+    // per-test-point constants, once: tv <- c1_k(t) = 1 / (8 v_k + 2 l_k^2), tm <- 2 m_k(t); reciprocal lengthscales of the
+    // global dimensions (no divisions in the staging below)
+    for (int idx = tid; idx < nt * Dw; idx += 256) {
+        const double l = a.len[idx % Dw];
+        tv[idx] = 1.0 / (8.0 * tv[idx] + 2.0 * l * l);
+        tm[idx] = 2.0 * tm[idx];
+    }
+    // staging of test point t: 128 point tasks (64 row points: A operand + row term; 64 column points: column term)
+    // on the even threads, so that the four waves share them evenly
+    auto stage = [&](int t, int buf) {
+        if (tid & 1) return;
+        const int task = tid >> 1;
+        const double *c1 = tv + t * Dw, *m2 = tm + t * Dw, *zt = tz + t * Dz;
+        if (task < 64) {
+            double rr = 0.0;
+            double *u = U + (buf * 64 + task) * LDU;
+            for (int k = 0; k < Dw; ++k) {
+                const double wi = WiT[k * 64 + task] - m2[k], cw = c1[k] * wi;
+                u[k] = 2.0 * cw;
+                rr = fma(cw, wi, rr);
+            }
+            for (int k = Dw; k < KP; ++k) u[k] = 0.0;
+            for (int g = 0; g < Dz; ++g) {
+                const double di = (WiT[(Dw + g) * 64 + task] - zt[g]) * ilg[g];
+                rr = fma(di, di, rr);
+            }
+            R[buf * 64 + task] = rr;
+        } else {
+            const int j = task - 64;
+            double ss = 0.0;
+            for (int k = 0; k < Dw; ++k) {
+                const double wj = WjT[k * 64 + j];
+                ss = fma(c1[k] * wj, wj, ss);
+            }
+            for (int g = 0; g < Dz; ++g) {
+                const double dj = (WjT[(Dw + g) * 64 + j] - zt[g]) * ilg[g];
+                ss = fma(dj, dj, ss);
+            }
+            S[buf * 64 + j] = ss;
+        }
+    };
+    __syncthreads();
+    if (nt > 0) stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        __syncthreads();   // stage(t) visible; everybody is done with the other buffer
+        if (t + 1 < nt) stage(t + 1, buf ^ 1);
+        const vlds_double *Ur = (const vlds_double *)(U + (buf * 64 + 16 * wave + mi) * LDU);
+        const vlds_double *Bv = (const vlds_double *)WjB;
+        d4 e[4] = {base[0], base[1], base[2], base[3]};
+        for (int k0 = 0; k0 < KP; k0 += 4) {
+            const double av = Ur[k0 + kq];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                e[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bv[(k0 + kq) * LDK + 16 * tt + mi], e[tt], 0, 0, 0);
+        }
+        double rr[4], acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rr[r] = R[buf * 64 + mrow + 4 * r];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const double ss = S[buf * 64 + 16 * tt + mcol];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = fma(Cr[tt][r], exp(-(e[tt][r] + rr[r] + ss)), acc);
+        }
+        acc = wave_sum_p(acc);
+        if (lane == 0) red[t * 4 + wave] = acc;
+    }
+    __syncthreads();
+    if (tid < nt)
+        a.partial[(int64_t)blockIdx.x * a.Mc + (tbase - a.t0) + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
+}
+
 // Matern-2.5 J through the separable S/T form (linkfun.hpp).
 //   matern_records_kernel : once per (test point, dimension, training point): S[0..11] T[12..26] f2[27]  (REC = 28)
 //   linkgp_Jsep_kernel    : one WG per (lower 64x64 tile of C) x (chunk of TCH test points); per (t, k) the 128
@@ -430,8 +576,6 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
 //                           ahead of the pair phase; every pair costs 30 FMAs (both orientations) and a select
 //                           instead of 3 erf + 5 exp + ~300 flops.  The grid runs tiles fastest so that a
 //                           test-chunk's records (TCH*Dw*n*224 B) are re-read from the Infinity Cache.
-// LDS-qualified volatile view: fragment reads stay single ds_read_b64 (see the pair loop)
-typedef volatile double __attribute__((address_space(3))) vlds_double;
 #define REC 28
 #define PST 30   // LDS stride of a record (+x at [28]); stride 30 doubles -> conflict-free column reads
 #define MC_SEP 256
@@ -743,7 +887,15 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
         const unsigned tb = (unsigned)((mc + TCH - 1) / TCH);
         if (kind == DGPAMD_SEXP) {
             hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_SEXP>, dim3((unsigned)mc), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_SEXP>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            if (ctx->linkgp_direct) {
+                hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_SEXP>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            } else {
+                const int KP = (Dw + 3) & ~3, LDU = KP + 2;
+                const size_t shm_s = ((size_t)2 * DT * 64 + (size_t)KP * LDK + (size_t)TCH * (2 * Dw + Dz) + TCH * 4 + 2 * 64 * LDU + 4 * 64 + Dz) * sizeof(double);
+                if (shm_s > 48 * 1024)
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsexp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_s));
+                hipLaunchKernelGGL(linkgp_Jsexp_kernel, dim3(ntiles, tb), dim3(256), shm_s, ctx->stream, a);
+            }
             hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_SEXP>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a, ntiles);
         } else {
             hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_MATERN25>, dim3((unsigned)mc), dim3(256), 0, ctx->stream, a);
