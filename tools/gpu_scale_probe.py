@@ -34,6 +34,32 @@ if which == 'cfg3':
     t = time.perf_counter(); mu, var = emu.predict(xt); sync(); dt = time.perf_counter() - t
     print('cfg3: predict %d pts x %d imputations %.2f s -> %.0f pts/s (x%d imputations = %.0f pt-imputations/s); finite=%s; mem %.1f GB'
           % (M, S, dt, M / dt, S, M * S / dt, np.all(np.isfinite(mu)) and np.all(np.isfinite(var)), torch.cuda.max_memory_allocated() / 2**30))
+elif which == 'cfg5':
+    # BASELINE config 5: GP -> DGP -> GP feed-forward chain, n = 1000 each, Matern-2.5, predict 1e4 points through lgp
+    from dgp_amd import gp, lgp, container
+    n, M = int(os.environ.get('N', '1000')), int(os.environ.get('M', '10000'))
+    rng = np.random.default_rng(5)
+    X1 = rng.uniform(size=(n, 3))
+    Y1 = np.sin(3 * X1[:, :1]) + X1[:, 1:2] ** 2 - X1[:, 2:]
+    Y1 = (Y1 - Y1.mean()) / Y1.std()
+    t = time.perf_counter()
+    g1 = gp(X1, Y1, kernel(length=np.array([0.8, 1.2, 1.0]), name='matern2.5', scale_est=True, nugget=1e-4)); g1.train()
+    Y2 = np.tanh(2 * Y1) + 0.3 * Y1 ** 2
+    Y2 = (Y2 - Y2.mean()) / Y2.std()
+    d2 = dgp(Y1, Y2, combine([kernel(length=np.array([1.0]), name='matern2.5')],
+                             [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(1))]), seed=2)
+    d2.train(N=20, ess_burn=10, disable=True)
+    Y3 = np.cos(2 * Y2)
+    Y3 = (Y3 - Y3.mean()) / Y3.std()
+    g3 = gp(Y2, Y3, kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, nugget=1e-4)); g3.train()
+    sync(); print('cfg5 n=%d: three emulators trained (GP, 20 SI iterations of the DGP, GP) in %.1f s' % (n, time.perf_counter() - t), flush=True)
+    sysm = lgp(combine([container(g1.export(), np.array([0, 1, 2]))], [container(d2.estimate(), np.array([0]))],
+                       [container(g3.export(), np.array([0]))]), N=10)
+    xt = rng.uniform(size=(M, 3))
+    mu, var = sysm.predict([xt[:64], [None], [None]]); sync()
+    t = time.perf_counter(); mu, var = sysm.predict([xt, [None], [None]]); sync(); dt = time.perf_counter() - t
+    y1 = np.sin(3 * xt[:, :1]) + xt[:, 1:2] ** 2 - xt[:, 2:]
+    print('cfg5: lgp.predict %d points x 10 imputations %.2f s -> %.0f pts/s; finite %s' % (M, dt, M / dt, bool(np.all(np.isfinite(mu[0])) and np.all(np.isfinite(var[0])))))
 elif which == 'cfg4train':
     # BASELINE config 4 through the public API: Vecchia DGP (default 2-layer structure), a few SI iterations + prediction
     n, d, m = int(os.environ.get('N', '50000')), 8, 25
