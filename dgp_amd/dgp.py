@@ -56,9 +56,9 @@ class dgp:
         self.n_layer = len(all_layer)
         for l, layer in enumerate(all_layer):
             for nd in layer:
-                if nd.type == 'likelihood' and (nd.name != 'Hetero' or l != self.n_layer - 1):
-                    raise NotImplementedError('of the likelihood nodes only Hetero (final layer) is supported; the other '
-                                              'likelihood-specific warm starts (dgp.py:263-564) are outside the path')
+                if nd.type == 'likelihood' and (nd.name not in ('Hetero', 'Poisson', 'NegBin') or l != self.n_layer - 1):
+                    raise NotImplementedError('likelihood nodes: Hetero, Poisson and NegBin (final layer) are supported; the '
+                                              'warm starts of ZIP / ZINB / Categorical (dgp.py:279-525) are outside the path')
         self.initialize()
         self.block = block
         self.draws = DrawStream(seed)
@@ -80,6 +80,52 @@ class dgp:
             from sklearn.decomposition import KernelPCA
             return KernelPCA(n_components=num_kernel, kernel='sigmoid').fit_transform(In)
         return np.concatenate((In, In[:, np.random.choice(d, num_kernel - d)]), 1)
+
+    def _count_warm_start(self, l):
+        """Initial latents of the layer feeding a lone Poisson / NegBin likelihood (dgp.py:327-336,526-566), or None:
+        log of the (site-pooled) counts + 1/2; NegBin's log-dispersion from the method of moments
+        Var = mu + sigma mu^2 per replicated site (clipped to [1e-3, 10], global estimate where that fails)."""
+        if l != self.n_layer - 2 or len(self.all_layer[l + 1]) != 1:
+            return None
+        name = getattr(self.all_layer[l + 1][0], 'name', None)
+        if name not in ('Poisson', 'NegBin'):
+            return None
+        y = self.Y.flatten()
+        G = self.X.shape[0]
+        M = len(self.all_layer[l])
+        if name == 'Poisson':
+            if self.indices is None:
+                return np.log(self.Y + .5 + 1e-12)
+            cnt = np.bincount(self.indices, minlength=G)
+            return np.log((np.bincount(self.indices, weights=y, minlength=G) + .5) / cnt + 1e-12).reshape(-1, 1)
+        Out = np.empty((G, M))
+        if self.indices is None:
+            Out[:, 0] = np.log(y + .5 + 1e-12)     # (the dispersion latent starts wherever the buffer is, as in the reference:
+            if M > 1:                               #  dgp.py:528-531 fills the first column only -- here: log of the global estimate)
+                mm, vv = y.mean(), y.var(ddof=1)
+                Out[:, 1:] = np.log(max((vv - mm) / (mm ** 2 + 1e-8), 1e-3))
+            return Out
+        eps = 1e-8
+        mm, vv = y.mean(), y.var(ddof=1)
+        sig_glob = max((vv - mm) / (mm ** 2 + eps), 1e-3)
+        cnt = np.bincount(self.indices, minlength=G).astype(float)
+        s1 = np.bincount(self.indices, weights=y, minlength=G)
+        s2 = np.bincount(self.indices, weights=y * y, minlength=G)
+        mu = (s1 + .5) / cnt
+        Out[:, 0] = np.log(mu + 1e-12)
+        var_hat = mu.copy()
+        mk = cnt > 1
+        var_hat[mk] = (s2[mk] - s1[mk] ** 2 / cnt[mk]) / (cnt[mk] - 1.0)
+        sig = (var_hat - mu) / (mu ** 2 + eps)
+        sig[(~np.isfinite(sig)) | (sig <= 0.0)] = sig_glob
+        Out[:, 1] = np.log(np.clip(sig, 1e-3, 10.0))
+        return Out
+
+    def _layer_warm_start(self, l, In, num_kernel):
+        if self._is_hetero_pair(l):
+            return self._hetero_warm_start()
+        cnt = self._count_warm_start(l)
+        return cnt if cnt is not None else self._warm_start(In, num_kernel)
 
     def _is_hetero_pair(self, l):
         """Layer l feeds a lone Hetero likelihood with exactly two GP nodes (dgp.py:163)."""
@@ -151,15 +197,17 @@ class dgp:
         global_in = In = self.X
         for l, layer in enumerate(self.all_layer):
             last = l == self.n_layer - 1
-            Out = None if last else (self._hetero_warm_start() if self._is_hetero_pair(l) else self._warm_start(In, len(layer)))
+            Out = None if last else self._layer_warm_start(l, In, len(layer))
             for k, nd in enumerate(layer):
                 if last and self.indices is not None:
                     nd.rep = self.indices
                 if nd.input_dim is None:
                     nd.input_dim = np.arange(In.shape[1])
                 if nd.type == 'likelihood':
-                    if len(nd.input_dim) != 2:
-                        raise Exception('You need two and only two GP nodes to feed the ' + nd.name + ' likelihood node.')
+                    need = 1 if nd.name == 'Poisson' else 2
+                    if len(nd.input_dim) != need:
+                        raise Exception(('You need one and only one GP node' if need == 1 else 'You need two and only two GP nodes')
+                                        + ' to feed the ' + nd.name + ' likelihood node.')
                     nd.input = In[nd.rep, :][:, nd.input_dim] if nd.rep is not None else In[:, nd.input_dim]
                     nd.output = self.Y[:, [k]]
                     continue
@@ -297,7 +345,7 @@ class dgp:
         global_in = In = self.X
         for l, layer in enumerate(self.all_layer):
             last = l == self.n_layer - 1
-            Out = None if last else (self._hetero_warm_start() if self._is_hetero_pair(l) else self._warm_start(In, len(layer)))
+            Out = None if last else self._layer_warm_start(l, In, len(layer))
             for k, nd in enumerate(layer):
                 if last:
                     nd.rep = self.indices

@@ -1,4 +1,4 @@
-"""Likelihood nodes (dgpsi likelihood_class.py).  They live on the host -- the 4-method plugin protocol
+"""Likelihood nodes (dgpsi likelihood_class.py): Hetero, Poisson, NegBin.  They live on the host -- the 4-method plugin protocol
 llik() / pllik(y, f) / prediction(m, v) / sampling(f) on numpy arrays, attributes type, name, input, output,
 input_dim, exact_post_idx, rep (likelihood_class.py:30-90) -- except for the one step that is as heavy as a GP node:
 the exact conditional posterior draw of the heteroskedastic Gaussian likelihood's mean latent (two n x n
@@ -18,6 +18,76 @@ def ghdiag(fct, mu, var, y):
     weights = np.prod(np.array(list(itertools.product(*(w,) * N))), 1)[:, None] * np.pi ** (-0.5 * N)
     fn = np.sqrt(2.0) * (np.sqrt(var[:, None]) * nodes) + mu[:, None]
     return np.sum(np.exp(np.log(weights[None, :]) + fct(y[:, None], fn)), axis=1)
+
+
+class _CountLikelihood:
+    """Shared state of the count likelihoods (attributes of the plugin protocol, likelihood_class.py:30-37)."""
+    name = None
+
+    def __init__(self, input_dim=None):
+        self.type = 'likelihood'
+        self.input = None
+        self.output = None
+        self.input_dim = input_dim
+        self.exact_post_idx = None     # no latent with a closed-form conditional posterior: all are slice sampled
+        self.rep = None
+
+
+class Poisson(_CountLikelihood):
+    """Poisson likelihood with log link (likelihood_class.py:8-90): y_i ~ Poisson(exp(f_i)), one feeding GP node."""
+    name = 'Poisson'
+
+    def llik(self):
+        from scipy.special import gammaln
+        f, y = self.input, self.output
+        with np.errstate(over='ignore', invalid='ignore'):
+            return np.sum(y * f - np.exp(f) - gammaln(y + 1))
+
+    @staticmethod
+    def pllik(y, f):
+        from scipy.special import gammaln
+        return y * f - np.exp(f) - gammaln(y + 1)
+
+    @staticmethod
+    def prediction(m, v):
+        """Moments of y when f ~ N(m, v): E = exp(m + v/2), Var = E + (exp(v) - 1) exp(2m + v)  (log-normal rate)."""
+        mean = np.exp(m + v / 2)
+        return mean.flatten(), (mean + (np.exp(v) - 1) * np.exp(2 * m + v)).flatten()
+
+    def sampling(self, f_sample):
+        return np.random.poisson(np.exp(f_sample)).flatten()
+
+
+class NegBin(_CountLikelihood):
+    """Negative binomial likelihood (likelihood_class.py:245-292): mean exp(f0), dispersion exp(f1) (size 1/exp(f1)),
+    two feeding GP nodes."""
+    name = 'NegBin'
+
+    @staticmethod
+    def _logpmf(y, f1, f2):
+        from scipy.special import gammaln
+        with np.errstate(over='ignore', invalid='ignore'):   # (wild slice-sampling proposals may overflow: they evaluate to nan / -inf and are rejected)
+            size, a = np.exp(-f2), f1 + f2            # a = log(mean * dispersion); success odds exp(a)
+            return gammaln(y + size) - gammaln(size) - gammaln(y + 1.0) + y * a - (y + size) * np.logaddexp(0.0, a)
+
+    def llik(self):
+        return np.sum(self._logpmf(np.asarray(self.output).flatten(), self.input[:, 0], self.input[:, 1]))
+
+    @staticmethod
+    def pllik(y, f):
+        return NegBin._logpmf(y, f[:, :, [0]], f[:, :, [1]])
+
+    @staticmethod
+    def prediction(m, v):
+        """E[y] = E[mu], Var[y] = Var[mu] + E[mu] + E[sigma] E[mu^2] for independent log-normal mu = exp(f0), sigma = exp(f1)."""
+        e_mu = np.exp(m[:, 0] + v[:, 0] / 2)
+        var = np.exp(2 * m[:, 0] + v[:, 0]) * (np.exp(v[:, 0]) - 1) + e_mu + np.exp(m[:, 1] + v[:, 1] / 2) * np.exp(2 * m[:, 0] + 2 * v[:, 0])
+        return e_mu.flatten(), var.flatten()
+
+    @staticmethod
+    def sampling(f_sample):
+        p, size = 1 / (1 + np.exp(f_sample[:, 0] + f_sample[:, 1])), np.exp(-f_sample[:, 1])
+        return np.random.negative_binomial(size, p).flatten()
 
 
 class Hetero:

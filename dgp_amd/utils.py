@@ -70,9 +70,9 @@ def save_structure(all_layer, npz_file):
         for k, nd in enumerate(layer):
             p = 'l%d_k%d_' % (l, k)
             if getattr(nd, 'type', 'gp') != 'gp':
-                if getattr(nd, 'name', None) != 'Hetero':
-                    raise NotImplementedError('of the likelihood nodes only Hetero is stored')
-                out[p + 'likelihood'] = np.array('Hetero')
+                if getattr(nd, 'name', None) not in ('Hetero', 'Poisson', 'NegBin'):
+                    raise NotImplementedError('likelihood nodes stored: Hetero, Poisson, NegBin')
+                out[p + 'likelihood'] = np.array(str(nd.name))
                 for a in ('input', 'output', 'input_dim', 'rep'):
                     v = getattr(nd, a, None)
                     if v is not None:
@@ -101,8 +101,8 @@ def load_structure(npz_file, engine=None):
             p = 'l%d_k%d_' % (l, k)
             g = lambda a: d[p + a].copy() if p + a in d else None   # noqa: E731
             if p + 'likelihood' in d:
-                from .likelihood_class import Hetero
-                nd = Hetero(input_dim=g('input_dim'))
+                from . import likelihood_class
+                nd = getattr(likelihood_class, str(d[p + 'likelihood']))(input_dim=g('input_dim'))
                 nd.input, nd.output, nd.rep = g('input'), g('output'), g('rep')
                 layer.append(nd)
                 continue

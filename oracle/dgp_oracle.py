@@ -870,3 +870,63 @@ def ghdiag(fct, mu, var, y):
     fn = np.sqrt(2.0) * (np.sqrt(var[:, None]) * xn) + mu[:, None]
     ll = fct(y[:, None], fn)
     return np.sum(np.exp(np.log((wn * np.pi ** (-0.5 * N))[None, :]) + ll), axis=1)
+
+
+# --------------------------------------------------------------------------
+# count likelihoods (likelihood_class.py:8-90 Poisson, :245-292 NegBin) and their latent warm starts (dgp.py:327-336,526-566)
+# --------------------------------------------------------------------------
+def poisson_pllik(y, f):
+    from scipy.special import gammaln
+    return y * f - np.exp(f) - gammaln(y + 1)
+
+
+def poisson_prediction(m, v):
+    mean = np.exp(m + v / 2)
+    return mean.flatten(), (mean + (np.exp(v) - 1) * np.exp(2 * m + v)).flatten()
+
+
+def negbin_pllik(y, f):
+    from scipy.special import gammaln
+    f1, f2 = f[..., [0]], f[..., [1]]
+    size, a = np.exp(-f2), f1 + f2
+    return gammaln(y + size) - gammaln(size) - gammaln(y + 1.0) + y * a - (y + size) * np.logaddexp(0.0, a)
+
+
+def negbin_prediction(m, v):
+    e_mu = np.exp(m[:, 0] + v[:, 0] / 2)
+    var = (np.exp(2 * m[:, 0] + v[:, 0]) * (np.exp(v[:, 0]) - 1) + e_mu
+           + np.exp(m[:, 1] + v[:, 1] / 2) * np.exp(2 * m[:, 0] + 2 * v[:, 0]))
+    return e_mu, var
+
+
+def count_warm_start(name, X, Y):
+    """Latents fed to a Poisson / NegBin likelihood at initialisation; X with possibly repeated rows.  Returns
+    (latent (G x q), rep or None).  NegBin without replicates: only column 0 is defined by the reference."""
+    X0, inv = np.unique(X, return_inverse=True, axis=0)
+    inv = np.asarray(inv).reshape(-1)
+    y = np.asarray(Y, float).ravel()
+    rep = None if len(X0) == len(X) else inv
+    G = len(X0)
+    if name == 'Poisson':
+        if rep is None:
+            return np.log(y + .5 + 1e-12)[:, None], None
+        cnt = np.bincount(rep, minlength=G)
+        return np.log((np.bincount(rep, weights=y, minlength=G) + .5) / cnt + 1e-12)[:, None], rep
+    out = np.full((G, 2), np.nan)
+    if rep is None:
+        out[:, 0] = np.log(y + .5 + 1e-12)
+        return out, None
+    eps = 1e-8
+    sig_glob = max((y.var(ddof=1) - y.mean()) / (y.mean() ** 2 + eps), 1e-3)
+    cnt = np.bincount(rep, minlength=G).astype(float)
+    s1 = np.bincount(rep, weights=y, minlength=G)
+    s2 = np.bincount(rep, weights=y * y, minlength=G)
+    mu = (s1 + .5) / cnt
+    out[:, 0] = np.log(mu + 1e-12)
+    var_hat = mu.copy()
+    mk = cnt > 1
+    var_hat[mk] = (s2[mk] - s1[mk] ** 2 / cnt[mk]) / (cnt[mk] - 1.0)
+    sig = (var_hat - mu) / (mu ** 2 + eps)
+    sig[(~np.isfinite(sig)) | (sig <= 0.0)] = sig_glob
+    out[:, 1] = np.log(np.clip(sig, 1e-3, 10.0))
+    return out, rep

@@ -490,6 +490,42 @@ def gen_export():
     save('g16_dgpsi_export_check', **out)
 
 
+def gen_counts():
+    """G17: Poisson and NegBin likelihood nodes (likelihood_class.py:8-90,245-292): llik / pllik / prediction, and the
+    latent warm starts of dgp.initialize (dgp.py:327-336,526-566) without and with replicated inputs (the imputer's
+    first sweeps are skipped so that the recorded latents are the warm start itself)."""
+    from dgpsi import Poisson, NegBin
+    rng = np.random.default_rng(123)
+    out = {}
+    n = 14
+    for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2)):
+        h = cls()
+        h.input = rng.normal(size=(n, q)) * 0.7
+        h.output = rng.poisson(3.0, size=(n, 1)).astype(float)
+        m, v = rng.normal(size=(9, q)) * 0.5, rng.uniform(0.05, 0.6, size=(9, q))
+        pm, pv = h.prediction(m, v)
+        yq = rng.poisson(2.0, size=(9, 1)).astype(float)
+        out.update({name + '_input': h.input, name + '_output': h.output, name + '_llik': np.array(h.llik()), name + '_m': m,
+                    name + '_v': v, name + '_pm': pm, name + '_pv': pv, name + '_yq': yq, name + '_gh': RF.ghdiag(h.pllik, m, v, yq)})
+    old_sample = RI.imputer.sample
+    RI.imputer.sample = lambda self, burnin=0: None
+    try:
+        for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2)):
+            for tag, rep in (('norep', False), ('rep', True)):
+                X = rng.uniform(size=(12, 2))
+                if rep:
+                    X = np.concatenate((X, X[:6], X[:3], X[:3]))
+                Y = rng.poisson(np.exp(1.0 + np.sin(4 * X[:, 0])) * (1 + 2 * X[:, 1]))[:, None].astype(float)
+                layers = combine([kernel(length=np.array([1.0]), name='sexp', scale_est=True) for _ in range(q)], [cls()])
+                model = dgp(X, Y, layers)
+                pre = 'ws_%s_%s_' % (name, tag)
+                out.update({pre + 'X': X, pre + 'Y': Y, pre + 'latent': np.concatenate([nd.output for nd in model.all_layer[0]], 1),
+                            pre + 'lik_input': model.all_layer[1][0].input.copy()})
+    finally:
+        RI.imputer.sample = old_sample
+    save('g17_count_likelihoods', **out)
+
+
 def gen_lgp():
     """G10: feed-forward chain GP -> DGP -> GP (+ one external input on the last emulator), lgp.predict
     (linkgp.py:285-501) from the reference's own imputations (dumped)."""
@@ -629,7 +665,7 @@ def gen_hetero():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch', 'export']
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch', 'export', 'counts']
     if 'kernel' in which:
         gen_kernel_cases()
     if 'fmvn' in which:
@@ -652,3 +688,5 @@ if __name__ == '__main__':
         gen_hetero_vecchia()
     if 'export' in which:
         gen_export()
+    if 'counts' in which:
+        gen_counts()

@@ -23,9 +23,9 @@ def export(all_layer, npz_file):
         for k, nd in enumerate(layer):
             p = 'l%d_k%d_' % (l, k)
             if getattr(nd, 'type', 'gp') != 'gp':
-                if getattr(nd, 'name', None) != 'Hetero':
-                    raise NotImplementedError('of the likelihood nodes only Hetero is supported by dgp_amd')
-                out[p + 'likelihood'] = np.array('Hetero')
+                if getattr(nd, 'name', None) not in ('Hetero', 'Poisson', 'NegBin'):
+                    raise NotImplementedError('likelihood nodes supported by dgp_amd: Hetero, Poisson, NegBin')
+                out[p + 'likelihood'] = np.array(str(nd.name))
                 arrays = ('input', 'output', 'input_dim', 'rep')
             else:
                 out[p + 'name'] = np.array(str(nd.name))
