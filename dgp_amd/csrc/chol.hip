@@ -502,6 +502,23 @@ __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const
         mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, sign);
     }
 }
+// The pivot chain's own update: acc = C - P P^T with ONE panel tile P = A[k][k-1] that serves as both operands.  It sits
+// on the critical path of every block step and its loads are first touches (the tile was written by another CU in the
+// previous launch), so C and BOTH halves of P are requested at once -- one exposed memory latency instead of two.
+__device__ __forceinline__ void diag_update1(d4 (&acc)[4], const double *C, const double *P, int64_t ld, double *As, double *Bs,
+                                             int tid, int wave, int lane) {
+    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
+    const HalfTile p0 = fetch_mk(P, ld, tid, 0), p1 = fetch_mk(P, ld, tid, 1);
+    load_acc(acc, C, ld, crow, ccol);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        commit_mk(h == 0 ? p0 : p1, As, tid);
+        commit_mk(h == 0 ? p0 : p1, Bs, tid);
+        __syncthreads();
+        mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, -1.0);
+    }
+}
 // out += sign * in * Bg^T   (in: accumulator-layout 64x64 tile, Bg: 64x64 row-major tile in global memory).  Both
 // halves of Bg are requested up front: one exposed load latency instead of two on the panel's critical path.
 __device__ __forceinline__ void mul_acc_bt(d4 (&out)[4], const d4 (&in)[4], const double *Bg, int64_t ldb, double sign,
@@ -626,9 +643,12 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
         if (g.guard && tid == 0)
             __hip_atomic_store(&cukey[b], ((k + 1) << 16) | cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    tile_update(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
-                g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
-                mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
+    if (post == T_CHAIN && nkb == 1)
+        diag_update1(acc.v, C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64, ld, As, Bs, tid, wave, lane);
+    else
+        tile_update(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
+                    g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
+                    mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
     if (post == T_STORE) {
         store_acc(acc.v, C, ld, crow, ccol);
         if (wtr) wtr[1] = wall_clock64();
