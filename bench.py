@@ -56,32 +56,36 @@ def cpu_baseline(model, counts, ess_burn):
     rng = np.random.default_rng(1)
     l1, l2 = model.all_layer[0][0], model.all_layer[1][0]
     n = len(l1.output)
-    t0 = time.perf_counter()
-    reps_f = 2
-    for _ in range(reps_f):   # fmvn(scale*k_matrix()) of a first-layer node   (imputation.py:63)
+    reps_f, reps_l, reps_g = 6, 10, 5     # (about 10 s of host work in all; one untimed call of each first)
+    t0 = None
+    for r in range(reps_f + 1):   # fmvn(scale*k_matrix()) of a first-layer node   (imputation.py:63)
+        if r == 1:
+            t0 = time.perf_counter()
         O.fmvn(l1.scale[0] * O.k_matrix(l1._X(), l1.length, l1.nugget[0], l1.name), rng.standard_normal(n))
     t_fmvn = (time.perf_counter() - t0) / reps_f
-    t0 = time.perf_counter()
-    reps_l = 3
-    for _ in range(reps_l):   # log_likelihood_func of the second-layer node   (imputation.py:76,104)
+    for r in range(reps_l + 1):   # log_likelihood_func of the second-layer node   (imputation.py:76,104)
+        if r == 1:
+            t0 = time.perf_counter()
         O.log_likelihood(l2._X(), l2.output, l2.length, l2.scale, l2.nugget[0], l2.name)
     t_ll = (time.perf_counter() - t0) / reps_l
     t_llik = []
     for nd in (l1, l2):       # kernel.llik: objective + gradient, one cho_solve(n x n) per parameter
-        t0 = time.perf_counter()
-        for _ in range(2):
+        for r in range(reps_g + 1):
+            if r == 1:
+                t0 = time.perf_counter()
             O.nll_grad(nd.log_t(), nd._X(), nd.output, nd.name, nd.scale, nd.nugget[0], nd.nugget_est, nd.scale_est,
                        nd.prior_name, nd.prior_coef)
-        t_llik.append((time.perf_counter() - t0) / 2)
+        t_llik.append((time.perf_counter() - t0) / reps_g)
     sweeps = ess_burn + 1
     n_l1 = len(model.all_layer[0])
     per_iter = (sweeps * n_l1 * t_fmvn                                   # reference refactors every sweep
                 + (sweeps + counts['proposals_per_iter']) * t_ll          # threshold + proposals
                 + counts['llik_l1_per_iter'] * t_llik[0] + counts['llik_l2_per_iter'] * t_llik[1])
     return dict(value=1.0 / per_iter, unit='SI it/s', cores=psutil.cpu_count(logical=False), kind='port',
-                sample=('%d fmvn + %d log_likelihood_func + 2x2 llik at n=%d timed (%.1f s), scaled by the per-iteration '
-                        'call counts of the GPU run: %d sweeps x %d fmvn, %.1f+%d log-liks, %.1f/%.1f llik calls (layer 1/2)'
-                        % (reps_f, reps_l, n, reps_f * t_fmvn + reps_l * t_ll + 2 * sum(t_llik), sweeps, n_l1,
+                sample=('%d fmvn + %d log_likelihood_func + 2x%d llik at n=%d timed (%.1f s, after one untimed call each), scaled '
+                        'by the per-iteration call counts of the GPU run: %d sweeps x %d fmvn, %.1f+%d log-liks, %.1f/%.1f llik '
+                        'calls (layer 1/2)'
+                        % (reps_f, reps_l, reps_g, n, reps_f * t_fmvn + reps_l * t_ll + reps_g * sum(t_llik), sweeps, n_l1,
                            counts['proposals_per_iter'], sweeps, counts['llik_l1_per_iter'], counts['llik_l2_per_iter'])),
                 seconds_per_call=dict(fmvn=t_fmvn, log_likelihood_func=t_ll, llik_layer1=t_llik[0], llik_layer2=t_llik[1]))
 
