@@ -290,7 +290,7 @@ def test_gp_and_linkgp_golden(eng, golden, direct):
     eng.set_linkgp_direct(False)
 
 
-@pytest.mark.parametrize('n,M,Dw,Dz', [(130, 40, 4, 1), (200, 37, 2, 0), (64, 5, 5, 3), (257, 19, 1, 2)])
+@pytest.mark.parametrize('n,M,Dw,Dz', [(130, 40, 4, 1), (200, 37, 2, 0), (64, 5, 5, 3), (257, 19, 1, 2), (70, 300, 3, 2)])   # (M = 300: two record chunks)
 def test_linkgp_separable_equals_direct(eng, n, M, Dw, Dz):
     """Same inputs through both evaluations of the Matern J factor, incl. tiny and zero input variances, with and
     without deterministic global inputs, sizes on and off the 64-point tile edge."""
