@@ -585,3 +585,32 @@ def test_vecchia_spsolve_batch_equals_single(eng):
             assert np.array_equal(xb[j, r], x1)
         ref = O.forward_solve_sp(npy(Ls[j]) * scs[j], npy(NNs[j]), npy(b[j, 0]))
         close(xb[j, 0], ref, rtol=1e-10, atol=1e-12)
+
+
+def test_linkgp_sexp_mfma_equals_direct_across_chunks(eng):
+    """SExp link_gp: the MFMA pair kernel (dot-product form of the exponent) against the direct evaluation, M = 2100
+    test points (two workspace chunks), incl. zero input variances; a slice against the oracle."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(5)
+    n, M, Dw, Dz = 70, 2100, 3, 1
+    X = rng.uniform(size=(n, Dw + Dz))
+    y = rng.normal(size=n)
+    length = rng.uniform(0.3, 1.2, size=Dw + Dz)
+    st = O.compute_stats(X, y, length, 1e-3, 'sexp', Dw)
+    mm = rng.uniform(-0.3, 1.3, size=(M, Dw))
+    vv = 10.0 ** rng.uniform(-5, 0, size=(M, Dw))
+    vv[::17] = 0.0
+    z = rng.uniform(size=(M, Dz))
+    args = (eng.tensor(mm), eng.tensor(vv), eng.tensor(z), eng.tensor(X[:, :Dw]), eng.tensor(X[:, Dw:]), length,
+            eng.tensor(st['Rinv']), n, eng.tensor(st['Rinv_y']), 1.7, 1e-3)
+    eng.set_linkgp_direct(True)
+    m1, v1 = eng.linkgp_predict('sexp', *args)
+    m1, v1 = npy(m1), npy(v1)
+    eng.set_linkgp_direct(False)
+    m2, v2 = eng.linkgp_predict('sexp', *args)
+    close(npy(m2), m1, rtol=1e-12, atol=1e-14)
+    close(npy(v2), v1, rtol=1e-6, atol=1e-9)     # (variance = difference of O(1e3) terms through R^-1)
+    sl = slice(2040, 2060)
+    lmr, lvr = O.link_gp_predict(mm[sl], vv[sl], z[sl], X[:, :Dw], X[:, Dw:], st['Rinv'], st['Rinv_y'], 1.7, length, 1e-3, 'sexp')
+    close(npy(m2)[sl], lmr, rtol=1e-8, atol=1e-10)
+    close(npy(v2)[sl], lvr, rtol=1e-6, atol=1e-8)
