@@ -615,3 +615,38 @@ def test_count_likelihood_dgp_end_to_end(eng, lik):
     assert smp[0].shape == (15, 150) and np.all(smp[0] >= 0)
     avg, per = emu.nllik(xt, rng.poisson(rt)[:, None].astype(float))
     assert np.isfinite(avg) and per.shape == (15,)
+
+
+def test_not_positive_definite_raises_and_train_restarts(eng):
+    """Error convention: a non-PD covariance surfaces as numpy.linalg.LinAlgError from the node methods, and
+    dgp.train restarts from the last good hyper-parameters like the reference (dgp.py:1402-1412), at most three times."""
+    from dgp_amd import dgp, kernel, combine
+    rng = np.random.default_rng(2)
+    X = rng.uniform(size=(30, 2))
+    k = kernel(length=np.array([1.0]), nugget=0.0, name='sexp', engine=eng)
+    k.input = np.concatenate((X, X[:3]))            # duplicated rows and no nugget: singular
+    k.output = rng.normal(size=(33, 1))
+    k.global_input, k.D = None, 2
+    with pytest.raises(np.linalg.LinAlgError):
+        k.log_likelihood_func()
+    with pytest.raises(np.linalg.LinAlgError):
+        k.llik(k.log_t())
+    Y = np.sin(4 * X[:, :1]) + X[:, 1:]
+    model = dgp(X, Y, combine([kernel(length=np.array([1.0]), name='sexp') for _ in range(2)],
+                              [kernel(length=np.array([1.0]), name='sexp', scale_est=True)]), seed=5)
+    model.train(N=2, ess_burn=2, disable=True)
+    calls = {'n': 0}
+    orig = model._m_step
+
+    def flaky():
+        calls['n'] += 1
+        if calls['n'] == 2:
+            raise np.linalg.LinAlgError('injected')
+        return orig()
+    model._m_step = flaky
+    model.train(N=3, ess_burn=2, disable=True)
+    assert model.N == 5 and calls['n'] == 2 + 3           # one failed attempt (2 calls) + a full rerun
+    assert all(nd.para_path.shape[0] == 6 for layer in model.all_layer for nd in layer)
+    model._m_step = lambda: (_ for _ in ()).throw(np.linalg.LinAlgError('always'))
+    with pytest.raises(RuntimeError):
+        model.train(N=1, ess_burn=1, disable=True)
