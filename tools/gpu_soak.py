@@ -8,6 +8,10 @@ from dgp_amd import emulator
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 model, X, Y = build_model(2000, 5, 100, 0)
+if os.environ.get('ESS_BATCH'):
+    model.imp.batch = int(os.environ['ESS_BATCH'])
+if os.environ.get('ESS_BATCH_NEXT'):
+    model.imp.batch_next = int(os.environ['ESS_BATCH_NEXT'])
 t0 = time.perf_counter()
 ts = []
 for blk in range(N // 10):
