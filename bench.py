@@ -205,7 +205,8 @@ def main():
             for nd in layer:
                 nd.engine = eng
         est = model.estimate(burnin=0)
-        emu = emulator(est, N=args.imputations, seed=7, device=local)
+        # weak scaling like the training leg: every rank draws args.imputations imputations, the emulator's N is their total
+        emu = emulator(est, N=args.imputations * world, seed=7, device=local)
         xt = np.random.default_rng(5).uniform(size=(args.predict_points, args.d))
         emu.predict(xt[:32])   # builds the per-imputation statistics + warms the kernels
         dd.barrier()
@@ -215,8 +216,8 @@ def main():
         torch.cuda.synchronize()
         dd.barrier()
         tp = dd.allreduce_max_scalar(time.perf_counter() - t0, dev if world > 1 else None)
-        pred = dict(points=args.predict_points, imputations=args.imputations, seconds=tp,
-                    pts_per_s=args.predict_points / tp, finite=bool(np.all(np.isfinite(mu)) and np.all(np.isfinite(var))))
+        pred = dict(points=args.predict_points, imputations=args.imputations * world, imputations_per_rank=args.imputations, seconds=tp,
+                    pts_per_s=args.predict_points / tp, point_imputations_per_s=args.predict_points * args.imputations * world / tp, finite=bool(np.all(np.isfinite(mu)) and np.all(np.isfinite(var))))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
