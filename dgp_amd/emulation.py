@@ -66,6 +66,29 @@ class emulator:
                                     for layer in all_layer])
         self._stats = None
 
+    def to_vecchia(self):
+        """Switch the emulator to Vecchia predictions (emulation.py:63-74): every node conditions on its nearest training
+        points instead of using stored n x n statistics."""
+        if self.vecch:
+            raise Exception('The DGP emulator is already in Vecchia mode.')
+        self.vecch = True
+        for layer in self.all_layer:
+            for nd in layer:
+                if nd.type == 'gp':
+                    nd.vecch = True
+        self._stats = None
+
+    def remove_vecchia(self):
+        """Back to dense predictions (emulation.py:76-88); the statistics are rebuilt on the next predict()."""
+        if not self.vecch:
+            raise Exception('The DGP emulator is already in non-Vecchia mode.')
+        self.vecch = False
+        for layer in self.all_layer:
+            for nd in layer:
+                if nd.type == 'gp':
+                    nd.vecch = False
+        self._stats = None
+
     def __getstate__(self):
         st = dict(self.__dict__)
         st['engine'] = None       # device context and statistics are rebuilt after unpickling (utils.write / read)

@@ -12,11 +12,19 @@ class gp:
     def __init__(self, X, Y, kernel, check_rep=True, vecchia=False, m=25, ord_fun=None, device=None):
         if Y.ndim == 1 or X.ndim == 1:
             raise Exception('The input and output data have to be numpy 2d-arrays.')
-        self.check_rep, self.indices = check_rep, None
+        self.check_rep = check_rep
+        self._set_data(X, Y)
+        self.kernel = kernel
+        self.kernel.engine = default_engine(device)
+        self._finish_init(vecchia, m, ord_fun)
+
+    def _set_data(self, X, Y):
+        """Deduplicate the design (gp.py:32-42,152-170): site means, weights 1/count and the pooled residual."""
+        self.indices = None
         self.X, self.Y = X, Y
-        if check_rep:
+        if self.check_rep:
             X0, inv = np.unique(X, return_inverse=True, axis=0)
-            if len(X0) != len(X):   # replicates: site means, weights 1/count and the pooled residual (gp.py:32-42)
+            if len(X0) != len(X):
                 inv = np.asarray(inv).reshape(-1)
                 G = inv.max() + 1
                 self.X, self.indices = X0, inv
@@ -24,8 +32,8 @@ class gp:
                 self.Y = (np.bincount(inv, weights=Y.flatten(), minlength=G) * self.W_diag).reshape(-1, 1)
                 res = Y - self.Y[inv, :]
                 self.sum_residual = (res.T @ res).flatten()
-        self.kernel = kernel
-        self.kernel.engine = default_engine(device)
+
+    def _finish_init(self, vecchia, m, ord_fun):
         self.vecch = vecchia
         self.n_data = self.X.shape[0]
         self.m = min(m, self.n_data - 1)
@@ -74,6 +82,71 @@ class gp:
             raise Exception('The GP emulator is already in non-Vecchia mode.')
         self.vecch = self.kernel.vecch = False
         self.kernel.compute_stats()
+
+    def update_xy(self, X, Y, reset=False):
+        """Replace the training data of the emulator (gp.py:144-181); reset=True also puts the hyper-parameters back
+        to their initial values."""
+        if Y.ndim == 1 or X.ndim == 1:
+            raise Exception('The input and output data have to be numpy 2d-arrays.')
+        self._set_data(X, Y)
+        self.n_data = self.X.shape[0]
+        self.m = min(self.m, self.n_data - 1)
+        self.update_kernel(reset_lengthscale=reset)
+        if self.vecch:
+            self.kernel.ord_nn()
+        else:
+            self.kernel.compute_stats()
+
+    def update_kernel(self, reset_lengthscale):
+        """Hand the current data to the node (gp.py:183-209)."""
+        k = self.kernel
+        if self.indices is not None:
+            k.rep, k.W_diag, k.sum_residual = self.indices, self.W_diag, self.sum_residual
+        else:
+            k.rep = k.W_diag = k.sum_residual = None
+        k.input = self.X[:, k.input_dim]
+        if k.connect is not None:
+            if len(np.intersect1d(k.connect, k.input_dim)) != 0:
+                raise Exception('The local input and global input should not have any overlap. Change input_dim or '
+                                'connect so they do not have any common indices.')
+            k.global_input = self.X[:, k.connect]
+        k.output = self.Y.copy()
+        k.m = self.m
+        k._stats = None
+        if reset_lengthscale:
+            h = k.para_path[0, :]
+            k.scale, k.length, k.nugget = h[[0]], h[1:-1], h[[-1]]
+        if k.prior_name == 'ref':
+            k.compute_cl()
+
+    def metric(self, x_cand, method='MICE', nugget_s=1., m=50, score_only=False):
+        """Sequential-design criterion at the rows of x_cand (gp.py:271-324): ALM = predictive variance; MICE = that
+        variance over the variance of a GP on the candidate set alone (functions.mice_var); VIGF = 4 s2 b + 2 s2^2 with b the
+        squared gap to the nearest training output."""
+        if method == 'ALM' or method == 'MICE':
+            _, s2 = self.predict(x=x_cand, m=m)
+            if method == 'MICE':
+                from .emulation import emulator
+                e = emulator.__new__(emulator)
+                e.engine = self.kernel.engine
+                s2 = s2 / e._mice_var(x_cand, x_cand, self.kernel, nugget_s).reshape(-1, 1)
+            score = s2
+        elif method == 'VIGF':
+            if self.indices is not None:
+                raise Exception('VIGF criterion is currently not applicable to GP emulators whose training data contain replicates.')
+            eng = self.kernel.engine
+            index = eng.nn_query(eng.tensor(x_cand), eng.tensor(self.X), 1).cpu().numpy().flatten()
+            mu, s2 = self.predict(x=x_cand, m=m)
+            bias = (mu - self.Y[index, :]) ** 2
+            score = 4 * s2 * bias + 2 * s2 ** 2
+        else:
+            raise Exception("method must be 'ALM', 'MICE' or 'VIGF'.")
+        if score_only:
+            return score
+        idx = np.argmax(score, axis=0)
+        return idx, score[idx, 0]
+
+    pmetric = metric
 
     def train(self):
         """One L-BFGS-B fit of the hyper-parameters (gp.py:211-216)."""

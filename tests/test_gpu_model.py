@@ -650,3 +650,52 @@ def test_not_positive_definite_raises_and_train_restarts(eng):
     model._m_step = lambda: (_ for _ in ()).throw(np.linalg.LinAlgError('always'))
     with pytest.raises(RuntimeError):
         model.train(N=1, ess_burn=1, disable=True)
+
+
+def test_gp_update_xy_and_metric(eng):
+    """gp.update_xy / update_kernel (gp.py:144-209) and gp.metric ALM / MICE / VIGF (gp.py:271-324, functions.mice_var)
+    against the oracle; emulator.to_vecchia / remove_vecchia switch the prediction mode."""
+    from dgp_amd import gp, kernel, dgp, combine, emulator
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(12)
+    X = rng.uniform(size=(40, 2))
+    f = lambda X: np.sin(5 * X[:, :1]) + X[:, 1:] ** 2
+    k = kernel(length=np.array([0.6, 0.9]), name='matern2.5', scale_est=True, nugget=1e-4)
+    model = gp(X[:30], f(X[:30]), k)
+    model.train()
+    length = k.length.copy()
+    xc = rng.uniform(size=(25, 2))
+    mu, s2 = model.predict(xc)
+    assert np.array_equal(model.metric(xc, method='ALM', score_only=True), s2)
+    mice = model.metric(xc, method='MICE', nugget_s=1.0, score_only=True)
+    ref = s2 / O.mice_var(xc, xc, k.input_dim, k.connect, k.name, k.length, k.scale, k.nugget[0], 1.0).reshape(-1, 1)
+    close(mice, ref, rtol=1e-8, atol=1e-12)
+    idx, best = model.metric(xc, method='MICE')
+    assert idx[0] == int(np.argmax(mice[:, 0])) and best[0] == mice[:, 0].max()
+    vig = model.metric(xc, method='VIGF', score_only=True)
+    near = np.argmin(((xc[:, None, :] - model.X[None]) ** 2).sum(-1), 1)
+    close(vig, 4 * s2 * (mu - model.Y[near]) ** 2 + 2 * s2 ** 2, rtol=1e-12)
+    # new data, hyper-parameters kept; then with replicates; then reset
+    model.update_xy(X, f(X))
+    assert model.n_data == 40 and k.input.shape == (40, 2) and np.array_equal(k.length, length) and k.rep is None
+    mu2, _ = model.predict(X[30:])
+    assert np.sqrt(np.mean((mu2 - f(X[30:])) ** 2)) < 0.05          # the ten new points are now interpolated
+    Xr = np.concatenate((X, X[:7]))
+    model.update_xy(Xr, f(Xr) + 0.01 * rng.normal(size=(47, 1)))
+    assert model.n_data == 40 and k.rep is not None and len(k.rep) == 47 and k.W_diag.shape == (40,)
+    model.update_xy(X, f(X), reset=True)
+    assert np.array_equal(k.length, np.array([0.6, 0.9])) and k.rep is None
+    # emulator mode switches
+    d = dgp(X, f(X), combine([kernel(length=np.array([1.0]), name='sexp') for _ in range(2)],
+                             [kernel(length=np.array([1.0]), name='sexp', scale_est=True, connect=np.arange(2))]), seed=1)
+    d.train(N=3, ess_burn=3, disable=True)
+    emu = emulator(d.estimate(), N=2, seed=2)
+    a, _ = emu.predict(xc)
+    emu.to_vecchia()
+    b, _ = emu.predict(xc, m=39)            # all 40 points but the shortcut boundary: close to the dense prediction
+    assert emu.vecch and np.sqrt(np.mean((a - b) ** 2)) < 0.05
+    emu.remove_vecchia()
+    c, _ = emu.predict(xc)
+    close(c, a, rtol=1e-9, atol=1e-12)
+    with pytest.raises(Exception):
+        emu.remove_vecchia()
