@@ -26,6 +26,24 @@ class container:
             self.imp.sample(burnin=50)
         self.local_input_idx = local_input_idx
 
+    def _gp_nodes(self):
+        return [self.structure] if self.type == 'gp' else [nd for layer in self.structure for nd in layer if nd.type == 'gp']
+
+    def to_vecchia(self):
+        """Vecchia predictions for this emulator (linkgp.py:64-75)."""
+        if not self.vecch:
+            self.vecch = True
+            for nd in self._gp_nodes():
+                nd.vecch = True
+
+    def remove_vecchia(self):
+        """Dense predictions (linkgp.py:77-89); the n x n statistics are rebuilt on first use."""
+        if self.vecch:
+            self.vecch = False
+            for nd in self._gp_nodes():
+                nd.vecch = False
+                nd._stats = None
+
     def set_local_input(self, idx, new=False):
         if not new:
             self.local_input_idx = idx
@@ -80,6 +98,19 @@ class lgp:
                     row.append(c._snapshot())
                 one.append(row)
             self.all_layer_set.append(one)
+
+    def set_vecchia(self, mode):
+        """Vecchia (True) or dense (False) predictions for all emulators of the system, or per emulator with a list
+        shaped like all_layer (linkgp.py:180-212)."""
+        if isinstance(mode, list):
+            if len(mode) != len(self.all_layer) or any(len(a) != len(b) for a, b in zip(mode, self.all_layer)):
+                raise Exception('mode has a different shape as all_layer.')
+        else:
+            mode = [[mode for _ in layer] for layer in self.all_layer]
+        for system in [self.all_layer] + list(self.all_layer_set):
+            for layer, ml in zip(system, mode):
+                for c, on in zip(layer, ml):
+                    c.to_vecchia() if on else c.remove_vecchia()
 
     # -------------------------------------------------------------- single emulators
     @staticmethod

@@ -322,6 +322,15 @@ def test_linked_chain_matches_reference(eng, golden, tag):
     for l in range(3):
         close(mul[l][0], d['mu_l%d' % l], rtol=1e-6, atol=1e-8)
         close(varl[l][0], d['var_l%d' % l], rtol=1e-5, atol=1e-6)
+    # lgp.set_vecchia (linkgp.py:180-212): with every training point in the conditioning set the Vecchia predictions are
+    # the dense ones up to rounding; switching back restores them
+    sysm.set_vecchia(True)
+    assert all(c.vecch for one in sysm.all_layer_set for layer in one for c in layer)
+    mu_v, var_v = sysm.predict(xin, m=len(d['X1']))
+    close(mu_v[0], d['mu'], rtol=1e-5, atol=1e-6)
+    sysm.set_vecchia([[False], [False], [False]])
+    mu_d, var_d = sysm.predict(xin)
+    close(mu_d[0], d['mu'], rtol=1e-6, atol=1e-8)
 
 
 def test_gp_class_predict_matches_reference(eng, golden):
