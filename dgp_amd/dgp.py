@@ -379,6 +379,32 @@ class dgp:
         self.imp.sample(burnin=10)
         self.compute_r2()
 
+    def update_all_layer(self, all_layer):
+        """Replace the structure by one that carries hyper-parameter and latent values already, e.g. `estimate()` of
+        another run (dgp.py:760-822): the parameter paths restart there, 10 sweeps of the sampler, N = 0."""
+        self.all_layer = all_layer
+        self.n_layer = len(all_layer)
+        for l, layer in enumerate(all_layer):
+            for nd in layer:
+                if l == self.n_layer - 1 and nd.rep is not None:
+                    self.indices = nd.rep
+                if nd.type != 'gp':
+                    continue
+                nd.engine = self.engine
+                nd.para_path = np.atleast_2d(np.concatenate((nd.scale, nd.length, nd.nugget)))
+                nd.D = nd.input.shape[1] + (0 if nd.connect is None else len(nd.connect))
+                if nd.prior_name == 'ref':
+                    p = nd.D
+                    nd.prior_coef[1] = 1 / len(nd.output) ** (1 / p) * (nd.prior_coef[0] + p)
+                    nd.compute_cl()
+            if self.vecch:
+                self._layer_ord_nn(layer)
+        self.imp = imputer(self.all_layer, self.block, draws=self.draws, engine=self.engine)
+        self.imp.sample(burnin=10)
+        self.compute_r2()
+        self.N = 0
+        self.burnin = None
+
     # ------------------------------------------------------------------ new data (sequential design)
     def update_xy(self, X, Y, reset=False):
         """Replace the training data of a trained DGP (dgp.py:824-888).  reset=True: latents and hyper-parameters start

@@ -529,6 +529,12 @@ def test_update_xy_warm_starts(eng):
     model.train(N=3, ess_burn=3, disable=True)
     mu, var = emulator(model.estimate(), N=2, seed=1).predict(Xn[:10])
     assert mu.shape == (10, 1) and np.all(np.isfinite(mu)) and np.all(var > 0)
+    # update_all_layer (dgp.py:760-822): continue from an estimated structure
+    est = model.estimate()
+    model.update_all_layer(est)
+    assert model.N == 0 and model.all_layer is est and est[1][0].para_path.shape == (1, 3 + 0)
+    model.train(N=2, ess_burn=2, disable=True)
+    assert est[1][0].para_path.shape[0] == 3
 
 
 def test_hetero_vecchia_posterior_matches_reference(eng, golden):
