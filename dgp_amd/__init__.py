@@ -8,6 +8,7 @@ from .emulation import emulator  # noqa: F401
 from .gp import gp  # noqa: F401
 from .linkgp import container, lgp  # noqa: F401
 from .likelihood_class import Hetero, Poisson, NegBin  # noqa: F401
-from .utils import nb_seed, set_thread, get_thread, write, read, save_structure, load_structure  # noqa: F401
+from .synthetic import path  # noqa: F401
+from .utils import nb_seed, set_thread, get_thread, write, read, summary, save_structure, load_structure  # noqa: F401
 
 __version__ = '0.1.0'

@@ -140,3 +140,50 @@ def read(pkl_file):
     import pickle
     with open(pkl_file + '.pkl', 'rb') as f:
         return pickle.load(f)
+
+
+def summary(obj, tablefmt='fancy_grid'):
+    """Print the key facts of a kernel / gp / dgp / emulator / lgp object as a table (dgpsi utils.summary,
+    utils.py:69-190): per node its type, lengthscales, variance, nugget (with "(fixed)" where not estimated) and wiring."""
+    from tabulate import tabulate
+
+    def num(v, est=True):
+        txt = np.array2string(np.atleast_1d(v)[0], precision=3, floatmode='fixed')
+        return txt if est else txt + ' (fixed)'
+
+    def fun(nd):
+        return {'sexp': 'Squared-Exp', 'matern2.5': 'Matern-2.5'}.get(nd.name, nd.name)
+
+    def node_row(nd, head):
+        if getattr(nd, 'type', 'gp') == 'likelihood':
+            return head + ['Likelihood (%s)' % nd.name, 'NA', 'NA', 'NA',
+                           np.array2string(np.asarray(nd.input_dim) + 1, separator=', '), 'NA']
+        dims = np.asarray(nd.input_dim) + 1 if nd.input_dim is not None else 'all'
+        return head + ['GP (%s)' % fun(nd), np.array2string(nd.length, precision=3, floatmode='fixed', separator=', '),
+                       num(nd.scale, nd.scale_est), num(nd.nugget, nd.nugget_est),
+                       np.array2string(dims, separator=', ') if not isinstance(dims, str) else dims,
+                       'No' if nd.connect is None else np.array2string(np.asarray(nd.connect) + 1, separator=', ')]
+
+    cols = ['Type', 'Length-scale(s)', 'Variance', 'Nugget', 'Input Dims', 'Global Connection']
+    kind = type(obj).__name__
+    if kind == 'kernel':
+        rows = [cols, node_row(obj, [])]
+    elif kind == 'gp':
+        rows = [cols, node_row(obj.kernel, [])]
+    elif kind in ('dgp', 'emulator'):
+        if kind == 'dgp' and obj.N != 0:
+            print('To get the summary of the trained DGP model, construct an emulator instance using the emulator() class '
+                  'and then apply summary() to it.')
+            return
+        rows = [['Layer No.', 'Node No.'] + cols]
+        for l, layer in enumerate(obj.all_layer):
+            for k, nd in enumerate(layer):
+                rows.append(node_row(nd, ['Layer %d' % (l + 1), 'Node %d' % (k + 1)]))
+    elif kind == 'lgp':
+        rows = [['Layer No.', 'Emulator No.', 'Type', 'Connection']]
+        for l, layer in enumerate(obj.all_layer):
+            for k, c in enumerate(layer):
+                rows.append(['Layer %d' % (l + 1), 'Emu %d' % (k + 1), c.type.upper(), str(c.local_input_idx)])
+    else:
+        raise Exception('summary() takes a kernel, gp, dgp, emulator or lgp object.')
+    print(tabulate(rows, headers='firstrow', tablefmt=tablefmt))

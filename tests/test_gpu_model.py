@@ -714,3 +714,32 @@ def test_gp_update_xy_and_metric(eng):
     close(c, a, rtol=1e-9, atol=1e-12)
     with pytest.raises(Exception):
         emu.remove_vecchia()
+
+
+def test_prior_paths_and_summary(eng, capsys):
+    """synthetic.path.generate (synthetic.py:20-46) against the oracle's fmvn with the same normals; utils.summary."""
+    from dgp_amd import path, kernel, combine, summary, gp
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(1)
+    X = rng.uniform(size=(35, 2))
+    layers = combine([kernel(length=np.array([0.5]), name='matern2.5', nugget=1e-6),
+                      kernel(length=np.array([0.8]), name='sexp', scale=2.0, nugget=1e-5)],
+                     [kernel(length=np.array([1.0]), name='matern2.5', scale=1.5, connect=np.arange(2), nugget=1e-6)])
+    np.random.seed(11)
+    got = path(X, layers).generate(2)
+    assert got.shape == (1, 2, 35)
+    np.random.seed(11)
+    for i in range(2):
+        x = X
+        for layer in layers:
+            out = np.empty((35, len(layer)))
+            for k, nd in enumerate(layer):
+                In = x if nd.connect is None else np.concatenate((x, X[:, nd.connect]), 1)
+                cov = nd.scale[0] * O.k_matrix(In, nd.length, nd.nugget[0], nd.name)
+                out[:, k] = O.fmvn(cov, np.random.normal(size=[35, 1]).ravel())
+            x = out
+        close(got[0, i], x[:, 0], rtol=1e-6, atol=1e-8)
+    summary(layers[0][0])
+    summary(gp(X, np.sin(X[:, :1]), kernel(length=np.array([1.0, 1.0]), scale_est=True)))
+    txt = capsys.readouterr().out
+    assert 'Matern-2.5' in txt and 'Squared-Exp' in txt and '(fixed)' in txt
