@@ -56,9 +56,9 @@ class dgp:
         self.n_layer = len(all_layer)
         for l, layer in enumerate(all_layer):
             for nd in layer:
-                if nd.type == 'likelihood' and (nd.name not in ('Hetero', 'Poisson', 'NegBin') or l != self.n_layer - 1):
-                    raise NotImplementedError('likelihood nodes: Hetero, Poisson and NegBin (final layer) are supported; the '
-                                              'warm starts of ZIP / ZINB / Categorical (dgp.py:279-525) are outside the path')
+                if nd.type == 'likelihood' and (nd.name not in ('Hetero', 'Poisson', 'NegBin', 'ZIP') or l != self.n_layer - 1):
+                    raise NotImplementedError('likelihood nodes: Hetero, Poisson, NegBin and ZIP (final layer) are supported; the '
+                                              'warm starts of ZINB / Categorical (dgp.py:279-326,411-525) are outside the path')
         self.initialize()
         self.block = block
         self.draws = DrawStream(seed)
@@ -88,11 +88,13 @@ class dgp:
         if l != self.n_layer - 2 or len(self.all_layer[l + 1]) != 1:
             return None
         name = getattr(self.all_layer[l + 1][0], 'name', None)
-        if name not in ('Poisson', 'NegBin'):
+        if name not in ('Poisson', 'NegBin', 'ZIP'):
             return None
         y = self.Y.flatten()
         G = self.X.shape[0]
         M = len(self.all_layer[l])
+        if name == 'ZIP':
+            return self._zip_warm_start(y, G, M)
         if name == 'Poisson':
             if self.indices is None:
                 return np.log(self.Y + .5 + 1e-12)
@@ -119,6 +121,39 @@ class dgp:
         sig = (var_hat - mu) / (mu ** 2 + eps)
         sig[(~np.isfinite(sig)) | (sig <= 0.0)] = sig_glob
         Out[:, 1] = np.log(np.clip(sig, 1e-3, 10.0))
+        return Out
+
+    def _zip_warm_start(self, y, G, M):
+        """(log rate, logit of the zero-inflation probability) for a ZIP likelihood (dgp.py:337-410): the share of zeros
+        beyond what a Poisson with the observed mean explains, globally without replicates and per site with them."""
+        Out = np.empty((G, M))
+        lam_floor, pi_min, pi_max = 1e-6, 1e-4, 0.99
+        if self.indices is None:
+            Out[:, 0] = np.log(np.maximum(y + 0.5, lam_floor) + 1e-12)
+            p0 = ((y == 0).sum() + 0.5) / (len(y) + 1.0)
+            mu = y.mean()
+            if mu <= 0:
+                pi0 = p0
+            else:
+                q0 = np.exp(-max(mu, lam_floor))
+                pi0 = 0.0 if q0 >= 1.0 - 1e-8 else np.clip((p0 - q0) / (1.0 - q0), 0.0, pi_max)
+            pi0 = np.clip(pi0, pi_min, 1.0 - pi_min)
+            Out[:, 1] = np.log(pi0 / (1.0 - pi0))
+            return Out
+        idx = np.asarray(self.indices)
+        n_g = np.bincount(idx, minlength=G)
+        mu_g = np.bincount(idx, weights=y, minlength=G) / np.maximum(n_g, 1)
+        p0_g = (np.bincount(idx, weights=(y == 0).astype(float), minlength=G) + 0.1) / (n_g + 0.2)
+        pos = y > 0
+        lam0 = mu_g.copy()
+        lam0[mu_g == 0.0] = y[pos].mean() if np.any(pos) else 1.0
+        lam0 = np.maximum(lam0, lam_floor)
+        q = np.exp(-lam0)
+        pi_g = np.clip(np.where(p0_g <= q, 0.0, (p0_g - q) / np.maximum(1.0 - q, 1e-8)), 0.0, pi_max)
+        lam = np.maximum(np.where(mu_g == 0.0, lam0, mu_g / np.maximum(1.0 - pi_g, 1e-3)), lam_floor)
+        pi_g = np.clip(pi_g, pi_min, 1.0 - pi_min)
+        Out[:, 0] = np.log(lam + 1e-12)
+        Out[:, 1] = np.log(pi_g / (1.0 - pi_g))
         return Out
 
     def _layer_warm_start(self, l, In, num_kernel):

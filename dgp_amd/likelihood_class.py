@@ -1,4 +1,4 @@
-"""Likelihood nodes (dgpsi likelihood_class.py): Hetero, Poisson, NegBin.  They live on the host -- the 4-method plugin protocol
+"""Likelihood nodes (dgpsi likelihood_class.py): Hetero, Poisson, NegBin, ZIP.  They live on the host -- the 4-method plugin protocol
 llik() / pllik(y, f) / prediction(m, v) / sampling(f) on numpy arrays, attributes type, name, input, output,
 input_dim, exact_post_idx, rep (likelihood_class.py:30-90) -- except for the one step that is as heavy as a GP node:
 the exact conditional posterior draw of the heteroskedastic Gaussian likelihood's mean latent (two n x n
@@ -88,6 +88,48 @@ class NegBin(_CountLikelihood):
     def sampling(f_sample):
         p, size = 1 / (1 + np.exp(f_sample[:, 0] + f_sample[:, 1])), np.exp(-f_sample[:, 1])
         return np.random.negative_binomial(size, p).flatten()
+
+
+class ZIP(_CountLikelihood):
+    """Zero-inflated Poisson (likelihood_class.py:470-621): with probability pi = logistic(f1) a structural zero, else
+    Poisson(exp(f0)); two feeding GP nodes."""
+    name = 'ZIP'
+
+    @staticmethod
+    def _logpmf(y, f_lam, f_pi):
+        from scipy.special import gammaln, expit
+        with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+            lam, pi = np.exp(f_lam), expit(f_pi)
+            zero = np.logaddexp(np.log(pi), np.log1p(-pi) - lam)                       # structural or Poisson zero
+            pos = np.log1p(-pi) - lam + y * f_lam - gammaln(y + 1.0)
+            return np.where(y == 0, zero, pos)
+
+    def llik(self):
+        return np.sum(self._logpmf(np.asarray(self.output).flatten(), self.input[:, 0], self.input[:, 1]))
+
+    @staticmethod
+    def pllik(y, f):
+        return ZIP._logpmf(y, f[..., [0]], f[..., [1]])
+
+    @staticmethod
+    def prediction(m, v):
+        """Moments of y with a log-normal rate and the logistic-normal zero probability in its probit-style
+        approximation E[pi] ~ logistic(m / sqrt(1 + pi v / 8)), Var[pi] by the delta method (clipped to p(1-p))."""
+        from scipy.special import expit
+        lam_mean = np.exp(m[:, 0] + 0.5 * v[:, 0])
+        lam_var = (np.exp(v[:, 0]) - 1.0) * np.exp(2.0 * m[:, 0] + v[:, 0])
+        den = np.maximum(1.0 + (np.pi / 8.0) * v[:, 1], 1e-12)
+        p = expit(m[:, 1] / np.sqrt(den))
+        p_var = np.clip((p * (1.0 - p)) ** 2 * (v[:, 1] / den), 0.0, p * (1.0 - p))
+        mean = (1.0 - p) * lam_mean
+        var = (1.0 - p) * lam_mean * (1.0 + p * lam_mean) + ((1.0 - p) ** 2 + p_var) * lam_var + p_var * lam_mean ** 2
+        return mean.flatten(), np.maximum(var, 0.0).flatten()
+
+    def sampling(self, f_sample):
+        from scipy.special import expit
+        lam, pi = np.exp(f_sample[:, 0]), expit(f_sample[:, 1])
+        u = np.random.rand(f_sample.shape[0])
+        return np.where(u < pi, 0, np.random.poisson(lam)).flatten()
 
 
 class Hetero:

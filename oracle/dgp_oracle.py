@@ -899,6 +899,62 @@ def negbin_prediction(m, v):
     return e_mu, var
 
 
+def zip_pllik(y, f):
+    """ZIP log-pmf (likelihood_class.py:497-572): zero = log(pi + (1-pi) e^-lam), y>0 = log(1-pi) - lam + y f - log y!."""
+    from scipy.special import gammaln, expit
+    f_lam, f_pi = f[..., [0]], f[..., [1]]
+    lam, pi = np.exp(f_lam), expit(f_pi)
+    y = np.broadcast_to(y, lam.shape)
+    out = np.empty(lam.shape)
+    z = y == 0
+    out[z] = np.logaddexp(np.log(pi[z]), np.log1p(-pi[z]) - lam[z])
+    out[~z] = np.log1p(-pi[~z]) - lam[~z] + y[~z] * f_lam[~z] - gammaln(y[~z] + 1.0)
+    return out
+
+
+def zip_prediction(m, v):
+    from scipy.special import expit
+    lam_mean = np.exp(m[:, 0] + 0.5 * v[:, 0])
+    lam_var = (np.exp(v[:, 0]) - 1.0) * np.exp(2.0 * m[:, 0] + v[:, 0])
+    den = np.maximum(1.0 + (np.pi / 8.0) * v[:, 1], 1e-12)
+    p = expit(m[:, 1] / np.sqrt(den))
+    p_var = np.clip((p * (1.0 - p))**2 * v[:, 1] / den, 0.0, p * (1.0 - p))
+    mean = (1.0 - p) * lam_mean
+    var = (1.0 - p) * lam_mean * (1.0 + p * lam_mean) + ((1.0 - p)**2 + p_var) * lam_var + p_var * lam_mean**2
+    return mean, np.maximum(var, 0.0)
+
+
+def zip_warm_start(y, rep, G):
+    """dgp.py:337-410."""
+    out = np.empty((G, 2))
+    lam_floor, pi_min, pi_max = 1e-6, 1e-4, 0.99
+    if rep is None:
+        out[:, 0] = np.log(np.maximum(y + 0.5, lam_floor) + 1e-12)
+        p0 = ((y == 0).sum() + 0.5) / (len(y) + 1.0)
+        mu = y.mean()
+        if mu <= 0:
+            pi0 = p0
+        else:
+            q0 = np.exp(-max(mu, lam_floor))
+            pi0 = 0.0 if q0 >= 1.0 - 1e-8 else np.clip((p0 - q0) / (1.0 - q0), 0.0, pi_max)
+        pi0 = np.clip(pi0, pi_min, 1.0 - pi_min)
+        out[:, 1] = np.log(pi0 / (1.0 - pi0))
+        return out
+    n_g = np.bincount(rep, minlength=G)
+    mu_g = np.bincount(rep, weights=y, minlength=G) / np.maximum(n_g, 1)
+    p0_g = (np.bincount(rep, weights=(y == 0).astype(float), minlength=G) + 0.1) / (n_g + 0.2)
+    lam0 = mu_g.copy()
+    lam0[mu_g == 0.0] = y[y > 0].mean() if np.any(y > 0) else 1.0
+    lam0 = np.maximum(lam0, lam_floor)
+    q = np.exp(-lam0)
+    pi_g = np.clip(np.where(p0_g <= q, 0.0, (p0_g - q) / np.maximum(1.0 - q, 1e-8)), 0.0, pi_max)
+    lam = np.maximum(np.where(mu_g == 0.0, lam0, mu_g / np.maximum(1.0 - pi_g, 1e-3)), lam_floor)
+    pi_g = np.clip(pi_g, pi_min, 1.0 - pi_min)
+    out[:, 0] = np.log(lam + 1e-12)
+    out[:, 1] = np.log(pi_g / (1.0 - pi_g))
+    return out
+
+
 def count_warm_start(name, X, Y):
     """Latents fed to a Poisson / NegBin likelihood at initialisation; X with possibly repeated rows.  Returns
     (latent (G x q), rep or None).  NegBin without replicates: only column 0 is defined by the reference."""
@@ -907,6 +963,8 @@ def count_warm_start(name, X, Y):
     y = np.asarray(Y, float).ravel()
     rep = None if len(X0) == len(X) else inv
     G = len(X0)
+    if name == 'ZIP':
+        return zip_warm_start(y, rep, G), rep
     if name == 'Poisson':
         if rep is None:
             return np.log(y + .5 + 1e-12)[:, None], None

@@ -494,28 +494,28 @@ def gen_counts():
     """G17: Poisson and NegBin likelihood nodes (likelihood_class.py:8-90,245-292): llik / pllik / prediction, and the
     latent warm starts of dgp.initialize (dgp.py:327-336,526-566) without and with replicated inputs (the imputer's
     first sweeps are skipped so that the recorded latents are the warm start itself)."""
-    from dgpsi import Poisson, NegBin
+    from dgpsi import Poisson, NegBin, ZIP
     rng = np.random.default_rng(123)
     out = {}
     n = 14
-    for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2)):
+    for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2), ('zip', ZIP, 2)):
         h = cls()
         h.input = rng.normal(size=(n, q)) * 0.7
-        h.output = rng.poisson(3.0, size=(n, 1)).astype(float)
+        h.output = (rng.poisson(3.0, size=(n, 1)) * (rng.uniform(size=(n, 1)) > 0.3)).astype(float)
         m, v = rng.normal(size=(9, q)) * 0.5, rng.uniform(0.05, 0.6, size=(9, q))
         pm, pv = h.prediction(m, v)
-        yq = rng.poisson(2.0, size=(9, 1)).astype(float)
+        yq = (rng.poisson(2.0, size=(9, 1)) * (rng.uniform(size=(9, 1)) > 0.3)).astype(float)
         out.update({name + '_input': h.input, name + '_output': h.output, name + '_llik': np.array(h.llik()), name + '_m': m,
                     name + '_v': v, name + '_pm': pm, name + '_pv': pv, name + '_yq': yq, name + '_gh': RF.ghdiag(h.pllik, m, v, yq)})
     old_sample = RI.imputer.sample
     RI.imputer.sample = lambda self, burnin=0: None
     try:
-        for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2)):
+        for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2), ('zip', ZIP, 2)):
             for tag, rep in (('norep', False), ('rep', True)):
                 X = rng.uniform(size=(12, 2))
                 if rep:
                     X = np.concatenate((X, X[:6], X[:3], X[:3]))
-                Y = rng.poisson(np.exp(1.0 + np.sin(4 * X[:, 0])) * (1 + 2 * X[:, 1]))[:, None].astype(float)
+                Y = (rng.poisson(np.exp(1.0 + np.sin(4 * X[:, 0])) * (1 + 2 * X[:, 1])) * (rng.uniform(size=len(X)) > 0.35))[:, None].astype(float)
                 layers = combine([kernel(length=np.array([1.0]), name='sexp', scale_est=True) for _ in range(q)], [cls()])
                 model = dgp(X, Y, layers)
                 pre = 'ws_%s_%s_' % (name, tag)

@@ -241,11 +241,11 @@ def test_structure_exported_from_dgpsi_loads(golden, tmp_path):
 def test_count_likelihood_nodes_match_reference(golden):
     """dgp_amd.Poisson / NegBin (host plugin protocol) and dgp's latent warm starts for them against the reference's
     values (g17_count_likelihoods)."""
-    from dgp_amd import Poisson, NegBin
+    from dgp_amd import Poisson, NegBin, ZIP
     from dgp_amd.likelihood_class import ghdiag
     from dgp_amd.dgp import dgp
     g = golden('g17_count_likelihoods')
-    for name, cls in (('poisson', Poisson), ('negbin', NegBin)):
+    for name, cls in (('poisson', Poisson), ('negbin', NegBin), ('zip', ZIP)):
         h = cls()
         h.input, h.output = g[name + '_input'], g[name + '_output']
         assert h.type == 'likelihood' and h.exact_post_idx is None and h.rep is None
