@@ -56,9 +56,9 @@ class dgp:
         self.n_layer = len(all_layer)
         for l, layer in enumerate(all_layer):
             for nd in layer:
-                if nd.type == 'likelihood' and (nd.name not in ('Hetero', 'Poisson', 'NegBin', 'ZIP') or l != self.n_layer - 1):
-                    raise NotImplementedError('likelihood nodes: Hetero, Poisson, NegBin and ZIP (final layer) are supported; the '
-                                              'warm starts of ZINB / Categorical (dgp.py:279-326,411-525) are outside the path')
+                if nd.type == 'likelihood' and (nd.name not in ('Hetero', 'Poisson', 'NegBin', 'ZIP', 'ZINB') or l != self.n_layer - 1):
+                    raise NotImplementedError('likelihood nodes: Hetero, Poisson, NegBin, ZIP and ZINB (final layer) are supported; the '
+                                              'Categorical likelihood (dgp.py:279-326) is outside the path')
         self.initialize()
         self.block = block
         self.draws = DrawStream(seed)
@@ -88,13 +88,15 @@ class dgp:
         if l != self.n_layer - 2 or len(self.all_layer[l + 1]) != 1:
             return None
         name = getattr(self.all_layer[l + 1][0], 'name', None)
-        if name not in ('Poisson', 'NegBin', 'ZIP'):
+        if name not in ('Poisson', 'NegBin', 'ZIP', 'ZINB'):
             return None
         y = self.Y.flatten()
         G = self.X.shape[0]
         M = len(self.all_layer[l])
         if name == 'ZIP':
             return self._zip_warm_start(y, G, M)
+        if name == 'ZINB':
+            return self._zinb_warm_start(y, G, M)
         if name == 'Poisson':
             if self.indices is None:
                 return np.log(self.Y + .5 + 1e-12)
@@ -154,6 +156,48 @@ class dgp:
         pi_g = np.clip(pi_g, pi_min, 1.0 - pi_min)
         Out[:, 0] = np.log(lam + 1e-12)
         Out[:, 1] = np.log(pi_g / (1.0 - pi_g))
+        return Out
+
+    def _zinb_warm_start(self, y, G, M):
+        """(log mean, log dispersion, logit zero-inflation) for a ZINB likelihood (dgp.py:411-525): NegBin's moment
+        estimates plus ZIP's zero-excess estimate (against a Poisson with the raw mean)."""
+        Out = np.empty((G, M))
+        lam_floor, pi_min, pi_max, eps = 1e-6, 1e-4, 0.99, 1e-8
+        y_mean = y.mean()
+        sig_glob = (y.var(ddof=1) - y_mean) / (y_mean ** 2 + eps) if y.size > 1 else 1.0
+        sig_glob = min(max(sig_glob, 1e-3), 10.0)
+        if self.indices is None:
+            Out[:, 0] = np.log(np.maximum(y + 0.5, lam_floor) + 1e-12)
+            Out[:, 1] = np.log(sig_glob)
+            p0 = ((y == 0).sum() + 0.5) / (len(y) + 1.0)
+            if y_mean <= 0:
+                pi0 = p0
+            else:
+                q0 = np.exp(-max(y_mean, lam_floor))
+                pi0 = 0.0 if q0 >= 1.0 - 1e-8 else np.clip((p0 - q0) / (1.0 - q0), 0.0, pi_max)
+            pi0 = np.clip(pi0, pi_min, 1.0 - pi_min)
+            Out[:, 2] = np.log(pi0 / (1.0 - pi0))
+            return Out
+        idx = np.asarray(self.indices)
+        cnt = np.bincount(idx, minlength=G).astype(float)
+        s1 = np.bincount(idx, weights=y, minlength=G)
+        s2 = np.bincount(idx, weights=y * y, minlength=G)
+        mu_g = (s1 + 0.5) / np.maximum(cnt, 1.0)
+        Out[:, 0] = np.log(mu_g + 1e-12)
+        var_hat = mu_g.copy()
+        mk = cnt > 1
+        var_hat[mk] = (s2[mk] - s1[mk] ** 2 / cnt[mk]) / (cnt[mk] - 1.0)
+        sig = (var_hat - mu_g) / (mu_g ** 2 + eps)
+        sig[(~np.isfinite(sig)) | (sig <= 0.0)] = sig_glob
+        Out[:, 1] = np.log(np.clip(sig, 1e-3, 10.0))
+        p0_g = (np.bincount(idx, weights=(y == 0).astype(float), minlength=G) + 0.1) / (cnt + 0.2)
+        mu_raw = s1 / np.maximum(cnt, 1.0)
+        lam0 = mu_raw.copy()
+        lam0[mu_raw == 0.0] = y[y > 0].mean() if np.any(y > 0) else 1.0
+        q = np.exp(-np.maximum(lam0, lam_floor))
+        pi_g = np.clip(np.where(p0_g <= q, 0.0, (p0_g - q) / np.maximum(1.0 - q, 1e-8)), 0.0, pi_max)
+        pi_g = np.clip(pi_g, pi_min, 1.0 - pi_min)
+        Out[:, 2] = np.log(pi_g / (1.0 - pi_g))
         return Out
 
     def _layer_warm_start(self, l, In, num_kernel):
@@ -239,9 +283,10 @@ class dgp:
                 if nd.input_dim is None:
                     nd.input_dim = np.arange(In.shape[1])
                 if nd.type == 'likelihood':
-                    need = 1 if nd.name == 'Poisson' else 2
+                    need = {'Poisson': 1, 'ZINB': 3}.get(nd.name, 2)
                     if len(nd.input_dim) != need:
-                        raise Exception(('You need one and only one GP node' if need == 1 else 'You need two and only two GP nodes')
+                        raise Exception(('You need one and only one GP node', 'You need two and only two GP nodes',
+                                         'You need three and only three GP nodes')[need - 1]
                                         + ' to feed the ' + nd.name + ' likelihood node.')
                     nd.input = In[nd.rep, :][:, nd.input_dim] if nd.rep is not None else In[:, nd.input_dim]
                     nd.output = self.Y[:, [k]]

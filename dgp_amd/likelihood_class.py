@@ -1,4 +1,4 @@
-"""Likelihood nodes (dgpsi likelihood_class.py): Hetero, Poisson, NegBin, ZIP.  They live on the host -- the 4-method plugin protocol
+"""Likelihood nodes (dgpsi likelihood_class.py): Hetero, Poisson, NegBin, ZIP, ZINB.  They live on the host -- the 4-method plugin protocol
 llik() / pllik(y, f) / prediction(m, v) / sampling(f) on numpy arrays, attributes type, name, input, output,
 input_dim, exact_post_idx, rep (likelihood_class.py:30-90) -- except for the one step that is as heavy as a GP node:
 the exact conditional posterior draw of the heteroskedastic Gaussian likelihood's mean latent (two n x n
@@ -130,6 +130,50 @@ class ZIP(_CountLikelihood):
         lam, pi = np.exp(f_sample[:, 0]), expit(f_sample[:, 1])
         u = np.random.rand(f_sample.shape[0])
         return np.where(u < pi, 0, np.random.poisson(lam)).flatten()
+
+
+class ZINB(_CountLikelihood):
+    """Zero-inflated negative binomial (likelihood_class.py:624-812): structural zero with probability logistic(f2), else
+    NegBin with mean exp(f0) and dispersion exp(f1); three feeding GP nodes."""
+    name = 'ZINB'
+
+    @staticmethod
+    def _logpmf(y, f1, f2, f_pi):
+        from scipy.special import expit
+        with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+            nb = NegBin._logpmf(y, f1, f2)
+            pi = expit(f_pi)
+            return np.where(y == 0, np.logaddexp(np.log(pi), np.log1p(-pi) + nb), np.log1p(-pi) + nb)
+
+    def llik(self):
+        return np.sum(self._logpmf(np.asarray(self.output).flatten(), self.input[:, 0], self.input[:, 1], self.input[:, 2]))
+
+    @staticmethod
+    def pllik(y, f):
+        return ZINB._logpmf(np.asarray(y), f[..., 0:1], f[..., 1:2], f[..., 2:3])
+
+    @staticmethod
+    def prediction(m, v):
+        """Moments of y: log-normal mean mu and dispersion sigma, E[mu^2 sigma] = E[mu^2] E[sigma], zero probability as in
+        ZIP; Var = E[(1-pi)(mu + mu^2 sigma)] + E[pi(1-pi)] E[mu^2] + Var[(1-pi) mu]."""
+        from scipy.special import expit
+        mu_mean = np.exp(m[:, 0] + 0.5 * v[:, 0])
+        mu_var = (np.exp(v[:, 0]) - 1.0) * np.exp(2.0 * m[:, 0] + v[:, 0])
+        mu2_mean = np.exp(2.0 * m[:, 0] + 2.0 * v[:, 0])
+        mu2_sigma = mu2_mean * np.exp(m[:, 1] + 0.5 * v[:, 1])
+        den = np.maximum(1.0 + (np.pi / 8.0) * v[:, 2], 1e-12)
+        p = expit(m[:, 2] / np.sqrt(den))
+        p_var = np.clip((p * (1.0 - p)) ** 2 * (v[:, 2] / den), 0.0, p * (1.0 - p))
+        e_p1m = np.clip(p * (1.0 - p) - p_var, 0.0, p * (1.0 - p))
+        var = (1.0 - p) * (mu_mean + mu2_sigma) + e_p1m * mu2_mean + ((1.0 - p) ** 2 + p_var) * mu_var + p_var * mu_mean ** 2
+        return ((1.0 - p) * mu_mean).flatten(), np.maximum(var, 0.0).flatten()
+
+    @staticmethod
+    def sampling(f_sample):
+        from scipy.special import expit
+        size, p = np.exp(-f_sample[:, 1]), 1.0 / (1.0 + np.exp(f_sample[:, 0] + f_sample[:, 1]))
+        u = np.random.rand(f_sample.shape[0])
+        return np.where(u < expit(f_sample[:, 2]), 0, np.random.negative_binomial(size, p)).flatten()
 
 
 class Hetero:

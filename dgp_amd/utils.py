@@ -70,8 +70,8 @@ def save_structure(all_layer, npz_file):
         for k, nd in enumerate(layer):
             p = 'l%d_k%d_' % (l, k)
             if getattr(nd, 'type', 'gp') != 'gp':
-                if getattr(nd, 'name', None) not in ('Hetero', 'Poisson', 'NegBin', 'ZIP'):
-                    raise NotImplementedError('likelihood nodes stored: Hetero, Poisson, NegBin, ZIP')
+                if getattr(nd, 'name', None) not in ('Hetero', 'Poisson', 'NegBin', 'ZIP', 'ZINB'):
+                    raise NotImplementedError('likelihood nodes stored: Hetero, Poisson, NegBin, ZIP, ZINB')
                 out[p + 'likelihood'] = np.array(str(nd.name))
                 for a in ('input', 'output', 'input_dim', 'rep'):
                     v = getattr(nd, a, None)

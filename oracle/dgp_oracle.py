@@ -955,6 +955,70 @@ def zip_warm_start(y, rep, G):
     return out
 
 
+def zinb_pllik(y, f):
+    """ZINB log-pmf (likelihood_class.py:653-739)."""
+    from scipy.special import expit
+    nb = negbin_pllik(y, f[..., :2])
+    pi = expit(f[..., 2:3])
+    yb = np.broadcast_to(y, nb.shape)
+    return np.where(yb == 0, np.logaddexp(np.log(pi), np.log1p(-pi) + nb), np.log1p(-pi) + nb)
+
+
+def zinb_prediction(m, v):
+    from scipy.special import expit
+    mu_mean = np.exp(m[:, 0] + 0.5 * v[:, 0])
+    mu_var = (np.exp(v[:, 0]) - 1.0) * np.exp(2.0 * m[:, 0] + v[:, 0])
+    mu2 = np.exp(2.0 * m[:, 0] + 2.0 * v[:, 0])
+    mu2_sig = mu2 * np.exp(m[:, 1] + 0.5 * v[:, 1])
+    den = np.maximum(1.0 + (np.pi / 8.0) * v[:, 2], 1e-12)
+    p = expit(m[:, 2] / np.sqrt(den))
+    p_var = np.clip((p * (1.0 - p))**2 * v[:, 2] / den, 0.0, p * (1.0 - p))
+    e_p1m = np.clip(p * (1.0 - p) - p_var, 0.0, p * (1.0 - p))
+    var = (1.0 - p) * (mu_mean + mu2_sig) + e_p1m * mu2 + ((1.0 - p)**2 + p_var) * mu_var + p_var * mu_mean**2
+    return (1.0 - p) * mu_mean, np.maximum(var, 0.0)
+
+
+def zinb_warm_start(y, rep, G):
+    """dgp.py:411-525."""
+    out = np.empty((G, 3))
+    lam_floor, pi_min, pi_max, eps = 1e-6, 1e-4, 0.99, 1e-8
+    y_mean = y.mean()
+    sg = (y.var(ddof=1) - y_mean) / (y_mean**2 + eps) if y.size > 1 else 1.0
+    sg = min(max(sg, 1e-3), 10.0)
+    if rep is None:
+        out[:, 0] = np.log(np.maximum(y + 0.5, lam_floor) + 1e-12)
+        out[:, 1] = np.log(sg)
+        p0 = ((y == 0).sum() + 0.5) / (len(y) + 1.0)
+        if y_mean <= 0:
+            pi0 = p0
+        else:
+            q0 = np.exp(-max(y_mean, lam_floor))
+            pi0 = 0.0 if q0 >= 1.0 - 1e-8 else np.clip((p0 - q0) / (1.0 - q0), 0.0, pi_max)
+        pi0 = np.clip(pi0, pi_min, 1.0 - pi_min)
+        out[:, 2] = np.log(pi0 / (1.0 - pi0))
+        return out
+    cnt = np.bincount(rep, minlength=G).astype(float)
+    s1 = np.bincount(rep, weights=y, minlength=G)
+    s2 = np.bincount(rep, weights=y * y, minlength=G)
+    mu_g = (s1 + 0.5) / np.maximum(cnt, 1.0)
+    out[:, 0] = np.log(mu_g + 1e-12)
+    var_hat = mu_g.copy()
+    mk = cnt > 1
+    var_hat[mk] = (s2[mk] - s1[mk]**2 / cnt[mk]) / (cnt[mk] - 1.0)
+    sig = (var_hat - mu_g) / (mu_g**2 + eps)
+    sig[(~np.isfinite(sig)) | (sig <= 0.0)] = sg
+    out[:, 1] = np.log(np.clip(sig, 1e-3, 10.0))
+    p0_g = (np.bincount(rep, weights=(y == 0).astype(float), minlength=G) + 0.1) / (cnt + 0.2)
+    mu_raw = s1 / np.maximum(cnt, 1.0)
+    lam0 = mu_raw.copy()
+    lam0[mu_raw == 0.0] = y[y > 0].mean() if np.any(y > 0) else 1.0
+    q = np.exp(-np.maximum(lam0, lam_floor))
+    pi_g = np.clip(np.where(p0_g <= q, 0.0, (p0_g - q) / np.maximum(1.0 - q, 1e-8)), 0.0, pi_max)
+    pi_g = np.clip(pi_g, pi_min, 1.0 - pi_min)
+    out[:, 2] = np.log(pi_g / (1.0 - pi_g))
+    return out
+
+
 def count_warm_start(name, X, Y):
     """Latents fed to a Poisson / NegBin likelihood at initialisation; X with possibly repeated rows.  Returns
     (latent (G x q), rep or None).  NegBin without replicates: only column 0 is defined by the reference."""
@@ -965,6 +1029,8 @@ def count_warm_start(name, X, Y):
     G = len(X0)
     if name == 'ZIP':
         return zip_warm_start(y, rep, G), rep
+    if name == 'ZINB':
+        return zinb_warm_start(y, rep, G), rep
     if name == 'Poisson':
         if rep is None:
             return np.log(y + .5 + 1e-12)[:, None], None

@@ -494,11 +494,11 @@ def gen_counts():
     """G17: Poisson and NegBin likelihood nodes (likelihood_class.py:8-90,245-292): llik / pllik / prediction, and the
     latent warm starts of dgp.initialize (dgp.py:327-336,526-566) without and with replicated inputs (the imputer's
     first sweeps are skipped so that the recorded latents are the warm start itself)."""
-    from dgpsi import Poisson, NegBin, ZIP
+    from dgpsi import Poisson, NegBin, ZIP, ZINB
     rng = np.random.default_rng(123)
     out = {}
     n = 14
-    for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2), ('zip', ZIP, 2)):
+    for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2), ('zip', ZIP, 2), ('zinb', ZINB, 3)):
         h = cls()
         h.input = rng.normal(size=(n, q)) * 0.7
         h.output = (rng.poisson(3.0, size=(n, 1)) * (rng.uniform(size=(n, 1)) > 0.3)).astype(float)
@@ -510,7 +510,7 @@ def gen_counts():
     old_sample = RI.imputer.sample
     RI.imputer.sample = lambda self, burnin=0: None
     try:
-        for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2), ('zip', ZIP, 2)):
+        for name, cls, q in (('poisson', Poisson, 1), ('negbin', NegBin, 2), ('zip', ZIP, 2), ('zinb', ZINB, 3)):
             for tag, rep in (('norep', False), ('rep', True)):
                 X = rng.uniform(size=(12, 2))
                 if rep:

@@ -600,7 +600,7 @@ def test_hetero_dgp_vecchia_end_to_end(eng, rep):
     assert var[xt[:, 0] > 0.75].mean() > 3 * var[xt[:, 0] < 0.3].mean()
 
 
-@pytest.mark.parametrize('lik', ['Poisson', 'NegBin', 'ZIP'])
+@pytest.mark.parametrize('lik', ['Poisson', 'NegBin', 'ZIP', 'ZINB'])
 def test_count_likelihood_dgp_end_to_end(eng, lik):
     """A DGP with a count likelihood on top (host plugin node, ESS on all latents, dgp.py:327-336,526-566 warm starts):
     the latent log-rate follows the truth and the emulator's predictive mean follows the rate."""
@@ -611,23 +611,24 @@ def test_count_likelihood_dgp_end_to_end(eng, lik):
     x = np.sort(rng.uniform(size=70))
     X = np.repeat(x, 2)[:, None]
     rate = np.exp(1.0 + 1.2 * np.sin(5 * X[:, 0]))
-    if lik == 'ZIP':
-        Y = (rng.poisson(rate) * (rng.uniform(size=len(rate)) > 0.25))[:, None].astype(float)
+    if lik in ('ZIP', 'ZINB'):
+        base = rng.poisson(rate) if lik == 'ZIP' else rng.negative_binomial(5.0, 5.0 / (5.0 + rate))
+        Y = (base * (rng.uniform(size=len(rate)) > 0.25))[:, None].astype(float)
     else:
         Y = (rng.poisson(rate) if lik == 'Poisson' else rng.negative_binomial(5.0, 5.0 / (5.0 + rate)))[:, None].astype(float)
-    q = 1 if lik == 'Poisson' else 2
+    q = {'Poisson': 1, 'ZINB': 3}.get(lik, 2)
     layers = combine([kernel(length=np.array([0.5]), name='sexp', scale_est=True) for _ in range(q)], [getattr(dgp_amd, lik)()])
     model = dgp(X, Y, layers, seed=3)
     assert model.all_layer[1][0].rep is not None and model.all_layer[1][0].input.shape == (140, q)
     model.train(N=25, ess_burn=5, disable=True)
     lat = model.all_layer[0][0].output[:, 0]
     truth = 1.0 + 1.2 * np.sin(5 * model.X[:, 0])
-    assert np.sqrt(np.mean((lat - truth) ** 2)) < (0.45 if lik == 'Poisson' else 0.7)   # (one posterior draw; NegBin data are over-dispersed)
+    assert np.sqrt(np.mean((lat - truth) ** 2)) < {'Poisson': 0.45, 'ZINB': 1.0}.get(lik, 0.7)   # (one posterior draw; NegBin data are over-dispersed)
     emu = emulator(model.estimate(), N=3, seed=1)
     xt = np.linspace(0.05, 0.95, 15)[:, None]
     mu, var = emu.predict(xt)
-    rt = np.exp(1.0 + 1.2 * np.sin(5 * xt[:, 0])) * (0.75 if lik == 'ZIP' else 1.0)     # (ZIP: a quarter structural zeros)
-    assert mu.shape == (15, 1) and np.all(var[:, 0] > 0) and np.mean(np.abs(mu[:, 0] - rt) / rt) < (0.6 if lik == 'ZIP' else 0.35)   # (ZIP: 140 counts hardly separate rate and inflation)
+    rt = np.exp(1.0 + 1.2 * np.sin(5 * xt[:, 0])) * (0.75 if lik in ('ZIP', 'ZINB') else 1.0)     # (a quarter structural zeros)
+    assert mu.shape == (15, 1) and np.all(var[:, 0] > 0) and np.mean(np.abs(mu[:, 0] - rt) / rt) < (0.6 if lik in ('ZIP', 'ZINB') else 0.35)   # (140 counts hardly separate rate and inflation)
     assert np.all(var[:, 0] >= mu[:, 0] * 0.9)        # count noise: variance at least about the mean
     smp = emu.predict(xt, method='sampling', sample_size=50)
     assert smp[0].shape == (15, 150) and np.all(smp[0] >= 0)

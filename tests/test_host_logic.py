@@ -241,11 +241,11 @@ def test_structure_exported_from_dgpsi_loads(golden, tmp_path):
 def test_count_likelihood_nodes_match_reference(golden):
     """dgp_amd.Poisson / NegBin (host plugin protocol) and dgp's latent warm starts for them against the reference's
     values (g17_count_likelihoods)."""
-    from dgp_amd import Poisson, NegBin, ZIP
+    from dgp_amd import Poisson, NegBin, ZIP, ZINB
     from dgp_amd.likelihood_class import ghdiag
     from dgp_amd.dgp import dgp
     g = golden('g17_count_likelihoods')
-    for name, cls in (('poisson', Poisson), ('negbin', NegBin), ('zip', ZIP)):
+    for name, cls in (('poisson', Poisson), ('negbin', NegBin), ('zip', ZIP), ('zinb', ZINB)):
         h = cls()
         h.input, h.output = g[name + '_input'], g[name + '_output']
         assert h.type == 'likelihood' and h.exact_post_idx is None and h.rep is None
@@ -254,7 +254,8 @@ def test_count_likelihood_nodes_match_reference(golden):
         np.testing.assert_allclose(pm, g[name + '_pm'], rtol=1e-13)
         np.testing.assert_allclose(pv, g[name + '_pv'], rtol=1e-13)
         np.testing.assert_allclose(ghdiag(h.pllik, g[name + '_m'], g[name + '_v'], g[name + '_yq']), g[name + '_gh'], rtol=1e-12)
-        assert h.sampling(np.zeros((5, 1 if name == 'poisson' else 2))).shape == (5,)
+        q = {'poisson': 1, 'negbin': 2, 'zip': 2, 'zinb': 3}[name]
+        assert h.sampling(np.zeros((5, q))).shape == (5,)
         for tag in ('norep', 'rep'):
             pre = 'ws_%s_%s_' % (name, tag)
             X, Y = g[pre + 'X'], g[pre + 'Y']
@@ -264,7 +265,6 @@ def test_count_likelihood_nodes_match_reference(golden):
             obj.X = X0 if len(X0) != len(X) else X
             if len(X0) != len(X):
                 obj.indices = np.asarray(inv).reshape(-1)
-            q = 1 if name == 'poisson' else 2
             obj.all_layer, obj.n_layer = [[None] * q, [cls()]], 2
             lat = obj._count_warm_start(0)
             cols = [0] if (name == 'negbin' and tag == 'norep') else list(range(q))

@@ -300,7 +300,7 @@ def test_count_likelihoods(golden):
     """Poisson / NegBin restatements against the reference (g17_count_likelihoods)."""
     g = golden('g17_count_likelihoods')
     for name, pll, pred in (('poisson', O.poisson_pllik, O.poisson_prediction), ('negbin', O.negbin_pllik, O.negbin_prediction),
-                            ('zip', O.zip_pllik, O.zip_prediction)):
+                            ('zip', O.zip_pllik, O.zip_prediction), ('zinb', O.zinb_pllik, O.zinb_prediction)):
         f, y = g[name + '_input'], g[name + '_output']
         ll = np.sum(pll(y, f) if name == 'poisson' else pll(y[:, None, :], f[:, None, :]))
         close(ll, float(g[name + '_llik']), rtol=1e-12)
@@ -310,7 +310,7 @@ def test_count_likelihoods(golden):
         close(O.ghdiag(pll, g[name + '_m'], g[name + '_v'], g[name + '_yq']), g[name + '_gh'], rtol=1e-12)
         for tag in ('norep', 'rep'):
             pre = 'ws_%s_%s_' % (name, tag)
-            lat, rep = O.count_warm_start({'poisson': 'Poisson', 'negbin': 'NegBin', 'zip': 'ZIP'}[name], g[pre + 'X'], g[pre + 'Y'])
+            lat, rep = O.count_warm_start({'poisson': 'Poisson', 'negbin': 'NegBin', 'zip': 'ZIP', 'zinb': 'ZINB'}[name], g[pre + 'X'], g[pre + 'Y'])
             cols = [0] if (name == 'negbin' and tag == 'norep') else list(range(lat.shape[1]))   # (column 1 is uninitialised there)
             close(lat[:, cols], g[pre + 'latent'][:, cols], rtol=1e-13)
             li = lat if rep is None else lat[rep]

@@ -23,8 +23,8 @@ def export(all_layer, npz_file):
         for k, nd in enumerate(layer):
             p = 'l%d_k%d_' % (l, k)
             if getattr(nd, 'type', 'gp') != 'gp':
-                if getattr(nd, 'name', None) not in ('Hetero', 'Poisson', 'NegBin', 'ZIP'):
-                    raise NotImplementedError('likelihood nodes supported by dgp_amd: Hetero, Poisson, NegBin, ZIP')
+                if getattr(nd, 'name', None) not in ('Hetero', 'Poisson', 'NegBin', 'ZIP', 'ZINB'):
+                    raise NotImplementedError('likelihood nodes supported by dgp_amd: Hetero, Poisson, NegBin, ZIP, ZINB')
                 out[p + 'likelihood'] = np.array(str(nd.name))
                 arrays = ('input', 'output', 'input_dim', 'rep')
             else:
