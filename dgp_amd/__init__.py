@@ -7,7 +7,7 @@ from .dgp import dgp  # noqa: F401
 from .emulation import emulator  # noqa: F401
 from .gp import gp  # noqa: F401
 from .linkgp import container, lgp  # noqa: F401
-from .likelihood_class import Hetero, Poisson, NegBin, ZIP, ZINB  # noqa: F401
+from .likelihood_class import Hetero, Poisson, NegBin, ZIP, ZINB, Categorical  # noqa: F401
 from .synthetic import path  # noqa: F401
 from .utils import nb_seed, set_thread, get_thread, write, read, summary, save_structure, load_structure  # noqa: F401
 

@@ -56,17 +56,85 @@ class dgp:
         self.n_layer = len(all_layer)
         for l, layer in enumerate(all_layer):
             for nd in layer:
-                if nd.type == 'likelihood' and (nd.name not in ('Hetero', 'Poisson', 'NegBin', 'ZIP', 'ZINB') or l != self.n_layer - 1):
-                    raise NotImplementedError('likelihood nodes: Hetero, Poisson, NegBin, ZIP and ZINB (final layer) are supported; the '
-                                              'Categorical likelihood (dgp.py:279-326) is outside the path')
+                if nd.type == 'likelihood' and (nd.name not in ('Hetero', 'Poisson', 'NegBin', 'ZIP', 'ZINB', 'Categorical') or l != self.n_layer - 1):
+                    raise NotImplementedError('likelihood nodes belong in the final layer (Hetero, Poisson, NegBin, ZIP, ZINB, Categorical)')
+        self._encode_labels(fit=True)
         self.initialize()
         self.block = block
         self.draws = DrawStream(seed)
         self.imp = imputer(self.all_layer, self.block, draws=self.draws, engine=self.engine)
-        self.imp.sample(burnin=10)
+        with self._init_scale():
+            self.imp.sample(burnin=10)
         self.compute_r2()
         self.N = 0
         self.burnin = None
+
+    def _encode_labels(self, fit=False):
+        """Categorical likelihood: class labels -> 0..K-1 (dgp.py:112-122,843-844); K and the link default from the data."""
+        lik = self.all_layer[-1][0]
+        if getattr(lik, 'name', None) != 'Categorical':
+            return
+        if fit:
+            from sklearn.preprocessing import LabelEncoder
+            lik.class_encoder = LabelEncoder()
+            self.Y = lik.class_encoder.fit_transform(self.Y.flatten()).reshape(-1, 1)
+            if lik.num_classes is None:
+                lik.num_classes = len(lik.class_encoder.classes_)
+            if lik.link is None:
+                lik.link = 'logit' if lik.num_classes == 2 else 'softmax'
+        else:
+            self.Y = lik.class_encoder.transform(self.Y.flatten()).reshape(-1, 1)
+
+    def _init_scale(self):
+        """Context of the first sweeps under a Categorical likelihood (dgp.py:1574-1589): the feeding nodes whose variance
+        is estimated sample with variance 40 (the warm-start latents are +-2 sqrt(40)), restored afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old = []
+            cat = getattr(self.all_layer[-1][0], 'name', None) == 'Categorical'
+            if cat:
+                for nd in self.all_layer[-2]:
+                    old.append(nd.scale)
+                    if nd.scale_est:
+                        nd.scale = np.array([40.0])
+            try:
+                yield
+            finally:
+                if cat:
+                    for o, nd in zip(old, self.all_layer[-2]):
+                        nd.scale = o
+        return ctx()
+
+    def _categorical_warm_start(self, l):
+        """Latents feeding a Categorical likelihood (dgp.py:279-326), or None: +-2 sqrt(40) on the observed class without
+        replicates; smoothed empirical logits per site with them."""
+        if l != self.n_layer - 2 or len(self.all_layer[l + 1]) != 1 or getattr(self.all_layer[l + 1][0], 'name', None) != 'Categorical':
+            return None
+        lik, M = self.all_layer[l + 1][0], len(self.all_layer[l])
+        K = lik.num_classes
+        if (K == 2 and M != 1) or (K != 2 and M != K):
+            raise Exception('You need %s to feed the Categorical likelihood node.' % ('one GP node' if K == 2 else '%d GP nodes' % K))
+        c = 2 * np.sqrt(40)
+        y = self.Y.ravel().astype(int)
+        if self.indices is None:
+            if K == 2:
+                return np.where(self.Y == 1, c, -c).astype(float)
+            Out = -c * np.ones((self.n_data, K))
+            Out[np.arange(self.n_data), y] = c
+            return Out
+        G = self.indices.max() + 1
+        eps = np.finfo(float).eps
+        if K == 2:
+            n_g = np.bincount(self.indices, minlength=G)
+            p = (np.bincount(self.indices, weights=y, minlength=G) + 0.5) / (n_g + 1.0)
+            return np.log(np.clip(p, eps, 1 - eps) / np.clip(1 - p, eps, 1)).reshape(-1, 1)
+        counts = np.zeros((G, K))
+        np.add.at(counts, (self.indices, y), 1.0)
+        logp = np.log(((counts + 0.5) / (counts.sum(axis=1, keepdims=True) + K * 0.5)).clip(eps, 1.0))
+        logp -= logp.mean(axis=1, keepdims=True)
+        return logp / 0.8
 
     # ------------------------------------------------------------------ wiring
     def _warm_start(self, In, num_kernel):
@@ -204,6 +272,8 @@ class dgp:
         if self._is_hetero_pair(l):
             return self._hetero_warm_start()
         cnt = self._count_warm_start(l)
+        if cnt is None:
+            cnt = self._categorical_warm_start(l)
         return cnt if cnt is not None else self._warm_start(In, num_kernel)
 
     def _is_hetero_pair(self, l):
@@ -284,6 +354,8 @@ class dgp:
                     nd.input_dim = np.arange(In.shape[1])
                 if nd.type == 'likelihood':
                     need = {'Poisson': 1, 'ZINB': 3}.get(nd.name, 2)
+                    if nd.name == 'Categorical':
+                        need = len(nd.input_dim)
                     if len(nd.input_dim) != need:
                         raise Exception(('You need one and only one GP node', 'You need two and only two GP nodes',
                                          'You need three and only three GP nodes')[need - 1]
@@ -386,7 +458,11 @@ class dgp:
             try:
                 pgb = trange(1, N + 1, disable=disable)
                 for i in pgb:
-                    self.imp.sample(burnin=ess_burn)
+                    if i == 1:
+                        with self._init_scale():
+                            self.imp.sample(burnin=ess_burn)
+                    else:
+                        self.imp.sample(burnin=ess_burn)
                     it = self.N + i
                     if self.vecch and (it & (it - 1)) == 0 and it > 1:   # NN refresh at iterations 2,4,8,.. (dgp.py:1388)
                         self.imp.update_ord_nn()
@@ -499,6 +575,7 @@ class dgp:
         if Y.ndim == 1 or X.ndim == 1:
             raise Exception('The input and output data have to be numpy 2d-arrays.')
         self.Y = Y
+        self._encode_labels(fit=False)
         self.indices = self.counts = None
         origin_X = self.X.copy()
         self.X = X

@@ -183,6 +183,10 @@ class emulator:
         xd = e.tensor(x)
         per_layer = []
         for l, layer in enumerate(self.all_layer):
+            if l == self.n_layer - 1 and self._cat() is not None:
+                idx = torch.as_tensor(np.asarray(self._cat().input_dim), device=xd.device)
+                per_layer.append((per_layer[-1][0][:, :, idx].contiguous(), per_layer[-1][1][:, :, idx].contiguous()))
+                continue
             K = len(layer)
             mean = e.empty(S, M, K)
             var = e.empty(S, M, K)
@@ -225,6 +229,10 @@ class emulator:
             al = self._structure(s)
             m_in = v_in = None
             for l, layer in enumerate(al):
+                if l == self.n_layer - 1 and self._cat() is not None:
+                    idx = np.asarray(layer[0].input_dim)
+                    layers[l].append((m_in[:, idx].copy(), v_in[:, idx].copy()))
+                    continue
                 mo, vo = np.empty((M, len(layer))), np.empty((M, len(layer)))
                 for k, nd in enumerate(layer):
                     if nd.type == 'gp':
@@ -241,6 +249,13 @@ class emulator:
                 m_in, v_in = mo, vo
                 layers[l].append((mo, vo))
         return [(np.stack([a for a, _ in L]), np.stack([b for _, b in L])) for L in layers]
+
+    def _cat(self):
+        """The Categorical likelihood node of the final layer, or None.  For it the last layer's moments are those of
+        its feeding latents (emulation.py:711-716,751-752): they are aggregated over the imputations first and turned
+        into class probabilities afterwards."""
+        nd = self.all_layer[-1][0]
+        return nd if getattr(nd, 'name', None) == 'Categorical' else None
 
     # ------------------------------------------------------------------ prediction
     def predict(self, x, method='mean_var', full_layer=False, sample_size=50, m=50, aggregation=True):
@@ -259,9 +274,14 @@ class emulator:
         if method == 'sampling':
             return self._draw_samples([(mean.cpu().numpy(), var.cpu().numpy()) for mean, var in per_layer], sample_size,
                                       full_layer)
+        cat = self._cat()
         if not aggregation and not full_layer:
             mu_s, v_s = per_layer[-1]
-            return [t.cpu().numpy() for t in mu_s], [t.cpu().numpy() for t in v_s]
+            mu_s, v_s = [t.cpu().numpy() for t in mu_s], [t.cpu().numpy() for t in v_s]
+            if cat is not None:
+                pr = [cat.prediction(a, b) for a, b in zip(mu_s, v_s)]
+                return [p[0] for p in pr], [p[1] for p in pr]
+            return mu_s, v_s
         outs = []
         for mean, var in (per_layer if full_layer else per_layer[-1:]):
             s1, s2 = e.zeros(M, mean.shape[2]), e.zeros(M, mean.shape[2])
@@ -271,6 +291,8 @@ class emulator:
                 ddist.allreduce_sum(s1, s2)
             e.moments_finalize(self.N_total if self.shard else S, s1, s2)
             outs.append((s1.cpu().numpy(), s2.cpu().numpy()))
+        if cat is not None:
+            outs[-1] = cat.prediction(outs[-1][0], outs[-1][1])
         if full_layer:
             return [o[0] for o in outs], [o[1] for o in outs]
         return outs[0]
@@ -290,7 +312,10 @@ class emulator:
             S, M, K = mean.shape
             mu_r, sd_r = np.repeat(mean, sample_size, axis=0), np.repeat(np.sqrt(var), sample_size, axis=0)
             draws = rng.normal(mu_r, sd_r)                       # (S*ss, M, K)
-            if last and lik:   # likelihood nodes sample y from draws of their feeding latents (emulation.py:785-822)
+            if last and self._cat() is not None:   # class probabilities at draws of the feeding latents (all columns at once)
+                cat = self._cat()
+                draws = np.stack([cat.sampling(prev[j][:, cat.input_dim]) for j in range(prev.shape[0])])
+            elif last and lik:   # likelihood nodes sample y from draws of their feeding latents (emulation.py:785-822)
                 for k, nd in enumerate(self.all_layer[-1]):
                     if nd.type == 'likelihood':
                         for j in range(draws.shape[0]):
@@ -331,14 +356,20 @@ class emulator:
         mus, vs = list(per_layer[-1][0]), list(per_layer[-1][1])
         if method == 'sampling':
             return self._draw_samples(per_layer, sample_size, full_layer)
+        cat = self._cat()
         if full_layer:
             outm, outv = [], []
             for mu_l, v_l in per_layer:
                 mbar = mu_l.mean(0)
                 outm.append(mbar)
                 outv.append((mu_l ** 2 + v_l).mean(0) - mbar ** 2)
+            if cat is not None:
+                outm[-1], outv[-1] = cat.prediction(outm[-1], outv[-1])
             return outm, outv
         if not aggregation:
+            if cat is not None:
+                pr = [cat.prediction(a, b) for a, b in zip(mus, vs)]
+                return [p[0] for p in pr], [p[1] for p in pr]
             return mus, vs
         e = self.engine
         s1, s2 = e.zeros(*mus[0].shape), e.zeros(*mus[0].shape)
@@ -347,6 +378,8 @@ class emulator:
         if self.shard:
             ddist.allreduce_sum(s1, s2)
         e.moments_finalize(self.N_total if self.shard else S, s1, s2)
+        if cat is not None:
+            return cat.prediction(s1.cpu().numpy(), s2.cpu().numpy())
         return s1.cpu().numpy(), s2.cpu().numpy()
 
     ppredict = predict   # test points / imputations already run in parallel on the device (emulation.py:578-629)

@@ -1,4 +1,4 @@
-"""Likelihood nodes (dgpsi likelihood_class.py): Hetero, Poisson, NegBin, ZIP, ZINB.  They live on the host -- the 4-method plugin protocol
+"""Likelihood nodes (dgpsi likelihood_class.py): Hetero, Poisson, NegBin, ZIP, ZINB, Categorical.  They live on the host -- the 4-method plugin protocol
 llik() / pllik(y, f) / prediction(m, v) / sampling(f) on numpy arrays, attributes type, name, input, output,
 input_dim, exact_post_idx, rep (likelihood_class.py:30-90) -- except for the one step that is as heavy as a GP node:
 the exact conditional posterior draw of the heteroskedastic Gaussian likelihood's mean latent (two n x n
@@ -174,6 +174,110 @@ class ZINB(_CountLikelihood):
         size, p = np.exp(-f_sample[:, 1]), 1.0 / (1.0 + np.exp(f_sample[:, 0] + f_sample[:, 1]))
         u = np.random.rand(f_sample.shape[0])
         return np.where(u < expit(f_sample[:, 2]), 0, np.random.negative_binomial(size, p)).flatten()
+
+
+class Categorical:
+    """Categorical likelihood (likelihood_class.py:294-467).  Two classes: one latent, link 'logit' (default) or 'probit';
+    K > 2 classes: K latents, link 'softmax' (default) or 'robustmax' (the arg-max class has probability 1 - eps, the
+    others eps/(K-1)).  Outputs are class indices 0..K-1 (dgp encodes the labels).  prediction() returns class
+    probabilities and their variances; for K > 2 by Monte Carlo over the latent Gaussians (1000 draws from numpy's
+    global stream, antithetic for softmax)."""
+
+    def __init__(self, num_classes=None, input_dim=None, link=None, robustmax_eps=1e-3):
+        self.type = 'likelihood'
+        self.name = 'Categorical'
+        self.input = None
+        self.output = None
+        self.input_dim = input_dim
+        self.exact_post_idx = None
+        self.rep = None
+        self.num_classes = num_classes
+        self.class_encoder = None
+        self.link = link
+        self.robustmax_eps = robustmax_eps
+
+    def _logp(self, y, f, axis):
+        """log P(y | f); f has the classes (or the single latent) along `axis`, y holds class indices."""
+        from scipy.special import log_ndtr
+        with np.errstate(over='ignore', invalid='ignore'):
+            if self.num_classes == 2:
+                if self.link == 'logit':
+                    return y * f - np.logaddexp(0, f)
+                return y * log_ndtr(f) + (1 - y) * log_ndtr(-f)
+            yi = np.asarray(y).astype(int)
+            if self.link == 'robustmax':
+                K, eps = self.num_classes, self.robustmax_eps
+                hit = np.argmax(f, axis=axis) == yi
+                return np.where(hit, np.log(1.0 - eps), np.log(eps / (K - 1)))
+            top = np.max(f, axis=axis, keepdims=True)
+            lse = np.log(np.sum(np.exp(f - top), axis=axis)) + np.squeeze(top, axis=axis)
+            return np.squeeze(np.take_along_axis(f, np.expand_dims(yi, axis), axis=axis), axis=axis) - lse
+
+    def llik(self):
+        y = np.asarray(self.output)
+        if self.num_classes == 2:
+            return np.sum(self._logp(y, self.input, 1))
+        return np.sum(self._logp(y.flatten(), self.input, 1))
+
+    def pllik(self, y, f):
+        if self.num_classes == 2:
+            return self._logp(y, f, 2)
+        return self._logp(np.asarray(y).reshape(-1, 1), f, 2)[:, :, None]
+
+    def prediction(self, m, v):
+        from scipy.special import expit, ndtr, owens_t
+        if self.num_classes == 2:
+            m, v = m.flatten(), v.flatten()
+            if self.link == 'logit':       # logistic-normal mean through the probit approximation, variance by the delta method
+                den = 1.0 + (np.pi / 8.0) * v
+                p = expit(m / np.sqrt(den))
+                pv = np.clip((p * (1.0 - p)) ** 2 * (v / den), 0.0, p * (1.0 - p))
+            else:                          # probit: E[Phi(f)] = Phi(t), E[Phi(f)^2] = Phi(t) - 2 T(t, 1/sqrt(1+2v))
+                t = m / np.sqrt(1.0 + v)
+                p = ndtr(t)
+                pv = np.maximum(p - 2.0 * owens_t(t, 1.0 / np.sqrt(1.0 + 2.0 * v)) - p * p, 0.0)
+            return p.reshape(-1, 1), pv.reshape(-1, 1)
+        K, S, chunk = self.num_classes, 1000, 200
+        sd = np.sqrt(np.maximum(v, 0.0))
+        M = m.shape[0]
+        if self.link == 'robustmax':
+            wins = np.zeros((M, K))
+            done = 0
+            while done < S:
+                this = min(chunk, S - done)
+                draws = m[:, None, :] + sd[:, None, :] * np.random.randn(M, this, K)
+                np.add.at(wins, (np.arange(M)[:, None], np.argmax(draws, axis=2)), 1.0)
+                done += this
+            q = wins / S
+            a, b = 1.0 - self.robustmax_eps, self.robustmax_eps / (K - 1)
+            return b + (a - b) * q, (a - b) ** 2 * q * (1.0 - q)
+        s1, s2 = np.zeros((M, K)), np.zeros((M, K))
+        done = 0
+        while done < S:
+            this = min(chunk, S - done)
+            half = np.random.randn(M, (this + 1) // 2, K)
+            draws = m[:, None, :] + sd[:, None, :] * np.concatenate([half, -half], axis=1)[:, :this, :]
+            draws -= np.max(draws, axis=2, keepdims=True)
+            np.exp(draws, out=draws)
+            draws /= np.sum(draws, axis=2, keepdims=True)
+            s1 += draws.sum(axis=1)
+            s2 += (draws * draws).sum(axis=1)
+            done += this
+        mean = s1 / S
+        return mean, s2 / S - mean ** 2
+
+    def sampling(self, f_sample):
+        """Class probabilities at latent samples (one column for two classes: the probability of class 1)."""
+        from scipy.special import expit, ndtr
+        if self.num_classes == 2:
+            return expit(f_sample) if self.link == 'logit' else ndtr(f_sample)
+        if self.link == 'robustmax':
+            K, eps = self.num_classes, self.robustmax_eps
+            out = np.full_like(f_sample, eps / (K - 1), dtype=float)
+            out[np.arange(f_sample.shape[0]), np.argmax(f_sample, axis=1)] = 1.0 - eps
+            return out
+        ex = np.exp(f_sample - np.max(f_sample, axis=1, keepdims=True))
+        return ex / np.sum(ex, axis=1, keepdims=True)
 
 
 class Hetero:

@@ -70,9 +70,15 @@ def save_structure(all_layer, npz_file):
         for k, nd in enumerate(layer):
             p = 'l%d_k%d_' % (l, k)
             if getattr(nd, 'type', 'gp') != 'gp':
-                if getattr(nd, 'name', None) not in ('Hetero', 'Poisson', 'NegBin', 'ZIP', 'ZINB'):
-                    raise NotImplementedError('likelihood nodes stored: Hetero, Poisson, NegBin, ZIP, ZINB')
+                if getattr(nd, 'name', None) not in ('Hetero', 'Poisson', 'NegBin', 'ZIP', 'ZINB', 'Categorical'):
+                    raise NotImplementedError('unknown likelihood node %r' % getattr(nd, 'name', None))
                 out[p + 'likelihood'] = np.array(str(nd.name))
+                if nd.name == 'Categorical':
+                    out[p + 'cat_num_classes'] = np.array(int(nd.num_classes))
+                    out[p + 'cat_link'] = np.array(str(nd.link))
+                    out[p + 'cat_eps'] = np.array(float(nd.robustmax_eps))
+                    if nd.class_encoder is not None:
+                        out[p + 'cat_classes'] = np.asarray(nd.class_encoder.classes_)
                 for a in ('input', 'output', 'input_dim', 'rep'):
                     v = getattr(nd, a, None)
                     if v is not None:
@@ -102,7 +108,15 @@ def load_structure(npz_file, engine=None):
             g = lambda a: d[p + a].copy() if p + a in d else None   # noqa: E731
             if p + 'likelihood' in d:
                 from . import likelihood_class
-                nd = getattr(likelihood_class, str(d[p + 'likelihood']))(input_dim=g('input_dim'))
+                if str(d[p + 'likelihood']) == 'Categorical':
+                    nd = likelihood_class.Categorical(num_classes=int(d[p + 'cat_num_classes']), input_dim=g('input_dim'),
+                                                      link=str(d[p + 'cat_link']), robustmax_eps=float(d[p + 'cat_eps']))
+                    if p + 'cat_classes' in d:
+                        from sklearn.preprocessing import LabelEncoder
+                        nd.class_encoder = LabelEncoder()
+                        nd.class_encoder.classes_ = d[p + 'cat_classes'].copy()
+                else:
+                    nd = getattr(likelihood_class, str(d[p + 'likelihood']))(input_dim=g('input_dim'))
                 nd.input, nd.output, nd.rep = g('input'), g('output'), g('rep')
                 layer.append(nd)
                 continue

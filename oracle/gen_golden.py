@@ -526,6 +526,49 @@ def gen_counts():
     save('g17_count_likelihoods', **out)
 
 
+def gen_categorical():
+    """G18: Categorical likelihood (likelihood_class.py:294-467) for its four links: llik / pllik / prediction (the
+    Monte-Carlo ones with numpy's global stream seeded), sampling; the latent warm starts of dgp.initialize
+    (dgp.py:279-326) without and with replicated inputs."""
+    from dgpsi import Categorical
+    rng = np.random.default_rng(321)
+    out = {}
+    n = 12
+    for tag, K, link in (('logit', 2, 'logit'), ('probit', 2, 'probit'), ('softmax', 3, 'softmax'), ('robustmax', 4, 'robustmax')):
+        h = Categorical(num_classes=K, link=link)
+        q = 1 if K == 2 else K
+        h.input = rng.normal(size=(n, q))
+        h.output = rng.integers(0, K, size=(n, 1)).astype(float if K == 2 else int)
+        m, v = rng.normal(size=(7, q)), rng.uniform(0.05, 0.8, size=(7, q))
+        np.random.seed(99)
+        pm, pv = h.prediction(m, v)
+        yq = rng.integers(0, K, size=(7, 1)).astype(float if K == 2 else int)
+        fq = rng.normal(size=(7, 5, q))
+        out.update({tag + '_input': h.input, tag + '_output': h.output.astype(float), tag + '_llik': np.array(h.llik()), tag + '_m': m,
+                    tag + '_v': v, tag + '_pm': pm, tag + '_pv': pv, tag + '_yq': yq.astype(float), tag + '_fq': fq,
+                    tag + '_pllik': h.pllik(yq.reshape(-1, 1, 1), fq), tag + '_samp': h.sampling(h.input)})
+    old_sample = RI.imputer.sample
+    RI.imputer.sample = lambda self, burnin=0: None
+    try:
+        for tag, K in (('bin', 2), ('multi', 3)):
+            for rtag, rep in (('norep', False), ('rep', True)):
+                X = rng.uniform(size=(12, 2))
+                if rep:
+                    X = np.concatenate((X, X[:6], X[:3], X[:3]))
+                lab = np.array(['a', 'b', 'c'])[:K]
+                Y = lab[rng.integers(0, K, size=len(X))].reshape(-1, 1)
+                q = 1 if K == 2 else K
+                layers = combine([kernel(length=np.array([1.0]), name='sexp', scale_est=True) for _ in range(q)], [Categorical()])
+                model = dgp(X, Y, layers)
+                pre = 'ws_%s_%s_' % (tag, rtag)
+                out.update({pre + 'X': X, pre + 'Ycode': np.searchsorted(lab, Y.ravel()).astype(float)[:, None],
+                            pre + 'latent': np.concatenate([nd.output for nd in model.all_layer[0]], 1),
+                            pre + 'link': np.array(model.all_layer[1][0].link), pre + 'K': np.array(model.all_layer[1][0].num_classes)})
+    finally:
+        RI.imputer.sample = old_sample
+    save('g18_categorical', **out)
+
+
 def gen_lgp():
     """G10: feed-forward chain GP -> DGP -> GP (+ one external input on the last emulator), lgp.predict
     (linkgp.py:285-501) from the reference's own imputations (dumped)."""
@@ -665,7 +708,7 @@ def gen_hetero():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch', 'export', 'counts']
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch', 'export', 'counts', 'categorical']
     if 'kernel' in which:
         gen_kernel_cases()
     if 'fmvn' in which:
@@ -690,3 +733,5 @@ if __name__ == '__main__':
         gen_export()
     if 'counts' in which:
         gen_counts()
+    if 'categorical' in which:
+        gen_categorical()

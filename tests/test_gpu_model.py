@@ -747,3 +747,48 @@ def test_prior_paths_and_summary(eng, capsys):
     summary(gp(X, np.sin(X[:, :1]), kernel(length=np.array([1.0, 1.0]), scale_est=True)))
     txt = capsys.readouterr().out
     assert 'Matern-2.5' in txt and 'Squared-Exp' in txt and '(fixed)' in txt
+
+
+@pytest.mark.parametrize('K', [2, 3])
+def test_categorical_dgp_end_to_end(eng, K):
+    """Classification DGP (Categorical likelihood: label encoding, +-2 sqrt(40) warm start, first sweeps with variance 40,
+    ESS on all latents; emulator: latent moments aggregated over the imputations, then class probabilities)."""
+    from dgp_amd import dgp, kernel, combine, emulator, Categorical, save_structure, load_structure
+    rng = np.random.default_rng(6)
+    np.random.seed(6)
+    X = rng.uniform(size=(90, 2))
+    score = np.sin(4 * X[:, 0]) + X[:, 1]
+    names = np.array(['low', 'mid', 'top'])
+    cls = (score > 0.9).astype(int) if K == 2 else np.digitize(score, [0.6, 1.2])
+    Y = names[cls].reshape(-1, 1)
+    q = 1 if K == 2 else K
+    layers = combine([kernel(length=np.array([0.5]), name='sexp', scale_est=True) for _ in range(q)], [Categorical()])
+    model = dgp(X, Y, layers, seed=2)
+    lik = model.all_layer[1][0]
+    assert lik.num_classes == K and lik.link == ('logit' if K == 2 else 'softmax') and set(np.unique(model.Y)) == set(range(K))
+    assert all(nd.scale[0] != 40.0 for nd in model.all_layer[0])            # the start-up variance is restored
+    model.train(N=15, ess_burn=5, disable=True)
+    emu = emulator(model.estimate(), N=3, seed=4)
+    xt = rng.uniform(size=(60, 2))
+    st = np.sin(4 * xt[:, 0]) + xt[:, 1]
+    truth = (st > 0.9).astype(int) if K == 2 else np.digitize(st, [0.6, 1.2])
+    np.random.seed(1)
+    p, pv = emu.predict(xt)
+    assert p.shape == (60, 1 if K == 2 else K) and np.all((p >= 0) & (p <= 1)) and np.all(pv >= 0)
+    pred = (p[:, 0] > 0.5).astype(int) if K == 2 else np.argmax(p, 1)
+    assert np.mean(pred == truth) > 0.8
+    if K > 2:
+        assert np.allclose(p.sum(1), 1.0, atol=1e-9)
+    smp = emu.predict(xt[:7], method='sampling', sample_size=20)
+    assert len(smp) == (1 if K == 2 else K) and smp[0].shape == (7, 60)
+    avg, per = emu.nllik(xt, truth.reshape(-1, 1).astype(float if K == 2 else int))
+    assert np.isfinite(avg) and per.shape == (60,) and np.all(per >= 0)     # (few iterations: confident latents, so a few
+    import os, tempfile                                                    #  misclassified points dominate the average)
+    with tempfile.TemporaryDirectory() as tmp:
+        save_structure(model.estimate(), os.path.join(tmp, 'c'))
+        back = load_structure(os.path.join(tmp, 'c'))
+        assert back[1][0].name == 'Categorical' and back[1][0].num_classes == K and list(back[1][0].class_encoder.classes_) == list(names[:K])
+    Xn = rng.uniform(size=(40, 2))
+    sn = np.sin(4 * Xn[:, 0]) + Xn[:, 1]
+    model.update_xy(Xn, names[(sn > 0.9).astype(int) if K == 2 else np.digitize(sn, [0.6, 1.2])].reshape(-1, 1))
+    assert model.n_data == 40 and set(np.unique(model.Y)) <= set(range(K))

@@ -270,3 +270,38 @@ def test_count_likelihood_nodes_match_reference(golden):
             cols = [0] if (name == 'negbin' and tag == 'norep') else list(range(q))
             np.testing.assert_allclose(lat[:, cols], g[pre + 'latent'][:, cols], rtol=1e-13)
             assert np.all(np.isfinite(lat))
+
+
+def test_categorical_likelihood_matches_reference(golden):
+    """dgp_amd.Categorical (logit / probit / softmax / robustmax) and dgp's latent warm starts for it against the
+    reference's values (g18_categorical); the Monte-Carlo predictions use numpy's global stream like the reference."""
+    from dgp_amd import Categorical
+    from dgp_amd.dgp import dgp
+    g = golden('g18_categorical')
+    for tag, K in (('logit', 2), ('probit', 2), ('softmax', 3), ('robustmax', 4)):
+        h = Categorical(num_classes=K, link=tag)
+        h.input = g[tag + '_input']
+        h.output = g[tag + '_output'] if K == 2 else g[tag + '_output'].astype(int)
+        np.testing.assert_allclose(h.llik(), float(g[tag + '_llik']), rtol=1e-12)
+        np.random.seed(99)
+        pm, pv = h.prediction(g[tag + '_m'], g[tag + '_v'])
+        np.testing.assert_allclose(pm, g[tag + '_pm'], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(pv, g[tag + '_pv'], rtol=1e-10, atol=1e-15)
+        yq = g[tag + '_yq'] if K == 2 else g[tag + '_yq'].astype(int)
+        np.testing.assert_allclose(h.pllik(yq.reshape(-1, 1, 1), g[tag + '_fq']), g[tag + '_pllik'], rtol=1e-12)
+        np.testing.assert_allclose(h.sampling(h.input), g[tag + '_samp'], rtol=1e-13)
+    for tag, K in (('bin', 2), ('multi', 3)):
+        for rtag in ('norep', 'rep'):
+            pre = 'ws_%s_%s_' % (tag, rtag)
+            X = g[pre + 'X']
+            obj = dgp.__new__(dgp)
+            obj.Y, obj.indices = g[pre + 'Ycode'].astype(int), None
+            X0, inv = np.unique(X, return_inverse=True, axis=0)
+            obj.X = X0 if len(X0) != len(X) else X
+            if len(X0) != len(X):
+                obj.indices = np.asarray(inv).reshape(-1)
+            obj.n_data = len(obj.X)
+            lik = Categorical(num_classes=K, link=str(g[pre + 'link']))
+            assert int(g[pre + 'K']) == K
+            obj.all_layer, obj.n_layer = [[None] * (1 if K == 2 else K), [lik]], 2
+            np.testing.assert_allclose(obj._categorical_warm_start(0), g[pre + 'latent'], rtol=1e-13)

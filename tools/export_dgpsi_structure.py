@@ -23,9 +23,13 @@ def export(all_layer, npz_file):
         for k, nd in enumerate(layer):
             p = 'l%d_k%d_' % (l, k)
             if getattr(nd, 'type', 'gp') != 'gp':
-                if getattr(nd, 'name', None) not in ('Hetero', 'Poisson', 'NegBin', 'ZIP', 'ZINB'):
-                    raise NotImplementedError('likelihood nodes supported by dgp_amd: Hetero, Poisson, NegBin, ZIP, ZINB')
                 out[p + 'likelihood'] = np.array(str(nd.name))
+                if nd.name == 'Categorical':
+                    out[p + 'cat_num_classes'] = np.array(int(nd.num_classes))
+                    out[p + 'cat_link'] = np.array(str(nd.link))
+                    out[p + 'cat_eps'] = np.array(float(nd.robustmax_eps))
+                    if nd.class_encoder is not None:
+                        out[p + 'cat_classes'] = np.asarray(nd.class_encoder.classes_)
                 arrays = ('input', 'output', 'input_dim', 'rep')
             else:
                 out[p + 'name'] = np.array(str(nd.name))
