@@ -423,8 +423,13 @@ class emulator:
         MICE and VIGF (GP hierarchies) are computed from the device layer walk."""
         if x_cand.ndim == 1:
             raise Exception('The candidate design set has to be a numpy 2d-array.')
+        lik = any(nd.type == 'likelihood' for nd in self.all_layer[-1])
+        L = self.n_layer - 2 if lik else self.n_layer - 1      # the last GP layer carries the criteria (emulation.py:347-420)
         if method == 'ALM':
-            _, sigma2 = self.predict(x=x_cand, m=m)
+            if lik:
+                sigma2 = self.predict(x=x_cand, full_layer=True, m=m)[1][-2]
+            else:
+                _, sigma2 = self.predict(x=x_cand, m=m)
             if score_only:
                 return sigma2
             idx = np.argmax(sigma2, axis=0)
@@ -441,17 +446,23 @@ class emulator:
             per_layer = self._layer_moments_vecchia(x_cand, m)
         else:
             per_layer = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in self._layer_moments(x_cand)]
-        sigma2 = per_layer[-1][1]
-        pred_in = per_layer[-2][0] if self.n_layer > 1 else None
-        M, D, S = len(x_cand), len(self.all_layer[-1]), self.N
-        mice = np.zeros((M, D))
-        for i in range(S):
-            s_i = np.empty((M, D))
-            for k, nd in enumerate(self.all_layer[-1]):
-                s_i[:, k] = self._mice_var(x_cand if pred_in is None else pred_in[i], x_cand, nd, nugget_s)
-            with np.errstate(divide='ignore'):
-                mice += np.log(sigma2[i] / s_i)
-        avg = mice / S
+        sigma2 = per_layer[L][1]
+        pred_in = per_layer[L - 1][0] if L > 0 else None
+        M, D, S = len(x_cand), len(self.all_layer[L]), self.N
+        if lik and self.n_layer == 2:
+            # one GP layer under a likelihood (emulation.py:366-375): its predictive variance does not depend on the
+            # imputation; the ratio itself is the score
+            s_0 = np.stack([self._mice_var(x_cand, x_cand, nd, nugget_s) for nd in self.all_layer[0]], 1)
+            avg = sigma2[0] / s_0
+        else:
+            mice = np.zeros((M, D))
+            for i in range(S):
+                s_i = np.empty((M, D))
+                for k, nd in enumerate(self.all_layer[L]):
+                    s_i[:, k] = self._mice_var(x_cand if pred_in is None else pred_in[i], x_cand, nd, nugget_s)
+                with np.errstate(divide='ignore'):
+                    mice += np.log(sigma2[i] / s_i)
+            avg = mice / S
         if score_only:
             return avg
         idx = np.argmax(avg, axis=0)
@@ -464,11 +475,11 @@ class emulator:
         if obj is None:
             raise Exception('The dgp object that is used to build the emulator must be supplied to the argument `obj` '
                             'when VIGF criterion is chosen.')
-        if obj.indices is not None:
+        lik = any(nd.type != 'gp' for nd in self.all_layer[-1])
+        if obj.indices is not None and not lik:
             raise Exception('VIGF criterion is currently not applicable to DGP emulators whose training data contain '
                             'replicates but without a likelihood node.')
-        if any(nd.type != 'gp' for nd in self.all_layer[-1]):
-            raise NotImplementedError('VIGF with a likelihood layer (predict_vigf_2layer_likelihood) is not implemented')
+        L = self.n_layer - 2 if lik else self.n_layer - 1
         X = obj.X
         e = self.engine
         if len(x_cand) * len(X) <= 20_000_000:
@@ -477,11 +488,14 @@ class emulator:
         else:
             index = e.nn_query(e.tensor(x_cand), e.tensor(X), 1).cpu().numpy().reshape(-1)
         if self.vecch:
-            mean, var = self._layer_moments_vecchia(x_cand, m)[-1]
+            mean, var = self._layer_moments_vecchia(x_cand, m)[L]
         else:
-            mean, var = (t.cpu().numpy() for t in self._layer_moments(x_cand)[-1])
-        Ytr = np.stack([np.asarray(nd.output, float).reshape(-1)[index] for nd in self.all_layer[-1]], 1)   # (M, D)
-        bias = (mean - Ytr[None]) ** 2
+            mean, var = (t.cpu().numpy() for t in self._layer_moments(x_cand)[L])
+        if lik:    # under a likelihood the last GP layer's "outputs" are the imputation's own latents (emulation.py:498-524,567-570)
+            Ytr = np.stack([self.latents[s_][L][index, :] for s_ in range(self.N)])                          # (S, M, D)
+        else:
+            Ytr = np.stack([np.asarray(nd.output, float).reshape(-1)[index] for nd in self.all_layer[-1]], 1)[None]   # (1, M, D)
+        bias = (mean - Ytr) ** 2
         E1 = np.mean(bias ** 2 + 6 * bias * var + 3 * var ** 2, axis=0)
         E2 = np.mean(bias + var, axis=0)
         vigf = E1 - E2 ** 2

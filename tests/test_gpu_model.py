@@ -461,6 +461,19 @@ def test_hetero_dgp_end_to_end(eng, rep):
         m_, v_ = rng.normal(size=(6, 2)), rng.uniform(0.1, 1.0, size=(6, 2))
         y_ = rng.normal(size=(6, 1))
         assert np.allclose(ghdiag(Hetero.pllik, m_, v_, y_), O.ghdiag(O.hetero_pllik, m_, v_, y_), rtol=1e-13)
+        # sequential-design criteria under a likelihood act on the last GP layer (emulation.py:347-420,498-524)
+        pl = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in emu._layer_moments(xt)]
+        alm = emu.metric(xt, method='ALM', score_only=True)
+        mbar = pl[0][0].mean(0)
+        assert alm.shape == (19, 2) and np.allclose(alm, (pl[0][0] ** 2 + pl[0][1]).mean(0) - mbar ** 2, rtol=1e-9)
+        mice = emu.metric(xt, method='MICE', score_only=True)
+        ref = np.stack([pl[0][1][0][:, k] / np.ravel(O.mice_var(xt, xt, nd.input_dim, nd.connect, nd.name, nd.length, nd.scale, nd.nugget[0], 1.0))
+                        for k, nd in enumerate(emu.all_layer[0])], 1)
+        assert np.allclose(mice, ref, rtol=1e-8)
+        vig = emu.metric(xt, method='VIGF', obj=model, score_only=True)
+        near = np.argmin(((xt[:, None, :] - model.X[None]) ** 2).sum(-1), 1)
+        b = (pl[0][0] - np.stack([emu.latents[s_][0][near] for s_ in range(emu.N)])) ** 2
+        assert np.allclose(vig, np.mean(b ** 2 + 6 * b * pl[0][1] + 3 * pl[0][1] ** 2, 0) - np.mean(b + pl[0][1], 0) ** 2, rtol=1e-10)
 
 
 def test_update_xy_warm_starts(eng):
