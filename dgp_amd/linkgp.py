@@ -135,8 +135,9 @@ class lgp:
         for l, layer in enumerate(structure):
             mo, vo = np.empty((M, len(layer))), np.empty((M, len(layer)))
             for k, nd in enumerate(layer):
-                if nd.type != 'gp':
-                    raise NotImplementedError('likelihood nodes in linked emulation are outside the accelerated path')
+                if nd.type != 'gp':   # likelihood node on top of the emulator (linkgp.py:574-576)
+                    mo[:, k], vo[:, k] = nd.prediction(m=mean_in[:, nd.input_dim], v=var_in[:, nd.input_dim])
+                    continue
                 nd.pred_m = pred_m
                 _ensure_stats(nd)
                 if l == 0:
@@ -164,17 +165,40 @@ class lgp:
                 mean_in, var_in = mo, vo
         return mean_in, var_in, mo, vo
 
-    def _emulate(self, model, x, m, v, z, pred_m):
+    def _emulate(self, model, x, m, v, z, pred_m, before=False):
         if model.type == 'gp':
-            return self.gp_pred(x, m, v, z, model.structure, pred_m)
-        return self.dgp_pred(x, m, v, z, model.structure, pred_m)[2:]
+            out = self.gp_pred(x, m, v, z, model.structure, pred_m)
+            return (None, None) + out if before else out
+        out = self.dgp_pred(x, m, v, z, model.structure, pred_m)
+        return out if before else out[2:]
+
+    @staticmethod
+    def _draw(model, mk, vk, m_before, v_before, sample_size):
+        """sample_size draws per test point from one emulator's predictive distributions, (q, M, sample_size)
+        (linkgp.py:383-386,408-421).  A likelihood node on top of a DGP emulator samples y from draws of its feeding
+        latents.  (For the GP nodes of a DGP emulator in the last layer the reference takes the spread from the layer
+        before, linkgp.py:416 -- a slip that fails as soon as the two layers differ in width; the nodes' own
+        predictive variances are used here.)"""
+        M, q = mk.shape
+        if model.type == 'gp' or all(nd.type == 'gp' for nd in model.structure[-1]):
+            return np.random.normal(mk, np.sqrt(vk), size=(sample_size, M, q)).transpose(2, 1, 0)
+        out = np.empty((q, M, sample_size))
+        for c, nd in enumerate(model.structure[-1]):
+            if nd.type == 'gp':
+                out[c] = np.random.normal(mk[:, [c]], np.sqrt(vk[:, [c]]), size=(M, sample_size))
+            else:
+                lat = np.random.normal(m_before, np.sqrt(v_before), size=(sample_size,) + m_before.shape)
+                out[c] = np.array([nd.sampling(lat[i][:, nd.input_dim]) for i in range(sample_size)]).T
+        return out
 
     # -------------------------------------------------------------- the system
     def predict(self, x, method='mean_var', full_layer=False, sample_size=50, m=50):
         """Means and variances of the final-layer emulators' outputs (lists of (M x q) arrays), or of every
-        layer if full_layer (linkgp.py:285-501, method='mean_var')."""
-        if method != 'mean_var':
-            raise NotImplementedError("method='sampling' is outside the accelerated path")
+        layer if full_layer (linkgp.py:285-501); method='sampling': per emulator an array (q, M, N * sample_size) of
+        draws from the imputations' predictive distributions."""
+        if method not in ('mean_var', 'sampling'):
+            raise Exception("method must be either 'mean_var' or 'sampling'.")
+        sampling = method == 'sampling'
         if isinstance(x, list):
             if len(x) != self.L:
                 raise Exception('When test input is given as a list, it must contain global inputs to the all layers '
@@ -184,16 +208,16 @@ class lgp:
             if x.ndim == 1:
                 raise Exception('The testing input has to be a numpy 2d-array.')
             x = [x] + [[None] * k for k in self.num_model]
-        means, variances = [], []
+        means, variances, draws = [], [], []
         for one in self.all_layer_set:
-            feed_m, feed_v, lay_m, lay_v = [], [], [], []
+            feed_m, feed_v, lay_m, lay_v, lay_s = [], [], [], [], []
             for l, layer in enumerate(one):
-                ms, vs = [], []
+                ms, vs, ss = [], [], []
                 for k, model in enumerate(layer):
                     if l == 0:
                         if isinstance(model.local_input_idx, list):
                             raise Exception('When an emulator is in the first layer, local_input_idx must be a 1d-array.')
-                        mk, vk = self._emulate(model, x[0][:, model.local_input_idx], None, None, None, m)
+                        mb, vb, mk, vk = self._emulate(model, x[0][:, model.local_input_idx], None, None, None, m, before=True)
                     else:
                         idx = model.local_input_idx
                         if not isinstance(idx, list):
@@ -202,15 +226,24 @@ class lgp:
                             raise Exception('local_input_idx should be a list that has length of %i.' % l)
                         m_in = np.concatenate([feed_m[i][:, j] for i, j in enumerate(idx) if j is not None], axis=1)
                         v_in = np.concatenate([feed_v[i][:, j] for i, j in enumerate(idx) if j is not None], axis=1)
-                        mk, vk = self._emulate(model, None, m_in, v_in, x[l][k], m)
+                        mb, vb, mk, vk = self._emulate(model, None, m_in, v_in, x[l][k], m, before=True)
                     ms.append(mk)
                     vs.append(vk)
+                    if sampling and (full_layer or l == self.L - 1):
+                        ss.append(self._draw(model, mk, vk, mb, vb, sample_size))
                 lay_m.append(ms)
                 lay_v.append(vs)
+                lay_s.append(ss)
                 feed_m.append(np.concatenate(ms, axis=1))
                 feed_v.append(np.concatenate(vs, axis=1))
             means.append(lay_m if full_layer else lay_m[-1])
             variances.append(lay_v if full_layer else lay_v[-1])
+            draws.append(lay_s if full_layer else lay_s[-1])
+        if sampling:    # per emulator (q, M, S * sample_size): the imputations' draws side by side (linkgp.py:496-500)
+            if full_layer:
+                return [[np.concatenate([draws[s_][l][k] for s_ in range(len(draws))], axis=2)
+                         for k in range(len(self.all_layer[l]))] for l in range(self.L)]
+            return [np.concatenate([draws[s_][k] for s_ in range(len(draws))], axis=2) for k in range(len(self.all_layer[-1]))]
 
         def agg(ms, vs):   # emulation.py:846-847 over the imputations
             ms, vs = np.asarray(ms), np.asarray(vs)

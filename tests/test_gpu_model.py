@@ -322,6 +322,14 @@ def test_linked_chain_matches_reference(eng, golden, tag):
     for l in range(3):
         close(mul[l][0], d['mu_l%d' % l], rtol=1e-6, atol=1e-8)
         close(varl[l][0], d['var_l%d' % l], rtol=1e-5, atol=1e-6)
+    # method='sampling' (linkgp.py:348-500): draws whose moments are the mixture's
+    np.random.seed(3)
+    smp = sysm.predict(xin, method='sampling', sample_size=400)
+    assert len(smp) == 1 and smp[0].shape == (1, len(d['xt']), S * 400)
+    sd = np.sqrt(d['var'][:, 0])
+    assert np.all(np.abs(smp[0][0].mean(1) - d['mu'][:, 0]) < 6 * sd / np.sqrt(S * 400) + 1e-6)
+    full = sysm.predict(xin, method='sampling', sample_size=3, full_layer=True)
+    assert len(full) == 3 and full[0][0].shape[2] == S * 3
     # lgp.set_vecchia (linkgp.py:180-212): with every training point in the conditioning set the Vecchia predictions are
     # the dense ones up to rounding; switching back restores them
     sysm.set_vecchia(True)
