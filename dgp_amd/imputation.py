@@ -363,7 +363,9 @@ class imputer:
                 dev_terms.append(ll)
                 infos.append(info)
                 if nd.prior_name == 'ref':
-                    raise NotImplementedError("prior_name='ref' inside the ESS target needs compute_cl per proposal")
+                    if FPh is None:
+                        FPh = FP.cpu().numpy()
+                    host += self._ref_prior_terms(nd, FPh)
             elif nd.type == 'gp':
                 cm = torch.as_tensor(np.asarray(nd.input_dim), device=FP.device, dtype=torch.long)
                 od = torch.as_tensor(nd.ord, device=FP.device, dtype=torch.long)
@@ -378,6 +380,10 @@ class imputer:
                     outs.append(e.vecchia_llik(nd.name, X[od].contiguous(), y, NN, nd.length, nd.nugget[0], nd_diag))
                 o = torch.stack(outs)
                 dev_terms.append(-0.5 * (o[:, 1] + o[:, 0] / float(nd.scale[0])))
+                if nd.prior_name == 'ref':
+                    if FPh is None:
+                        FPh = FP.cpu().numpy()
+                    host += self._ref_prior_terms(nd, FPh)
             else:
                 # likelihood node: host plugin protocol llik() on .input (likelihood_class.py:30-90)
                 if FPh is None:
@@ -401,6 +407,19 @@ class imputer:
         else:
             info = np.zeros(B)
         return host, info
+
+    @staticmethod
+    def _ref_prior_terms(nd, FPh):
+        """Reference-prior term of the ESS target for every candidate block (kernel_class.py:489-491,507-509): the prior's
+        scaling constant depends on the node's inputs, i.e. on the proposal."""
+        keep, keep_cl = nd.input, getattr(nd, 'cl', None)
+        out = np.empty(FPh.shape[0])
+        for b in range(FPh.shape[0]):
+            nd.input = FPh[b][:, nd.input_dim]
+            nd.compute_cl()
+            out[b] = float(np.sum(nd.log_prior()))
+        nd.input, nd.cl = keep, keep_cl
+        return out
 
     def _ess_plan(self, l):
         """dgpamd_ess_update arguments for layer l when the layer above is ONE dense GP node without a reference prior

@@ -813,3 +813,28 @@ def test_categorical_dgp_end_to_end(eng, K):
     sn = np.sin(4 * Xn[:, 0]) + Xn[:, 1]
     model.update_xy(Xn, names[(sn > 0.9).astype(int) if K == 2 else np.digitize(sn, [0.6, 1.2])].reshape(-1, 1))
     assert model.n_data == 40 and set(np.unique(model.Y)) <= set(range(K))
+
+
+def test_reference_prior_in_the_ess_target(eng):
+    """A second-layer node with prior_name='ref': the ESS target carries the prior term with its input-dependent scaling
+    constant (kernel_class.py:489-491); checked against the oracle for one candidate block, then a short training run."""
+    from dgp_amd import dgp, kernel, combine
+    from dgp_amd.imputation import imputer
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(9)
+    X = rng.uniform(size=(40, 2))
+    Y = np.sin(4 * X[:, :1]) * X[:, 1:]
+    layers = combine([kernel(length=np.array([1.0]), name='sexp') for _ in range(2)],
+                     [kernel(length=np.array([0.8, 1.1]), name='matern2.5', scale_est=True, prior_name='ref', nugget=1e-3)])
+    model = dgp(X, Y, layers, seed=4)
+    imp, nd = model.imp, model.all_layer[1][0]
+    imp._attach()
+    F = imp.F[0]
+    ll, info = imp._upper_loglik(0, F[None])
+    Fh = F.cpu().numpy()
+    base = O.log_likelihood(Fh[:, nd.input_dim], nd.output, nd.length, nd.scale, nd.nugget[0], nd.name)
+    cl = (Fh.max(0) - Fh.min(0)) / 40 ** (1 / 2)
+    t = np.sum(cl / nd.length) + nd.nugget[0]
+    close(ll[0], float(np.ravel(base)[0]) + nd.prior_coef[0] * np.log(t) - nd.prior_coef[1] * t, rtol=1e-9)
+    model.train(N=3, ess_burn=2, disable=True)
+    assert np.all(np.isfinite(nd.para_path)) and nd.para_path.shape[0] == 4
