@@ -73,6 +73,7 @@ SIGNATURES = {
     'dgpamd_gp_predict': (_i, [_p, _i, _l, _l, _i, _p, _p, _p, _i, _p, _l, _p, _i, _d, _d, _p, _p, _p]),
     'dgpamd_linkgp_workspace': (_z, [_l, _l, _i]),
     'dgpamd_linkgp_predict': (_i, [_p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p, _d, _d, _p, _p, _p]),
+    'dgpamd_linkgp_loo': (_i, [_p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p, _d, _d, _p, _p, _p]),
     'dgpamd_moments_accumulate': (_i, [_p, _l, _p, _p, _p, _p]),
     'dgpamd_moments_finalize': (_i, [_p, _l, _d, _p, _p]),
     'dgpamd_nn_ordered': (_i, [_p, _l, _i, _p, _i, _p]),

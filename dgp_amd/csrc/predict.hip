@@ -218,6 +218,7 @@ struct LinkArgs {
     double *gfac;      // [Mc][npad] Matern factor of the deterministic global inputs (linkgp_Jsep)
     int64_t npad;
     double *mean, *var;
+    const int32_t *drop;   // leave-one-out: training point left out of the conditioning set of test point t (else null)
 };
 
 // mean_t = sum_i I_i(t) ry_i : one workgroup per test point (the training points strided over its 256 threads)
@@ -229,8 +230,13 @@ __global__ __launch_bounds__(256) void linkgp_mean_kernel(LinkArgs a) {
     if (t >= a.M || t >= a.t0 + a.Mc) return;
     const double *mt = a.m + t * a.Dw, *vt = a.v + t * a.Dw;
     const double *zt = a.Dz ? a.z + t * a.Dz : nullptr;
+    // leave-one-out: (R_-d)^-1 y = Rinv y - u (Rinv y)_d / u_d with u = Rinv[:, d], zero at d itself
+    const int64_t dr = a.drop ? a.drop[t] : -1;
+    const double *ud = a.drop ? a.Rinv + dr * a.ldr : nullptr;
+    const double cd = a.drop ? a.ry[dr] / ud[dr] : 0.0;
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < a.n; i += 256) {
+        if (i == dr) continue;
         double I;
         if (KIND == DGPAMD_SEXP) {
             double e = 0.0;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void linkgp_mean_kernel(LinkArgs a) {
             for (int g = 0; g < a.Dz; ++g) corr_accum_matern((a.Wg[i * a.Dz + g] - zt[g]) / a.len[a.Dw + g], pr, s);
             I *= pr * exp(-SQRT5 * s);
         }
-        acc = fma(I, a.ry[i], acc);
+        acc = fma(I, ud ? a.ry[i] - cd * ud[i] : a.ry[i], acc);
     }
     acc = wave_sum_p(acc);
     if (lane == 0) part[wave] = acc;
@@ -268,7 +274,10 @@ __global__ __launch_bounds__(256) void linkgp_mean_kernel(LinkArgs a) {
 
 // partial[tile][t] = sum_{(i,j) in tile} wt (ry_i ry_j - scale Rinv_ij) Jhat_ij(t)
 // (sexp: Jhat = J / J_coef1, the prefactor is applied in the finalize kernel)
-template <int KIND>
+// LOO: test point t conditions on every training point but d = drop[t].  With u = Rinv[:, d], rho = u_d the inverse of
+// the reduced correlation matrix (embedded, zero row / column d) is Rinv - u u^T / rho, so the pair weight becomes
+//   wt [ (ry_i - c u_i)(ry_j - c u_j) - scale (Rinv_ij - u_i u_j / rho) ],   c = ry_d / rho.
+template <int KIND, bool LOO>
 __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
     extern __shared__ double lds[];
     const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
@@ -279,6 +288,10 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
     double *tz = tv + TCH * Dw;           // [TCH][Dz]
     double *red = tz + TCH * Dz;          // [TCH][4]
     double *Cs = red + TCH * 4;           // [64][65]  (matern only)
+    double *ui = Cs + (KIND == DGPAMD_MATERN25 ? 64 * 65 : 0);   // LOO only: [TCH][64] u rows of the tile
+    double *uj = ui + TCH * 64;           // [TCH][64] u columns of the tile
+    double *ryi = uj + TCH * 64, *ryj = ryi + 64;
+    double *ct = ryj + 64, *gt = ct + TCH;   // [TCH] c and wt scale / rho
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, wave = tid >> 6, lane = tid & 63;
@@ -309,6 +322,23 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
     for (int idx = tid; idx < nt * Dz; idx += 256) tz[idx] = a.z[tbase * Dz + idx];
 
     const double wt = (bi == bj) ? 1.0 : 2.0;
+    if (LOO) {
+        if (tid < 64) ryi[tid] = i0 + tid < n ? a.ry[i0 + tid] : 0.0;
+        else if (tid < 128) ryj[tid - 64] = j0 + tid - 64 < n ? a.ry[j0 + tid - 64] : 0.0;
+        for (int idx = tid; idx < nt * 64; idx += 256) {
+            const int t = idx >> 6, r = idx & 63;
+            const double *u = a.Rinv + (int64_t)a.drop[tbase + t] * a.ldr;
+            ui[idx] = i0 + r < n ? u[i0 + r] : 0.0;
+            uj[idx] = j0 + r < n ? u[j0 + r] : 0.0;
+        }
+        if (tid < nt) {
+            const int64_t d = a.drop[tbase + tid];
+            const double rho = a.Rinv[d * a.ldr + d];
+            ct[tid] = a.ry[d] / rho;
+            gt[tid] = wt * a.scale / rho;
+        }
+    }
+    // Cr: the pair weight (LOO: only its t-independent part wt scale Rinv_ij, subtracted per test point)
     double Cr[4][4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -317,7 +347,8 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
         for (int q = 0; q < 4; ++q) {
             const int64_t gj = j0 + tx + 16 * q;
             double c = 0.0;
-            if (gi < n && gj < n) c = wt * (a.ry[gi] * a.ry[gj] - a.scale * a.Rinv[gi * a.ldr + gj]);
+            if (gi < n && gj < n)
+                c = LOO ? wt * a.scale * a.Rinv[gi * a.ldr + gj] : wt * (a.ry[gi] * a.ry[gj] - a.scale * a.Rinv[gi * a.ldr + gj]);
             Cr[p][q] = c;
             if (KIND == DGPAMD_MATERN25) Cs[(ty + 16 * p) * 65 + tx + 16 * q] = c;
         }
@@ -380,10 +411,27 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
                     }
             }
             double acc = 0.0;
+            if (LOO) {
+                double ai[4], aj[4], gi_[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < 4; ++p) {
+                    const double u1 = ui[t * 64 + ty + 16 * p], u2 = uj[t * 64 + tx + 16 * p];
+                    ai[p] = wt * (ryi[ty + 16 * p] - ct[t] * u1);
+                    aj[p] = ryj[tx + 16 * p] - ct[t] * u2;
+                    gi_[p] = gt[t] * u1;
+                    ej[p] = u2;
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = fma(Cr[p][q], exp(-e[p][q]), acc);
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc = fma(fma(ai[p], aj[q], fma(gi_[p], ej[q], -Cr[p][q])), exp(-e[p][q]), acc);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = fma(Cr[p][q], exp(-e[p][q]), acc);
+            }
             acc = wave_sum_p(acc);
             if (lane == 0) red[t * 4 + wave] = acc;
         }
@@ -393,8 +441,12 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
 #pragma unroll 1
             for (int e = 0; e < 16; ++e) {
                 const int r = ty + 16 * (e >> 2), c = tx + 16 * (e & 3);
-                const double cij = Cs[r * 65 + c];
-                if (cij == 0.0) continue;
+                double cij = Cs[r * 65 + c];
+                if (LOO ? (i0 + r >= n || j0 + c >= n) : cij == 0.0) continue;
+                if (LOO) {
+                    const double u1 = ui[t * 64 + r], u2 = uj[t * 64 + c];
+                    cij = fma(wt * (ryi[r] - ct[t] * u1), ryj[c] - ct[t] * u2, fma(gt[t] * u1, u2, -cij));
+                }
                 const bool diag = (i0 + r == j0 + c);
                 double prod = 1.0;
                 for (int k = 0; k < Dw; ++k) {
@@ -851,11 +903,10 @@ extern "C" size_t dgpamd_linkgp_workspace(int64_t n, int64_t M, int Dw) {
     return (size_t)(nb * (nb + 1) / 2 * Mc + Ms * (int64_t)Dw * nb * 64 * REC + Ms * nb * 64) * sizeof(double);
 }
 
-extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz, const double *m,
-                                     const double *v, const double *z, const double *Wtr, const double *Wg,
-                                     const double *length_h, int nlen, const double *Rinv, int64_t ldr,
-                                     const double *ry, double scale, double nugget, double *mean, double *var,
-                                     void *work) {
+static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz, const double *m, const double *v,
+                      const double *z, const double *Wtr, const double *Wg, const double *length_h, int nlen,
+                      const double *Rinv, int64_t ldr, const double *ry, const int32_t *drop, double scale,
+                      double nugget, double *mean, double *var, void *work) {
     if (!ctx) return DGPAMD_BAD_ARG;
     if (n <= 0 || M <= 0 || !m || !v || !Wtr || !length_h || !Rinv || !ry || !mean || !var || !work)
         BAD_ARG(ctx, "null pointer or empty problem");
@@ -869,10 +920,12 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
     for (int d = 0; d < Dw + Dz; ++d) a.len[d] = length_h[nlen == 1 ? 0 : d];   // functions.py:402-410 broadcast
     a.Rinv = Rinv; a.ldr = ldr; a.ry = ry; a.scale = scale; a.nugget = nugget; a.mean = mean; a.var = var;
     a.partial = (double *)work;
+    a.drop = drop;
     int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
     if (Mc > MC_MAX) Mc = MC_MAX;
     const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
-    const bool sep = (kind == DGPAMD_MATERN25) && !ctx->linkgp_direct;
+    const bool direct = ctx->linkgp_direct || drop;   // the leave-one-out weights change per test point: direct kernels
+    const bool sep = (kind == DGPAMD_MATERN25) && !direct;
     a.recs = a.partial + (int64_t)ntiles * Mc;
     a.npad = (int64_t)nb * 64;
     if (sep && Mc > MC_SEP) Mc = MC_SEP;   // records of one chunk: Mc*Dw*npad*224 B
@@ -881,14 +934,23 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
     const int DT = Dw + Dz;
     size_t shm = ((size_t)2 * DT * 64 + (size_t)TCH * (2 * Dw + Dz) + TCH * 4) * sizeof(double);
     if (kind == DGPAMD_MATERN25) shm += 64 * 65 * sizeof(double);
+    if (drop) {
+        shm += ((size_t)2 * TCH * 64 + 128 + 2 * TCH) * sizeof(double);
+        if (kind == DGPAMD_SEXP)
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_J_kernel<DGPAMD_SEXP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        else
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_J_kernel<DGPAMD_MATERN25, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    }
     for (int64_t t0 = 0; t0 < M; t0 += Mc) {
         a.t0 = t0;
         const int64_t mc = M - t0 < Mc ? M - t0 : Mc;
         const unsigned tb = (unsigned)((mc + TCH - 1) / TCH);
         if (kind == DGPAMD_SEXP) {
             hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_SEXP>, dim3((unsigned)mc), dim3(256), 0, ctx->stream, a);
-            if (ctx->linkgp_direct) {
-                hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_SEXP>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            if (drop) {
+                hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_SEXP, true>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            } else if (direct) {
+                hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_SEXP, false>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else {
                 const int KP = (Dw + 3) & ~3, LDU = KP + 2;
                 const size_t shm_s = ((size_t)2 * DT * 64 + (size_t)KP * LDK + (size_t)TCH * (2 * Dw + Dz) + TCH * 4 + 2 * 64 * LDU + 4 * 64 + Dz) * sizeof(double);
@@ -899,8 +961,10 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
             hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_SEXP>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a, ntiles);
         } else {
             hipLaunchKernelGGL(linkgp_mean_kernel<DGPAMD_MATERN25>, dim3((unsigned)mc), dim3(256), 0, ctx->stream, a);
-            if (ctx->linkgp_direct) {
-                hipLaunchKernelGGL(linkgp_J_kernel<DGPAMD_MATERN25>, dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            if (drop) {
+                hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_MATERN25, true>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            } else if (direct) {
+                hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_MATERN25, false>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else {
                 const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)TCH * Dz + TCH * 4 + 2 * 128 * PST) * sizeof(double);
                 if (shm_sep > 48 * 1024)
@@ -917,6 +981,25 @@ extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64
     }
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz, const double *m,
+                                     const double *v, const double *z, const double *Wtr, const double *Wg,
+                                     const double *length_h, int nlen, const double *Rinv, int64_t ldr,
+                                     const double *ry, double scale, double nugget, double *mean, double *var,
+                                     void *work) {
+    return linkgp_run(ctx, kind, n, M, Dw, Dz, m, v, z, Wtr, Wg, length_h, nlen, Rinv, ldr, ry, nullptr, scale, nugget,
+                      mean, var, work);
+}
+
+extern "C" int dgpamd_linkgp_loo(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz, const double *m,
+                                 const double *v, const double *z, const double *Wtr, const double *Wg,
+                                 const double *length_h, int nlen, const double *Rinv, int64_t ldr, const double *ry,
+                                 const int32_t *drop, double scale, double nugget, double *mean, double *var,
+                                 void *work) {
+    if (ctx && !drop) BAD_ARG(ctx, "drop is null");
+    return linkgp_run(ctx, kind, n, M, Dw, Dz, m, v, z, Wtr, Wg, length_h, nlen, Rinv, ldr, ry, drop, scale, nugget, mean,
+                      var, work);
 }
 
 // ---------------------------------------------------------------------------

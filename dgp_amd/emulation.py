@@ -220,6 +220,64 @@ class emulator:
             per_layer.append((mean, var))
         return per_layer
 
+    def _layer_moments_loo(self, x):
+        """Leave-one-out layer walk of a dense emulator (emulation.py:90-143 with vecch False: every node conditions
+        on all training points but the one nearest to its input, kernel_class.py:610-611,655-656).  Nothing is
+        refactorised: first-layer nodes use the block-inverse identities  mean = y_d - (R^-1 y)_d / (R^-1)_dd,
+        var = scale (1 / (R^-1)_dd + nugget (1 - W_d));  linked nodes go through dgpamd_linkgp_loo, which applies the
+        rank-one downdate of R^-1 inside the pair weights.  Returns device (S, M, K) pairs per layer."""
+        if self._stats is None:
+            self._build_stats()
+        e = self.engine
+        M, S = len(x), self.N
+        xd = e.tensor(x)
+        per_layer = []
+        for l, layer in enumerate(self.all_layer):
+            if l == self.n_layer - 1 and self._cat() is not None:
+                idx = torch.as_tensor(np.asarray(self._cat().input_dim), device=xd.device)
+                per_layer.append((per_layer[-1][0][:, :, idx].contiguous(), per_layer[-1][1][:, :, idx].contiguous()))
+                continue
+            K = len(layer)
+            mean, var = e.empty(S, M, K), e.empty(S, M, K)
+            for k, nd in enumerate(layer):
+                if nd.type != 'gp':
+                    pm, pv = (t.cpu().numpy() for t in per_layer[-1])
+                    for s in range(S):
+                        mk, vk = nd.prediction(m=pm[s][:, nd.input_dim], v=pv[s][:, nd.input_dim])
+                        mean[s, :, k], var[s, :, k] = e.tensor(mk), e.tensor(vk)
+                    continue
+                st = self._stats[(l, k)]
+                n = st['n']
+                z = None if nd.connect is None else xd[:, torch.as_tensor(nd.connect, device=xd.device)].contiguous()
+                length = e.tensor(np.broadcast_to(np.asarray(nd.length, float), (len(nd.input_dim) + (0 if z is None else z.shape[1]),)))
+                if l == 0:
+                    xin = xd[:, torch.as_tensor(nd.input_dim, device=xd.device)]
+                    xin = (xin if z is None else torch.cat((xin, z), 1)).contiguous()
+                    d = e.nn_query((xin / length).contiguous(), (st['Wall'] / length).contiguous(), 1)[:, 0]
+                    if not torch.equal(st['Wall'][d], xin):
+                        raise Exception('loo: the rows of X must be training input positions of the emulator.')
+                    rho = st['Rinv'][:n, :n].diagonal()[d]
+                    wd = 1.0 if nd.rep is None else e.tensor(nd.W_diag)[d]
+                    for s in range(S):
+                        y = e.tensor(self.latents[s][l][:, k] if l < self.n_layer - 1 else
+                                     np.asarray(nd.output, float).reshape(-1))
+                        mean[s, :, k] = y[d] - st['ry'][s][d] / rho
+                    var[:, :, k] = (nd.scale[0] * (1.0 / rho + nd.nugget[0] * (1.0 - wd)))[None, :]
+                else:
+                    pm, pv = per_layer[-1]
+                    idx = torch.as_tensor(nd.input_dim, device=xd.device)
+                    for s in range(S):
+                        ps = st['per'][s]
+                        ms, vs = pm[s][:, idx].contiguous(), pv[s][:, idx].contiguous()
+                        q = ms if z is None else torch.cat((ms, z), 1)
+                        w = ps['W'] if z is None else torch.cat((ps['W'], st['Wg']), 1)
+                        d = e.nn_query((q / length).contiguous(), (w / length).contiguous(), 1)[:, 0].to(torch.int32).contiguous()
+                        mk, vk = e.linkgp_predict(nd.name, ms, vs, z, ps['W'], st['Wg'], nd.length, ps['Rinv'], st['ld'],
+                                                  ps['ry'], nd.scale[0], nd.nugget[0], drop=d)
+                        mean[s, :, k], var[s, :, k] = mk, vk
+            per_layer.append((mean, var))
+        return per_layer
+
     def _layer_moments_vecchia(self, x, m):
         """The same layer walk in Vecchia mode (no stored statistics; every node conditions on its pred_m nearest
         neighbours, kernel_class.py:603-619,647-664).  Returns numpy (S, M, K) pairs per layer."""
@@ -348,11 +406,12 @@ class emulator:
         nl = -np.log(np.mean(lik, axis=0)).flatten()
         return np.mean(nl), nl
 
-    def _predict_vecchia(self, x, full_layer, m, aggregation, method='mean_var', sample_size=50):
+    def _predict_vecchia(self, x, full_layer, m, aggregation, method='mean_var', sample_size=50, per_layer=None):
         """Vecchia mode: no stored statistics; every node conditions on its pred_m nearest neighbours
         (kernel_class.py:603-619,647-664) with the imputation's own latents."""
         M, S = len(x), self.N
-        per_layer = self._layer_moments_vecchia(x, m)
+        if per_layer is None:
+            per_layer = self._layer_moments_vecchia(x, m)
         mus, vs = list(per_layer[-1][0]), list(per_layer[-1][1])
         if method == 'sampling':
             return self._draw_samples(per_layer, sample_size, full_layer)
@@ -385,33 +444,29 @@ class emulator:
     ppredict = predict   # test points / imputations already run in parallel on the device (emulation.py:578-629)
 
     def loo(self, X, method=None, sample_size=50, m=30):
-        """Leave-one-out cross validation at the training inputs X (emulation.py:109-143).  As in the reference the
-        walk goes through the Vecchia prediction branches with `loo_state` set: every GP node conditions on its
-        nearest training points with the nearest one (the point itself) dropped -- all other n-1 points for a dense
-        emulator, m for a Vecchia one.  Conditioning sets live in LDS, so a dense emulator is limited to n of roughly
-        140 (larger ones: `to_vecchia()` first, as the reference's own cost of n factorisations of size n suggests)."""
+        """Leave-one-out cross validation at the training inputs X (emulation.py:109-143): every GP node conditions on
+        its nearest training points with the nearest one (at the first layer the point itself) dropped
+        (kernel_class.py:610-611,655-656) -- m of them for a Vecchia emulator, all other n-1 points for a dense one.
+        The dense case does not run n factorisations of size n-1 as the reference does: it reuses the emulator's R^-1
+        through the rank-one downdate of `_layer_moments_loo`."""
         if method is None:
             method = 'mean_var'
         n_train = len(self.all_layer[0][0].input)
         isrep = len(X) != n_train
         if isrep:
             X, indices = np.unique(X, return_inverse=True, axis=0)
-        m_pred = m + 1 if self.vecch else X.shape[0]
-        gps = [nd for layer in self.all_layer for nd in layer if nd.type == 'gp']
-        was = [nd.vecch for nd in gps]
-        for nd in gps:
-            nd.loo_state, nd.vecch = True, True     # (emulation.py:90-108: the Vecchia branches also serve a dense emulator)
-        try:
-            res = self._predict_vecchia(X, False, m_pred, True, method, sample_size)
-        except RuntimeError as err:
-            if 'too large for LDS' in str(err) and not self.vecch:
-                raise NotImplementedError('loo() of a dense emulator conditions every prediction on all other %d training '
-                                          'points; beyond ~140 points convert the emulator with to_vecchia() first (%s)'
-                                          % (X.shape[0] - 1, err))
-            raise
-        finally:
-            for nd, v in zip(gps, was):
-                nd.loo_state, nd.vecch = False, v
+        if not self.vecch:
+            per_layer = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in self._layer_moments_loo(X)]
+            res = self._predict_vecchia(X, False, m, True, method, sample_size, per_layer=per_layer)
+        else:
+            gps = [nd for layer in self.all_layer for nd in layer if nd.type == 'gp']
+            for nd in gps:
+                nd.loo_state = True
+            try:
+                res = self._predict_vecchia(X, False, m + 1, True, method, sample_size)
+            finally:
+                for nd in gps:
+                    nd.loo_state = False
         if isrep:
             res = type(res)(item[np.asarray(indices).reshape(-1), :] for item in res)
         return res

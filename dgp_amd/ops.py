@@ -335,7 +335,9 @@ class Engine:
                                         ldr, _dp(ry), nry, float(scale), float(nugget), _dp(mean), _dp(var), _dp(work)))
         return mean, var
 
-    def linkgp_predict(self, kind, m, v, z, Wtr, Wg, length, Rinv, ldr, ry, scale, nugget, mean=None, var=None):
+    def linkgp_predict(self, kind, m, v, z, Wtr, Wg, length, Rinv, ldr, ry, scale, nugget, mean=None, var=None,
+                       drop=None):
+        """drop (M,) int32 device tensor: leave training point drop[t] out of test point t's conditioning set."""
         M, Dw = m.shape
         Dz = 0 if z is None else z.shape[1]
         n = Wtr.shape[0]
@@ -345,6 +347,12 @@ class Engine:
             mean = self.empty(M)
         if var is None:
             var = self.empty(M)
+        if drop is not None:
+            assert drop.dtype == torch.int32 and drop.numel() == M and drop.is_contiguous()
+            self._chk(lib.dgpamd_linkgp_loo(self.h, KIND[kind], n, M, Dw, Dz, _dp(m), _dp(v), _dp(z), _dp(Wtr), _dp(Wg),
+                                            _hp(length), len(length), _dp(Rinv), ldr, _dp(ry), _dp(drop), float(scale),
+                                            float(nugget), _dp(mean), _dp(var), _dp(work)))
+            return mean, var
         self._chk(lib.dgpamd_linkgp_predict(self.h, KIND[kind], n, M, Dw, Dz, _dp(m), _dp(v), _dp(z), _dp(Wtr), _dp(Wg),
                                             _hp(length), len(length), _dp(Rinv), ldr, _dp(ry), float(scale),
                                             float(nugget), _dp(mean), _dp(var), _dp(work)))

@@ -142,6 +142,56 @@ def test_emulator_loo_matches_reference(eng, golden, tag):
     close(var, d['loo_var_vecch'], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('name', ['sexp', 'matern2.5'])
+def test_emulator_loo_dense_downdate_equals_refit(eng, name):
+    """The dense emulator's leave-one-out walk reuses R^-1 through a rank-one downdate (dgpamd_linkgp_loo); it must
+    agree with the reference's route -- every test point re-conditioned on the other n-1 points through the Vecchia
+    prediction branches (emulation.py:90-108) -- on a three-layer hierarchy with a global connection, and it keeps
+    working beyond the LDS limit of that route."""
+    from dgp_amd import dgp, kernel, combine, emulator
+    rng = np.random.default_rng(5)
+    n, d = 90, 2
+    X = rng.uniform(size=(n, d))
+    Y = np.sin(6.0 * X[:, [0]]) * np.cos(4.0 * X[:, [1]]) + 0.5 * X[:, [1]]
+    layers = combine([kernel(length=np.array([1.0]), name=name) for _ in range(d)],
+                     [kernel(length=np.array([1.0]), name=name, connect=np.arange(d)) for _ in range(d)],
+                     [kernel(length=np.array([1.0]), name=name, scale_est=True)])
+    model = dgp(X, Y, layers, seed=2)
+    model.train(N=6, ess_burn=3, disable=True)
+    emu = emulator(model.estimate(), N=3)
+    mu, var = emu.loo(X)
+    gps = [nd for layer in emu.all_layer for nd in layer if nd.type == 'gp']
+    for nd in gps:
+        nd.loo_state, nd.vecch = True, True
+    try:
+        mu_ref, var_ref = emu._predict_vecchia(X, False, n, True)
+    finally:
+        for nd in gps:
+            nd.loo_state, nd.vecch = False, False
+    # two algebraic routes through matrices of condition ~1e8 (sexp): each carries ~1e-8 of rounding
+    close(mu, mu_ref, rtol=1e-5, atol=5e-7)
+    # variances are O(scale) terms cancelling through R^-1: absolute tolerance 1e-6 x prior variance
+    close(var, var_ref, rtol=1e-5, atol=1e-6)
+    assert np.sqrt(np.mean((mu - Y) ** 2)) < 0.2 and np.all(var > 0)
+    s = emu.loo(X, method='sampling', sample_size=5)
+    assert len(s) == 1 and s[0].shape == (n, 3 * 5)
+    with pytest.raises(Exception, match='training input positions'):
+        emu.loo(X + 1e-3)
+    # a design far beyond what the re-conditioning route holds in LDS
+    n2 = 600
+    X2 = rng.uniform(size=(n2, d))
+    Y2 = np.sin(6.0 * X2[:, [0]]) * np.cos(4.0 * X2[:, [1]]) + 0.5 * X2[:, [1]]
+    model = dgp(X2, Y2, combine([kernel(length=np.array([1.0]), name=name) for _ in range(d)],
+                                [kernel(length=np.array([1.0]), name=name, scale_est=True, connect=np.arange(d))]), seed=2)
+    model.train(N=5, ess_burn=3, disable=True)
+    emu = emulator(model.estimate(), N=2)
+    mu, var = emu.loo(X2)
+    pm, pv = emu.predict(X2)
+    assert np.all(np.isfinite(mu)) and np.all(var > 0)
+    assert np.sqrt(np.mean((mu - Y2) ** 2)) < 0.1
+    assert np.mean(var) > np.mean(pv)          # leaving the point out can only lose information on average
+
+
 def test_estimate_is_path_mean(eng, golden):
     """dgp.estimate (dgp.py:1529-1540)."""
     from dgp_amd.dgp import dgp

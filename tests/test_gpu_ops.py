@@ -614,3 +614,35 @@ def test_linkgp_sexp_mfma_equals_direct_across_chunks(eng):
     lmr, lvr = O.link_gp_predict(mm[sl], vv[sl], z[sl], X[:, :Dw], X[:, Dw:], st['Rinv'], st['Rinv_y'], 1.7, length, 1e-3, 'sexp')
     close(npy(m2)[sl], lmr, rtol=1e-8, atol=1e-10)
     close(npy(v2)[sl], lvr, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize('name,n,Dz', [('sexp', 70, 1), ('matern2.5', 131, 2), ('matern2.5', 64, 0)])
+def test_linkgp_loo_equals_oracle_refit(eng, name, n, Dz):
+    """dgpamd_linkgp_loo: test point t conditioned on all training points but drop[t] (arbitrary indices, as the
+    nearest latent of a deeper layer need not be the point itself) against the oracle's link_gp with the statistics
+    refitted on the n-1 remaining points."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(12)
+    M, Dw = 40, 2
+    X = rng.uniform(size=(n, Dw + Dz))
+    y = rng.normal(size=n)
+    length = rng.uniform(0.4, 1.2, size=Dw + Dz)
+    nug = 1e-2
+    st = O.compute_stats(X, y, length, nug, name, Dw)
+    mm = rng.uniform(-0.2, 1.2, size=(M, Dw))
+    vv = 10.0 ** rng.uniform(-5, -1, size=(M, Dw))
+    vv[3] = 0.0
+    z = rng.uniform(size=(M, Dz)) if Dz else None
+    drop = rng.integers(0, n, size=M).astype(np.int32)
+    drop[0], drop[1] = 0, n - 1
+    m1, v1 = eng.linkgp_predict(name, eng.tensor(mm), eng.tensor(vv), eng.tensor(z) if Dz else None, eng.tensor(X[:, :Dw]),
+                                eng.tensor(X[:, Dw:]) if Dz else None, length, eng.tensor(st['Rinv']), n,
+                                eng.tensor(st['Rinv_y']), 1.3, nug, drop=eng.tensor(drop, dtype=__import__("torch").int32))
+    m1, v1 = npy(m1), npy(v1)
+    for t in range(M):
+        keep = np.delete(np.arange(n), drop[t])
+        s2 = O.compute_stats(X[keep], y[keep], length, nug, name, Dw)
+        mr, vr = O.link_gp_predict(mm[t:t + 1], vv[t:t + 1], z[t:t + 1] if Dz else None, X[keep, :Dw],
+                                   X[keep, Dw:] if Dz else None, s2['Rinv'], s2['Rinv_y'], 1.3, length, nug, name)
+        close(m1[t], mr[0], rtol=1e-8, atol=1e-10)
+        close(v1[t], vr[0], rtol=1e-6, atol=1e-9)
