@@ -481,7 +481,11 @@ class dgp:
                 self.N = N0
                 self.reinit_all_layer(reset_lengthscale=True, row=self.N)
 
-    ptrain = train   # nodes are already optimised concurrently (dgp.py:1414-1472 used a process pool)
+    def ptrain(self, N=500, ess_burn=10, disable=False, core_num=None):
+        """dgp.py:1414-1472 optimised the nodes of a layer in a process pool; here they already run concurrently on the
+        device (`core_num` is accepted and unused)."""
+        return self.train(N=N, ess_burn=ess_burn, disable=disable)
+
 
     def _set_final_output(self, nd, k):
         """Observed output of final-layer node k from self.Y (site means / weights with replicates, dgp.py:1344-1356)."""
@@ -672,6 +676,32 @@ class dgp:
                     nd.compute_cl()
             if self.vecch:
                 self._layer_ord_nn(layer)
+
+    update_all_layer_larger = _update_all_layer_larger      # the reference's names (dgp.py:933,1014)
+    update_all_layer_smaller = _update_all_layer_smaller
+
+    def plot(self, layer_no, ker_no, width=4., height=1., ticksize=5., labelsize=8., hspace=0.1):
+        """Trace plots of the parameters (variance, lengthscales, nugget) of GP node ker_no of layer layer_no, both
+        counted from one (dgp.py:1543-1572)."""
+        nd = self.all_layer[layer_no - 1][ker_no - 1]
+        if nd.type != 'gp':
+            print('There is nothing to plot for a likelihood node, please choose a GP node instead.')
+            return
+        import matplotlib.pyplot as plt
+        n_para = nd.para_path.shape[1]
+        labels = [r'$\sigma^2$'] + [r'$\gamma_{%i}$' % p for p in range(1, n_para - 1)] + [r'$\eta$']
+        fig, axes = plt.subplots(n_para, figsize=(width, n_para * height), dpi=100, sharex=True)
+        fig.tight_layout()
+        fig.subplots_adjust(hspace=hspace)
+        for ax, trace, lab in zip(np.atleast_1d(axes), nd.para_path.T, labels):
+            ax.plot(trace)
+            ax.tick_params(axis='both', which='major', labelsize=ticksize)
+            ax.set_ylabel(lab, fontsize=labelsize)
+        plt.show()
+
+    def change_init_scale(self):
+        """dgp.py:1575-1586 under its reference name."""
+        return self._init_scale()
 
     def estimate(self, burnin=None):
         """Point estimates = mean of para_path[burnin:], burnin default int(0.75 N) (dgp.py:1517-1541)."""

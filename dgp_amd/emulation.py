@@ -17,6 +17,7 @@ Multi-GPU: with torch.distributed initialised, each rank draws its share of the 
 imputations from its own chain (own burn-in) and one all-reduce(sum) of the two
 moment arrays precedes the finalisation (RCCL over xGMI on the GPU box).
 """
+import contextlib
 import copy
 
 import numpy as np
@@ -441,7 +442,23 @@ class emulator:
             return cat.prediction(s1.cpu().numpy(), s2.cpu().numpy())
         return s1.cpu().numpy(), s2.cpu().numpy()
 
-    ppredict = predict   # test points / imputations already run in parallel on the device (emulation.py:578-629)
+    def ppredict(self, x, method='mean_var', full_layer=False, sample_size=50, m=50, chunk_num=None, core_num=None):
+        """emulation.py:578-629 split x over a process pool; test points and imputations already run in parallel on the
+        device (`chunk_num` / `core_num` are accepted and unused)."""
+        return self.predict(x, method=method, full_layer=full_layer, sample_size=sample_size, m=m)
+
+    @contextlib.contextmanager
+    def change_vecch_state(self):
+        """Leave-one-out state of the Vecchia prediction branches (emulation.py:90-108): within the context every GP
+        node drops the nearest of its conditioning points."""
+        gps = [nd for layer in self.all_layer for nd in layer if nd.type == 'gp']
+        for nd in gps:
+            nd.loo_state = True
+        try:
+            yield
+        finally:
+            for nd in gps:
+                nd.loo_state = False
 
     def loo(self, X, method=None, sample_size=50, m=30):
         """Leave-one-out cross validation at the training inputs X (emulation.py:109-143): every GP node conditions on
@@ -459,19 +476,15 @@ class emulator:
             per_layer = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in self._layer_moments_loo(X)]
             res = self._predict_vecchia(X, False, m, True, method, sample_size, per_layer=per_layer)
         else:
-            gps = [nd for layer in self.all_layer for nd in layer if nd.type == 'gp']
-            for nd in gps:
-                nd.loo_state = True
-            try:
+            with self.change_vecch_state():
                 res = self._predict_vecchia(X, False, m + 1, True, method, sample_size)
-            finally:
-                for nd in gps:
-                    nd.loo_state = False
         if isrep:
             res = type(res)(item[np.asarray(indices).reshape(-1), :] for item in res)
         return res
 
-    ploo = loo
+    def ploo(self, X, method=None, sample_size=50, m=30, core_num=None):
+        """emulation.py:146-168 (`core_num` is accepted and unused)."""
+        return self.loo(X, method=method, sample_size=sample_size, m=m)
 
     def metric(self, x_cand, method='ALM', obj=None, nugget_s=1., m=50, score_only=False):
         """Sequential-design criterion at the rows of x_cand (emulation.py:323-420).  ALM (the predictive variance)
@@ -579,4 +592,6 @@ class emulator:
         d = torch.diagonal(Ainv)[:n]
         return (float(nd.scale[0]) / d).cpu().numpy()
 
-    pmetric = metric
+    def pmetric(self, x_cand, method='ALM', obj=None, nugget_s=1., m=50, score_only=False, chunk_num=None, core_num=None):
+        """emulation.py:170-321 (`chunk_num` / `core_num` are accepted and unused)."""
+        return self.metric(x_cand, method=method, obj=obj, nugget_s=nugget_s, m=m, score_only=score_only)

@@ -146,7 +146,9 @@ class gp:
         idx = np.argmax(score, axis=0)
         return idx, score[idx, 0]
 
-    pmetric = metric
+    def pmetric(self, x_cand, method='MICE', nugget_s=1., m=50, score_only=False, chunk_num=None, core_num=None):
+        """gp.py:224-290 (`chunk_num` / `core_num` are accepted and unused: the candidates run in parallel on the device)."""
+        return self.metric(x_cand, method=method, nugget_s=nugget_s, m=m, score_only=score_only)
 
     def train(self):
         """One L-BFGS-B fit of the hyper-parameters (gp.py:211-216)."""
@@ -174,7 +176,9 @@ class gp:
             return np.random.normal(mu, np.sqrt(s2), size=(sample_size, len(x))).T
         raise Exception("method must be 'mean_var' or 'sampling'.")
 
-    ppredict = predict
+    def ppredict(self, x, method='mean_var', sample_size=50, m=50, chunk_num=None, core_num=None):
+        """gp.py:373-410 (`chunk_num` / `core_num` are accepted and unused)."""
+        return self.predict(x, method=method, sample_size=sample_size, m=m)
 
     def loo(self, method='mean_var', sample_size=50, m=30):
         """Leave-one-out predictions at the training inputs (gp.py:326-371).  Dense mode: the closed form on the
@@ -210,4 +214,5 @@ class gp:
             return np.random.normal(mu.flatten(), np.sqrt(s2.flatten()), size=(sample_size, len(mu))).T
         raise Exception("method must be 'mean_var' or 'sampling'.")
 
-    ploo = loo
+    def ploo(self, method='mean_var', sample_size=50, m=30, core_num=None):
+        return self.loo(method=method, sample_size=sample_size, m=m)

@@ -145,6 +145,11 @@ class kernel:
         rsq = 1 - resid / (len(self.input) * np.var(self.input, axis=0))
         self.R2 = np.atleast_2d(rsq) if overwritten else np.vstack((self.R2, rsq))
 
+    def gfod(self, x):
+        """Derivative of the gamma / inverse-gamma log prior with respect to log x (kernel_class.py:361-365)."""
+        c = self.prior_coef
+        return c[0] - c[1] * x if self.prior_name == 'ga' else -c[0] + c[1] / x
+
     def log_prior(self):
         """kernel_class.py:367-381."""
         c = self.prior_coef

@@ -1,6 +1,7 @@
 """Linked (D)GP emulation of a feed-forward system of emulators -- mirror of dgpsi.container / dgpsi.lgp
 (linkgp.py:12-608), mean/variance prediction.  Pure orchestration over kernel.gp_prediction /
 linkgp_prediction / linkgp_prediction_full; aggregation over imputations as emulation.py:846-847."""
+import contextlib
 import copy
 
 import numpy as np
@@ -257,4 +258,11 @@ class lgp:
                for k in range(len(self.all_layer[-1]))]
         return [o[0] for o in out], [o[1] for o in out]
 
-    ppredict = predict
+    @contextlib.contextmanager
+    def temp_all_layer(self):
+        """A deep copy of the linked structure to work on (linkgp.py:172-178)."""
+        yield copy.deepcopy(self.all_layer)
+
+    def ppredict(self, x, method='mean_var', full_layer=False, sample_size=50, m=50, chunk_num=None, core_num=None):
+        """linkgp.py:214-262 (`chunk_num` / `core_num` are accepted and unused)."""
+        return self.predict(x, method=method, full_layer=full_layer, sample_size=sample_size, m=m)

@@ -19,6 +19,15 @@ class path:
                 if nd.connect is not None:
                     nd.global_input = self.X[:, nd.connect].copy()
 
+    @staticmethod
+    def k_matrix(X, length, name):
+        """Correlation matrix with a unit diagonal as a numpy array (synthetic.py:46-60); `generate` assembles its
+        matrices itself and does not call this."""
+        e = default_engine(None)
+        n = len(X)
+        A = e.kmatrix(name, e.tensor(np.asarray(X, float)), None, None, np.atleast_1d(np.asarray(length, float)), 0.0, full=True)
+        return A[:n, :n].cpu().numpy()
+
     def generate(self, N):
         """N sample paths at the rows of X: array (D_out, N, n)."""
         e = self.engine

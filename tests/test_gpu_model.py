@@ -888,3 +888,39 @@ def test_reference_prior_in_the_ess_target(eng):
     close(ll[0], float(np.ravel(base)[0]) + nd.prior_coef[0] * np.log(t) - nd.prior_coef[1] * t, rtol=1e-9)
     model.train(N=3, ess_burn=2, disable=True)
     assert np.all(np.isfinite(nd.para_path)) and nd.para_path.shape[0] == 4
+
+
+def test_small_api_pieces(eng, tmp_path):
+    """path.k_matrix, kernel.gfod, dgp.plot (headless), the p* entry points with their pool arguments, lgp.temp_all_layer."""
+    import matplotlib
+    matplotlib.use('Agg')
+    from dgp_amd import dgp, kernel, combine, emulator, path, gp
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(3)
+    X = rng.uniform(size=(30, 2))
+    for name in ('sexp', 'matern2.5'):
+        K = path.k_matrix(X, np.array([0.4, 0.9]), name)
+        Kr = O.corr_matrix(X, np.array([0.4, 0.9]), name)
+        np.fill_diagonal(Kr, 1.0)
+        close(K, Kr, rtol=1e-12, atol=1e-14)
+    k = kernel(length=np.array([0.5]), name='sexp', prior_name='ga', prior_coef=np.array([1.6, 0.3]))
+    close(k.gfod(np.array([2.0])), [k.prior_coef[0] - k.prior_coef[1] * 2.0])
+    k = kernel(length=np.array([0.5]), name='sexp', prior_name='inv_ga', prior_coef=np.array([1.6, 0.3]))
+    close(k.gfod(np.array([2.0])), [-k.prior_coef[0] + k.prior_coef[1] / 2.0])
+    Y = np.sin(5 * X[:, [0]]) + X[:, [1]]
+    model = dgp(X, Y, combine([kernel(length=np.array([1.0]), name='sexp') for _ in range(2)],
+                              [kernel(length=np.array([1.0]), name='sexp', scale_est=True)]), seed=1)
+    model.ptrain(N=3, ess_burn=2, disable=True, core_num=2)
+    model.plot(1, 1)
+    model.plot(2, 1, width=3., height=0.8)
+    emu = emulator(model.estimate(), N=2)
+    xt = rng.uniform(size=(7, 2))
+    a = emu.ppredict(xt, chunk_num=3, core_num=2)
+    b = emu.predict(xt)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(emu.ploo(X, core_num=2)[0], emu.loo(X)[0])
+    assert np.array_equal(emu.pmetric(xt, method='ALM', score_only=True, chunk_num=2, core_num=2), emu.metric(xt, method='ALM', score_only=True))
+    g = gp(X, Y, kernel(length=np.array([0.5, 0.5]), name='matern2.5', scale_est=True, nugget_est=True))
+    g.train()
+    assert np.array_equal(g.ppredict(xt, chunk_num=2, core_num=2)[0], g.predict(xt)[0])
+    assert np.array_equal(g.pmetric(xt, method='MICE', score_only=True, core_num=2), g.metric(xt, method='MICE', score_only=True))

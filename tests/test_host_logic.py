@@ -305,3 +305,34 @@ def test_categorical_likelihood_matches_reference(golden):
             assert int(g[pre + 'K']) == K
             obj.all_layer, obj.n_layer = [[None] * (1 if K == 2 else K), [lik]], 2
             np.testing.assert_allclose(obj._categorical_warm_start(0), g[pre + 'latent'], rtol=1e-13)
+
+
+def test_public_api_accepts_the_reference_calls():
+    """Every public method of the classes dgpsi exports (names and parameter names read from the reference's sources by
+    oracle/gen_api_signatures.py -> tests/golden/api_signatures.json) exists here and accepts the same parameters.
+    The only absences are numerical helpers whose work moved into device kernels."""
+    import inspect
+    import json
+    import dgp_amd
+    api = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'api_signatures.json')))
+    moved_to_device = {('Hetero', 'post_het1'), ('Hetero', 'post_het2'), ('Hetero', 'post_het_vecch'),
+                       ('Hetero', 'posterior_vecch'),                    # -> Engine.post_het / vecchia_post_het
+                       ('emulator', 'predict_mice'), ('emulator', 'predict_mice_2layer_likelihood'),
+                       ('emulator', 'predict_vigf'), ('emulator', 'predict_vigf_2layer_likelihood')}   # -> the layer walk
+    missing, bad = set(), []
+    for cname, meths in api['classes'].items():
+        cls = getattr(dgp_amd, cname)
+        for m, ps in meths.items():
+            f = getattr(cls, m, None)
+            if f is None:
+                missing.add((cname, m))
+                continue
+            sig = inspect.signature(f).parameters
+            if any(p.kind == p.VAR_KEYWORD for p in sig.values()):
+                continue
+            bad += [(cname, m, p) for p in ps if p not in sig]
+    for fn, ps in api['functions'].items():
+        sig = inspect.signature(getattr(dgp_amd, fn)).parameters
+        bad += [(fn, p) for p in ps if p not in sig]
+    assert missing == moved_to_device, missing ^ moved_to_device
+    assert not bad, bad
