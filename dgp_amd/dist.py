@@ -54,5 +54,9 @@ def allreduce_max_scalar(value, device=None):
 
 
 def barrier():
-    if is_active():
+    if not is_active():
+        return
+    if td.get_backend() == 'nccl':   # name the device: RCCL otherwise guesses it from the rank
+        td.barrier(device_ids=[torch.cuda.current_device()])
+    else:
         td.barrier()

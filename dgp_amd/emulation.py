@@ -152,9 +152,11 @@ class emulator:
                     _, info = e.potrf(n, A, work=work)
                     r = Y.shape[0]
                     e.potri(n, A, Ainv, r, work)
-                    bad = int(info.cpu().numpy()[0])
-                    if bad:
-                        raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite' % bad)
+                    if int(info.cpu().numpy()[0]):   # not numerically PD: pseudo-inverse (kernel_class.py:749-751)
+                        K = e.kmatrix(nd.name, Xl, None, Xg, nd.length, nd.nugget[0], W=W, full=True)
+                        Ainv.zero_()
+                        Ainv[:n, :n] = e.pinvh(K)
+                        return Ainv, (Y @ Ainv[:n, :n]).contiguous()
                     return Ainv, (-Ainv[n:n + r, :n]).contiguous()
 
                 if l == 0:

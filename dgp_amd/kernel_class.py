@@ -412,8 +412,8 @@ class kernel:
 
     # ----------------------------------------------------------------- prediction
     def compute_stats(self):
-        """R^-1 and R^-1 y for prediction (kernel_class.py:735-764), device resident.
-        The reference's pinvh fallback for a non-PD R is not reproduced: LinAlgError is raised."""
+        """R^-1 and R^-1 y for prediction (kernel_class.py:735-764), device resident.  When R is not numerically
+        positive definite the pseudo-inverse takes over, as in the reference (:749-751)."""
         e, s = self.engine, self._stage()
         n = len(self.output)
         Np = e.padded_dim(n)
@@ -423,8 +423,13 @@ class kernel:
         work = e.potrf_workspace(n, 1)
         _, info = e.potrf(n, A, work=work)
         e.potri(n, A, Ainv, 1, work)
-        self._raise_if_not_pd(info.cpu().numpy()[0])
-        ry = (-Ainv[n, :n]).contiguous()
+        if int(info.cpu().numpy()[0]):
+            K = e.kmatrix(self.name, s['Xl'], None, s['Xg'], self.length, self.nugget[0], W=s['W'], full=True)
+            Ainv.zero_()
+            Ainv[:n, :n] = e.pinvh(K)
+            ry = e.gemv(Ainv[:n, :n], s['y'])
+        else:
+            ry = (-Ainv[n, :n]).contiguous()
         self._stats = dict(Rinv=Ainv, ld=Np, ry=ry, W=e.tensor(self.input),
                            Wg=None if self.global_input is None else e.tensor(self.global_input),
                            Wall=e.tensor(self._X()), n=n)

@@ -265,6 +265,16 @@ class Engine:
         self._chk(lib.dgpamd_gemv(self.h, rows, cols, _dp(A), A.stride(0), _dp(x), _dp(out)))
         return out
 
+    def pinvh(self, K):
+        """Pseudo-inverse of the symmetric matrix K (n x n device tensor) with scipy.linalg.pinvh's rule: eigenvalues
+        of magnitude <= n eps max|eigenvalue| are dropped.  The rare fallback of `compute_stats` when R is not
+        numerically positive definite (kernel_class.py:745-751); the eigen-decomposition is the vendor solver's
+        (hipSOLVER through torch.linalg.eigh) and runs on the device like everything else."""
+        s, u = torch.linalg.eigh(K)
+        cut = s.abs().max() * K.shape[0] * torch.finfo(K.dtype).eps
+        inv = torch.where(s.abs() > cut, 1.0 / s, torch.zeros_like(s))
+        return (u * inv) @ u.T
+
     def post_het(self, K, scale, gamma_eff, y_eff, sd):
         """One draw of the mean latent of a heteroskedastic Gaussian likelihood from its exact conditional posterior
         (Hetero.post_het1 / post_het2, likelihood_class.py:184-243) with v = scale K:

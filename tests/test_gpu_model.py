@@ -924,3 +924,37 @@ def test_small_api_pieces(eng, tmp_path):
     g.train()
     assert np.array_equal(g.ppredict(xt, chunk_num=2, core_num=2)[0], g.predict(xt)[0])
     assert np.array_equal(g.pmetric(xt, method='MICE', score_only=True, core_num=2), g.metric(xt, method='MICE', score_only=True))
+
+
+def test_compute_stats_falls_back_to_the_pseudo_inverse(eng):
+    """kernel.compute_stats on an indefinite R (a repeated input row and a slightly negative nugget, so that no rounding
+    decides which branch runs): the factorisation fails and the pseudo-inverse takes over as in kernel_class.py:745-751; R^-1, R^-1 y and the predictions agree with scipy's pinvh
+    on the oracle's R.  The emulator's per-imputation statistics take the same route."""
+    from scipy.linalg import pinvh
+    from dgp_amd import kernel, emulator
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(9)
+    n = 40
+    X = rng.uniform(size=(n, 2))
+    X[17] = X[4]
+    y = np.sin(4 * X[:, 0]) + X[:, 1]
+    y[17] = y[4]
+    nd = kernel(length=np.array([0.6, 0.9]), name='matern2.5', nugget=-1e-3, scale=1.7)
+    nd.input, nd.output, nd.global_input, nd.engine = X, y[:, None], None, eng
+    nd.input_dim, nd.D = np.arange(2), 2
+    nd.compute_stats()
+    R = O.corr_matrix(X, nd.length, 'matern2.5')
+    R[np.arange(n), np.arange(n)] = 1.0 - 1e-3
+    with pytest.raises(np.linalg.LinAlgError):
+        np.linalg.cholesky(R)
+    Rinv = pinvh(R, check_finite=False)
+    close(nd.Rinv, Rinv, rtol=1e-7, atol=1e-7 * np.abs(Rinv).max())
+    close(nd.Rinv_y, Rinv @ y, rtol=1e-7, atol=1e-7 * np.abs(Rinv @ y).max())
+    xt = rng.uniform(size=(9, 2))
+    m, v = nd.gp_prediction(xt, None)
+    mr, vr = O.gp_predict(xt, X, Rinv, Rinv @ y, 1.7, nd.length, -1e-3, 'matern2.5')
+    close(m, mr, rtol=1e-6, atol=1e-8)
+    close(v, vr, rtol=1e-5, atol=1e-7)
+    emu = emulator([[nd]], N=1)
+    mu, var = emu.predict(xt)
+    close(mu[:, 0], mr, rtol=1e-6, atol=1e-8)
