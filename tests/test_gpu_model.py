@@ -958,3 +958,48 @@ def test_compute_stats_falls_back_to_the_pseudo_inverse(eng):
     emu = emulator([[nd]], N=1)
     mu, var = emu.predict(xt)
     close(mu[:, 0], mr, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize('block', [True, False])
+def test_ess_stationary_distribution_is_the_analytic_posterior(eng, block):
+    """long-run mean and covariance of a one-node latent layer under a Gaussian likelihood plugged in
+    through the likelihood-node protocol (llik on .input, likelihood_class.py:30-90) against the conjugate posterior
+    N(K (K + s^2 I)^-1 y,  K - K (K + s^2 I)^-1 K).  Statistical tolerance: 4000 kept sweeps, thinned by 5."""
+    from dgp_amd import kernel
+    from dgp_amd.imputation import imputer, DrawStream
+    from oracle import dgp_oracle as O
+
+    class Gauss:
+        type, name, rep, exact_post_idx = 'likelihood', 'Gauss', None, None
+
+        def __init__(self, s2):
+            self.s2, self.input_dim = s2, np.array([0])
+
+        def llik(self):
+            return -0.5 * np.sum((self.output - self.input) ** 2) / self.s2
+
+    rng = np.random.default_rng(4)
+    n, s2, scale = 6, 0.3, 1.4
+    X = np.sort(rng.uniform(size=(n, 1)), 0)
+    y = np.sin(5 * X) + rng.normal(size=(n, 1)) * np.sqrt(s2)
+    nd = kernel(length=np.array([0.4]), scale=scale, nugget=1e-8, name='matern2.5', input_dim=np.array([0]), engine=eng)
+    nd.input, nd.output, nd.global_input, nd.vecch, nd.D = X, np.zeros((n, 1)), None, False, 1
+    lik = Gauss(s2)
+    lik.input, lik.output = nd.output.copy(), y
+    imp = imputer([[nd], [lik]], block=block, draws=DrawStream(seed=11), engine=eng, batch=4)
+    imp.sample(burnin=200)
+    keep = []
+    for _ in range(4000):
+        imp.sample(burnin=5)
+        keep.append(nd.output[:, 0].copy())
+    F = np.asarray(keep)
+    K = scale * O.corr_matrix(X, nd.length, 'matern2.5')
+    K[np.arange(n), np.arange(n)] = scale * (1.0 + 1e-8)
+    G = K @ np.linalg.inv(K + s2 * np.eye(n))
+    mean, cov = (G @ y)[:, 0], K - G @ K
+    sd = np.sqrt(np.diag(cov))
+    # Monte-Carlo error of a mean of 4000 (mildly autocorrelated) draws ~ sd / sqrt(2000); 5 sigma
+    assert np.all(np.abs(F.mean(0) - mean) < 5 * sd / np.sqrt(2000)), (F.mean(0), mean)
+    emp = np.cov(F.T)
+    assert np.all(np.abs(emp - cov) < 0.12 * np.sqrt(np.outer(np.diag(cov), np.diag(cov)))), (emp, cov)
+    assert np.allclose(lik.input[:, 0], nd.output[:, 0])
