@@ -44,6 +44,30 @@ def allreduce_sum(*tensors):
         td.all_reduce(t, op=td.ReduceOp.SUM)
 
 
+def row_range(total, r, w):
+    """Rows [lo, hi) of `total` independent rows (test points) owned by rank r of w: equal chunks, the last ones shorter."""
+    chunk = -(-total // w)
+    return min(total, r * chunk), min(total, (r + 1) * chunk)
+
+
+def allgather_rows(local, total, device=None):
+    """Concatenate over ranks the row blocks of `row_range` (numpy array, rows first): every rank gets all `total` rows.
+    Blocks are padded to the common chunk so that one equal-size all-gather does it (emulation.py:607-613 concatenated
+    the pool's chunks the same way)."""
+    import numpy as np
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if not is_active():
+        return local
+    w = world()
+    chunk = -(-total // w)
+    pad = np.zeros((chunk,) + local.shape[1:])
+    pad[:len(local)] = local
+    t = torch.from_numpy(pad).to(device if device is not None else 'cpu')
+    parts = [torch.empty_like(t) for _ in range(w)]
+    td.all_gather(parts, t)
+    return np.concatenate([p.cpu().numpy() for p in parts], 0)[:total]
+
+
 def allreduce_max_scalar(value, device=None):
     """max over ranks of a python float (bench.py: the slowest rank's time)."""
     if not is_active():

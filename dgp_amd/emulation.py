@@ -30,7 +30,10 @@ from . import dist as ddist
 
 class emulator:
     """Args as dgpsi.emulator (emulation.py:24): all_layer (from dgp.estimate()), N, block;
-    plus `seed`, `device` and `shard` (None: shard iff torch.distributed is initialised)."""
+    plus `seed`, `device` and `shard`: None / True / False -- the N imputations are split over the ranks of an
+    initialised torch.distributed group (None: iff there is one) and predictions cost one all-reduce of the two moment
+    sums; 'points' -- every rank holds all N imputations (same seed, same chain) and predict() splits the rows of x over
+    the ranks instead, one all-gather of the results (what ppredict's pool did, emulation.py:578-629)."""
 
     def __init__(self, all_layer, N=10, block=True, seed=None, device=None, shard=None):
         self.all_layer = all_layer
@@ -42,9 +45,14 @@ class emulator:
                 if nd.type == 'gp':
                     nd.engine = self.engine
         self.N_total = int(N)
-        self.shard = ddist.is_active() if shard is None else bool(shard)
+        self.shard_points = shard == 'points' and ddist.is_active()
+        self.shard = False if shard == 'points' else (ddist.is_active() if shard is None else bool(shard))
         rank, world = (ddist.rank(), ddist.world()) if self.shard else (0, 1)
         self.N = ddist.share(self.N_total, rank, world)
+        if self.shard_points and seed is None:      # all ranks must draw the same imputations: rank 0's entropy for everyone
+            box = [np.random.SeedSequence().entropy]
+            ddist.td.broadcast_object_list(box, src=0)
+            seed = box[0]
         ss = np.random.SeedSequence(seed)
         self.imp = imputer(all_layer, block, draws=DrawStream(ss.spawn(world)[rank]), engine=self.engine)
         self._sample_rng = np.random.default_rng(ss.spawn(world)[rank])   # predict(method='sampling')
@@ -327,6 +335,8 @@ class emulator:
             raise Exception('The testing input has to be a numpy 2d-array')
         if method not in ('mean_var', 'sampling'):
             raise Exception("method must be either 'mean_var' or 'sampling'.")
+        if getattr(self, 'shard_points', False) and not getattr(self, '_in_points', False):
+            return self._predict_points(x, method, full_layer, sample_size, m, aggregation)
         if self.vecch:
             return self._predict_vecchia(x, full_layer, m, aggregation, method, sample_size)
         e = self.engine
@@ -408,6 +418,24 @@ class emulator:
         lik = [ghdiag(self.all_layer[-1][0].pllik, pm[s][indices, :], pv[s][indices, :], y) for s in range(self.N)]
         nl = -np.log(np.mean(lik, axis=0)).flatten()
         return np.mean(nl), nl
+
+    def _predict_points(self, x, method, full_layer, sample_size, m, aggregation):
+        """shard='points': this rank predicts its block of rows of x with all N imputations; the blocks are gathered."""
+        if method != 'mean_var' or not aggregation:
+            raise NotImplementedError("shard='points' covers predict(method='mean_var') with aggregation")
+        M = len(x)
+        lo, hi = ddist.row_range(M, ddist.rank(), ddist.world())
+        xs = x[lo:hi] if hi > lo else x[:1]         # (a rank without rows still takes part in the gather)
+        self._in_points = True
+        try:
+            mu, var = self.predict(xs, method, full_layer, sample_size, m, True)
+        finally:
+            self._in_points = False
+        dev = self.engine.device if ddist.td.get_backend() == 'nccl' else None
+        g = lambda a: ddist.allgather_rows(a[:hi - lo], M, dev)
+        if full_layer:
+            return [g(a) for a in mu], [g(a) for a in var]
+        return g(mu), g(var)
 
     def _predict_vecchia(self, x, full_layer, m, aggregation, method='mean_var', sample_size=50, per_layer=None):
         """Vecchia mode: no stored statistics; every node conditions on its pred_m nearest neighbours

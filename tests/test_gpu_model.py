@@ -1003,3 +1003,57 @@ def test_ess_stationary_distribution_is_the_analytic_posterior(eng, block):
     emp = np.cov(F.T)
     assert np.all(np.abs(emp - cov) < 0.12 * np.sqrt(np.outer(np.diag(cov), np.diag(cov)))), (emp, cov)
     assert np.allclose(lik.input[:, 0], nd.output[:, 0])
+
+
+def test_emulator_points_sharding_two_ranks(tmp_path):
+    """emulator(shard='points') on two processes (gloo rendezvous, both on this GPU): every rank holds the same
+    imputations and predicts its block of test points; the gathered result equals the single-process prediction, and
+    the imputation-sharded emulator (shard=True) of the same run reduces to one consistent answer on both ranks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'worker.py'
+    script.write_text("""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from dgp_amd import dgp, kernel, combine, emulator, dist as dd
+dd.init_from_env('gloo')
+rng = np.random.default_rng(1)
+X = rng.uniform(size=(60, 2)); Y = np.sin(5 * X[:, [0]]) + X[:, [1]] ** 2
+layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(2)],
+                 [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(2))])
+model = dgp(X, Y, layers, seed=5)
+model.train(N=4, ess_burn=3, disable=True)
+est = model.estimate()
+xt = rng.uniform(size=(37, 2))
+import copy
+ref = emulator(copy.deepcopy(est), N=4, seed=9, shard=False).predict(xt)
+emu = emulator(copy.deepcopy(est), N=4, seed=9, shard='points')
+assert emu.N == 4 and emu.shard_points
+mu, var = emu.predict(xt)
+np.testing.assert_allclose(mu, ref[0], rtol=1e-10, atol=1e-12)
+np.testing.assert_allclose(var, ref[1], rtol=1e-9, atol=1e-13)
+ml, vl = emu.predict(xt, full_layer=True)
+np.testing.assert_allclose(ml[-1], ref[0], rtol=1e-10, atol=1e-12)
+assert ml[0].shape == (37, 2)
+one = emu.predict(xt[:1])                      # fewer rows than ranks
+np.testing.assert_allclose(one[0], ref[0][:1], rtol=1e-10, atol=1e-12)
+sh = emulator(copy.deepcopy(est), N=4, seed=9)  # imputations sharded: 2 per rank, one all-reduce
+assert sh.shard and sh.N == 2
+ms, vs = sh.predict(xt)
+box = [ms if dd.rank() == 0 else None]
+dd.td.broadcast_object_list(box, src=0)
+assert np.array_equal(box[0], ms)               # both ranks hold the reduced moments
+assert np.sqrt(np.mean((ms - ref[0]) ** 2)) < 0.1
+dd.barrier()
+print('rank', dd.rank(), 'ok')
+""" % root)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK='0'),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert 'ok' in o

@@ -86,6 +86,9 @@ def test_share_partitions_exactly():
         for w in (1, 2, 3, 8):
             parts = [share(total, r, w) for r in range(w)]
             assert sum(parts) == total and max(parts) - min(parts) <= 1
+            from dgp_amd.dist import row_range
+            rows = [row_range(total, r, w) for r in range(w)]
+            assert rows[0][0] == 0 and rows[-1][1] == total and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
 
 
 def test_gloo_two_rank_moment_reduction(tmp_path):
@@ -111,6 +114,12 @@ dd.allreduce_sum(s1, s2)
 mu = s1 / S; var = s2 / S - mu ** 2
 t = dd.allreduce_max_scalar(float(dd.rank()))
 assert t == 1.0
+# test points sharded instead (emulator(shard='points')): row blocks of unequal size gathered on every rank
+for M in (7, 8, 1):
+    full = np.arange(M * 3, dtype=float).reshape(M, 3)
+    lo, hi = dd.row_range(M, dd.rank(), 2)
+    got = dd.allgather_rows(full[lo:hi], M)
+    assert got.shape == (M, 3) and np.array_equal(got, full)
 np.testing.assert_allclose(mu.numpy(), g['mu'], rtol=1e-12, atol=1e-14)
 np.testing.assert_allclose(var.numpy(), g['var'], rtol=1e-9, atol=1e-14)
 dd.barrier()
