@@ -233,7 +233,8 @@ class emulator:
 
     def _layer_moments_loo(self, x):
         """Leave-one-out layer walk of a dense emulator (emulation.py:90-143 with vecch False: every node conditions
-        on all training points but the one nearest to its input, kernel_class.py:610-611,655-656).  Nothing is
+        on all training points but its own -- test row k leaves out training row k at every layer, which is what
+        get_pred_nn's all-points shortcut (vecchia.py:23-26) followed by kernel_class.py:610-611,655-656 does).  Nothing is
         refactorised: first-layer nodes use the block-inverse identities  mean = y_d - (R^-1 y)_d / (R^-1)_dd,
         var = scale (1 / (R^-1)_dd + nugget (1 - W_d));  linked nodes go through dgpamd_linkgp_loo, which applies the
         rank-one downdate of R^-1 inside the pair weights.  Returns device (S, M, K) pairs per layer."""
@@ -260,13 +261,12 @@ class emulator:
                 st = self._stats[(l, k)]
                 n = st['n']
                 z = None if nd.connect is None else xd[:, torch.as_tensor(nd.connect, device=xd.device)].contiguous()
-                length = e.tensor(np.broadcast_to(np.asarray(nd.length, float), (len(nd.input_dim) + (0 if z is None else z.shape[1]),)))
                 if l == 0:
                     xin = xd[:, torch.as_tensor(nd.input_dim, device=xd.device)]
                     xin = (xin if z is None else torch.cat((xin, z), 1)).contiguous()
-                    d = e.nn_query((xin / length).contiguous(), (st['Wall'] / length).contiguous(), 1)[:, 0]
-                    if not torch.equal(st['Wall'][d], xin):
-                        raise Exception('loo: the rows of X must be training input positions of the emulator.')
+                    if M != n or not torch.equal(st['Wall'], xin):
+                        raise Exception('loo: the rows of X must be the training input positions of the emulator, in order.')
+                    d = torch.arange(n, device=xd.device)
                     rho = st['Rinv'][:n, :n].diagonal()[d]
                     wd = 1.0 if nd.rep is None else e.tensor(nd.W_diag)[d]
                     for s in range(S):
@@ -280,9 +280,7 @@ class emulator:
                     for s in range(S):
                         ps = st['per'][s]
                         ms, vs = pm[s][:, idx].contiguous(), pv[s][:, idx].contiguous()
-                        q = ms if z is None else torch.cat((ms, z), 1)
-                        w = ps['W'] if z is None else torch.cat((ps['W'], st['Wg']), 1)
-                        d = e.nn_query((q / length).contiguous(), (w / length).contiguous(), 1)[:, 0].to(torch.int32).contiguous()
+                        d = torch.arange(n, device=xd.device, dtype=torch.int32)
                         mk, vk = e.linkgp_predict(nd.name, ms, vs, z, ps['W'], st['Wg'], nd.length, ps['Rinv'], st['ld'],
                                                   ps['ry'], nd.scale[0], nd.nugget[0], drop=d)
                         mean[s, :, k], var[s, :, k] = mk, vk

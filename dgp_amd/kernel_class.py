@@ -462,8 +462,17 @@ class kernel:
         return np.stack([Xl[:, d][:, None] + Xl[:, d][None, :] for d in range(Xl.shape[1])])
 
     def _pred_nn(self, x, w):
+        """Conditioning sets of the test rows (vecchia.get_pred_nn, vecchia.py:20-40): the pred_m nearest training
+        points, nearest first -- or, when pred_m covers all n of them, the reference's shortcut: row k = k, k+1, ...
+        cyclically, no search (so that the leave-one-out walk of a dense emulator drops training point k for test
+        row k, emulation.py:90-143)."""
         e = self.engine
-        NN = e.nn_query(e.tensor(x / self.length), e.tensor(w / self.length), self.pred_m)
+        n = len(w)
+        if self.pred_m >= n:
+            import torch
+            NN = ((torch.arange(n, device=e.device)[None, :] + torch.arange(len(x), device=e.device)[:, None]) % n).contiguous()
+        else:
+            NN = e.nn_query(e.tensor(x / self.length), e.tensor(w / self.length), self.pred_m)
         if self.loo_state:
             NN = NN[:, 1:].contiguous()
         return NN

@@ -265,9 +265,9 @@ int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int D
                           const double *Wtr, const double *Wg, const double *length_h, int nlen,
                           const double *Rinv, int64_t ldr, const double *ry, double scale, double nugget,
                           double *mean, double *var, void *work);
-/* Leave-one-out form of the same prediction (emulation.py:90-143 with a dense emulator: kernel_class.py:647-664 hands
- * every test point all training points but its nearest one): drop[t] in [0, n) is the training point left out of
- * the conditioning set of test point t.  Nothing is refactorised: with u = Rinv[:, d], (R_-d)^-1 = Rinv - u u^T / u_d
+/* Leave-one-out form of the same prediction (emulation.py:90-143 with a dense emulator: vecchia.py:23-26 and
+ * kernel_class.py:647-664 hand test row k all training points but row k): drop[t] in [0, n) is the training point
+ * left out of the conditioning set of test point t (any index: the kernel does not assume drop[t] == t).  Nothing is refactorised: with u = Rinv[:, d], (R_-d)^-1 = Rinv - u u^T / u_d
  * (embedded), applied inside the pair weights.  Same workspace as dgpamd_linkgp_predict. */
 int dgpamd_linkgp_loo(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz,
                       const double *m, const double *v, const double *z,

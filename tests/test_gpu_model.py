@@ -1057,3 +1057,39 @@ print('rank', dd.rank(), 'ok')
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'ok' in o
+
+
+@pytest.mark.parametrize('lik', ['Poisson', 'Categorical'])
+def test_emulator_loo_under_a_likelihood_layer(eng, lik):
+    """Dense leave-one-out with a likelihood node on top (emulation.py:109-143, :711-716 for Categorical): the downdate
+    walk feeds the same likelihood post-processing as the reference's re-conditioning route and agrees with it."""
+    from dgp_amd import dgp, kernel, combine, emulator, Poisson, Categorical
+    rng = np.random.default_rng(6)
+    n = 50
+    X = rng.uniform(size=(n, 2))
+    # (Matern with a 1e-4 nugget: the two routes differ by rounding x cond(R) x scale, kept small here)
+    K = lambda **kw: kernel(length=np.array([1.0]), name='matern2.5', nugget=1e-4, **kw)
+    if lik == 'Poisson':
+        Y = rng.poisson(np.exp(1 + np.sin(4 * X[:, [0]]))).astype(float)
+        layers = combine([K() for _ in range(2)], [K(scale_est=True)], [Poisson()])
+    else:
+        Y = (X[:, [0]] + 0.3 * np.sin(6 * X[:, [1]]) > 0.55).astype(int)
+        layers = combine([K() for _ in range(2)], [K(scale_est=True)], [Categorical(num_classes=2)])
+    model = dgp(X, Y, layers, seed=4)
+    model.train(N=5, ess_burn=3, disable=True)
+    emu = emulator(model.estimate(), N=3, seed=2)
+    mu, var = emu.loo(X)
+    gps = [nd for layer in emu.all_layer for nd in layer if nd.type == 'gp']
+    for nd in gps:
+        nd.loo_state, nd.vecch = True, True
+    try:
+        mu_ref, var_ref = emu._predict_vecchia(X, False, n, True)
+    finally:
+        for nd in gps:
+            nd.loo_state, nd.vecch = False, False
+    assert mu.shape == mu_ref.shape and mu.shape[0] == n
+    close(mu, mu_ref, rtol=1e-4, atol=1e-6)
+    close(var, var_ref, rtol=1e-3, atol=1e-6)
+    assert np.all(np.isfinite(mu)) and np.all(var >= 0)
+    if lik == 'Categorical':
+        assert np.all(mu >= 0) and np.all(mu <= 1)
