@@ -14,268 +14,18 @@
 // doubling over block pairs) and K^-1 = L^-T L^-1.
 #include "common.hpp"
 #include "tile.hpp"
+#include "diagfac.hpp"
 
 // ----------------------------------------------------------------------------
-// diagonal block: Cholesky + inverse of the factor, in registers
+// diagonal block: Cholesky + inverse of the factor (diagfac.hpp)
 // ----------------------------------------------------------------------------
-__device__ __forceinline__ double rsqrt_f64(double d) {
-    // Goldschmidt: g -> sqrt(d), h -> 1/(2 sqrt(d)) refined in parallel from the hardware estimate (two rounds
-    // reach full f64); dependency depth 6 instead of 9 for Newton on the reciprocal alone.  The pivot chain of the
-    // factorisation is latency bound (a dependent f64 op is ~13 ns on MI355X), so depth is what counts.
-    const double y = __builtin_amdgcn_rsq(d);
-    double g = d * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    h = fma(h, r, h);
-    return h + h;
-}
-
-__device__ __forceinline__ double rcp_f64(double d) {
-    // hardware estimate (~23 bits) + two Newton rounds: depth 5
-    double x = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
-    e = fma(-d, x, 1.0);
-    return fma(x, e, x);
-}
-
-// The 64 pivots are taken FOUR at a time.  The tile and the running inverse stay in registers in the MFMA
-// accumulator layout (wave w owns rows 16w..16w+15; a[t][r] = A[16w + (lane>>4) + 4r][16t + (lane&15)]), so the
-// rank-4 trailing update of a group is ONE v_mfma_f64_16x16x4 per 16x16 tile.  The serial part is the 4x4 pivot
-// block of each group (LDL^T with Newton reciprocals: ~26 dependent f64 operations, ~13 ns each).  It is taken off
-// the update path by WAVE SPECIALISATION: wave 0 (whose rows are finished after the first four groups) runs the
-// pivot chain of group g+1 while waves 1-3 apply the update of group g (operands, MFMAs, stores).  The chain does
-// not wait for the MFMAs: its 4x4 block is (block of g+1 before the update of g, staged one iteration earlier)
-// - (rows of the panel of g)(rows)^T, recomputed from LDS.  Per group: ONE barrier; LDS holds the four raw pivot
-// columns (64x4), the four raw rows of the running inverse (4x64), the next 4x4 block and the chain's results.
-//   panel          L[:, J]  = T diag(s),   T = raw N^T      (N = unit-lower inverse of the 4x4 LDL^T factor)
-//   update         A       -= T diag(r) T^T                 (r = 1/pivot, s = 1/sqrt(pivot))
-//   inverse rows   Y[J, :]  = diag(s) N rawY,   Y[below] -= T diag(r) (N rawY)
-struct DiagShared {
-    double colraw[2][64][4];   // [ping-pong][row][v]  = A[row][j0+v]
-    double rowraw[2][64][4];   // [ping-pong][col][v]  = Y[j0+v][col]   (Y = running inverse)
-    double blk[2][4][4];       // [ping-pong][v][u]    = A[j0+4+v][j0+4+u] before the update of the current group
-    double chain[2][4][6];     // [ping-pong][pivot u] row u of the unit-lower inverse N (c0..c3), 1/pivot, pivot
-    double piv[64];
-};
-
-// LDL^T of a 4x4 block (lower part c..): unit-lower inverse N, reciprocal pivots r (0 for inactive pivots), pivots p
-__device__ __forceinline__ void pivot_chain(double c00, double c10, double c11, double c20, double c21, double c22,
-                                            double c30, double c31, double c32, double c33, int nact, int j0, int &bad,
-                                            double *out) {
-    double p0 = c00;
-    if (nact < 1) p0 = 1.0;
-    if (!(p0 > 0.0)) { if (!bad) bad = j0 + 1; p0 = 1.0; }
-    const double r0 = rcp_f64(p0);
-    const double l10 = c10 * r0, l20 = c20 * r0, l30 = c30 * r0;
-    double p1 = fma(-l10, c10, c11);
-    const double w21 = fma(-l20, c10, c21), w31 = fma(-l30, c10, c31);
-    double q2 = fma(-l20, c20, c22), w32 = fma(-l30, c20, c32), q3 = fma(-l30, c30, c33);
-    if (nact < 2) p1 = 1.0;
-    if (!(p1 > 0.0)) { if (!bad) bad = j0 + 2; p1 = 1.0; }
-    const double r1 = rcp_f64(p1);
-    const double l21 = w21 * r1, l31 = w31 * r1;
-    double p2 = fma(-l21, w21, q2);
-    w32 = fma(-l31, w21, w32);
-    q3 = fma(-l31, w31, q3);
-    if (nact < 3) p2 = 1.0;
-    if (!(p2 > 0.0)) { if (!bad) bad = j0 + 3; p2 = 1.0; }
-    const double r2 = rcp_f64(p2);
-    const double l32 = w32 * r2;
-    double p3 = fma(-l32, w32, q3);
-    if (nact < 4) p3 = 1.0;
-    if (!(p3 > 0.0)) { if (!bad) bad = j0 + 4; p3 = 1.0; }
-    const double r3 = rcp_f64(p3);
-    const double n20 = fma(l21, l10, -l20), n31 = fma(l32, l21, -l31);
-    const double n30 = fma(-l32, n20, fma(l31, l10, -l30));
-    out[0] = -l10; out[1] = n20; out[2] = n30; out[3] = -l21;
-    out[4] = n31; out[5] = -l32; out[6] = nact > 0 ? r0 : 0.0; out[7] = nact > 1 ? r1 : 0.0;
-    out[8] = nact > 2 ? r2 : 0.0; out[9] = nact > 3 ? r3 : 0.0; out[10] = p0; out[11] = p1;
-    out[12] = p2; out[13] = p3;
-}
-
-// o[] (pivot_chain) -> LDS rows {N[u][0..3], r_u, p_u}, written by lane 0 of the chain wave
-__device__ __forceinline__ void publish_chain(const double *o, double (*dst)[6]) {
-    double2 *d = reinterpret_cast<double2 *>(&dst[0][0]);
-    d[0] = make_double2(1.0, 0.0);   d[1] = make_double2(0.0, 0.0);   d[2] = make_double2(o[6], o[10]);
-    d[3] = make_double2(o[0], 1.0);  d[4] = make_double2(0.0, 0.0);   d[5] = make_double2(o[7], o[11]);
-    d[6] = make_double2(o[1], o[3]); d[7] = make_double2(1.0, 0.0);   d[8] = make_double2(o[8], o[12]);
-    d[9] = make_double2(o[2], o[4]); d[10] = make_double2(o[5], 1.0); d[11] = make_double2(o[9], o[13]);
-}
-
-// Factor the 64x64 tile held in registers, write the factor to Ab (ld; strictly upper part zeroed) and the inverse
-// of the factor to Wb (64x64); the pivots stay in sh.piv for diag_logdet.  ncol = pivots in this block (rows/columns
-// beyond are carried right-hand sides).  Returns (in wave 0) 1 + the index of the first non-positive pivot, or 0.
-struct Tile64 {
-    d4 v[4];
-};
-__device__ __forceinline__ int diag_factor(Tile64 &tile, DiagShared &sh, double *Ab, int64_t ld, double *Wb, int ncol,
-                                           long long *trace = nullptr) {
-    d4 (&a)[4] = tile.v;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lm = l & 15, lu = l >> 4;
-    const int myrow = 16 * w + lm;   // row this lane serves as MFMA A operand / stores as finished column
-    d4 y[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[t][r] = (16 * w + lu + 4 * r == 16 * t + lm) ? 1.0 : 0.0;
-    if (tid < 64) sh.piv[tid] = 1.0;
-    int bad = 0;   // wave 0 only
-    double o[14];  // wave 0: results of the newest pivot chain (kept in registers for the next one)
-    if ((lm >> 2) == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sh.colraw[0][16 * w + lu + 4 * r][lm & 3] = a[0][r];
-    }
-    if (w == 0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) sh.rowraw[0][16 * t + lm][lu] = y[t][0];
-        if ((lm >> 2) == 1) sh.blk[0][lu][lm & 3] = a[0][1];   // A[4+lu][4+(lm&3)]
-    }
-    __syncthreads();
-    if (w == 0) {   // pivot chain of group 0
-        const double2 *cr = reinterpret_cast<const double2 *>(&sh.colraw[0][0][0]);
-        const double2 C0 = cr[0], C1 = cr[2], C2a = cr[4], C2b = cr[5], C3a = cr[6], C3b = cr[7];
-        pivot_chain(C0.x, C1.x, C1.y, C2a.x, C2a.y, C2b.x, C3a.x, C3a.y, C3b.x, C3b.y, ncol >= 4 ? 4 : ncol, 0, bad, o);
-        if (l == 0) publish_chain(o, sh.chain[0]);
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int jb = g >> 2, j0 = 4 * g, buf = g & 1;
-        if (j0 >= ncol) break;
-        const int nact = ncol - j0 >= 4 ? 4 : ncol - j0;   // active pivots of this group
-        const bool more = (g + 1 < 16) && (j0 + 4 < ncol);  // a further group follows
-        const int jbn = (g + 1) >> 2, jqn = (g + 1) & 3;
-        if (trace && tid == 0) trace[4 * g] = wall_clock64();
-        const double2 *cr = reinterpret_cast<const double2 *>(&sh.colraw[buf][0][0]);
-        // ---- wave 0: pivot chain of the NEXT group (needs no result of this group's MFMAs) ----
-        if (w == 0 && more) {
-            const double n10 = o[0], n20 = o[1], n30 = o[2], n21 = o[3], n31 = o[4], n32 = o[5];
-            const double r0 = o[6], r1 = o[7], r2 = o[8], r3 = o[9];
-            double2 Ra[4], Rb[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                Ra[v] = cr[2 * (j0 + 4 + v)];
-                Rb[v] = cr[2 * (j0 + 4 + v) + 1];
-            }
-            const double2 *bk = reinterpret_cast<const double2 *>(&sh.blk[buf][0][0]);
-            const double2 B0 = bk[0], B1 = bk[2], B2a = bk[4], B2b = bk[5], B3a = bk[6], B3b = bk[7];
-            double T0[4], T1[4], T2[4], T3[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                T0[v] = Ra[v].x;
-                T1[v] = fma(Ra[v].x, n10, Ra[v].y);
-                T2[v] = fma(Ra[v].y, n21, fma(Ra[v].x, n20, Rb[v].x));
-                T3[v] = fma(Rb[v].x, n32, fma(Ra[v].y, n31, fma(Ra[v].x, n30, Rb[v].y)));
-            }
-            double c[4][4];
-            c[0][0] = B0.x;
-            c[1][0] = B1.x; c[1][1] = B1.y;
-            c[2][0] = B2a.x; c[2][1] = B2a.y; c[2][2] = B2b.x;
-            c[3][0] = B3a.x; c[3][1] = B3a.y; c[3][2] = B3b.x; c[3][3] = B3b.y;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const double e0 = T0[i] * r0, e1 = T1[i] * r1, e2 = T2[i] * r2, e3 = T3[i] * r3;
-#pragma unroll
-                for (int j = 0; j <= i; ++j)
-                    c[i][j] = fma(-e3, T3[j], fma(-e2, T2[j], fma(-e1, T1[j], fma(-e0, T0[j], c[i][j]))));
-            }
-            const int nan_ = ncol - (j0 + 4) >= 4 ? 4 : ncol - (j0 + 4);
-            pivot_chain(c[0][0], c[1][0], c[1][1], c[2][0], c[2][1], c[2][2], c[3][0], c[3][1], c[3][2], c[3][3], nan_,
-                        j0 + 4, bad, o);
-            if (l == 0) publish_chain(o, sh.chain[buf ^ 1]);
-            if (trace && tid == 0) trace[4 * g + 1] = wall_clock64();
-        }
-        if (w >= jb) {
-            // ---- update of THIS group ----
-            const double2 *rr = reinterpret_cast<const double2 *>(&sh.rowraw[buf][0][0]);
-            const double2 rAa = cr[2 * myrow], rAb = cr[2 * myrow + 1];
-            double2 rBa[4], rBb[4], rYa[4], rYb[4];
-#pragma unroll
-            for (int t = jb; t < 4; ++t)
-                if (t <= w) {   // tiles right of the wave's own rows are strictly upper: never needed
-                    rBa[t] = cr[2 * (16 * t + lm)];
-                    rBb[t] = cr[2 * (16 * t + lm) + 1];
-                }
-#pragma unroll
-            for (int t = 0; t <= jb; ++t) {
-                rYa[t] = rr[2 * (16 * t + lm)];
-                rYb[t] = rr[2 * (16 * t + lm) + 1];
-            }
-            const double2 *ck = reinterpret_cast<const double2 *>(&sh.chain[buf][lu][0]);
-            const double2 K0 = ck[0], K1 = ck[1], K2 = ck[2];
-            const double c0 = K0.x, c1 = K0.y, c2 = K1.x, c3 = K1.y, rl = K2.x, pl = K2.y;
-            if (w == 3 && lm == 0 && lu < nact) sh.piv[j0 + lu] = pl;
-            const double tA = fma(rAb.y, c3, fma(rAb.x, c2, fma(rAa.y, c1, rAa.x * c0)));
-            const double opA = (myrow >= j0 + nact) ? -tA * rl : 0.0;
-            const int tn = jbn < 4 ? jbn : 3;   // tile of the next group's columns: update it first
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int t = (tt == 0) ? tn : ((tt <= tn) ? tt - 1 : tt);
-                if (t < jb || t > w) continue;
-                const double tB = fma(rBb[t].y, c3, fma(rBb[t].x, c2, fma(rBa[t].y, c1, rBa[t].x * c0)));
-                const double opB = (16 * t + lm >= j0 + nact) ? tB : 0.0;
-                a[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, opB, a[t], 0, 0, 0);
-            }
-            double tY[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                tY[t] = 0.0;
-                if (t <= jb) {
-                    tY[t] = fma(rYb[t].y, c3, fma(rYb[t].x, c2, fma(rYa[t].y, c1, rYa[t].x * c0)));
-                    y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA, tY[t], y[t], 0, 0, 0);
-                }
-            }
-            const double sl = rsqrt_f64(pl);   // off the MFMA path: only the stored values are scaled
-            if (lu < nact) Ab[(int64_t)myrow * ld + j0 + lu] = (myrow >= j0 + lu) ? tA * sl : 0.0;
-            if (w == 3 && lu < nact) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) Wb[(j0 + lu) * 64 + 16 * t + lm] = tY[t] * sl;
-            }
-        } else if (lu < nact) {
-            Ab[(int64_t)myrow * ld + j0 + lu] = 0.0;   // rows above the pivots: strictly upper part
-        }
-        if (trace && tid == 192) trace[4 * g + 2] = wall_clock64();
-        // ---- raw columns / inverse rows of the next group, 4x4 block of the one after ----
-        if (more) {
-            if (w >= jbn && (lm >> 2) == jqn) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sh.colraw[buf ^ 1][16 * w + lu + 4 * r][lm & 3] = a[jbn < 4 ? jbn : 3][r];
-            }
-            if (w == jbn) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) sh.rowraw[buf ^ 1][16 * t + lm][lu] = y[t][jqn];
-            }
-            if (g + 2 < 16 && j0 + 8 < ncol) {
-                const int jb2 = (g + 2) >> 2, jq2 = (g + 2) & 3;
-                if (w == jb2 && (lm >> 2) == jq2) sh.blk[buf ^ 1][lu][lm & 3] = a[jb2 < 4 ? jb2 : 3][jq2];
-            }
-        }
-        if (trace && tid == 192) trace[4 * g + 3] = wall_clock64();
-        __syncthreads();
-    }
-    if (ncol < 64) {   // last block: carried right-hand-side rows / columns are still in registers
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * w + lu + 4 * r, col = 16 * t + lm;
-                if (col >= ncol) Ab[(int64_t)row * ld + col] = (row >= ncol) ? a[t][r] : 0.0;
-                if (row >= ncol) Wb[row * 64 + col] = y[t][r];
-            }
-    }
-    return bad;
-}
-
 // logdet / info of the block just factored (wave 0 knows about failed pivots; the factor's last barrier made the
 // pivots visible).  Kept out of diag_factor so that the chain publishes its block BEFORE this reduction.
 __device__ __forceinline__ void diag_logdet(DiagShared &sh, int ncol, int k, int b, int bad, double *logdet, int32_t *info) {
     const int tid = threadIdx.x;
     if (tid < 64) {
-        double v = (tid < ncol && !(tid == 0 && bad)) ? log(sh.piv[tid]) : 0.0;
+        const double pv = sh.piv[tid];
+        double v = (tid < ncol && pv > 0.0) ? log(pv) : 0.0;   // (a failed pivot is reported through info)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (tid == 0) {
@@ -422,8 +172,8 @@ struct StepArgs {
     const int4 *tasks;   // this launch's tasks
     int nhead, npanel, lead;   // task order in the table: head (chain, tdiag), panel (solve), bulk; the panel workgroups
                                // are dispatched after the first `lead` bulk tasks (they only wait: no slot hogging)
-    int guard;           // > 0: workgroups guard .. guard+batch-1 (guard = number of CUs) are placeholders that keep the
-                         // chain workgroups' CUs to themselves
+    int guard, nph;      // guard > 0: workgroups m * guard .. m * guard + batch - 1 (guard = number of CUs, m = 1 .. nph) are
+                         // placeholders that keep the chain workgroups' CUs to themselves (nph + 1 workgroups fit a CU)
     double *logdet;
     int32_t *info;
     int32_t *flags;
@@ -502,21 +252,41 @@ __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const
         mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, sign);
     }
 }
-// The pivot chain's own update: acc = C - P P^T with ONE panel tile P = A[k][k-1] that serves as both operands.  It sits
-// on the critical path of every block step and its loads are first touches (the tile was written by another CU in the
-// previous launch), so C and BOTH halves of P are requested at once -- one exposed memory latency instead of two.
-__device__ __forceinline__ void diag_update1(d4 (&acc)[4], const double *C, const double *P, int64_t ld, double *As, double *Bs,
-                                             int tid, int wave, int lane) {
-    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
+// The pivot chain's diagonal tile in the COLUMN-BLOCK layout of diagfac.hpp (wave w: acc[t][r] = S[16t + lu + 4r][16w + lm]),
+// read from the LOWER triangle of the stored tile (the last block's upper part does not mirror the carried rows).
+__device__ __forceinline__ void load_cb_lower(d4 (&acc)[4], const double *C, int64_t ld, int wave, int lane) {
+    const int lm = lane & 15, lu = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int R = 16 * t + lu + 4 * r, Cc = 16 * wave + lm;
+            acc[t][r] = (t <= wave) ? (R >= Cc ? C[(int64_t)R * ld + Cc] : C[(int64_t)Cc * ld + R]) : 0.0;
+        }
+}
+// ... and its update acc = C - P P^T with ONE panel tile P = A[k][k-1] that serves as both operands.  It sits on the
+// critical path of every block step and its loads are first touches (the tile was written by another CU in the previous
+// launch), so C and BOTH halves of P are requested at once -- one exposed memory latency instead of two.
+__device__ __forceinline__ void diag_update_cb(d4 (&acc)[4], const double *C, const double *P, int64_t ld, double *As, int tid,
+                                               int wave, int lane) {
     const HalfTile p0 = fetch_mk(P, ld, tid, 0), p1 = fetch_mk(P, ld, tid, 1);
-    load_acc(acc, C, ld, crow, ccol);
+    load_cb_lower(acc, C, ld, wave, lane);
+    const vlds_double *Ap = (const vlds_double *)As;
+    const int m = lane & 15, kk = lane >> 4;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
         commit_mk(h == 0 ? p0 : p1, As, tid);
-        commit_mk(h == 0 ? p0 : p1, Bs, tid);
         __syncthreads();
-        mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, -1.0);
+#pragma unroll
+        for (int k0 = 0; k0 < KC; k0 += 4) {
+            const double bv = -Ap[(16 * wave + m) * LDM + k0 + kk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double av = Ap[(16 * t + m) * LDM + k0 + kk];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+            }
+        }
     }
 }
 // out += sign * in * Bg^T   (in: accumulator-layout 64x64 tile, Bg: 64x64 row-major tile in global memory).  Both
@@ -581,13 +351,14 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     int32_t *cukey = g.flags + DGPAMD_MAXB;   // per matrix: (launch + 1) << 16 | CU key of its chain workgroup
     int bidx = blockIdx.x;
     if (g.guard && bidx >= g.guard) {
-        // The pivot chain is issue- and LDS-bound: a bulk workgroup on the same CU slows it by ~40 % (measured).  With two
-        // workgroups per CU, workgroup (number of CUs) + b lands beside chain workgroup b: it is a placeholder that sleeps until
-        // that chain has published its block, so the slot is taken and the chain has the CU to itself.  (If the
-        // hardware placed it elsewhere it leaves at once.)
-        if (bidx < g.guard + batch) {
+        // The pivot chain is issue- and LDS-bound: a bulk workgroup on the same CU slows it by ~40 % (measured).  With nph + 1
+        // workgroups per CU, workgroups m * (number of CUs) + b (m = 1 .. nph) land beside chain workgroup b: they are placeholders
+        // that sleep until that chain has published its block, so the slots are taken and the chain has the CU to itself.  (If
+        // the hardware placed one elsewhere it leaves at once.)
+        const int row = bidx / g.guard, pos = bidx - row * g.guard;
+        if (row <= g.nph && pos < batch) {
             if (tid == 0) {
-                const int c = bidx - g.guard, tag = (k + 1) << 16;
+                const int c = pos, tag = (k + 1) << 16;
                 int key = 0, spins = 0;
                 while (((key = __hip_atomic_load(&cukey[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 16) != k + 1 &&
                        ++spins < 64)
@@ -600,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
             }
             return;
         }
-        bidx -= batch;
+        bidx -= batch * (row <= g.nph ? row : g.nph);   // placeholders of this and the earlier rows
     }
     const int b = bidx % batch;
     int slot = bidx / batch;
@@ -643,9 +414,12 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
         if (g.guard && tid == 0)
             __hip_atomic_store(&cukey[b], ((k + 1) << 16) | cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (post == T_CHAIN && nkb == 1)
-        diag_update1(acc.v, C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64, ld, As, Bs, tid, wave, lane);
-    else
+    if (post == T_CHAIN) {
+        if (nkb == 1)
+            diag_update_cb(acc.v, C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64, ld, As, tid, wave, lane);
+        else
+            load_cb_lower(acc.v, C, ld, wave, lane);
+    } else
         tile_update(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
                     g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
                     mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
@@ -658,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
         STAMP(1);
         const int64_t rem = g.n - (int64_t)k * 64;
         const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        const int bad = diag_factor(acc, sh, C, ld, Wk, ncol, (g.trace && b == 0) ? g.trace + 1024 + 64 * k : nullptr);
+        const int bad = diag_factor(acc, sh, C, ld, Wk, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr);
         STAMP(2);
         wg_release_store(g.flags + b, k + 1, tid);   // the panel can start; the log-determinant is nobody's input
         STAMP(3);
@@ -838,6 +612,17 @@ static int get_tasks(dgpamd_ctx *ctx, int nbk, bool inv, TaskTable *&out) {
     return DGPAMD_OK;
 }
 
+// workgroups of potrf_step_kernel that one CU holds (registers / LDS): decides how many placeholder rows guard a chain
+static int step_kernel_wgs_per_cu() {
+    static int n = 0;
+    if (!n) {
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, potrf_step_kernel, 256, 0) != hipSuccess || q < 1) q = 2;
+        n = q > 4 ? 4 : q;
+    }
+    return n;
+}
+
 static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *T, double *S, int64_t stride_a, int batch,
                           double *logdet, int32_t *info, double *ws, int32_t *flags, const TaskTable *tt) {
     const int64_t Np = padded_dim(n);
@@ -860,8 +645,12 @@ static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *T, doub
         }
         const int64_t nwg = (int64_t)batch * tt->count[k];
         st.guard = (k < (size_t)nbk && nwg > ctx->num_cu) ? ctx->num_cu : 0;   // (tail launches: no chain; small ones: no neighbours)
+        st.nph = step_kernel_wgs_per_cu() - 1;
+        int64_t grid = nwg;
+        if (st.guard)   // smallest grid that holds nwg tasks beside the placeholders of the rows it reaches
+            for (int m = 1; m <= st.nph && grid > (int64_t)m * st.guard; ++m) grid += batch;
         PROF_BEGIN(ctx, PROF_SYRK, (double)batch * tt->tile_ops[k] * tile_flops);
-        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)(nwg + (st.guard ? batch : 0))), dim3(256), 0, ctx->stream, st);
+        hipLaunchKernelGGL(potrf_step_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, st);
         PROF_END(ctx, PROF_SYRK);
     }
     if (T)
@@ -891,6 +680,7 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     TaskTable *tt = nullptr;
     int rc = get_tasks(ctx, (int)nbk, T != nullptr, tt);   // (uploads the table on first use: outside the capture)
     if (rc) return rc;
+    (void)step_kernel_wgs_per_cu();   // (occupancy query: outside the capture as well)
     const std::array<uint64_t, 10> key = {1, (uint64_t)n, (uint64_t)batch, (uint64_t)A, (uint64_t)stride_a, (uint64_t)ws,
                                           (uint64_t)T, (uint64_t)S, 0, 0};
     rc = graph_run(ctx, key, [&]() { return potrf_launches(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, flags, tt); });

@@ -38,10 +38,8 @@ for k in range(1, nbk):
     print('%2d | %5.1f  %5.1f  %5.1f | %5.1f %5.1f | %6.1f' % (k, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[9] - r[8] if r[8] else 0,
                                                         r[10] - r[9] if r[8] else 0, nxt))
 
-d = tr.cpu().numpy()[1024:].reshape(-1, 16, 4).astype(np.float64) / 100.0
+d = tr.cpu().numpy()[1024:1024 + 16 * nbk].reshape(-1, 16).astype(np.float64) / 100.0
 kk = 5
-print('block %d, per group (us from group start): chain done (wave 0) | update done (wave 3) | writes done | next group start' % kk)
-for g in range(16):
-    r = d[kk][g]
-    nxt = d[kk][g + 1][0] - r[0] if g < 15 else float('nan')
-    print('%2d | %5.2f | %5.2f | %5.2f | %5.2f' % (g, r[1] - r[0], r[2] - r[0], r[3] - r[0], nxt))
+r = d[kk]
+print('block %d, diagonal factor (us from its start): ' % kk + ' | '.join(
+    '16-block %d: start %.2f, factored %.2f' % (J, r[2 * J] - r[0], r[2 * J + 1] - r[0]) for J in range(4)) + ' | end %.2f' % (r[8] - r[0]))
