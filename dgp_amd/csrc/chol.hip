@@ -253,24 +253,39 @@ __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const
     }
 }
 // The pivot chain's diagonal tile in the COLUMN-BLOCK layout of diagfac.hpp (wave w: acc[t][r] = S[16t + lu + 4r][16w + lm]),
-// read from the LOWER triangle of the stored tile (the last block's upper part does not mirror the carried rows).
-__device__ __forceinline__ void load_cb_lower(d4 (&acc)[4], const double *C, int64_t ld, int wave, int lane) {
+// read from the LOWER triangle of the stored tile (the last block's upper part does not mirror the carried rows): the
+// 16x16 tiles (w, t), t <= w, are loaded row-contiguously (four full 128-byte lines per load instruction; the transposed
+// access touches sixteen) and transposed inside the wave through `scratch` (16 x 17 doubles of LDS per wave).
+__device__ __forceinline__ void load_cb_lower(d4 (&acc)[4], const double *C, int64_t ld, int wave, int lane, double *scratch) {
     const int lm = lane & 15, lu = lane >> 4;
+    d4 nat[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int R = 16 * t + lu + 4 * r, Cc = 16 * wave + lm;
-            acc[t][r] = (t <= wave) ? (R >= Cc ? C[(int64_t)R * ld + Cc] : C[(int64_t)Cc * ld + R]) : 0.0;
+        for (int r = 0; r < 4; ++r) nat[t][r] = (t <= wave) ? C[(int64_t)(16 * wave + lu + 4 * r) * ld + 16 * t + lm] : 0.0;
+    vlds_double *S = (vlds_double *)scratch + wave * (16 * 17);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t <= wave) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(lu + 4 * r) * 17 + lm] = nat[t][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double tr = S[lm * 17 + lu + 4 * r];
+                acc[t][r] = (t == wave && lu + 4 * r >= lm) ? nat[t][r] : tr;
+            }
+        } else {
+            acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
         }
+    }
 }
 // ... and its update acc = C - P P^T with ONE panel tile P = A[k][k-1] that serves as both operands.  It sits on the
 // critical path of every block step and its loads are first touches (the tile was written by another CU in the previous
 // launch), so C and BOTH halves of P are requested at once -- one exposed memory latency instead of two.
-__device__ __forceinline__ void diag_update_cb(d4 (&acc)[4], const double *C, const double *P, int64_t ld, double *As, int tid,
-                                               int wave, int lane) {
+__device__ __forceinline__ void diag_update_cb(d4 (&acc)[4], const double *C, const double *P, int64_t ld, double *As, double *Bs,
+                                               int tid, int wave, int lane) {
     const HalfTile p0 = fetch_mk(P, ld, tid, 0), p1 = fetch_mk(P, ld, tid, 1);
-    load_cb_lower(acc, C, ld, wave, lane);
+    load_cb_lower(acc, C, ld, wave, lane, Bs);
     const vlds_double *Ap = (const vlds_double *)As;
     const int m = lane & 15, kk = lane >> 4;
 #pragma unroll
@@ -416,9 +431,9 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     }
     if (post == T_CHAIN) {
         if (nkb == 1)
-            diag_update_cb(acc.v, C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64, ld, As, tid, wave, lane);
+            diag_update_cb(acc.v, C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64, ld, As, Bs, tid, wave, lane);
         else
-            load_cb_lower(acc.v, C, ld, wave, lane);
+            load_cb_lower(acc.v, C, ld, wave, lane, Bs);
     } else
         tile_update(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
                     g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
@@ -432,10 +447,11 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
         STAMP(1);
         const int64_t rem = g.n - (int64_t)k * 64;
         const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        const int bad = diag_factor(acc, sh, C, ld, Wk, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr);
+        const int bad = diag_factor(acc, sh, Wk, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr);
         STAMP(2);
-        wg_release_store(g.flags + b, k + 1, tid);   // the panel can start; the log-determinant is nobody's input
+        wg_release_store(g.flags + b, k + 1, tid);   // the panel can start: it needs W_k only
         STAMP(3);
+        diag_store_factor(acc, C, ld, ncol);         // the factor's own tile and the log-determinant are nobody's input
         diag_logdet(sh, ncol, k, b, bad, g.logdet, g.info);
         if (wtr) wtr[1] = wall_clock64();
         return;

@@ -44,12 +44,12 @@ __device__ __forceinline__ double rcp_f64(double d) {
 }
 
 struct DiagShared {
-    double f[16 * 16];      // the 16x16 diagonal tile on its way from accumulator layout to one column per lane
-    double nt[16 * 17];     // nt[c * 17 + i] = N[i][c]: unit-lower inverse of the tile's LDL^T factor, unscaled
+    double f[16 * 17];      // the 16x16 diagonal tile, f[row * 17 + col]: in, then the elimination's result (upper part: the
+                            // unscaled factor, below the diagonal of pivot columns: -pivot_col * (unit lower factor)^-1)
     double s[16];           // 1 / sqrt(pivot) of the current 16-block (1 for carried rows)
+    double cs[16];          // -1 / pivot (0 for carried columns)
     double u[4][4][64];     // u[w][r][lane] = U[J][w] in accumulator layout (wave w's tile of the current block row)
     double piv[64];         // pivots (1 for carried rows): the log-determinant's input
-    double ident[16 * 16];  // identity (the start of the inverse's columns; read instead of 16 compares per lane)
     int bad[4];             // per 16-block: 1 + index of its first non-positive pivot, or 0
 };
 
@@ -60,51 +60,66 @@ struct Tile64 {
 typedef volatile double __attribute__((address_space(3))) vlds_f64;
 
 // ---- the elimination of a full 16x16 tile, hand scheduled -------------------------------------------------------
-// Pivot J: rows i > J of the lane's columns x (block) and y (identity) take  row_i += (lane J's x[i]) * (np | nq), with
-// np / nq = -x[J]/pivot, -y[J]/pivot of THIS lane (the scaled pivot row) -- two DPP multiply-adds per row.  The chain of
-// the NEXT pivot (broadcast, hardware reciprocal, two Newton rounds, its np / nq: eight dependent operations) starts as
-// soon as row J+1 is final and is interleaved one operation at a time with the remaining rows of pivot J: the wave
-// issues in order, so the placement is fixed here with volatile asm instead of being left to the compiler (which puts
-// the chain into one run of dependent instructions and stalls ~50 cycles per pivot).
+// One register column z per lane holds BOTH results.  At pivot j the lanes c > j still carry the block (z_c[i] = X[i][c]),
+// the lanes c < j carry the inverse of the unit lower factor scaled by -pivot_c (z_c[i] = -d_c N[i][c], i > c), and lane j
+// changes sides: its entries below the pivot are the multipliers' numerators X[i][j] and ARE -d_j N[i][j] = X[i][j] as they
+// stand.  With nz_c = -z_c[j] / d_j  (0 in lane j) every row i > j takes
+//        z_c[i] += (lane j's z[i]) * nz_c
+// in ONE v_fmac_f64_dpp (row_newbcast:j reads lane j of the 16-lane row): block and inverse advance together.
+// The chain of the NEXT pivot (broadcast, hardware reciprocal, two Newton rounds, nz: seven dependent operations)
+// starts as soon as row j+1 is final and is interleaved one operation at a time with the remaining rows of pivot j: the
+// wave issues in order, so the placement is fixed here with volatile asm instead of being left to the compiler (which
+// puts the chain into one run of dependent instructions and stalls ~50 cycles per pivot).
 template <int JN>
-__device__ __forceinline__ void chain_op(const int k, const double &xj, const double &yj, double &db, double &r0, double &e,
-                                         double &np2, double &nq2) {
+__device__ __forceinline__ void chain_op(const int k, const double &zj, const double &zz, double &db, double &r0, double &e,
+                                         double &nz) {
     switch (k) {
         case 0:   // s_nop 1: a DPP source written by the previous VALU instruction needs two wait states
-            asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(db) : "v"(xj), "i"(JN));
+            asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(db) : "v"(zj), "i"(JN));
             break;
         case 1: asm volatile("v_rcp_f64_e32 %0, %1" : "=v"(r0) : "v"(db)); break;
         case 2: asm volatile("s_nop 0\n\tv_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(db), "v"(r0)); break;   // (trans result: 1 wait state)
         case 3: asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(r0) : "v"(e)); break;
         case 4: asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(db), "v"(r0)); break;
         case 5: asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(r0) : "v"(e)); break;
-        case 6: asm volatile("v_mul_f64 %0, -%1, %2" : "=v"(np2) : "v"(xj), "v"(r0)); break;
-        default: asm volatile("v_mul_f64 %0, -%1, %2" : "=v"(nq2) : "v"(yj), "v"(r0)); break;
+        default: asm volatile("v_mul_f64 %0, -%1, %2" : "=v"(nz) : "v"(zz), "v"(r0)); break;
     }
 }
-// row-pair index (0 = row J+1) after which chain operation k is issued (or after the last row when there are fewer)
-__host__ __device__ constexpr int chain_slot(int k) { return k == 0 ? 0 : (k == 1 ? 1 : (k < 7 ? k + 1 : 7)); }
+// row index (0 = row j+1) after which chain operation k is issued (or after the last row when there are fewer)
+__host__ __device__ constexpr int chain_slot(int k) { return k == 0 ? 0 : (k == 1 ? 1 : k + 1); }
+
+// zz = (lane == JN) ? 0 : z   (in asm: left to the compiler the sixteen lane compares are hoisted and cost 32 SGPRs)
+template <int JN>
+__device__ __forceinline__ double zero_in_lane(const double &z, const int lm) {
+    const int zlo = __double2loint(z), zhi = __double2hiint(z);
+    int lo, hi;
+    asm volatile("v_cmp_ne_u32_e32 vcc, %4, %5\n\tv_cndmask_b32_e32 %0, 0, %2, vcc\n\tv_cndmask_b32_e32 %1, 0, %3, vcc"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(zlo), "v"(zhi), "i"(JN), "v"(lm)
+                 : "vcc");
+    return __hiloint2double(hi, lo);
+}
 
 template <int J>
 struct ElimFull {
-    static __device__ __forceinline__ void run(double (&x)[16], double (&y)[16], const double np, const double nq) {
+    static __device__ __forceinline__ void run(double (&z)[16], const int lm, const double nz) {
         if constexpr (J < 15) {
             constexpr int P = 15 - J;            // rows below the pivot
             constexpr bool next = (J + 1 < 15);  // pivot 15 eliminates nothing: no reciprocal needed
-            double db = 0.0, r0 = 0.0, e = 0.0, np2 = 0.0, nq2 = 0.0;
+            constexpr int JN = J + 1 < 16 ? J + 1 : 15;
+            double db = 0.0, r0 = 0.0, e = 0.0, nz2 = 0.0, zz = 0.0;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const int i = J + 1 + p;
-                asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y[i]) : "v"(x[i]), "v"(nq), "i"(J));
-                asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(x[i]) : "v"(x[i]), "v"(np), "i"(J));
+                asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(z[i]) : "v"(nz), "i"(J));
                 if (next) {
+                    if (p == 0) zz = zero_in_lane<JN>(z[JN], lm);   // (off the chain: needs row J+1 only)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if ((chain_slot(k) < P - 1 ? chain_slot(k) : P - 1) == p)
-                            chain_op<(J + 1 < 16 ? J + 1 : 15)>(k, x[J + 1 < 16 ? J + 1 : 15], y[J + 1 < 16 ? J + 1 : 15], db, r0, e, np2, nq2);
+                    for (int k = 0; k < 7; ++k)
+                        if ((chain_slot(k) < P - 1 ? chain_slot(k) : P - 1) == p) chain_op<JN>(k, z[JN], zz, db, r0, e, nz2);
                 }
             }
-            ElimFull<J + 1>::run(x, y, np2, nq2);
+            ElimFull<J + 1>::run(z, lm, nz2);
         }
     }
 };
@@ -123,8 +138,7 @@ template <int W>
 __device__ __forceinline__ void diag_wave(d4 (&X)[4], d4 (&Y)[4], DiagShared &sh, const int ncol, const int l,
                                           long long *stamp) {
     const int lm = l & 15, lu = l >> 4;
-    vlds_f64 *f = (vlds_f64 *)sh.f, *nt = (vlds_f64 *)sh.nt, *ss = (vlds_f64 *)sh.s, *piv = (vlds_f64 *)sh.piv,
-             *ident = (vlds_f64 *)sh.ident;
+    vlds_f64 *f = (vlds_f64 *)sh.f, *ss = (vlds_f64 *)sh.s, *cs = (vlds_f64 *)sh.cs, *piv = (vlds_f64 *)sh.piv;
 #pragma unroll
     for (int J = 0; J < 4; ++J) {
         const int nact = ncol - 16 * J >= 16 ? 16 : (ncol - 16 * J > 0 ? ncol - 16 * J : 0);   // pivots of this 16-block
@@ -132,73 +146,59 @@ __device__ __forceinline__ void diag_wave(d4 (&X)[4], d4 (&Y)[4], DiagShared &sh
         if (W == J) {
             // ---- accumulator layout -> LDS (same wave from here to B1: the LDS operations of a wave are in order) ----
 #pragma unroll
-            for (int r = 0; r < 4; ++r) f[(lu + 4 * r) * 16 + lm] = X[J][r];
+            for (int r = 0; r < 4; ++r) f[(lu + 4 * r) * 17 + lm] = X[J][r];
             if (nact == 16) {
-                // one column per lane (the four DPP rows hold copies), the identity beside it
-                double x[16], y[16];
+                // one column per lane (the four DPP rows hold copies)
+                double z[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    x[i] = f[i * 16 + lm];
-                    y[i] = ident[i * 16 + lm];
-                }
-                double db, r0, e, np, nq;
+                for (int i = 0; i < 16; ++i) z[i] = f[i * 17 + lm];
+                double db, r0, e, nz;
+                const double zz = zero_in_lane<0>(z[0], lm);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) chain_op<0>(k, x[0], y[0], db, r0, e, np, nq);
-                ElimFull<0>::run(x, y, np, nq);
+                for (int k = 0; k < 7; ++k) chain_op<0>(k, z[0], zz, db, r0, e, nz);
+                ElimFull<0>::run(z, lm, nz);
                 if (lu == 0) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        f[i * 16 + lm] = x[i];
-                        nt[lm * 17 + i] = y[i];
-                    }
+                    for (int i = 0; i < 16; ++i) f[i * 17 + lm] = z[i];
                 }
             } else {
                 // the block that holds the end of the matrix (at most one per factorisation), or carried rows only:
-                // the same elimination on the tile in LDS, pivot by pivot, four entries of each matrix per lane
-                double xv[4], yv[4];
+                // the same recurrence on the tile in LDS, pivot by pivot, four entries per lane
+                double zv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    xv[r] = X[J][r];
-                    yv[r] = (lu + 4 * r == lm) ? 1.0 : 0.0;
-                }
+                for (int r = 0; r < 4; ++r) zv[r] = X[J][r];
                 for (int j = 0; j < nact; ++j) {
+                    const double rp = rcp_f64(f[j * 18]), zz = (lm == j) ? 0.0 : f[j * 17 + lm];
+                    const double nzj = -zz * rp;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        f[(lu + 4 * r) * 16 + lm] = xv[r];
-                        nt[lm * 17 + lu + 4 * r] = yv[r];
+                        const double m = (lu + 4 * r > j) ? f[(lu + 4 * r) * 17 + j] : 0.0;
+                        zv[r] = fma(m, nzj, zv[r]);
                     }
-                    const double rp = rcp_f64(f[j * 17]), px = f[j * 16 + lm], py = nt[lm * 17 + j];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double m = (lu + 4 * r > j) ? f[(lu + 4 * r) * 16 + j] * rp : 0.0;
-                        xv[r] = fma(-m, px, xv[r]);
-                        yv[r] = fma(-m, py, yv[r]);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f[(lu + 4 * r) * 16 + lm] = xv[r];
-                    nt[lm * 17 + lu + 4 * r] = yv[r];
+                    for (int r = 0; r < 4; ++r) f[(lu + 4 * r) * 17 + lm] = zv[r];
                 }
             }
             // pivots, Cholesky scaling 1/sqrt(pivot) of the rows, first non-positive pivot
             const bool act = lm < nact;
-            const double dsel = act ? f[lm * 17] : 1.0;
+            const double dsel = act ? f[lm * 18] : 1.0;
             const double s = act ? rsqrt_f64(dsel) : 1.0;
             const unsigned long long bm = __ballot(act && !(dsel > 0.0)) & 0xffffull;
             if (lu == 0) {
                 ss[lm] = s;
+                cs[lm] = act ? -s * s : 0.0;   // column scale of the inverse: -1 / pivot (carried columns: identity)
                 piv[16 * J + lm] = dsel;
                 if (lm == 0) sh.bad[J] = bm ? 16 * J + __builtin_ctzll(bm) + 1 : 0;
             }
             // U_JJ and V_J in accumulator layout
+            const double csl = cs[lm];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = lu + 4 * r;
-                const double sr = ss[row];
-                // below the diagonal of a pivot column the eliminated entries are zero up to rounding: exact zeros
-                X[J][r] = (row > lm && lm < nact) ? 0.0 : f[row * 16 + lm] * sr;
-                Y[J][r] = nt[lm * 17 + row] * sr;
+                const double sr = ss[row], fv = f[row * 17 + lm] * sr;
+                // below the diagonal of a pivot column the tile holds the inverse
+                X[J][r] = (row > lm && lm < nact) ? 0.0 : fv;
+                Y[J][r] = (row == lm) ? sr : (row > lm ? fv * csl : 0.0);
             }
         }
         lds_barrier();   // B1: V_J (nt, s) visible
@@ -208,7 +208,11 @@ __device__ __forceinline__ void diag_wave(d4 (&X)[4], d4 (&Y)[4], DiagShared &sh
             const double sl = ss[lm];
             double vf[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) vf[kk] = nt[(4 * kk + lu) * 17 + lm] * sl;   // V[lm][4kk + lu]
+            for (int kk = 0; kk < 4; ++kk) {   // V[lm][4kk + lu]: s on the diagonal, s_row * f * (-1/pivot_col) below it
+                const int col = 4 * kk + lu;
+                const double below = f[lm * 17 + col] * sl * cs[col];
+                vf[kk] = (lm == col) ? sl : (lm > col ? below : 0.0);
+            }
             d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
             d4 &B = (W > J) ? X[J] : Y[J];
 #pragma unroll
@@ -245,20 +249,16 @@ __device__ __forceinline__ void diag_wave(d4 (&X)[4], d4 (&Y)[4], DiagShared &sh
     }
 }
 
-// Factor the 64x64 block held as X (column-block layout above; only tiles t <= w are read), write the lower factor to
-// Ab (row stride ld; strictly upper part zeroed, carried corner kept) and its inverse to Wb (64x64, row-major).
-// ncol = pivots in this block.  Leaves the pivots in sh.piv and returns (every thread) 1 + the index of the first
+// Factor the 64x64 block held as X (column-block layout above; only tiles t <= w are read) in place (X becomes the upper
+// factor U = L^T) and write the inverse of the lower factor to Wb (64x64, row-major).  ncol = pivots in this block.  Leaves the pivots in sh.piv and returns (every thread) 1 + the index of the first
 // non-positive pivot, or 0.  `stamp`: optional 9 slots of wall_clock64 stamps (wave 0, lane 0): start of 16-block J, its first barrier, end.
-__device__ __forceinline__ int diag_factor(Tile64 &tile, DiagShared &sh, double *Ab, int64_t ld, double *Wb, int ncol_,
-                                           long long *stamp = nullptr) {
+__device__ __forceinline__ int diag_factor(Tile64 &tile, DiagShared &sh, double *Wb, int ncol_, long long *stamp = nullptr) {
     d4 (&X)[4] = tile.v;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lm = l & 15, lu = l >> 4;
     const int ncol = __builtin_amdgcn_readfirstlane(ncol_);
     d4 Y[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) Y[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    sh.ident[tid] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
-    lds_barrier();
     switch (w) {
         case 0: diag_wave<0>(X, Y, sh, ncol, l, stamp); break;
         case 1: diag_wave<1>(X, Y, sh, ncol, l, stamp); break;
@@ -272,7 +272,19 @@ __device__ __forceinline__ int diag_factor(Tile64 &tile, DiagShared &sh, double 
     for (int I = 0; I < 4; ++I)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Wb[(16 * I + lu + 4 * r) * 64 + 16 * w + lm] = (I >= w) ? Y[I][r] : 0.0;
-    // ---- L = U^T: tile (t, w) of U is tile (w, t) of L, element (row 16w + lm, column 16t + lu + 4r) ----
+    lds_barrier();
+    int bad = 0;
+#pragma unroll
+    for (int J = 3; J >= 0; --J) bad = sh.bad[J] ? sh.bad[J] : bad;
+    return bad;
+}
+
+// The lower factor L = U^T of a block factored by diag_factor to Ab (row stride ld): strictly upper part zeroed, carried
+// corner (rows and columns >= ncol) kept symmetric.
+__device__ __forceinline__ void diag_store_factor(const Tile64 &tile, double *Ab, int64_t ld, int ncol) {
+    const d4 (&X)[4] = tile.v;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lm = l & 15, lu = l >> 4;
+    // L = U^T: tile (t, w) of U is tile (w, t) of L, element (row 16w + lm, column 16t + lu + 4r) ----
     const int64_t lrow = 16 * w + lm;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -287,9 +299,4 @@ __device__ __forceinline__ int diag_factor(Tile64 &tile, DiagShared &sh, double 
                 Ab[lrow * ld + lcol] = 0.0;   // strictly upper part of the factor
             }
         }
-    lds_barrier();
-    int bad = 0;
-#pragma unroll
-    for (int J = 3; J >= 0; --J) bad = sh.bad[J] ? sh.bad[J] : bad;
-    return bad;
 }
