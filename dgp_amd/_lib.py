@@ -51,6 +51,7 @@ SIGNATURES = {
     'dgpamd_fetch2': (_i, [_p, _p, _z, _p, _z, _p]),
     'dgpamd_set_graphs': (_i, [_p, _i]),
     'dgpamd_set_linkgp_direct': (_i, [_p, _i]),
+    'dgpamd_set_potrf_mode': (_i, [_p, _i]),
     'dgpamd_debug_trace': (_i, [_p, _p]),
     'dgpamd_prof_enable': (_i, [_p, _i]),
     'dgpamd_prof_event_overhead_us': (_i, [_p, C.POINTER(_d)]),

@@ -255,7 +255,7 @@ __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const
 // The pivot chain's diagonal tile in the COLUMN-BLOCK layout of diagfac.hpp (wave w: acc[t][r] = S[16t + lu + 4r][16w + lm]),
 // read from the LOWER triangle of the stored tile (the last block's upper part does not mirror the carried rows): the
 // 16x16 tiles (w, t), t <= w, are loaded row-contiguously (four full 128-byte lines per load instruction; the transposed
-// access touches sixteen) and transposed inside the wave through `scratch` (16 x 17 doubles of LDS per wave).
+// access touches sixteen) and transposed inside the wave through `scratch` (16 x 16 doubles of LDS per wave).
 __device__ __forceinline__ void load_cb_lower(d4 (&acc)[4], const double *C, int64_t ld, int wave, int lane, double *scratch) {
     const int lm = lane & 15, lu = lane >> 4;
     d4 nat[4];
@@ -263,15 +263,15 @@ __device__ __forceinline__ void load_cb_lower(d4 (&acc)[4], const double *C, int
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) nat[t][r] = (t <= wave) ? C[(int64_t)(16 * wave + lu + 4 * r) * ld + 16 * t + lm] : 0.0;
-    vlds_double *S = (vlds_double *)scratch + wave * (16 * 17);
+    vlds_double *S = (vlds_double *)scratch + wave * 256;   // element (i, j) at i * 16 + (j ^ i): both passes conflict-free
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (t <= wave) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S[(lu + 4 * r) * 17 + lm] = nat[t][r];
+            for (int r = 0; r < 4; ++r) S[(lu + 4 * r) * 16 + (lm ^ (lu + 4 * r))] = nat[t][r];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double tr = S[lm * 17 + lu + 4 * r];
+                const double tr = S[lm * 16 + ((lu + 4 * r) ^ lm)];
                 acc[t][r] = (t == wave && lu + 4 * r >= lm) ? nat[t][r] : tr;
             }
         } else {
@@ -447,7 +447,9 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
         STAMP(1);
         const int64_t rem = g.n - (int64_t)k * 64;
         const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        const int bad = diag_factor(acc, sh, Wk, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr);
+        Tile64 winv;
+        const int bad = diag_factor(acc, winv, sh, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr);
+        diag_store_inverse<false>(winv, Wk);
         STAMP(2);
         wg_release_store(g.flags + b, k + 1, tid);   // the panel can start: it needs W_k only
         STAMP(3);
@@ -468,6 +470,308 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     store_acc(out, C, ld, crow, ccol);
     if (stamp) STAMP(10);
     if (wtr) wtr[1] = wall_clock64();
+}
+
+// ----------------------------------------------------------------------------
+// The whole factorisation (with or without the fused inverse) as ONE persistent launch: dataflow over tile versions.
+//
+// Workgroups 0 .. batch-1 are the pivot CHAINS, one per matrix, alive for all block steps; every other workgroup is a
+// WORKER that pulls 64x64-tile tasks from one queue (an agent-scope counter) in the order of a host-built table.
+// A chain never hands its critical data to another workgroup: after factoring block k it publishes W_k, solves the
+// first panel tile P = A[k+1][k] W_k^T itself, applies it to the next diagonal tile, D = A[k+1][k+1] - P P^T, keeps D
+// in registers and factors on.  What it needs from the workers -- A[k+1][k] and A[k+1][k+1] with the panels <= k-1
+// applied -- depends only on block k-1, so it is produced while the chain factors block k (look-ahead of one block,
+// no launch boundary, no hand-off on the critical path).
+// Every tile has a VERSION word: the number of finished visits, or VER_FINAL once nobody will write it again.  A task
+// waits (one wave, one flag per lane, bounded) until its output tile has seen all earlier visits and its operand tiles
+// are final, takes ONE agent-scope acquire, works with plain loads, stores its tile WRITE-THROUGH (sc1) and publishes
+// the new version after every storing wave has drained (MI355X_MICROARCH.md, hand-off recipe R1).  Panel tasks wait
+// for the chain's W_k the same way.  Deadlock freedom: the table is a topological order of the task graph and is
+// pulled in order, so the oldest unfinished task always has its inputs finished or in progress on a resident
+// workgroup; the chains are the first workgroups of the grid.  Every spin is bounded (status word -> DGPAMD_HANDOFF).
+// Workers that share a CU with a chain leave at once (the chain is issue- and LDS-bound; see the CU guard above).
+// ----------------------------------------------------------------------------
+#define VER_FINAL 0x40000000
+#define MEGA_SPIN_LIMIT (1 << 20)   // polls of ~1 us: a lost hand-off gives up after about a second
+
+struct MegaSync {   // zeroed by a memset node ahead of every launch; the version words follow it
+    int32_t qhead;                  // queue head
+    int32_t status;                 // 0, or the code of the first spin that gave up
+    int32_t pad[14];
+    int32_t wflag[DGPAMD_MAXB];     // per matrix: blocks factored (W_k is readable for k < wflag)
+    int32_t cukey[DGPAMD_MAXB];     // per matrix: CU of its chain workgroup (cu_key())
+};
+
+struct MTask {
+    int4 a;   // as the per-launch tables: what / where (make_task)
+    int4 b;   // x: visits of the output tile before this one; y: 1 = this visit makes it final; z: block whose inverse a
+              // SOLVE / TDIAG task multiplies with
+};
+
+struct MegaArgs {
+    double *buf[3];
+    double *ws;
+    int64_t ld, stride_a, stride_ws, n;
+    int nbk, batch, inv;
+    const MTask *tasks;
+    int ntask;               // per matrix
+    const int2 *chain_need;  // per block k: worker visits of A[k+1][k] and of A[k+1][k+1] the chain waits for
+    MegaSync *sync;
+    int32_t *ver;            // [batch][3][nbk * nbk]
+    double *logdet;
+    int32_t *info;
+    long long *trace;
+};
+
+__device__ __forceinline__ void store_acc_sc1(const d4 (&acc)[4], double *C, int64_t ld, int crow, int ccol) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            __hip_atomic_store(C + (int64_t)(crow + 4 * r) * ld + 16 * t + ccol, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every storing wave drains its stores, then one lane publishes
+__device__ __forceinline__ void wg_publish(int32_t *flag, int value, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Wave 0: lane l < nflag polls flag[l] until it reaches need[l] (relaxed, bounded), then ONE agent-scope acquire;
+// the workgroup's barrier follows.  Returns (to every thread, through LDS word `bc`) 0 or the give-up code.
+__device__ __forceinline__ void wg_wait_flags(const int32_t *addr, int need, int code, int32_t *status, int tid) {
+    if (tid < 64) {
+        bool ok = (addr == nullptr);
+        int spins = 0;
+        for (;;) {
+            if (!ok) ok = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+            // give up after the limit -- or at once when another workgroup already has (its inputs may never come)
+            if (spins > MEGA_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (tid == 0) atomicCAS(status, 0, code);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// acc (column-block layout) -= P P^T for the 32-column half of P staged MK in As
+__device__ __forceinline__ void mfma_cb_half(const double *As, d4 (&acc)[4], int wave, int lane) {
+    const vlds_double *Ap = (const vlds_double *)As;
+    const int m = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 4) {
+        const double bv = -Ap[(16 * wave + m) * LDM + k0 + kk];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double av = Ap[(16 * t + m) * LDM + k0 + kk];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, double *As, double *Bs, DiagShared &sh, double *scratch) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lu = lane >> 4;
+    const int crow = 16 * wave + lu, ccol = lm;
+    const int64_t ld = g.ld;
+    double *A = g.buf[BUF_A] + (int64_t)b * g.stride_a;
+    int32_t *ver = g.ver + (int64_t)b * 3 * g.nbk * g.nbk;   // buffer A's versions first
+    int32_t *wflag = g.sync->wflag + b;
+    long long *tr = (g.trace && b == 0 && tid == 0) ? g.trace : nullptr;
+    __builtin_amdgcn_s_setprio(3);
+    if (tid == 0) __hip_atomic_store(&g.sync->cukey[b], cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Tile64 D;
+    load_cb_lower(D.v, A, ld, wave, lane, scratch);
+    double logdet = 0.0;
+    int info = 0;
+    for (int k = 0; k < g.nbk; ++k) {
+        if (tr) tr[16 * k + 0] = wall_clock64();
+        const int64_t rem = g.n - (int64_t)k * 64;
+        const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+        double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096;
+        Tile64 winv;
+        const int bad = diag_factor(D, winv, sh, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr);
+        if (tr) tr[16 * k + 1] = wall_clock64();
+        diag_store_inverse<true>(winv, Wk);
+        wg_publish(wflag, k + 1, tid);   // the panel tasks of this block can run
+        if (tr) tr[16 * k + 2] = wall_clock64();
+        diag_store_factor(D, A + ((int64_t)k * 64) * ld + (int64_t)k * 64, ld, ncol);   // nobody's input
+        if (bad && !info) info = k * 64 + bad;
+        if (tid < 64) {
+            const double pv = sh.piv[tid];
+            double v = (tid < ncol && pv > 0.0) ? log(pv) : 0.0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            logdet += v;
+        }
+        if (k + 1 == g.nbk) break;
+        if (__hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // (a lost hand-off ends the launch)
+        // ---- the next block's inputs from the workers: A[k+1][k] and A[k+1][k+1] with the panels <= k-1 applied ----
+        const int2 need = g.chain_need[k];
+        {
+            const int32_t *addr = nullptr;
+            int nd = 0;
+            if (tid == 0) { addr = ver + (k + 1) * g.nbk + k; nd = need.x; }
+            if (tid == 1) { addr = ver + (k + 1) * g.nbk + k + 1; nd = need.y; }
+            wg_wait_flags(addr, nd, 100 + k, &g.sync->status, tid);
+        }
+        if (tr) tr[16 * k + 3] = wall_clock64();
+        double *Pg = A + ((int64_t)(k + 1) * 64) * ld + (int64_t)k * 64;
+        const double *Cn = A + ((int64_t)(k + 1) * 64) * ld + (int64_t)(k + 1) * 64;
+        const HalfTile a0 = fetch_mk(Pg, ld, tid, 0), a1 = fetch_mk(Pg, ld, tid, 1);
+        Tile64 Dn;
+        load_cb_lower(Dn.v, Cn, ld, wave, lane, scratch);
+        // ---- P = A[k+1][k] W_k^T, W_k straight from the registers ----
+        d4 P[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) P[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            commit_mk(h == 0 ? a0 : a1, As, tid);
+            if ((wave >> 1) == h) {
+#pragma unroll
+                for (int I = 0; I < 4; ++I)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Bs[(16 * I + lu + 4 * r) * LDM + 16 * (wave & 1) + lm] = (I >= wave) ? winv.v[I][r] : 0.0;
+            }
+            __syncthreads();
+            mfma_tile<OP_MK, OP_MK>(As, Bs, P, wave, lane, 1.0);
+        }
+        if (tr) tr[16 * k + 4] = wall_clock64();
+        store_acc_sc1(P, Pg, ld, crow, ccol);
+        // ---- D = A[k+1][k+1] - P P^T in the column-block layout; the panel tile is published between the halves ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // P's stores have drained by now
+            __syncthreads();
+            if (h == 1 && tid == 0)
+                __hip_atomic_store(ver + (k + 1) * g.nbk + k, VER_FINAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) As[(crow + 4 * r) * LDM + 16 * t + ccol] = P[2 * h + t][r];
+            __syncthreads();
+            mfma_cb_half(As, Dn.v, wave, lane);
+        }
+        D = Dn;
+        if (tr) tr[16 * k + 5] = wall_clock64();
+    }
+    if (tid == 0) {
+        g.logdet[b] = logdet;
+        g.info[b] = info;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
+    __shared__ double tiles[2 * 64 * LDM];   // As | Bs
+    __shared__ DiagShared sh;
+    __shared__ int32_t bc[4];
+    double *As = tiles, *Bs = tiles + 64 * LDM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
+    const int batch = g.batch;
+    if ((int)blockIdx.x < batch) {
+        mega_chain(g, blockIdx.x, As, Bs, sh, &sh.u[0][0][0]);
+    } else {
+        // a worker beside a chain leaves (bounded wait for the chains' keys: they are dispatched first)
+        if (tid < 64) {
+            int key = 0, spins = 0;
+            const bool mine = tid < batch;
+            while (mine && (key = __hip_atomic_load(&g.sync->cukey[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++spins < 2000)
+                __builtin_amdgcn_s_sleep(4);
+            const bool beside = __any(mine && key == cu_key());
+            if (tid == 0) bc[0] = beside ? 1 : 0;
+        }
+        __syncthreads();
+        if (bc[0]) return;
+    }
+    // ---- worker loop (the chains join it when their matrix is factored) ----
+    const int64_t ld = g.ld;
+    const int64_t rem_last = g.n - (int64_t)(g.nbk - 1) * 64;
+    const int ncol_last = rem_last > 0 ? (int)rem_last : 0;
+    const int total = g.ntask * batch;
+    // debug (dgpamd_debug_trace): the first 80 tasks of one worker, 5 stamps each, from trace[2048]: pulled, inputs ready,
+    // computed, stored, published (+ the task's kind / panels in the sixth word)
+    long long *wst = (g.trace && tid == 0 && (int)blockIdx.x == batch + 40) ? g.trace + 2048 : nullptr;
+    int nst = 0;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            const int q0 = __hip_atomic_fetch_add(&g.sync->qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bc[1] = __hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? total : q0;   // (a lost hand-off ends the launch)
+        }
+        __syncthreads();
+        const int q = __builtin_amdgcn_readfirstlane(bc[1]);
+        if (q >= total) break;
+        const int slot = q / batch, b = q - slot * batch;
+        const MTask mt = g.tasks[slot];
+        long long *st = (wst && nst < 80) ? wst + 8 * nst++ : nullptr;
+        if (st) { st[0] = wall_clock64(); st[5] = (mt.a.x & 15) | ((mt.a.w >> 16) << 8) | ((long long)slot << 16); }
+        const int4 tk = mt.a;
+        const int post = tk.x & 15, first = (tk.x >> 4) & 1, plus = (tk.x >> 5) & 1, mask_last = (tk.x >> 6) & 1;
+        const int bufC = (tk.x >> 8) & 3, bufL = (tk.x >> 10) & 3, bufR = (tk.x >> 12) & 3;
+        const int ci = tk.y & 0xffff, cj = tk.y >> 16, li = tk.z & 0xffff, ri = tk.z >> 16;
+        const int kb0 = tk.w & 0xffff, nkb = tk.w >> 16;
+        const int need_c = mt.b.x, fin = mt.b.y, wk = mt.b.z;
+        const int64_t mo = (int64_t)b * g.stride_a;
+        const int nb2 = g.nbk * g.nbk;
+        int32_t *ver = g.ver + (int64_t)b * 3 * nb2;
+        int32_t *vC = ver + bufC * nb2 + ci * g.nbk + cj;
+        double *C = g.buf[bufC] + mo + ((int64_t)ci * 64) * ld + (int64_t)cj * 64;
+        double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)wk * 4096;
+        int32_t *wflag = g.sync->wflag + b;
+        const int newver = fin ? VER_FINAL : need_c + 1;
+
+        if (post == T_TDIAG) {   // T[k][k] = W_k^T, rows of the carried right-hand sides zeroed
+            wg_wait_flags(tid == 0 ? wflag : nullptr, wk + 1, 2000 + wk, &g.sync->status, tid);
+            const int nrow = (wk == g.nbk - 1) ? ncol_last : 64;
+            for (int idx = tid; idx < 4096; idx += 256) tiles[(idx >> 6) * 65 + (idx & 63)] = Wk[idx];
+            __syncthreads();
+            for (int idx = tid; idx < 4096; idx += 256) {
+                const int r = idx >> 6, c = idx & 63;
+                __hip_atomic_store(C + (int64_t)r * ld + c, r < nrow ? tiles[c * 65 + r] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wg_publish(vC, newver, tid);
+            continue;
+        }
+        // ---- inputs: the output tile's earlier visits, the operand tiles final ----
+        {
+            const int32_t *addr = nullptr;
+            int nd = VER_FINAL;
+            if (tid == 0) { addr = vC; nd = need_c; }
+            else if (tid <= nkb) addr = ver + bufL * nb2 + li * g.nbk + kb0 + tid - 1;
+            else if (tid <= 2 * nkb) addr = ver + bufR * nb2 + ri * g.nbk + kb0 + tid - 1 - nkb;
+            wg_wait_flags(addr, nd, 1000 + slot % 1000, &g.sync->status, tid);
+        }
+        if (st) st[1] = wall_clock64();
+        Tile64 acc;
+        tile_update(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
+                    g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
+                    mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
+        if (st) st[2] = wall_clock64();
+        if (post == T_STORE) {
+            store_acc_sc1(acc.v, C, ld, crow, ccol);
+            if (st) st[3] = wall_clock64();
+            wg_publish(vC, newver, tid);
+            if (st) st[4] = wall_clock64();
+            continue;
+        }
+        // T_SOLVE: wait for W_k, then tile <- tile * W_k^T
+        wg_wait_flags(tid == 0 ? wflag : nullptr, wk + 1, 3000 + wk, &g.sync->status, tid);
+        d4 out[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) out[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        mul_acc_bt(out, acc.v, Wk, 64, 1.0, As, Bs, tid, wave, lane);
+        store_acc_sc1(out, C, ld, crow, ccol);
+        if (st) st[3] = wall_clock64();
+        wg_publish(vC, newver, tid);
+        if (st) st[4] = wall_clock64();
+    }
 }
 
 // column n of T holds -K^-1 y: copy it into row n of S (the layout dgpamd_potri leaves: row n of Ainv = -alpha^T)
@@ -534,8 +838,14 @@ size_t potrf_ws_doubles(int64_t n, int batch) {
     return (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB;   // diagonal inverses + {logdet (loglik), logdet (graph)} scratch; info words follow
 }
 
+static size_t mega_sync_bytes(int64_t nbk, int batch);
+// offset of the one-launch kernel's synchronisation block inside the workspace (16-byte aligned)
+static size_t mega_sync_offset(int64_t n, int batch) {
+    const size_t b = potrf_ws_doubles(n, batch) * sizeof(double) + 3 * DGPAMD_MAXB * sizeof(int32_t);   // + info, step flags, chain CU keys
+    return (b + 15) / 16 * 16;
+}
 extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
-    return potrf_ws_doubles(n, batch) * sizeof(double) + 3 * DGPAMD_MAXB * sizeof(int32_t);   // + info, step flags, chain CU keys
+    return mega_sync_offset(n, batch) + mega_sync_bytes(padded_dim(n) / 64, batch);
 }
 
 // Task tables (see potrf_step_kernel): one vector of tasks per launch, cached on the device per (nbk, inverse).
@@ -628,6 +938,144 @@ static int get_tasks(dgpamd_ctx *ctx, int nbk, bool inv, TaskTable *&out) {
     return DGPAMD_OK;
 }
 
+// ---- task table of the one-launch kernel -------------------------------------------------------------------------
+// The same right-looking schedule as build_tasks (lazy bulk: a tile takes LAZY panels per visit), restated per tile:
+// `applied` panels so far, `visits` so far.  Differences: no chain tasks (the chain workgroups run on their own); the
+// first panel tile A[k+1][k] gets its last worker visit as a plain update (the chain does the solve); diagonal tiles are
+// brought up to date one block step early, so that the visit the chain waits for applies the newest panel only.
+struct MegaTable {
+    MTask *dev = nullptr;
+    int2 *need_dev = nullptr;
+    int ntask = 0;
+};
+
+static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::vector<int2> &need) {
+    const int nb2 = nbk * nbk;
+    std::vector<int> appliedA(nb2, 0), visitsA(nb2, 0), appliedT(nb2, 0), visitsT(nb2, 0), visitsS(nb2, 0);
+    if (inv)
+        for (int q = 0; q < nbk; ++q)
+            for (int j = 0; j < nbk; ++j) appliedT[q * nbk + j] = q;   // T[q][j] sums the panels kb >= q
+    need.assign(nbk, make_int2(0, 0));
+    auto emit = [&](int4 a, int need_c, int fin, int wk) {
+        MTask t;
+        t.a = a;
+        t.b = make_int4(need_c, fin, wk, 0);
+        out.push_back(t);
+    };
+    // bring A[i][j] up to the panels < upto (plain update, stored)
+    auto updA = [&](int i, int j, int upto) {
+        int &ap = appliedA[i * nbk + j];
+        if (upto <= ap) return;
+        emit(make_task(T_STORE, 0, 0, 0, BUF_A, i, j, BUF_A, i, BUF_A, j, ap, upto - ap), visitsA[i * nbk + j]++, 0, 0);
+        ap = upto;
+    };
+    // bring T[q][j] up to the panels < upto
+    auto updT = [&](int q, int j, int upto) {
+        int &ap = appliedT[q * nbk + j];
+        if (upto <= ap) return;
+        emit(make_task(T_STORE, ap == q, 0, 0, BUF_T, q, j, BUF_T, q, BUF_A, j, ap, upto - ap), visitsT[q * nbk + j]++, 0, 0);
+        ap = upto;
+    };
+    const int nl = nbk + (inv ? 2 : 0);
+    for (int k = 0; k < nl; ++k) {
+        if (k < nbk) {
+            // what the chain picks up after factoring block k: first, and the newest panel only
+            if (k + 1 < nbk) {
+                updA(k + 1, k + 1, k);
+                updA(k + 1, k, k);
+                need[k] = make_int2(visitsA[(k + 1) * nbk + k], visitsA[(k + 1) * nbk + k + 1]);
+            }
+            if (inv) emit(make_task(T_TDIAG, 1, 0, 0, BUF_T, k, k, BUF_A, 0, BUF_A, 0, 0, 0), visitsT[k * nbk + k]++, 1, k);
+            // panel column k: the remaining updates, then the solve with W_k
+            for (int i = k + 2; i < nbk; ++i) {
+                const int ap = appliedA[i * nbk + k];
+                emit(make_task(T_SOLVE, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap), visitsA[i * nbk + k]++, 1, k);
+                appliedA[i * nbk + k] = k;
+            }
+            if (inv)
+                for (int q = k - 1; q >= 0; --q) {
+                    const int ap = appliedT[q * nbk + k];
+                    emit(make_task(T_SOLVE, ap == q, 0, 0, BUF_T, q, k, BUF_T, q, BUF_A, k, ap, k - ap), visitsT[q * nbk + k]++, 1, k);
+                    appliedT[q * nbk + k] = k;
+                }
+            // lazy bulk: columns k+1, k+1+LAZY, ... below the diagonal; diagonal tiles one block step ahead of that
+            for (int j = k + 2; j < nbk; j += LAZY) updA(j, j, k);
+            for (int j = k + 1; j < nbk; j += LAZY)
+                for (int i = j + 1; i < nbk; ++i) updA(i, j, k);
+            if (inv)
+                for (int j = k + 1; j < nbk; j += LAZY)
+                    for (int q = 0; q <= k - 1; ++q) updT(q, j, k);
+        }
+        if (inv)   // S[q][q'] += Pt_q Pt_q'^T for the panels (k-2, k-1), rows q = k-2, k-4, ...
+            for (int q = k - 2; q >= 0; q -= 2) {
+                const int nkb = (k - 1 < nbk ? k : nbk) - (k - 2);
+                if (nkb <= 0) continue;
+                const int mask = (k - 2 + nkb - 1 == nbk - 1) ? 1 : 0;
+                for (int q2 = 0; q2 <= q; ++q2)
+                    emit(make_task(T_STORE, q == k - 2, 1, mask, BUF_S, q, q2, BUF_T, q, BUF_T, q2, k - 2, nkb), visitsS[q * nbk + q2]++, 0, 0);
+            }
+    }
+}
+
+static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, MegaTable *&out) {
+    static std::map<std::pair<dgpamd_ctx *, std::pair<int, int>>, MegaTable> cache;
+    MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0}}];
+    if (!mt.dev) {
+        std::vector<MTask> tasks;
+        std::vector<int2> need;
+        build_mega_tasks(nbk, inv, tasks, need);
+        mt.ntask = (int)tasks.size();
+        HIP_TRY(ctx, hipMalloc((void **)&mt.dev, (tasks.size() + 1) * sizeof(MTask)));
+        HIP_TRY(ctx, hipMemcpy(mt.dev, tasks.data(), tasks.size() * sizeof(MTask), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc((void **)&mt.need_dev, need.size() * sizeof(int2)));
+        HIP_TRY(ctx, hipMemcpy(mt.need_dev, need.data(), need.size() * sizeof(int2), hipMemcpyHostToDevice));
+    }
+    out = &mt;
+    return DGPAMD_OK;
+}
+
+static int mega_wgs_per_cu() {
+    static int n = 0;
+    if (!n) {
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, potrf_mega_kernel, 256, 0) != hipSuccess || q < 1) q = 2;
+        n = q > 4 ? 4 : q;
+    }
+    return n;
+}
+
+// bytes of the one-launch kernel's synchronisation block (MegaSync + tile versions), a multiple of 16
+static size_t mega_sync_bytes(int64_t nbk, int batch) {
+    size_t b = sizeof(MegaSync) + (size_t)batch * 3 * nbk * nbk * sizeof(int32_t);
+    return (b + 15) / 16 * 16;
+}
+
+static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, double *S, int64_t stride_a, int batch,
+                             double *logdet, int32_t *info, double *ws, void *syncmem, const MegaTable *mt) {
+    const int64_t Np = padded_dim(n);
+    const int nbk = (int)(Np / 64);
+    HIP_TRY(ctx, hipMemsetAsync(syncmem, 0, mega_sync_bytes(nbk, batch), ctx->stream));
+    MegaArgs g;
+    g.buf[BUF_A] = A; g.buf[BUF_T] = T; g.buf[BUF_S] = S;
+    g.ws = ws; g.ld = Np; g.stride_a = stride_a; g.stride_ws = (int64_t)nbk * 4096; g.n = n; g.nbk = nbk; g.batch = batch;
+    g.inv = T != nullptr;
+    g.tasks = mt->dev; g.ntask = mt->ntask; g.chain_need = mt->need_dev;
+    g.sync = reinterpret_cast<MegaSync *>(syncmem);
+    g.ver = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(syncmem) + sizeof(MegaSync));
+    g.logdet = logdet; g.info = info; g.trace = ctx->trace;
+    // every workgroup resident at once (not needed for progress, but a queued worker would only start late)
+    int64_t grid = (int64_t)mega_wgs_per_cu() * ctx->num_cu;
+    const int64_t useful = (int64_t)batch * (mt->ntask + 1 + mega_wgs_per_cu());
+    if (grid > useful) grid = useful;
+    if (grid < batch + 1) grid = batch + 1;
+    hipLaunchKernelGGL(potrf_mega_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, g);
+    if (T)
+        hipLaunchKernelGGL(copy_alpha_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, ctx->stream,
+                           (const double *)T, S, Np, n, stride_a);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
 // workgroups of potrf_step_kernel that one CU holds (registers / LDS): decides how many placeholder rows guard a chain
 static int step_kernel_wgs_per_cu() {
     static int n = 0;
@@ -676,11 +1124,15 @@ static int potrf_launches(dgpamd_ctx *ctx, int64_t n, double *A, double *T, doub
     return DGPAMD_OK;
 }
 
-__global__ void potrf_copy_out_kernel(const double *ld_ws, const int32_t *info_ws, double *logdet, int32_t *info, int batch) {
+// status: the one-launch kernel's give-up word (null for the per-step launches, whose spins write info = -1 themselves).
+// A lost hand-off is reported as info = -1 for every matrix of the call: not a numerical failure (ops.py raises
+// DgpAmdError for it, not LinAlgError).
+__global__ void potrf_copy_out_kernel(const double *ld_ws, const int32_t *info_ws, double *logdet, int32_t *info, int batch,
+                                      const int32_t *status) {
     const int b = threadIdx.x;
     if (b < batch) {
         logdet[b] = ld_ws[b];
-        info[b] = info_ws[b];
+        info[b] = (status && *status) ? -1 : info_ws[b];
     }
 }
 
@@ -693,6 +1145,19 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     double *ld_ws = ws + (size_t)batch * nbk * 4096 + DGPAMD_MAXB;
     int32_t *info_ws = reinterpret_cast<int32_t *>(ws + (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB);
     int32_t *flags = info_ws + DGPAMD_MAXB;
+    if (ctx->potrf_mode == 1) {
+        MegaTable *mt = nullptr;
+        int rc = get_mega_tasks(ctx, (int)nbk, T != nullptr, mt);   // (uploads the table on first use)
+        if (rc) return rc;
+        (void)mega_wgs_per_cu();
+        void *syncmem = reinterpret_cast<char *>(ws) + mega_sync_offset(n, batch);
+        rc = potrf_mega_launch(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, syncmem, mt);
+        if (rc) return rc;
+        hipLaunchKernelGGL(potrf_copy_out_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)ld_ws,
+                           (const int32_t *)info_ws, logdet, info, batch, (const int32_t *)&reinterpret_cast<MegaSync *>(syncmem)->status);
+        LAUNCH_CHECK(ctx);
+        return DGPAMD_OK;
+    }
     TaskTable *tt = nullptr;
     int rc = get_tasks(ctx, (int)nbk, T != nullptr, tt);   // (uploads the table on first use: outside the capture)
     if (rc) return rc;
@@ -702,8 +1167,15 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     rc = graph_run(ctx, key, [&]() { return potrf_launches(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, flags, tt); });
     if (rc) return rc;
     hipLaunchKernelGGL(potrf_copy_out_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)ld_ws,
-                       (const int32_t *)info_ws, logdet, info, batch);
+                       (const int32_t *)info_ws, logdet, info, batch, (const int32_t *)nullptr);
     LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_set_potrf_mode(dgpamd_ctx *ctx, int mode) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (mode != 0 && mode != 1) BAD_ARG(ctx, "mode must be 0 (one launch per block step) or 1 (one persistent launch)");
+    ctx->potrf_mode = mode;
     return DGPAMD_OK;
 }
 

@@ -29,6 +29,7 @@ struct dgpamd_ctx {
     std::vector<hipEvent_t> prof_events;              // start/stop pairs
     int use_graphs;                                   // replay static launch sequences as hipGraphs
     int linkgp_direct;                                // 1: evaluate the Matern J factor in the reference's direct form
+    int potrf_mode;                                   // 1: factorisation as one persistent dataflow launch; 0: one launch per block step
     long long *trace;                                 // device buffer for in-kernel timestamps (diagnostics), or null
     double *pinned;                                   // small pinned staging buffer for result copies (lazy)
     char *devargs, *hostargs;                         // argument arrays of the multi-node launches (device / pinned host)

@@ -22,6 +22,7 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->prof_work = 0.0;
     ctx->use_graphs = 1;
     ctx->linkgp_direct = 0;
+    ctx->potrf_mode = 0;   // (the one-launch kernel is opt-in until it beats the per-step launches at every batch size)
     ctx->trace = nullptr;
     {
         int ncu = 0;

@@ -249,14 +249,20 @@ __device__ __forceinline__ void diag_wave(d4 (&X)[4], d4 (&Y)[4], DiagShared &sh
     }
 }
 
-// Factor the 64x64 block held as X (column-block layout above; only tiles t <= w are read) in place (X becomes the upper
-// factor U = L^T) and write the inverse of the lower factor to Wb (64x64, row-major).  ncol = pivots in this block.  Leaves the pivots in sh.piv and returns (every thread) 1 + the index of the first
-// non-positive pivot, or 0.  `stamp`: optional 9 slots of wall_clock64 stamps (wave 0, lane 0): start of 16-block J, its first barrier, end.
-__device__ __forceinline__ int diag_factor(Tile64 &tile, DiagShared &sh, double *Wb, int ncol_, long long *stamp = nullptr) {
+// Factor the 64x64 block held as X (column-block layout above; only tiles t <= w are read) in place: X becomes the upper
+// factor U = L^T, and Winv column block w of the inverse L^-1 in the same layout (tiles above the diagonal zero).
+// ncol = pivots in this block.  Leaves the pivots in sh.piv and returns (every thread) 1 + the index of the first
+// non-positive pivot, or 0.  `stamp`: optional 9 slots of wall_clock64 stamps (wave 0, lane 0): start of 16-block J, its
+// first barrier, end.
+__device__ __forceinline__ int diag_factor(Tile64 &tile, Tile64 &Winv, DiagShared &sh, int ncol_, long long *stamp = nullptr) {
     d4 (&X)[4] = tile.v;
-    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lm = l & 15, lu = l >> 4;
+    d4 (&Y)[4] = Winv.v;
+    int tid = threadIdx.x;
+    // opaque to the optimiser: inside a loop over block steps the dozens of lane predicates below would otherwise be
+    // hoisted out of it and held in SGPR pairs for the whole loop (spills)
+    asm volatile("" : "+v"(tid));
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int ncol = __builtin_amdgcn_readfirstlane(ncol_);
-    d4 Y[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) Y[t] = (d4){0.0, 0.0, 0.0, 0.0};
     switch (w) {
@@ -266,17 +272,29 @@ __device__ __forceinline__ int diag_factor(Tile64 &tile, DiagShared &sh, double 
         default: diag_wave<3>(X, Y, sh, ncol, l, stamp); break;
     }
     if (stamp && tid == 0) stamp[8] = wall_clock64();
-
-    // ---- results: W (row-major 64x64, coalesced) ----
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Wb[(16 * I + lu + 4 * r) * 64 + 16 * w + lm] = (I >= w) ? Y[I][r] : 0.0;
     lds_barrier();
     int bad = 0;
 #pragma unroll
     for (int J = 3; J >= 0; --J) bad = sh.bad[J] ? sh.bad[J] : bad;
     return bad;
+}
+
+// W = L^-1 (row-major 64x64, coalesced rows) from the column blocks diag_factor leaves in registers.
+// SC1: write-through stores (MI355X_MICROARCH.md hand-off recipe: payload of an in-launch hand-off).
+template <bool SC1>
+__device__ __forceinline__ void diag_store_inverse(const Tile64 &Winv, double *Wb) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lm = l & 15, lu = l >> 4;
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double *p = Wb + (16 * I + lu + 4 * r) * 64 + 16 * w + lm;
+            const double v = (I >= w) ? Winv.v[I][r] : 0.0;
+            if (SC1)
+                __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                *p = v;
+        }
 }
 
 // The lower factor L = U^T of a block factored by diag_factor to Ab (row stride ld): strictly upper part zeroed, carried

@@ -79,6 +79,10 @@ class Engine:
     def set_graphs(self, enable):
         self._chk(lib.dgpamd_set_graphs(self.h, 1 if enable else 0))
 
+    def set_potrf_mode(self, mode):
+        """1 (default): the factorisation is one persistent dataflow launch; 0: one launch per 64-column block step."""
+        self._chk(lib.dgpamd_set_potrf_mode(self.h, int(mode)))
+
     def stream(self):
         """Context manager making this engine's HIP stream torch's current stream (so that torch's
         allocator and copies are ordered with the library's launches)."""

@@ -116,6 +116,12 @@ int dgpamd_kmatrix(dgpamd_ctx *ctx, int kind, int64_t n,
 size_t dgpamd_potrf_workspace(int64_t n, int batch);
 int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch,
                  double *logdet, int32_t *info, void *work);
+/* How dgpamd_potrf / dgpamd_potrf_inv (and everything built on them) run the blocked factorisation:
+ * mode 1: ONE persistent launch -- a pivot-chain workgroup per matrix plus workers that pull tile tasks
+ * from a queue, ordered by per-tile version words (csrc/chol.hip, potrf_mega_kernel); mode 0 (default): one launch per 64-column
+ * block step, replayed as a hipGraph.  Same results up to the rounding of a different summation order.
+ * info[b] = -1 reports a lost in-kernel hand-off (a bounded spin gave up), never a numerical failure. */
+int dgpamd_set_potrf_mode(dgpamd_ctx *ctx, int mode);
 
 /* Read the quadratic forms out of factored buffers: quad[b*r*r + q*r + q'] =
  * y_q^T K^-1 y_q'  (= -corner).                                               */

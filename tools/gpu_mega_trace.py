@@ -1,0 +1,57 @@
+"""Phase stamps of the one-launch factorisation (dgpamd_debug_trace): the chain of matrix 0 per block step and the first
+tasks of one worker.  usage: gpu_mega_trace.py n B [inv]"""
+import sys, os, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dgp_amd.ops import Engine
+from dgp_amd._lib import lib
+
+eng = Engine(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+inv = len(sys.argv) > 3 and sys.argv[3] == 'inv'
+Np = eng.padded_dim(n)
+rng = np.random.default_rng(0)
+X = eng.tensor(rng.uniform(size=(B, n, 5)))
+G = eng.tensor(rng.uniform(size=(n, 5)))
+y = eng.tensor(rng.normal(size=n))
+A = eng.empty(B, Np, Np)
+work = eng.potrf_workspace(n, B)
+T, S = eng.empty(B, Np, Np), eng.empty(B, Np, Np)
+tr = torch.zeros(8192, dtype=torch.int64, device=A.device)
+eng.set_potrf_mode(1)
+for rep in range(3):
+    eng.kmatrix('matern2.5', X, None, G, [1.0], 1e-6, out=A, full=False, Y=y, batch=B)
+    if rep == 2:
+        lib.dgpamd_debug_trace(eng.h, C.c_void_p(tr.data_ptr()))
+    if inv:
+        eng.potrf_inv(n, A, T, S, batch=B, work=work)
+    else:
+        eng.potrf(n, A, batch=B, work=work)
+torch.cuda.synchronize()
+lib.dgpamd_debug_trace(eng.h, None)
+raw = tr.cpu().numpy().astype(np.float64) / 100.0   # us
+nbk = Np // 64
+t = raw[:16 * nbk].reshape(-1, 16)
+print('n=%d B=%d inv=%s: chain of matrix 0, us' % (n, B, inv))
+print(' k | factor  publish W  wait inputs  solve  update | step')
+for k in range(nbk - 1):
+    r = t[k]
+    print('%2d | %5.1f  %5.1f  %5.1f  %5.1f  %5.1f | %5.1f' % (k, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], t[k + 1][0] - r[0]))
+print('total chain %.1f us' % (t[nbk - 1][1] - t[0][0]))
+d = raw[1024:1024 + 16 * nbk].reshape(-1, 16)
+r = d[5]
+print('block 5, diagonal factor (us from its start): ' + ' | '.join(
+    '16-block %d: start %.2f, factored %.2f' % (J, r[2 * J] - r[0], r[2 * J + 1] - r[0]) for J in range(4)) + ' | end %.2f' % (r[8] - r[0]))
+w = raw[2048:2048 + 640].reshape(-1, 8)
+iw = tr.cpu().numpy()[2048:2048 + 640].reshape(-1, 8)
+print('one worker, per task (us): kind panels | wait inputs  compute  store  publish | total   gap to next pull')
+kinds = {0: 'store', 1: 'solve', 3: 'tdiag'}
+for i in range(len(w)):
+    if w[i][0] == 0:
+        break
+    code = int(iw[i][5])
+    gap = w[i + 1][0] - w[i][4] if i + 1 < len(w) and w[i + 1][0] > 0 else float('nan')
+    print('%3d %5s %d | %5.1f  %5.1f  %5.1f  %5.1f | %5.1f   %5.1f' % (i, kinds.get(code & 15, '?'), (code >> 8) & 255, w[i][1] - w[i][0], w[i][2] - w[i][1],
+                                                              w[i][3] - w[i][2], w[i][4] - w[i][3], w[i][4] - w[i][0], gap))

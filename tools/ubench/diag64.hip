@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256, 2) void k_diag(const double *A, double *L, dou
         int nc = ncol;
         asm volatile("" : "+s"(nc));   // keep the compiler from hoisting the per-pivot conditions out of the timing loop
         const long long t0 = wall_clock64(), c0 = clock64();
-        b = diag_factor(tile, sh, W, nc, rep == reps - 1 ? stamps : nullptr);
+        Tile64 winv;
+        b = diag_factor(tile, winv, sh, nc, rep == reps - 1 ? stamps : nullptr);
+        diag_store_inverse<false>(winv, W);
         diag_store_factor(tile, L, 64, nc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
