@@ -200,6 +200,13 @@ __device__ __forceinline__ void load_acc(d4 (&acc)[4], const double *C, int64_t 
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = C[(int64_t)(crow + 4 * r) * ld + 16 * t + ccol];
 }
+__device__ __forceinline__ void load_acc_sc1(d4 (&acc)[4], const double *C, int64_t ld, int crow, int ccol) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[t][r] = __hip_atomic_load(C + (int64_t)(crow + 4 * r) * ld + 16 * t + ccol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void store_acc(const d4 (&acc)[4], double *C, int64_t ld, int crow, int ccol) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -209,6 +216,8 @@ __device__ __forceinline__ void store_acc(const d4 (&acc)[4], double *C, int64_t
 // acc = (C ? C : 0) + sign * sum over nkb consecutive 64-blocks  L_kb R_kb^T.  Software pipelined: the global loads of
 // the next half tile are in flight (registers) while the MFMAs of the current one run.  In the 64-block number
 // mask_kb (relative to the first) the columns >= klim of both operands read as zero.
+// SC1: every global load bypasses L1 (operands handed over inside a launch: the one-launch kernel).
+template <bool SC1 = false>
 __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const double *Lp, const double *Rp, int64_t ld,
                                             int nkb, double sign, int mask_kb, int klim, double *As, double *Bs, int tid,
                                             int wave, int lane) {
@@ -216,17 +225,28 @@ __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
     double2 pa[4], pb[4];
     const int nh = 2 * nkb;
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void *)Lp, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)Rp, 0, 0x7fffffff, 0x00020000);
     auto fetch = [&](int hh) {
         const int64_t off = 32 * hh;   // consecutive half tiles are consecutive 32-column slabs
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            pa[it] = *reinterpret_cast<const double2 *>(Lp + (int64_t)(r0 + 16 * it) * ld + off + c2);
-            pb[it] = *reinterpret_cast<const double2 *>(Rp + (int64_t)(r0 + 16 * it) * ld + off + c2);
+            if (SC1) {
+                const int bo = (int)(((int64_t)(r0 + 16 * it) * ld + off + c2) * 8);
+                const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsL, bo, 0, 16);
+                const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsR, bo, 0, 16);
+                pa[it] = make_double2(__hiloint2double(va.y, va.x), __hiloint2double(va.w, va.z));
+                pb[it] = make_double2(__hiloint2double(vb.y, vb.x), __hiloint2double(vb.w, vb.z));
+            } else {
+                pa[it] = *reinterpret_cast<const double2 *>(Lp + (int64_t)(r0 + 16 * it) * ld + off + c2);
+                pb[it] = *reinterpret_cast<const double2 *>(Rp + (int64_t)(r0 + 16 * it) * ld + off + c2);
+            }
         }
     };
     if (nh > 0) fetch(0);
     if (C) {
-        load_acc(acc, C, ld, crow, ccol);
+        if (SC1) load_acc_sc1(acc, C, ld, crow, ccol);
+        else load_acc(acc, C, ld, crow, ccol);
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -256,13 +276,17 @@ __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const
 // read from the LOWER triangle of the stored tile (the last block's upper part does not mirror the carried rows): the
 // 16x16 tiles (w, t), t <= w, are loaded row-contiguously (four full 128-byte lines per load instruction; the transposed
 // access touches sixteen) and transposed inside the wave through `scratch` (16 x 16 doubles of LDS per wave).
+template <bool SC1 = false>
 __device__ __forceinline__ void load_cb_lower(d4 (&acc)[4], const double *C, int64_t ld, int wave, int lane, double *scratch) {
     const int lm = lane & 15, lu = lane >> 4;
     d4 nat[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nat[t][r] = (t <= wave) ? C[(int64_t)(16 * wave + lu + 4 * r) * ld + 16 * t + lm] : 0.0;
+        for (int r = 0; r < 4; ++r) {
+            const double *p = C + (int64_t)(16 * wave + lu + 4 * r) * ld + 16 * t + lm;
+            nat[t][r] = (t <= wave) ? (SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p) : 0.0;
+        }
     vlds_double *S = (vlds_double *)scratch + wave * 256;   // element (i, j) at i * 16 + (j ^ i): both passes conflict-free
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -306,10 +330,12 @@ __device__ __forceinline__ void diag_update_cb(d4 (&acc)[4], const double *C, co
 }
 // out += sign * in * Bg^T   (in: accumulator-layout 64x64 tile, Bg: 64x64 row-major tile in global memory).  Both
 // halves of Bg are requested up front: one exposed load latency instead of two on the panel's critical path.
+template <bool SC1 = false>
 __device__ __forceinline__ void mul_acc_bt(d4 (&out)[4], const d4 (&in)[4], const double *Bg, int64_t ldb, double sign,
                                            double *As, double *Bs, int tid, int wave, int lane) {
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
-    const HalfTile b0 = fetch_mk(Bg, ldb, tid, 0), b1 = fetch_mk(Bg, ldb, tid, 1);
+    const HalfTile b0 = SC1 ? fetch_mk_sc1(Bg, ldb, tid, 0) : fetch_mk(Bg, ldb, tid, 0);
+    const HalfTile b1 = SC1 ? fetch_mk_sc1(Bg, ldb, tid, 1) : fetch_mk(Bg, ldb, tid, 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
@@ -358,8 +384,10 @@ __device__ __forceinline__ int cu_key() {
 
 __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     __shared__ double tiles[2 * 64 * LDM];   // As | Bs
-    __shared__ DiagShared sh;
     double *As = tiles, *Bs = tiles + 64 * LDM;
+    // the diagonal factor's LDS lives in Bs (idle while a chain workgroup factors): 35 KB per workgroup, four per CU
+    static_assert(sizeof(DiagShared) <= 64 * LDM * sizeof(double), "DiagShared must fit the B staging tile");
+    DiagShared &sh = *reinterpret_cast<DiagShared *>(Bs);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
     const int k = g.k, batch = g.batch;
@@ -432,8 +460,10 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     if (post == T_CHAIN) {
         if (nkb == 1)
             diag_update_cb(acc.v, C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64, ld, As, Bs, tid, wave, lane);
-        else
+        else {
             load_cb_lower(acc.v, C, ld, wave, lane, Bs);
+            __syncthreads();   // (the factor's LDS lives in Bs as well: every wave is done with its transposition scratch)
+        }
     } else
         tile_update(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
                     g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
@@ -523,12 +553,30 @@ struct MegaArgs {
     long long *trace;
 };
 
+// Write-through (sc1) store of an accumulator tile, 16 bytes per lane: neighbouring lanes hold neighbouring columns of the
+// same rows, so each pair swaps one value (DPP quad_perm [1,0,3,2]) -- the even lane ends up with two columns of row r0, the odd
+// lane with two columns of row r1 -- and every store instruction still writes whole 128-byte lines (8-byte sc1 stores cost
+// 2.7x the time per byte: MI355X_MICROARCH.md, stores of each flavour).
+__device__ __forceinline__ double swap_pair(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void store_acc_sc1(const d4 (&acc)[4], double *C, int64_t ld, int crow, int ccol) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)C, 0, 0x7fffffff, 0x00020000);
+    const bool odd = ccol & 1;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            __hip_atomic_store(C + (int64_t)(crow + 4 * r) * ld + 16 * t + ccol, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int rp = 0; rp < 2; ++rp) {
+            const double a0 = acc[t][2 * rp], a1 = acc[t][2 * rp + 1];
+            const double got = swap_pair(odd ? a0 : a1);
+            const double lo = odd ? got : a0, hi = odd ? a1 : got;
+            const int row = crow + 4 * (2 * rp + (odd ? 1 : 0)), col = 16 * t + (ccol & ~1);
+            u32x4 v;
+            v.x = __double2loint(lo); v.y = __double2hiint(lo); v.z = __double2loint(hi); v.w = __double2hiint(hi);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((int64_t)row * ld + col) * 8), 0, 16);
+        }
 }
 // every storing wave drains its stores, then one lane publishes
 __device__ __forceinline__ void wg_publish(int32_t *flag, int value, int tid) {
@@ -538,6 +586,9 @@ __device__ __forceinline__ void wg_publish(int32_t *flag, int value, int tid) {
 }
 // Wave 0: lane l < nflag polls flag[l] until it reaches need[l] (relaxed, bounded), then ONE agent-scope acquire;
 // the workgroup's barrier follows.  Returns (to every thread, through LDS word `bc`) 0 or the give-up code.
+// ACQ false would rely on sc1 loads alone (L1 bypassed, no acquire); it is measured valid only for one workgroup per CU
+// (MI355X_MICROARCH.md, valid forms) and saves ~1 us per task here -- not used: the acquire stays.
+template <bool ACQ>
 __device__ __forceinline__ void wg_wait_flags(const int32_t *addr, int need, int code, int32_t *status, int tid) {
     if (tid < 64) {
         bool ok = (addr == nullptr);
@@ -553,8 +604,12 @@ __device__ __forceinline__ void wg_wait_flags(const int32_t *addr, int need, int
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ACQ) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
     __syncthreads();
 }
@@ -586,6 +641,7 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
     if (tid == 0) __hip_atomic_store(&g.sync->cukey[b], cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Tile64 D;
     load_cb_lower(D.v, A, ld, wave, lane, scratch);
+    __syncthreads();   // (scratch and the factor's LDS share Bs)
     double logdet = 0.0;
     int info = 0;
     for (int k = 0; k < g.nbk; ++k) {
@@ -594,7 +650,14 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
         const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
         double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096;
         Tile64 winv;
-        const int bad = diag_factor(D, winv, sh, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr);
+        // (whether the workers' tiles for the next block have arrived is asked during the factorisation: DiagPoll)
+        const int2 need = g.chain_need[k < g.nbk - 1 ? k : 0];
+        DiagPoll poll;
+        poll.f0 = ver + (k + 1) * g.nbk + k; poll.f1 = ver + (k + 1) * g.nbk + k + 1;
+        poll.need0 = need.x; poll.need1 = need.y;
+        const int bad = diag_factor(D, winv, sh, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr,
+                                    k + 1 < g.nbk ? &poll : nullptr);
+        const int ready = sh.ready;   // (read before Bs, which holds the factor's LDS, is reused)
         if (tr) tr[16 * k + 1] = wall_clock64();
         diag_store_inverse<true>(winv, Wk);
         wg_publish(wflag, k + 1, tid);   // the panel tasks of this block can run
@@ -611,20 +674,17 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
         if (k + 1 == g.nbk) break;
         if (__hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // (a lost hand-off ends the launch)
         // ---- the next block's inputs from the workers: A[k+1][k] and A[k+1][k+1] with the panels <= k-1 applied ----
-        const int2 need = g.chain_need[k];
-        {
+        if (!ready) {
             const int32_t *addr = nullptr;
             int nd = 0;
             if (tid == 0) { addr = ver + (k + 1) * g.nbk + k; nd = need.x; }
             if (tid == 1) { addr = ver + (k + 1) * g.nbk + k + 1; nd = need.y; }
-            wg_wait_flags(addr, nd, 100 + k, &g.sync->status, tid);
+            wg_wait_flags<true>(addr, nd, 100 + k, &g.sync->status, tid);
         }
         if (tr) tr[16 * k + 3] = wall_clock64();
         double *Pg = A + ((int64_t)(k + 1) * 64) * ld + (int64_t)k * 64;
         const double *Cn = A + ((int64_t)(k + 1) * 64) * ld + (int64_t)(k + 1) * 64;
-        const HalfTile a0 = fetch_mk(Pg, ld, tid, 0), a1 = fetch_mk(Pg, ld, tid, 1);
-        Tile64 Dn;
-        load_cb_lower(Dn.v, Cn, ld, wave, lane, scratch);
+        const HalfTile a0 = fetch_mk_sc1(Pg, ld, tid, 0), a1 = fetch_mk_sc1(Pg, ld, tid, 1);
         // ---- P = A[k+1][k] W_k^T, W_k straight from the registers ----
         d4 P[4];
 #pragma unroll
@@ -644,6 +704,9 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
         }
         if (tr) tr[16 * k + 4] = wall_clock64();
         store_acc_sc1(P, Pg, ld, crow, ccol);
+        __syncthreads();   // (Bs, which holds the transposition scratch, is no longer read)
+        Tile64 Dn;         // loaded only now: the registers of W_k and of the panel tile's halves are free again
+        load_cb_lower<true>(Dn.v, Cn, ld, wave, lane, scratch);
         // ---- D = A[k+1][k+1] - P P^T in the column-block layout; the panel tile is published between the halves ----
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -669,9 +732,9 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
 
 __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
     __shared__ double tiles[2 * 64 * LDM];   // As | Bs
-    __shared__ DiagShared sh;
     __shared__ int32_t bc[4];
     double *As = tiles, *Bs = tiles + 64 * LDM;
+    DiagShared &sh = *reinterpret_cast<DiagShared *>(Bs);   // (idle while a chain workgroup factors)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
     const int batch = g.batch;
@@ -699,14 +762,13 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
     // computed, stored, published (+ the task's kind / panels in the sixth word)
     long long *wst = (g.trace && tid == 0 && (int)blockIdx.x == batch + 40) ? g.trace + 2048 : nullptr;
     int nst = 0;
+    // The pull of the NEXT task is issued when a task's arithmetic is done and lands while its tile is stored and
+    // published (an agent-scope atomic plus the descriptor read are several microseconds under load).
+    if (tid == 0) bc[1] = __hip_atomic_fetch_add(&g.sync->qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         __syncthreads();
-        if (tid == 0) {
-            const int q0 = __hip_atomic_fetch_add(&g.sync->qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bc[1] = __hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? total : q0;   // (a lost hand-off ends the launch)
-        }
-        __syncthreads();
         const int q = __builtin_amdgcn_readfirstlane(bc[1]);
+        __syncthreads();
         if (q >= total) break;
         const int slot = q / batch, b = q - slot * batch;
         const MTask mt = g.tasks[slot];
@@ -726,17 +788,28 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)wk * 4096;
         int32_t *wflag = g.sync->wflag + b;
         const int newver = fin ? VER_FINAL : need_c + 1;
+        int qn = 0;
+        auto pull_next = [&]() {
+            if (tid == 0) qn = __hip_atomic_fetch_add(&g.sync->qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto finish = [&]() {   // drain (the tile's stores and the pull), publish, hand the next task to the loop's head
+            wg_publish(vC, newver, tid);
+            if (tid == 0) bc[1] = qn;
+            if (st) st[4] = wall_clock64();
+        };
 
         if (post == T_TDIAG) {   // T[k][k] = W_k^T, rows of the carried right-hand sides zeroed
-            wg_wait_flags(tid == 0 ? wflag : nullptr, wk + 1, 2000 + wk, &g.sync->status, tid);
+            wg_wait_flags<true>(tid == 0 ? wflag : nullptr, wk + 1, 2000 + wk, &g.sync->status, tid);
             const int nrow = (wk == g.nbk - 1) ? ncol_last : 64;
-            for (int idx = tid; idx < 4096; idx += 256) tiles[(idx >> 6) * 65 + (idx & 63)] = Wk[idx];
+            for (int idx = tid; idx < 4096; idx += 256)
+                tiles[(idx >> 6) * 65 + (idx & 63)] = __hip_atomic_load(Wk + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
+            pull_next();
             for (int idx = tid; idx < 4096; idx += 256) {
                 const int r = idx >> 6, c = idx & 63;
                 __hip_atomic_store(C + (int64_t)r * ld + c, r < nrow ? tiles[c * 65 + r] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            wg_publish(vC, newver, tid);
+            finish();
             continue;
         }
         // ---- inputs: the output tile's earlier visits, the operand tiles final ----
@@ -746,31 +819,31 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
             if (tid == 0) { addr = vC; nd = need_c; }
             else if (tid <= nkb) addr = ver + bufL * nb2 + li * g.nbk + kb0 + tid - 1;
             else if (tid <= 2 * nkb) addr = ver + bufR * nb2 + ri * g.nbk + kb0 + tid - 1 - nkb;
-            wg_wait_flags(addr, nd, 1000 + slot % 1000, &g.sync->status, tid);
+            wg_wait_flags<true>(addr, nd, 1000 + slot % 1000, &g.sync->status, tid);
         }
         if (st) st[1] = wall_clock64();
         Tile64 acc;
-        tile_update(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
-                    g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
-                    mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
+        tile_update<true>(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
+                          g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
+                          mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
         if (st) st[2] = wall_clock64();
         if (post == T_STORE) {
+            pull_next();
             store_acc_sc1(acc.v, C, ld, crow, ccol);
             if (st) st[3] = wall_clock64();
-            wg_publish(vC, newver, tid);
-            if (st) st[4] = wall_clock64();
+            finish();
             continue;
         }
         // T_SOLVE: wait for W_k, then tile <- tile * W_k^T
-        wg_wait_flags(tid == 0 ? wflag : nullptr, wk + 1, 3000 + wk, &g.sync->status, tid);
+        wg_wait_flags<true>(tid == 0 ? wflag : nullptr, wk + 1, 3000 + wk, &g.sync->status, tid);
         d4 out[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) out[t] = (d4){0.0, 0.0, 0.0, 0.0};
-        mul_acc_bt(out, acc.v, Wk, 64, 1.0, As, Bs, tid, wave, lane);
+        mul_acc_bt<true>(out, acc.v, Wk, 64, 1.0, As, Bs, tid, wave, lane);
+        pull_next();
         store_acc_sc1(out, C, ld, crow, ccol);
         if (st) st[3] = wall_clock64();
-        wg_publish(vC, newver, tid);
-        if (st) st[4] = wall_clock64();
+        finish();
     }
 }
 
@@ -941,8 +1014,8 @@ static int get_tasks(dgpamd_ctx *ctx, int nbk, bool inv, TaskTable *&out) {
 // ---- task table of the one-launch kernel -------------------------------------------------------------------------
 // The same right-looking schedule as build_tasks (lazy bulk: a tile takes LAZY panels per visit), restated per tile:
 // `applied` panels so far, `visits` so far.  Differences: no chain tasks (the chain workgroups run on their own); the
-// first panel tile A[k+1][k] gets its last worker visit as a plain update (the chain does the solve); diagonal tiles are
-// brought up to date one block step early, so that the visit the chain waits for applies the newest panel only.
+// first panel tile A[k+1][k] gets its last worker visit as a plain update (the chain does the solve); what the chain
+// waits for is produced one block step ahead of the rest (look-ahead, see below).
 struct MegaTable {
     MTask *dev = nullptr;
     int2 *need_dev = nullptr;
@@ -976,21 +1049,33 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
         emit(make_task(T_STORE, ap == q, 0, 0, BUF_T, q, j, BUF_T, q, BUF_A, j, ap, upto - ap), visitsT[q * nbk + j]++, 0, 0);
         ap = upto;
     };
+    auto solveA = [&](int i, int k) {   // panel tile (i, k): the remaining updates, then the solve with W_k
+        const int ap = appliedA[i * nbk + k];
+        emit(make_task(T_SOLVE, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap), visitsA[i * nbk + k]++, 1, k);
+        appliedA[i * nbk + k] = k;
+    };
     const int nl = nbk + (inv ? 2 : 0);
     for (int k = 0; k < nl; ++k) {
         if (k < nbk) {
-            // what the chain picks up after factoring block k: first, and the newest panel only
-            if (k + 1 < nbk) {
-                updA(k + 1, k + 1, k);
-                updA(k + 1, k, k);
-                need[k] = make_int2(visitsA[(k + 1) * nbk + k], visitsA[(k + 1) * nbk + k + 1]);
+            // LOOK-AHEAD: what the chain picks up after factoring block k+1 -- A[k+2][k+1] and A[k+2][k+2] with the panels
+            // <= k -- needs only W_k and the chain's own panel tile A[k+1][k]: it comes first in the tasks of block k,
+            // ahead of their bulk, so the chain's serial part (solve, update, factor: ~15 us) runs beside that bulk
+            // instead of after it.
+            if (k + 2 < nbk) {
+                solveA(k + 2, k);
+                updA(k + 2, k + 2, k + 1);
+                updA(k + 2, k + 1, k + 1);
+                need[k + 1] = make_int2(visitsA[(k + 2) * nbk + k + 1], visitsA[(k + 2) * nbk + k + 2]);
             }
             if (inv) emit(make_task(T_TDIAG, 1, 0, 0, BUF_T, k, k, BUF_A, 0, BUF_A, 0, 0, 0), visitsT[k * nbk + k]++, 1, k);
-            // panel column k: the remaining updates, then the solve with W_k
-            for (int i = k + 2; i < nbk; ++i) {
-                const int ap = appliedA[i * nbk + k];
-                emit(make_task(T_SOLVE, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap), visitsA[i * nbk + k]++, 1, k);
-                appliedA[i * nbk + k] = k;
+            // panel column k; behind its first tile the catch-up of the NEXT look-ahead's two tiles (panels <= k), so that
+            // the visits the chain waits for apply one panel each
+            for (int i = k + 3; i < nbk; ++i) {
+                solveA(i, k);
+                if (i == k + 3) {
+                    updA(k + 3, k + 3, k + 1);
+                    updA(k + 3, k + 2, k + 1);
+                }
             }
             if (inv)
                 for (int q = k - 1; q >= 0; --q) {
@@ -1145,7 +1230,11 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     double *ld_ws = ws + (size_t)batch * nbk * 4096 + DGPAMD_MAXB;
     int32_t *info_ws = reinterpret_cast<int32_t *>(ws + (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB);
     int32_t *flags = info_ws + DGPAMD_MAXB;
-    if (ctx->potrf_mode == 1) {
+    // mode 2: whichever is faster for the call (measured at n = 2000, profiles/r02_potrf_modes.txt): the one persistent
+    // launch while the pivot chains bound the time (few matrices), the per-step launches (four workgroups per CU) when
+    // the bulk does.
+    const bool mega = ctx->potrf_mode == 1 || (ctx->potrf_mode == 2 && batch <= (T ? 4 : 8));
+    if (mega) {
         MegaTable *mt = nullptr;
         int rc = get_mega_tasks(ctx, (int)nbk, T != nullptr, mt);   // (uploads the table on first use)
         if (rc) return rc;
@@ -1174,7 +1263,7 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
 
 extern "C" int dgpamd_set_potrf_mode(dgpamd_ctx *ctx, int mode) {
     if (!ctx) return DGPAMD_BAD_ARG;
-    if (mode != 0 && mode != 1) BAD_ARG(ctx, "mode must be 0 (one launch per block step) or 1 (one persistent launch)");
+    if (mode < 0 || mode > 2) BAD_ARG(ctx, "mode must be 0 (one launch per block step), 1 (one persistent launch) or 2 (chosen per call)");
     ctx->potrf_mode = mode;
     return DGPAMD_OK;
 }

@@ -2,6 +2,7 @@
 #include "common.hpp"
 
 #include <new>
+#include <stdlib.h>
 
 extern "C" const char *dgpamd_version(void) { return "dgp_amd 0.1 (gfx950)"; }
 
@@ -22,7 +23,8 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->prof_work = 0.0;
     ctx->use_graphs = 1;
     ctx->linkgp_direct = 0;
-    ctx->potrf_mode = 0;   // (the one-launch kernel is opt-in until it beats the per-step launches at every batch size)
+    ctx->potrf_mode = 2;
+    if (const char *pm = getenv("DGPAMD_POTRF_MODE")) ctx->potrf_mode = (pm[0] >= '0' && pm[0] <= '2') ? pm[0] - '0' : 2;   // (experiments)
     ctx->trace = nullptr;
     {
         int ncu = 0;

@@ -51,6 +51,21 @@ __device__ __forceinline__ HalfTile fetch_mk(const double *__restrict__ g, int64
         f.v[it] = *reinterpret_cast<const double2 *>(g + (int64_t)((tid >> 4) + 16 * it) * ldg + 32 * h + c2);
     return f;
 }
+// The same fetch as sc1 loads (L1 bypassed: the way data handed over by another workgroup inside a launch is read when
+// no agent-scope acquire is taken; MI355X_MICROARCH.md, hand-off recipe).  16 bytes per lane through a buffer resource
+// whose base is the tile itself (offsets stay far below 4 GB).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ HalfTile fetch_mk_sc1(const double *g, int64_t ldg, int tid, int h) {
+    HalfTile f;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 0x7fffffff, 0x00020000);
+    const int c2 = (tid & 15) * 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((((tid >> 4) + 16 * it) * ldg + 32 * h + c2) * 8), 0, 16);
+        f.v[it] = make_double2(__hiloint2double(v.y, v.x), __hiloint2double(v.w, v.z));
+    }
+    return f;
+}
 __device__ __forceinline__ void commit_mk(const HalfTile &f, double *__restrict__ s, int tid) {
     const int c2 = (tid & 15) * 2;
 #pragma unroll

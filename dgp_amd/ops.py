@@ -80,7 +80,7 @@ class Engine:
         self._chk(lib.dgpamd_set_graphs(self.h, 1 if enable else 0))
 
     def set_potrf_mode(self, mode):
-        """1 (default): the factorisation is one persistent dataflow launch; 0: one launch per 64-column block step."""
+        """1: the factorisation is one persistent dataflow launch; 0: one launch per 64-column block step; 2 (default): chosen per call."""
         self._chk(lib.dgpamd_set_potrf_mode(self.h, int(mode)))
 
     def stream(self):

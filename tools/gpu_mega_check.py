@@ -31,17 +31,25 @@ for n, B in ((64, 1), (130, 2), (200, 1), (1000, 3), (2000, 1), (2000, 6), (2000
         ld, info = eng.potrf(n, A, batch=B, work=work)
         torch.cuda.synchronize()
         T, S = eng.empty(B, Np, Np), eng.empty(B, Np, Np)
+        T.fill_(float('nan')); S.fill_(float('nan'))   # the results must not depend on what these buffers held
         A2 = eng.empty(B, Np, Np)
         eng.kmatrix('matern2.5', X, None, G, [1.0], 1e-4, out=A2, full=False, Y=y, batch=B)
         ld2, info2 = eng.potrf_inv(n, A2, T, S, batch=B, work=work)
         torch.cuda.synchronize()
         res[mode] = (A.cpu().numpy(), ld.cpu().numpy(), info.cpu().numpy(), S.cpu().numpy(), ld2.cpu().numpy(), info2.cpu().numpy(), A2.cpu().numpy())
+    for mode in (0, 1):
+        Sm = res[mode][3]
+        nn = [int(np.isnan(np.tril(Sm[b][:n, :n])).sum()) + int(np.isnan(Sm[b][n, :n]).sum()) for b in range(B)]
+        if any(nn):
+            bad = np.argwhere(np.isnan(np.tril(Sm[int(np.argmax(nn))][:n + 1, :n])))
+            print('   mode %d: NaNs in K^-1 per matrix %s; first at %s, last at %s (tile rows/cols /64: %s .. %s)' % (
+                mode, nn, bad[0].tolist(), bad[-1].tolist(), (bad[0] // 64).tolist(), (bad[-1] // 64).tolist()))
     A0, l0, i0, S0, l20, i20, A20 = res[0]
     A1, l1, i1, S1, l21, i21, A21 = res[1]
     tl = np.tril_indices(n)
     eL = max(np.abs(A0[b][:n, :n][tl] - A1[b][:n, :n][tl]).max() for b in range(B))
     eR = max(np.abs(A0[b][n, :n + 1] - A1[b][n, :n + 1]).max() for b in range(B))
-    eS = max(np.abs(np.tril(S0[b][:n, :n]) - np.tril(S1[b][:n, :n])).max() / np.abs(S0[b][:n, :n]).max() for b in range(B))
+    eS = max(np.abs(np.tril(S0[b][:n, :n]) - np.tril(S1[b][:n, :n])).max() / np.abs(np.tril(S0[b][:n, :n])).max() for b in range(B))
     eA = max(np.abs(S0[b][n, :n] - S1[b][n, :n]).max() / (np.abs(S0[b][n, :n]).max() + 1e-300) for b in range(B))
     eld = np.abs(l0 - l1).max()
     good = eL < 1e-9 and eR < 1e-8 and eS < 1e-7 and eA < 1e-7 and eld < 1e-8 and not i0.any() and not i1.any() and not i21.any()

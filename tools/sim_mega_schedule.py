@@ -34,18 +34,25 @@ def build(nbk, inv):
         emit(STORE, int(apT[q, j] == q), 0, T_, q, j, T_, q, A_, j, apT[q, j], upto - apT[q, j], viT[q, j], 0, 0)
         viT[q, j] += 1; apT[q, j] = upto
 
+    def solveA(i, k):
+        ap = apA[i, k]
+        emit(SOLVE, 0, 0, A_, i, k, A_, i, A_, k, ap, k - ap, viA[i, k], 1, k); viA[i, k] += 1; apA[i, k] = k
+
     nl = nbk + (2 if inv else 0)
     for k in range(nl):
         if k < nbk:
-            if k + 1 < nbk:
-                updA(k + 1, k + 1, k)
-                updA(k + 1, k, k)
-                need[k] = (viA[k + 1, k], viA[k + 1, k + 1])
+            if k + 2 < nbk:   # look-ahead: the chain's inputs for block k+1
+                solveA(k + 2, k)
+                updA(k + 2, k + 2, k + 1)
+                updA(k + 2, k + 1, k + 1)
+                need[k + 1] = (viA[k + 2, k + 1], viA[k + 2, k + 2])
             if inv:
                 emit(TDIAG, 1, 0, T_, k, k, A_, 0, A_, 0, 0, 0, viT[k, k], 1, k); viT[k, k] += 1
-            for i in range(k + 2, nbk):
-                ap = apA[i, k]
-                emit(SOLVE, 0, 0, A_, i, k, A_, i, A_, k, ap, k - ap, viA[i, k], 1, k); viA[i, k] += 1; apA[i, k] = k
+            for i in range(k + 3, nbk):
+                solveA(i, k)
+                if i == k + 3:   # catch-up of the next look-ahead's tiles
+                    updA(k + 3, k + 3, k + 1)
+                    updA(k + 3, k + 2, k + 1)
             if inv:
                 for q in range(k - 1, -1, -1):
                     ap = apT[q, k]
