@@ -68,6 +68,8 @@ SIGNATURES = {
     'dgpamd_grad_workspace': (_z, [_l, _i]),
     'dgpamd_grad_reduce': (_i, [_p, _i, _l, _p, _l, _p, _i, _p, _i, _p, _i, _d, _p, _i, _p, _p, _p]),
     'dgpamd_ess_update': (_i, [_p, _l, _i, _p, _p, _p, _d, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'dgpamd_ess_queue_scratch': (_z, []),
+    'dgpamd_ess_queue': (_i, [_p, _l, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     'dgpamd_llik_batch': (_i, [_p, _l, _i, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l]),
     'dgpamd_potrf_inv': (_i, [_p, _l, _p, _p, _p, _l, _i, _p, _p, _p]),
     'dgpamd_gp_workspace': (_z, [_l, _l]),

@@ -551,6 +551,7 @@ struct MegaArgs {
     double *logdet;
     int32_t *info;
     long long *trace;
+    const int32_t *pred;     // null, or a device word: the launch does nothing when it is non-zero
 };
 
 // Write-through (sc1) store of an accumulator tile, 16 bytes per lane: neighbouring lanes hold neighbouring columns of the
@@ -738,6 +739,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
     const int batch = g.batch;
+    if (g.pred && *g.pred) return;   // (a speculative batch that an earlier one has made unnecessary: dgpamd_ess_queue)
     if ((int)blockIdx.x < batch) {
         mega_chain(g, blockIdx.x, As, Bs, sh, &sh.u[0][0][0]);
     } else {
@@ -1147,7 +1149,7 @@ static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, d
     g.tasks = mt->dev; g.ntask = mt->ntask; g.chain_need = mt->need_dev;
     g.sync = reinterpret_cast<MegaSync *>(syncmem);
     g.ver = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(syncmem) + sizeof(MegaSync));
-    g.logdet = logdet; g.info = info; g.trace = ctx->trace;
+    g.logdet = logdet; g.info = info; g.trace = ctx->trace; g.pred = ctx->pred;
     // every workgroup resident at once (not needed for progress, but a queued worker would only start late)
     int64_t grid = (int64_t)mega_wgs_per_cu() * ctx->num_cu;
     const int64_t useful = (int64_t)batch * (mt->ntask + 1 + mega_wgs_per_cu());
@@ -1233,7 +1235,7 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     // mode 2: whichever is faster for the call (measured at n = 2000, profiles/r02_potrf_modes.txt): the one persistent
     // launch while the pivot chains bound the time (few matrices), the per-step launches (four workgroups per CU) when
     // the bulk does.
-    const bool mega = ctx->potrf_mode == 1 || (ctx->potrf_mode == 2 && batch <= (T ? 4 : 8));
+    const bool mega = ctx->potrf_mode == 1 || (ctx->potrf_mode == 2 && batch <= (T ? 4 : 8)) || (ctx->pred && ctx->potrf_mode != 0);
     if (mega) {
         MegaTable *mt = nullptr;
         int rc = get_mega_tasks(ctx, (int)nbk, T != nullptr, mt);   // (uploads the table on first use)

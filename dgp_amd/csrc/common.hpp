@@ -29,6 +29,7 @@ struct dgpamd_ctx {
     std::vector<hipEvent_t> prof_events;              // start/stop pairs
     int use_graphs;                                   // replay static launch sequences as hipGraphs
     int linkgp_direct;                                // 1: evaluate the Matern J factor in the reference's direct form
+    const int32_t *pred;                              // device word: kernels launched while it is set return at once when it is non-zero (dgpamd_ess_queue)
     int potrf_mode;                                   // 1: factorisation as one persistent dataflow launch; 0: one launch per block step
     long long *trace;                                 // device buffer for in-kernel timestamps (diagnostics), or null
     double *pinned;                                   // small pinned staging buffer for result copies (lazy)
@@ -180,6 +181,7 @@ struct KmatArgs {
     const double *Y;
     int64_t ldy, stride_y;
     int r;
+    const int32_t *pred;   // null, or a device word: the launch does nothing when it is non-zero
 };
 int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch);
 int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatArgs *host_args, int count);   // same n / mode

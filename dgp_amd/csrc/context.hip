@@ -23,8 +23,9 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->prof_work = 0.0;
     ctx->use_graphs = 1;
     ctx->linkgp_direct = 0;
-    ctx->potrf_mode = 2;
-    if (const char *pm = getenv("DGPAMD_POTRF_MODE")) ctx->potrf_mode = (pm[0] >= '0' && pm[0] <= '2') ? pm[0] - '0' : 2;   // (experiments)
+    ctx->potrf_mode = 1;
+    ctx->pred = nullptr;
+    if (const char *pm = getenv("DGPAMD_POTRF_MODE")) ctx->potrf_mode = (pm[0] >= '0' && pm[0] <= '2') ? pm[0] - '0' : 1;   // (experiments)
     ctx->trace = nullptr;
     {
         int ncu = 0;

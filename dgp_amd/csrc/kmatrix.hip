@@ -147,6 +147,7 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
 
 template <int KIND>
 __global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
+    if (a.pred && *a.pred) return;   // (a speculative batch that an earlier one has made unnecessary: dgpamd_ess_queue)
     kmatrix_body<KIND>(a, blockIdx.z);
 }
 
@@ -174,7 +175,9 @@ int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatAr
     return DGPAMD_OK;
 }
 
-int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch) {
+int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a_, int batch) {
+    KmatArgs a = a_;
+    a.pred = ctx->pred;
     const int D = a.kp.Dl + a.kp.Dg;
     int64_t rows = a.full ? a.n : padded_dim(a.n);
     int nbk = (int)((rows + 63) / 64);
@@ -209,6 +212,7 @@ int build_kmat_args(dgpamd_ctx *ctx, KmatArgs &a, int kind, int64_t n, const dou
     }
     int rc = fill_kern_params(ctx, a.kp, kind, colmap_h, Dl, Dg, length_h, nlen, nugget);
     if (rc) return rc;
+    a.pred = nullptr;
     a.n = n;
     a.Xloc = Xloc;
     a.ldloc = ldloc;

@@ -490,3 +490,190 @@ extern "C" int dgpamd_ess_update(dgpamd_ctx *ctx, int64_t n, int M, double *F, c
         pending = true;
     }
 }
+
+// ----------------------------------------------------------------------------
+// a7  elliptical-slice updates queued WITHOUT host synchronisation (imputation.py:44-119)
+//
+// The accept / shrink loop of an update depends on the data only through "which proposal is the first above the
+// threshold"; everything it needs -- the bracket, the cursor into the sampler's uniform stream, the threshold, the
+// current log-likelihood -- lives in a small device state that a one-thread DECIDE kernel advances after every
+// speculative batch.  The launches of the later batches of an update are predicated on its `done` word (ctx->pred:
+// K assembly and the one-launch factorisation return at once), so a whole sequence of updates is queued back to back and
+// the host fetches the state ONCE at the end.  An update that is not accepted within `max_batches` batches, or runs out of
+// uniforms, sets a status; every later update of the queue then leaves the latents alone and the host resumes from the
+// state (it holds the bracket, the cursor and the pending shrink exactly as the sequential loop would have them).
+// ----------------------------------------------------------------------------
+enum { ES_THETA = 0, ES_LO, ES_HI, ES_PENDING, ES_CURSOR, ES_STATUS, ES_INFO, ES_LL, ES_LOGY, ES_PROPOSALS, ES_BATCHES,
+       ES_UPDATES, ES_NWORDS = DGPAMD_ESS_STATE };
+struct EssScratch {   // device scratch of one queue (dgpamd_ess_queue_scratch bytes)
+    double th[DGPAMD_MAXB], lo[DGPAMD_MAXB], hi[DGPAMD_MAXB], cs[DGPAMD_MAXB], sn[DGPAMD_MAXB], ll[DGPAMD_MAXB], logdet[DGPAMD_MAXB];
+    int32_t info[DGPAMD_MAXB], infomax[DGPAMD_MAXB];
+    int32_t nb, done, acc, halt;   // halt: the queue has stopped (status != 0): later updates launch nothing
+};
+#define ESS_TWO_PI 6.283185307179586
+
+__global__ void ess_begin_kernel(double *st, const double *u, const double *logu, int nuni, EssScratch *sc) {
+    if (threadIdx.x) return;
+    sc->acc = -1;
+    sc->nb = 0;
+    if (st[ES_STATUS] != 0.0) { sc->done = 1; sc->halt = 1; return; }   // an earlier update of the queue has stopped it
+    int cur = (int)st[ES_CURSOR];
+    if (cur + 2 > nuni) { st[ES_STATUS] = 4.0; sc->done = 1; sc->halt = 1; return; }   // (before the update has begun)
+    st[ES_LOGY] = st[ES_LL] + logu[cur];                   // log_y = ll + log u   (imputation.py:79)
+    const double theta = ESS_TWO_PI * u[cur + 1];          // theta ~ U(0, 2 pi), bracket [theta - 2 pi, theta]  (:81-82)
+    st[ES_THETA] = theta; st[ES_LO] = theta - ESS_TWO_PI; st[ES_HI] = theta; st[ES_PENDING] = 0.0;
+    st[ES_CURSOR] = cur + 2;
+    sc->done = 0;
+    sc->halt = 0;
+}
+// the angles of the next speculative batch: theta, then what consecutive rejections would produce (imputation.py:115-119)
+__global__ void ess_prepare_kernel(double *st, const double *u, int nuni, int B, EssScratch *sc) {
+    if (threadIdx.x) return;
+    sc->acc = -1;
+    sc->nb = 0;
+    if (sc->done) return;
+    int cur = (int)st[ES_CURSOR];
+    double theta = st[ES_THETA], lo = st[ES_LO], hi = st[ES_HI];
+    if (st[ES_PENDING] != 0.0) {   // closing shrink of the previous, fully rejected batch
+        if (cur >= nuni) { st[ES_STATUS] = 1.0; sc->done = 1; return; }
+        if (theta < 0.0) lo = theta; else hi = theta;
+        theta = lo + (hi - lo) * u[cur++];
+        st[ES_THETA] = theta; st[ES_LO] = lo; st[ES_HI] = hi; st[ES_PENDING] = 0.0; st[ES_CURSOR] = cur;
+    }
+    int nb = 1;
+    sc->th[0] = theta; sc->lo[0] = lo; sc->hi[0] = hi;
+    while (nb < B && cur + nb - 1 < nuni) {
+        if (theta < 0.0) lo = theta; else hi = theta;
+        theta = lo + (hi - lo) * u[cur + nb - 1];
+        sc->th[nb] = theta; sc->lo[nb] = lo; sc->hi[nb] = hi;
+        ++nb;
+    }
+    for (int b = nb; b < B; ++b) sc->th[b] = sc->th[nb - 1];   // (unused slots: a valid angle keeps their matrices harmless)
+    for (int b = 0; b < B; ++b) { sc->cs[b] = cos(sc->th[b]); sc->sn[b] = sin(sc->th[b]); }
+    sc->nb = nb;
+}
+__global__ __launch_bounds__(256) void ess_propose_dev_kernel(const double *F, const double *NU, double *FP, int64_t count,
+                                                              const EssScratch *sc) {
+    if (sc->done) return;
+    const int b = blockIdx.y;
+    const double c = sc->cs[b], s = sc->sn[b];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        FP[(int64_t)b * count + i] = F[i] * c + NU[i] * s;
+}
+// log-likelihood of one upper node for every proposal of the batch, summed over the nodes (imputation.py:91-106)
+__global__ void ess_node_ll_kernel(const double *A, int64_t ld, int64_t stride_a, int64_t n, double scale, int B, int first,
+                                   EssScratch *sc) {
+    const int b = threadIdx.x;
+    if (sc->done || b >= B) return;
+    const double quad = -A[(int64_t)b * stride_a + n * ld + n];
+    const double ll = -0.5 * ((double)n * log(scale) + sc->logdet[b] + quad / scale);
+    sc->ll[b] = (first ? 0.0 : sc->ll[b]) + ll;
+    sc->infomax[b] = first ? sc->info[b] : (sc->infomax[b] ? sc->infomax[b] : sc->info[b]);
+}
+__global__ void ess_decide_kernel(double *st, EssScratch *sc) {
+    if (threadIdx.x || sc->done) return;
+    const int nb = sc->nb;
+    int cur = (int)st[ES_CURSOR];
+    st[ES_BATCHES] += 1.0;
+    for (int b = 0; b < nb; ++b) {
+        if (sc->infomax[b] != 0) {   // (only a proposal the sequential loop would have reached can stop the update)
+            st[ES_STATUS] = 2.0; st[ES_INFO] = sc->infomax[b]; st[ES_PROPOSALS] += b + 1; sc->done = 1;
+            return;
+        }
+        if (sc->ll[b] > st[ES_LOGY]) {
+            st[ES_CURSOR] = cur + b; st[ES_PROPOSALS] += b + 1;
+            st[ES_THETA] = sc->th[b]; st[ES_LO] = sc->lo[b]; st[ES_HI] = sc->hi[b]; st[ES_PENDING] = 0.0;
+            st[ES_LL] = sc->ll[b]; st[ES_UPDATES] += 1.0;
+            sc->acc = b; sc->done = 1;
+            return;
+        }
+    }
+    st[ES_CURSOR] = cur + nb - 1; st[ES_PROPOSALS] += nb;
+    st[ES_THETA] = sc->th[nb - 1]; st[ES_LO] = sc->lo[nb - 1]; st[ES_HI] = sc->hi[nb - 1]; st[ES_PENDING] = 1.0;
+}
+__global__ __launch_bounds__(256) void ess_accept_kernel(double *F, const double *FP, int64_t count, const EssScratch *sc) {
+    const int acc = sc->acc;
+    if (acc < 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        F[i] = FP[(int64_t)acc * count + i];
+}
+__global__ void ess_end_kernel(double *st, EssScratch *sc) {
+    if (threadIdx.x) return;
+    if (!sc->done && st[ES_STATUS] == 0.0) st[ES_STATUS] = 3.0;   // not accepted within the queued batches
+    sc->acc = -1;
+}
+__global__ void ess_set_ll_kernel(double *st, const EssScratch *sc) {
+    if (threadIdx.x) return;
+    if (sc->infomax[0] != 0) { st[ES_STATUS] = 2.0; st[ES_INFO] = sc->infomax[0]; }
+    st[ES_LL] = sc->ll[0];
+}
+
+extern "C" size_t dgpamd_ess_queue_scratch(void) { return (sizeof(EssScratch) + 15) / 16 * 16; }
+
+// all upper nodes' log-likelihoods of the B candidate blocks X (B x n x M; stride 0: one block) into sc->ll / infomax
+static int ess_queue_logliks(dgpamd_ctx *ctx, int64_t n, int M, const double *X, int64_t stride_x, int B, const dgpamd_node *nodes,
+                             const double *scales_h, int nnodes, double *A, void *work, EssScratch *sc) {
+    const int64_t Np = padded_dim(n);
+    double *ws = (double *)work;
+    for (int k = 0; k < nnodes; ++k) {
+        const dgpamd_node &nd = nodes[k];
+        if (!(scales_h[k] > 0.0)) BAD_ARG(ctx, "scale must be positive");
+        KmatArgs a;
+        int rc = build_kmat_args(ctx, a, nd.kind, n, X, M, stride_x, (const int32_t *)nd.colmap, nd.Dl, nd.Xglob, nd.Dg, nd.length,
+                                 nd.nlen, nd.nugget, nd.W, A, Np, Np * Np, 0, nd.y, n, 0, 1, B);
+        if (rc) return rc;
+        rc = launch_kmatrix(ctx, a, B);
+        if (rc) return rc;
+        rc = run_potrf(ctx, n, A, Np * Np, B, sc->logdet, sc->info, ws);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ess_node_ll_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)A, Np, Np * Np, n,
+                           scales_h[k], B, k == 0 ? 1 : 0, sc);
+    }
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double *NU, int nupd, const dgpamd_node *nodes,
+                                const double *scales_h, int nnodes, double *state, const double *uniforms, const double *log_uniforms,
+                                int nuni, int batch_first, int batch_next, int max_batches, int compute_ll0, double *FP, double *A,
+                                void *work, void *scratch) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || M <= 0 || nupd <= 0 || nnodes <= 0 || !F || !NU || !nodes || !scales_h || !state || !FP || !A || !work || !scratch)
+        BAD_ARG(ctx, "null pointer or empty block");
+    if (nuni < 0 || (nuni > 0 && (!uniforms || !log_uniforms))) BAD_ARG(ctx, "bad uniform stream");
+    if (batch_first <= 0 || batch_first > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch_first <= DGPAMD_MAXB");
+    if (batch_next <= 0 || batch_next > batch_first) batch_next = batch_first;
+    if (max_batches < 1) max_batches = 1;
+    EssScratch *sc = reinterpret_cast<EssScratch *>(scratch);
+    const int64_t count = n * (int64_t)M;
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    int rc;
+    HIP_TRY(ctx, hipMemsetAsync(sc, 0, sizeof(EssScratch), ctx->stream));
+    if (compute_ll0) {   // log-likelihood of the current state (imputation.py:70-78): the first threshold's base
+        rc = ess_queue_logliks(ctx, n, M, F, 0, 1, nodes, scales_h, nnodes, A, work, sc);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ess_set_ll_kernel, dim3(1), dim3(64), 0, ctx->stream, state, (const EssScratch *)sc);
+    }
+    for (int u = 0; u < nupd; ++u) {
+        const double *NUu = NU + (int64_t)u * count;
+        hipLaunchKernelGGL(ess_begin_kernel, dim3(1), dim3(64), 0, ctx->stream, state, uniforms, log_uniforms, nuni, sc);
+        for (int j = 0; j < max_batches; ++j) {
+            const int B = j == 0 ? batch_first : batch_next;
+            hipLaunchKernelGGL(ess_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, state, uniforms, nuni, B, sc);
+            hipLaunchKernelGGL(ess_propose_dev_kernel, dim3((unsigned)blocks, B), dim3(256), 0, ctx->stream, (const double *)F, NUu, FP,
+                               count, (const EssScratch *)sc);
+            // every launch is predicated on the update being open (the first batch: on the queue not having stopped)
+            ctx->pred = &sc->done;
+            rc = ess_queue_logliks(ctx, n, M, FP, count, B, nodes, scales_h, nnodes, A, work, sc);
+            ctx->pred = nullptr;
+            if (rc) return rc;
+            hipLaunchKernelGGL(ess_decide_kernel, dim3(1), dim3(64), 0, ctx->stream, state, sc);
+            hipLaunchKernelGGL(ess_accept_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, F, (const double *)FP, count,
+                               (const EssScratch *)sc);
+        }
+        hipLaunchKernelGGL(ess_end_kernel, dim3(1), dim3(64), 0, ctx->stream, state, sc);
+    }
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}

@@ -212,8 +212,15 @@ class imputer:
         """ESS-within-Gibbs over the layers (imputation.py:22-42)."""
         self._attach()
         n_layer = len(self.all_layer)
-        ahead = self._prior_draws_ahead(burnin + 1) if n_layer > 1 else None
-        for sweep in range(burnin + 1):
+        first, ahead = self._sample_queued(burnin + 1) if n_layer == 2 else (0, None)   # sweeps done without host round trips
+        if first > burnin:
+            self._detach()
+            return
+        if ahead is None:
+            ahead = self._prior_draws_ahead(burnin + 1) if n_layer > 1 else None
+        else:
+            ahead = ahead[first:]   # (the prior draws of every sweep were made for the queue)
+        for sweep in range(burnin + 1 - first):
             for l in range(n_layer - 1):
                 upper = self.all_layer[l + 1]
                 hetero = any(nd.type == 'likelihood' and getattr(nd, 'exact_post_idx', None) is not None for nd in upper)
@@ -223,6 +230,67 @@ class imputer:
                     for k in range(len(self.all_layer[l])):
                         self.one_sample(l, k)
         self._detach()
+
+    queue_max_batches = 2   # speculative batches queued per update (batch, then batch_next): 12 + 4 proposals; an update that
+                            # needs more (a few per cent) is finished by the host loop and the rest of the I-step queued anew
+
+    def _sample_queued(self, sweeps):
+        """All `sweeps` block updates of a two-layer model's hidden layer queued on the device without a single host
+        synchronisation (dgpamd_ess_queue; imputation.py:22-119): the accept / shrink loop runs in one-thread kernels on a
+        device state, the uniform stream is uploaded ahead and consumed exactly as the sequential loop would.  Returns the
+        number of sweeps completed and the prior draws of all sweeps (an update that ran out of queued batches or uniforms is finished by the host loop,
+        and the remaining sweeps take the ordinary path).  (0, None): not applicable (Vecchia / likelihood / reference-prior
+        nodes, node-wise updates)."""
+        if not self.block or not getattr(self, 'queued', True):
+            return 0, None
+        layer, upper = self.all_layer[0], self.all_layer[1]
+        if any(nd.type != 'gp' or nd.vecch for nd in layer) or any(nd.type != 'gp' or nd.vecch or nd.prior_name == 'ref' for nd in upper):
+            return 0, None
+        nu = self._prior_draws_ahead(sweeps)   # (sweeps, n, M)
+        if nu is None:
+            return 0, None
+        e = self.engine
+        F = self.F[0]
+        n, M = F.shape
+        key = tuple((tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), self._node_y(1, k).data_ptr(),
+                     None if self._glob[(1, k)] is None else self._glob[(1, k)].data_ptr()) for k, nd in enumerate(upper)) + (self.batch,)
+        hit = self._ess_plans.get('queue')
+        if hit is None or hit[0] != key:
+            nodes = [dict(kind=nd.name, colmap=np.asarray(nd.input_dim, dtype=np.int32), Xglob=self._glob[(1, k)], length=nd.length,
+                          nugget=nd.nugget[0], W=None if nd.rep is None else e.tensor(nd.W_diag), y=self._node_y(1, k))
+                     for k, nd in enumerate(upper)]
+            self._ess_plans['queue'] = hit = (key, e.ess_queue_plan(n, M, nodes, self.batch))
+        plan = hit[1]
+        bn = int(self.batch_next) if self.batch_next else self.batch
+        per = 2 + (self.batch - 1) + (self.queue_max_batches - 1) * bn + 2
+        scales = [float(nd.scale[0]) for nd in upper]
+        first = 0
+        while first < sweeps:
+            us = self.draws.uniform_peek((sweeps - first) * per)
+            cur = self._ll_cache.get(0)
+            plan.queue(F, nu[first:], scales, us, 0, cur, cur is None, self.batch_next, self.queue_max_batches)
+            st = plan.fetch()   # the one synchronisation of the queue (of the whole I-step unless an update was left open)
+            status, done = int(st['status']), int(st['updates'])
+            self.draws.uniform_take(int(st['cursor']))
+            self.stats['proposals'] += int(st['proposals'])
+            self.stats['batches'] += int(st['batches'])
+            self.stats['updates'] += done
+            self._ll_cache[0] = float(st['ll'])
+            first += done
+            if status == 0:
+                break
+            if status == 2:
+                raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(st['info']))
+            if status == 4:   # the uploaded uniforms ran out between two updates
+                if not us:
+                    raise RuntimeError('injected uniform stream exhausted')
+                continue
+            # the open update (out of queued batches, status 3, or of uploaded uniforms, status 1): the host loop finishes it,
+            # the remaining sweeps are queued anew
+            self.one_sample_block(0, nu=nu[first], resume=dict(log_y=float(st['log_y']), theta=float(st['theta']), lo=float(st['lo']),
+                                                                 hi=float(st['hi']), pending=bool(st['pending'])))
+            first += 1
+        return sweeps, nu
 
     def _layer_factors(self, l, dense):
         """Cholesky factors of the dense nodes `dense` of layer l in ONE batched buffer (stride Np^2) so that the draws
@@ -443,27 +511,31 @@ class imputer:
             self._ess_plans[l] = hit = (key, plan)
         return hit[1]
 
-    def one_sample_block(self, l, nu=None):
-        """Layer-wise ESS update of layer l given layer l+1 (imputation.py:44-119); nu: prior draw made ahead."""
+    def one_sample_block(self, l, nu=None, resume=None):
+        """Layer-wise ESS update of layer l given layer l+1 (imputation.py:44-119); nu: prior draw made ahead; resume:
+        threshold, angle and bracket of an update that dgpamd_ess_queue left open."""
         e = self.engine
         F = self.F[l]
         if nu is None:
             nu = self._prior_draw(l)
-        cur = self._ll_cache.get(l)
-        if cur is None:
-            ll, info = self._upper_loglik(l, F[None])
-            if info[0] != 0:
-                raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[0]))
-            cur = ll[0]
-        log_y = cur + np.log(self.draws.uniform_take(1)[0])
-        theta = TWO_PI * self.draws.uniform_take(1)[0]
-        lo, hi = theta - TWO_PI, theta
+        pending = False
+        if resume is None:
+            cur = self._ll_cache.get(l)
+            if cur is None:
+                ll, info = self._upper_loglik(l, F[None])
+                if info[0] != 0:
+                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[0]))
+                cur = ll[0]
+            log_y = cur + np.log(self.draws.uniform_take(1)[0])
+            theta = TWO_PI * self.draws.uniform_take(1)[0]
+            lo, hi = theta - TWO_PI, theta
+        else:
+            log_y, theta, lo, hi, pending = resume['log_y'], resume['theta'], resume['lo'], resume['hi'], resume['pending']
         B = self.batch
         self.stats['updates'] += 1
         plan = self._ess_plan(l)
         if plan is not None:   # one dense GP node upstairs: the whole shrinking-bracket loop is one library call
             nd = self.all_layer[l + 1][0]
-            pending = False
             while True:
                 us = self.draws.uniform_peek(64)
                 status, used, props, nbat, ll_acc, info, theta, lo, hi, pending = plan.run(
@@ -479,6 +551,8 @@ class imputer:
                     return
                 if len(us) == used and self.draws._injected_u:
                     raise RuntimeError('injected uniform stream exhausted')
+        if pending:   # (resumed after a fully rejected batch: its closing shrink is still due)
+            theta, lo, hi = shrink(theta, lo, hi, self.draws.uniform_take(1)[0])
         while True:
             us = self.draws.uniform_peek(B - 1)
             thetas, brackets = speculative_angles(theta, lo, hi, us)

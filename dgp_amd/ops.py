@@ -80,7 +80,7 @@ class Engine:
         self._chk(lib.dgpamd_set_graphs(self.h, 1 if enable else 0))
 
     def set_potrf_mode(self, mode):
-        """1: the factorisation is one persistent dataflow launch; 0: one launch per 64-column block step; 2 (default): chosen per call."""
+        """1 (default): the factorisation is one persistent dataflow launch; 0: one launch per 64-column block step; 2: chosen per call."""
         self._chk(lib.dgpamd_set_potrf_mode(self.h, int(mode)))
 
     def stream(self):
@@ -324,6 +324,9 @@ class Engine:
         self._chk(lib.dgpamd_fetch2(self.h, _dp(ll), 8 * B, _dp(info), 4 * B, buf.ctypes.data_as(C.c_void_p)))
         return buf[:8 * B].view(np.float64), buf[8 * B:].view(np.int32)
 
+    def ess_queue_plan(self, n, M, nodes, batch):
+        return _EssQueue(self, n, M, nodes, batch)
+
     def ess_plan(self, n, M, kind, colmap, Xglob, length, nugget, W, y, batch):
         """Static arguments of dgpamd_ess_update for one upper GP node (see _EssPlan.run)."""
         return _EssPlan(self, n, M, kind, colmap, Xglob, length, nugget, W, y, batch)
@@ -541,6 +544,63 @@ class _LlikPlan:
             P = self.P[i]
             out[i] = np.concatenate((host[r, :2], host[r, 3:3 + 2 * P], host[r, 2:3]))
         return out
+
+
+class _EssQueue:
+    """Several elliptical-slice updates of one latent block queued without host synchronisation (dgpamd_ess_queue):
+    node structs, scratch and the device state are kept alive here; fetch() is the one synchronisation."""
+    STATE = 16
+    FIELDS = ('theta', 'lo', 'hi', 'pending', 'cursor', 'status', 'info', 'll', 'log_y', 'proposals', 'batches', 'updates')
+
+    def __init__(self, eng, n, M, nodes, batch):
+        """nodes: list of dicts {kind, colmap, Xglob, length, nugget, W, y} -- the dense GP nodes of the layer above."""
+        self.e, self.n, self.M, self.batch = eng, int(n), int(M), int(batch)
+        Np = eng.padded_dim(n)
+        self.keep = []
+        arr = (_lib.Node * len(nodes))()
+        for i, d in enumerate(nodes):
+            colmap = np.ascontiguousarray(np.asarray(d['colmap'], dtype=np.int32))
+            length = np.ascontiguousarray(np.asarray(d['length'], dtype=np.float64))
+            self.keep += [colmap, length, d['Xglob'], d['W'], d['y']]
+            nd = arr[i]
+            nd.kind, nd.Dl, nd.Dg = KIND[d['kind']], len(colmap), 0 if d['Xglob'] is None else d['Xglob'].shape[1]
+            nd.nlen, nd.nugget_est, nd.ldloc = len(length), 0, M
+            nd.Xloc, nd.colmap = None, colmap.ctypes.data
+            nd.Xglob = None if d['Xglob'] is None else d['Xglob'].data_ptr()
+            nd.length, nd.nugget = length.ctypes.data, float(d['nugget'])
+            nd.W = None if d['W'] is None else d['W'].data_ptr()
+            nd.y = d['y'].data_ptr()
+        self.nodes, self.nnodes = arr, len(nodes)
+        self.FP = eng.workspace(('essFP', n, M, batch), batch * n * M * 8)
+        self.A = eng.workspace(('essA', n, batch), batch * Np * Np * 8)
+        self.work = eng.potrf_workspace(n, batch)
+        self.scratch = eng.workspace(('essQ',), int(lib.dgpamd_ess_queue_scratch()))
+        self.state = eng.empty(self.STATE)
+        self.udev = None
+
+    def queue(self, F, NU, scales, uniforms, cursor, ll, compute_ll0, batch_next, max_batches):
+        """Queue NU.shape[0] updates (NU: (nupd, n, M) device tensor).  uniforms: the sampler's upcoming uniforms (host);
+        cursor: how many of them earlier queues of this I-step have consumed."""
+        e = self.e
+        us = np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64))
+        if self.udev is None or self.udev[0] is not uniforms:
+            with np.errstate(divide='ignore'):
+                both = np.concatenate((us, np.log(us)))
+            self.udev = (uniforms, e.tensor(both), len(us))
+        ud, nuni = self.udev[1], self.udev[2]
+        st0 = np.zeros(self.STATE)
+        st0[4], st0[7] = cursor, 0.0 if ll is None else ll
+        self.state.copy_(e.tensor(st0))
+        sc = np.ascontiguousarray(np.asarray(scales, dtype=np.float64))
+        e._chk(lib.dgpamd_ess_queue(e.h, self.n, self.M, _dp(F), _dp(NU), int(NU.shape[0]), C.cast(self.nodes, C.c_void_p),
+                                    sc.ctypes.data_as(C.c_void_p), self.nnodes, _dp(self.state), _dp(ud), _dp(ud[nuni:]), nuni,
+                                    self.batch, int(batch_next) if batch_next else self.batch, int(max_batches),
+                                    1 if compute_ll0 else 0, _dp(self.FP), _dp(self.A), _dp(self.work), _dp(self.scratch)))
+
+    def fetch(self):
+        """The ONE synchronisation: the device state as a dict."""
+        v = self.e.fetch(self.state)
+        return dict(zip(self.FIELDS, v[:len(self.FIELDS)]))
 
 
 class _EssPlan:

@@ -117,9 +117,9 @@ size_t dgpamd_potrf_workspace(int64_t n, int batch);
 int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch,
                  double *logdet, int32_t *info, void *work);
 /* How dgpamd_potrf / dgpamd_potrf_inv (and everything built on them) run the blocked factorisation:
- * mode 1: ONE persistent launch -- a pivot-chain workgroup per matrix plus workers that pull tile tasks
+ * mode 1 (default): ONE persistent launch -- a pivot-chain workgroup per matrix plus workers that pull tile tasks
  * from a queue, ordered by per-tile version words (csrc/chol.hip, potrf_mega_kernel); mode 0: one launch per 64-column
- * block step, replayed as a hipGraph; mode 2 (default): mode 1 for small batches (chain-bound), mode 0 for large ones
+ * block step, replayed as a hipGraph; mode 2: mode 1 for small batches (chain-bound), mode 0 for large ones
  * (bulk-bound).  The results are bit-identical (every tile applies its panels in the same order).
  * info[b] = -1 reports a lost in-kernel hand-off (a bounded spin gave up), never a numerical failure. */
 int dgpamd_set_potrf_mode(dgpamd_ctx *ctx, int mode);
@@ -207,6 +207,30 @@ typedef struct {
 int dgpamd_ess_update(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double *NU, const dgpamd_node *node, double scale,
                       double log_y, double *state, const double *uniforms, int nuni, int batch_first, int batch_next,
                       double *FP, double *A, void *work, double *ll_dev, int32_t *info_dev, double *out);
+
+/* ---- a7  several elliptical-slice updates of a latent block queued without host synchronisation ------------
+ * imputation.py:44-119, the accept / shrink loop advanced on the device: after every speculative batch a one-thread
+ * kernel compares the batch's log-likelihoods (summed over the `nnodes` dense GP nodes of the layer above) with the
+ * threshold, takes the first accepted proposal into F or shrinks the bracket, and moves the cursor into the uniform
+ * stream exactly as the sequential loop would; the launches of an update's later batches are predicated on its `done`
+ * word.  `nupd` updates (prior draws NU: nupd x n x M) are queued on the context's stream and the call returns at once.
+ *   state (device, DGPAMD_ESS_STATE doubles): {theta, lo, hi, pending, cursor, status, info, ll, log_y, proposals,
+ *     batches, updates}; the caller zeroes it and sets cursor / ll as needed (compute_ll0 != 0: ll is computed from F first).
+ *     status after the queue: 0 = every update accepted; 1 = uniforms used up; 2 = a proposal the sequential loop reaches
+ *     is not positive definite (info); 3 = an update was not accepted within max_batches batches; 4 = uniforms used up
+ *     before an update began (nothing of it is in the state).  After a non-zero status
+ *     the later updates leave F alone: `updates` tells how many were completed, and {theta, lo, hi, pending, cursor, log_y}
+ *     are those of the open update (resume it with dgpamd_ess_update).
+ *   uniforms / log_uniforms (device, nuni): the sampler's next uniforms and their logarithms (taken on the host so
+ *     that the thresholds are bit-identical to the host loop's).
+ *   FP (batch_first x n x M), A (batch_first x Np x Np), work (dgpamd_potrf_workspace(n, batch_first)),
+ *   scratch (dgpamd_ess_queue_scratch() bytes): device scratch. */
+#define DGPAMD_ESS_STATE 16
+size_t dgpamd_ess_queue_scratch(void);
+int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double *NU, int nupd, const dgpamd_node *nodes,
+                     const double *scales_h, int nnodes, double *state, const double *uniforms, const double *log_uniforms,
+                     int nuni, int batch_first, int batch_next, int max_batches, int compute_ll0, double *FP, double *A,
+                     void *work, void *scratch);
 
 /* ---- a8  M-step objective pieces -------------------------------------------
  * kernel.llik  kernel_class.py:403-449 restructured:

@@ -1093,3 +1093,38 @@ def test_emulator_loo_under_a_likelihood_layer(eng, lik):
     assert np.all(np.isfinite(mu)) and np.all(var >= 0)
     if lik == 'Categorical':
         assert np.all(mu >= 0) and np.all(mu <= 1)
+
+
+@pytest.mark.parametrize('nout', [1, 3])
+@pytest.mark.parametrize('batch', [12, 2])
+def test_queued_ess_equals_host_loop(eng, nout, batch):
+    """imputer.sample on a two-layer model: the device-resident accept / shrink loop (dgpamd_ess_queue, zero host round trips
+    inside the I-step) takes the same decisions as the host loop -- same latents, same number of proposals, the
+    uniform stream left at the same position -- with one and with several GP nodes in the layer above (their
+    log-likelihoods are summed, imputation.py:91-106); batch=2 forces updates that run out of queued batches and
+    are finished by the host loop."""
+    from dgp_amd import dgp, kernel, combine
+    rng = np.random.default_rng(5)
+    n, d = 300, 3
+    X = rng.uniform(size=(n, d))
+    Y = np.stack([np.sin(3 * X[:, 0] + k) + X[:, 1] ** 2 * (k + 1) for k in range(nout)], 1)
+    Y = (Y - Y.mean(0)) / Y.std(0)
+
+    def run(queued):
+        layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                         [kernel(length=np.array([0.8]), name='matern2.5' if k % 2 == 0 else 'sexp', scale_est=True, connect=np.arange(d))
+                          for k in range(nout)])
+        model = dgp(X, Y, layers, seed=3)
+        model.imp.batch = batch
+        model.imp.batch_next = min(4, batch)
+        model.imp.queued = queued
+        for _ in range(2):
+            model.imp.sample(burnin=6)
+        F = np.stack([nd.output[:, 0] for nd in model.all_layer[0]], 1)
+        return F, dict(model.imp.stats), model.imp.draws.uniform_peek(3)
+
+    Fq, sq, uq = run(True)
+    Fh, sh, uh = run(False)
+    close(Fq, Fh, rtol=1e-9, atol=1e-11)
+    assert sq == sh, (sq, sh)   # proposals, updates, batches
+    assert uq == uh
