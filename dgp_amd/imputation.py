@@ -22,6 +22,7 @@ both can be injected for deterministic replay.
 """
 import numpy as np
 from numpy.linalg import LinAlgError
+from .ops import raise_not_pd
 import torch
 
 from .ops import default_engine
@@ -280,7 +281,7 @@ class imputer:
             if status == 0:
                 break
             if status == 2:
-                raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(st['info']))
+                raise_not_pd(int(st['info']))
             if status == 4:   # the uploaded uniforms ran out between two updates
                 if not us:
                     raise RuntimeError('injected uniform stream exhausted')
@@ -314,7 +315,7 @@ class imputer:
                 _, info = e.potrf(n, buf[c0:c0 + nb], batch=nb)
                 info = info.cpu().numpy()
                 if info.any():
-                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[info != 0][0]))
+                    raise_not_pd(int(info[info != 0][0]))
             self._factor_cache[l] = (sigs, buf)
         return self._factor_cache[l][1]
 
@@ -524,7 +525,7 @@ class imputer:
             if cur is None:
                 ll, info = self._upper_loglik(l, F[None])
                 if info[0] != 0:
-                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[0]))
+                    raise_not_pd(int(info[0]))
                 cur = ll[0]
             log_y = cur + np.log(self.draws.uniform_take(1)[0])
             theta = TWO_PI * self.draws.uniform_take(1)[0]
@@ -544,7 +545,7 @@ class imputer:
                 self.stats['proposals'] += props
                 self.stats['batches'] += nbat
                 if status == 2:
-                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % info)
+                    raise_not_pd(info)
                 if status == 0:
                     self._ll_cache[l] = ll_acc
                     self._ll_cache.pop(l - 1, None)
@@ -564,7 +565,7 @@ class imputer:
             self.stats['batches'] += 1
             for b in range(nb):
                 if info[b] != 0:
-                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[b]))
+                    raise_not_pd(int(info[b]))
                 if ll[b] > log_y:
                     self.draws.uniform_take(b)
                     self.stats['proposals'] += b + 1
@@ -638,7 +639,7 @@ class imputer:
         nu = self._prior_draw(l, [k])
         ll, info = self._upper_loglik(l, F[None], only=linked)
         if info[0] != 0:
-            raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[0]))
+            raise_not_pd(int(info[0]))
         log_y = ll[0] + np.log(self.draws.uniform_take(1)[0])
         theta = TWO_PI * self.draws.uniform_take(1)[0]
         lo, hi = theta - TWO_PI, theta
@@ -658,7 +659,7 @@ class imputer:
             self.stats['batches'] += 1
             for b in range(nb):
                 if info[b] != 0:
-                    raise LinAlgError('%d-th leading minor of the array is not positive definite' % int(info[b]))
+                    raise_not_pd(int(info[b]))
                 if ll[b] > log_y:
                     self.draws.uniform_take(b)
                     self.stats['proposals'] += b + 1

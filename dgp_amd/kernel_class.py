@@ -13,6 +13,7 @@ R^-1 / R^-1 y on the device and never materialises Psexp.
 """
 import numpy as np
 from numpy.linalg import LinAlgError
+from .ops import raise_not_pd
 from scipy.optimize import minimize, Bounds
 
 from .ops import default_engine
@@ -100,7 +101,7 @@ class kernel:
     def _raise_if_not_pd(self, info):
         bad = int(info)
         if bad != 0:
-            raise LinAlgError('%d-th leading minor of the array is not positive definite' % bad)
+            raise_not_pd(bad)
 
     # ---------------------------------------------------------------- parameters
     def log_t(self):

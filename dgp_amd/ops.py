@@ -18,6 +18,17 @@ class DgpAmdError(RuntimeError):
     pass
 
 
+def raise_not_pd(info):
+    """A non-zero factorisation status as the exception it stands for.  info > 0: LAPACK's index of the first
+    non-positive pivot -> numpy.linalg.LinAlgError, the reference's signal (dgp.train restarts on it, compute_stats
+    falls back to pinvh).  info < 0: a bounded in-kernel spin gave up (a lost workgroup hand-off) -- a device problem,
+    never a numerical one, so it must not be swallowed by those recovery paths: DgpAmdError."""
+    info = int(info)
+    if info < 0:
+        raise DgpAmdError('factorisation: an in-kernel hand-off timed out (info = %d); this is not a numerical failure' % info)
+    raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite' % info)
+
+
 def _hp(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -306,7 +317,7 @@ class Engine:
         f = self.gemv(K, alpha.contiguous()) + u
         bad = int(self.fetch(info1)[0]) or int(self.fetch(info2)[0])
         if bad:
-            raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite' % bad)
+            raise_not_pd(bad)
         return f
 
     def fetch(self, t):

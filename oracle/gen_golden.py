@@ -707,8 +707,122 @@ def gen_hetero():
     save('g13_hetero', **out)
 
 
+# ---------------------------------------------------------------- G19-G21: sizes that cross 64x64 tile edges
+def gen_multitile():
+    """The same recordings as G1 / G5 / G9 at sizes that span several 64-wide tiles of the device factorisation (the small
+    fixtures all fit one tile): kernel.llik at n = 130, an ESS trajectory at n = 200 with a global input, emulator.predict
+    at n = 150; plus mice_var / ghdiag (functions.py:233-256) and emulator.nllik (emulation.py:856-914) at small n."""
+    # ---- G19: llik / loglik at n = 130
+    rng = np.random.default_rng(303)
+    out = {}
+    c = 0
+    for name, per_dim, d_glob, nugget_est, scale_est, prior in (('sexp', False, 0, False, True, 'ga'), ('matern2.5', True, 2, True, True, 'ga'),
+                                                               ('matern2.5', False, 2, True, False, None), ('sexp', True, 0, True, True, 'ref')):
+        k = make_node(rng, 130, 3, d_glob, name, per_dim, nugget_est, scale_est, prior, False)
+        pre = 'c%d_' % c
+        out[pre + 'X'] = node_X(k); out[pre + 'y'] = k.output.copy(); out[pre + 'length'] = k.length.copy()
+        out[pre + 'scale'] = k.scale.copy(); out[pre + 'nugget'] = k.nugget.copy(); out[pre + 'name'] = np.array(name)
+        out[pre + 'flags'] = np.array([per_dim, d_glob, nugget_est, False, scale_est], dtype=np.int64)
+        out[pre + 'prior'] = np.array('none' if prior is None else prior)
+        if prior is not None:
+            out[pre + 'prior_coef'] = np.asarray(k.prior_coef, float).copy()
+        if prior == 'ref':
+            out[pre + 'cl'] = np.atleast_1d(np.asarray(k.cl, float)).copy()
+        out[pre + 'K'] = k.k_matrix()
+        if prior != 'ref':
+            out[pre + 'loglik'] = np.atleast_1d(k.log_likelihood_func()).flatten()
+        x = k.log_t() + rng.normal(scale=0.1, size=len(k.log_t()))
+        nll, g = k.llik(x.copy())
+        out[pre + 'x'] = x; out[pre + 'nll'] = np.atleast_1d(nll).flatten(); out[pre + 'grad'] = np.asarray(g, float).flatten()
+        out[pre + 'scale_after'] = np.atleast_1d(k.scale).flatten()
+        c += 1
+    out['n_cases'] = np.array(c)
+    save('g19_kernel_llik_n130', **out)
+
+    # ---- G20: ESS trajectory at n = 200 (three Matern nodes, upper node with the global input connected)
+    X, Y, layers = build_small_dgp(21, 200, 3, ('matern2.5', 'matern2.5'))
+    model = dgp(X, Y, layers)
+    log = DrawLog(8)
+    oldr, oldu = RF.randn, RI.uniform
+    RI.fmvn.__globals__['randn'] = log.randn
+    RI.uniform = log.uniform
+    try:
+        before = dump_structure(model.all_layer, 'pre_')
+        model.imp.sample(burnin=1)
+        after = dump_structure(model.all_layer, 'post_')
+    finally:
+        RI.fmvn.__globals__['randn'] = oldr
+        RI.uniform = oldu
+    o = dict(before); o.update(after)
+    o['z'] = np.stack(log.z); o['u'] = np.array(log.u); o['X'] = X; o['Y'] = Y
+    save('g5_ess_matern200', **o)
+    print('   ess n=200: z draws', len(log.z), 'u draws', len(log.u))
+
+    # ---- G21: emulator.predict at n = 150 (hyper-parameters as initialised: no training, the imputations are what matters)
+    X, Y, layers = build_small_dgp(7, 150, 2, ('matern2.5', 'matern2.5'), n_out=2)
+    model = dgp(X, Y, layers)
+    for layer in model.all_layer:
+        for nd in layer:
+            nd.para_path = np.atleast_2d(np.concatenate((nd.scale, nd.length, nd.nugget)))
+    model.N = 1
+    est = model.estimate(burnin=0)
+    o = dump_structure(est, 'est_')
+    emu = emulator(est, N=2)
+    o['n_imp'] = np.array(len(emu.all_layer_set))
+    for s_, al in enumerate(emu.all_layer_set):
+        o.update(dump_structure(al, 's%d_' % s_))
+    xt = np.random.default_rng(9).uniform(size=(9, 2))
+    mu, var = emu.predict(xt)
+    mus, vars_ = emu.predict(xt, aggregation=False)
+    o.update(xt=xt, mu=mu, var=var, mu_s=np.stack(mus), var_s=np.stack(vars_), X=X, Y=Y)
+    save('g9_emulator_matern150', **o)
+
+    # ---- G22: mice_var, ghdiag
+    rng = np.random.default_rng(404)
+    o = {}
+    for i, (name, has_glob) in enumerate((('sexp', False), ('matern2.5', True))):
+        x = rng.uniform(size=(23, 3)); xe = rng.uniform(size=(23, 2))
+        length = rng.uniform(0.5, 1.5, size=5 if has_glob else 3)
+        sig = RF.mice_var(x, xe, np.arange(3), np.arange(2) if has_glob else None, name, length, 1.7, 1e-6, 1e-3)
+        o['m%d_x' % i] = x; o['m%d_xe' % i] = xe; o['m%d_length' % i] = length; o['m%d_name' % i] = np.array(name)
+        o['m%d_glob' % i] = np.array(has_glob); o['m%d_sigma2' % i] = sig
+    from dgpsi.likelihood_class import Poisson, Hetero
+    mu = rng.normal(size=(7, 1)); var = rng.uniform(0.05, 0.5, size=(7, 1)); yv = rng.integers(0, 6, size=(7, 1)).astype(float)
+    o['gh_mu'], o['gh_var'], o['gh_y'] = mu, var, yv
+    o['gh_poisson'] = RF.ghdiag(Poisson(input_dim=np.array([0])).pllik, mu, var, yv)
+    mu2 = rng.normal(size=(6, 2)); var2 = rng.uniform(0.05, 0.5, size=(6, 2)); y2 = rng.normal(size=(6, 1))
+    o['gh_mu2'], o['gh_var2'], o['gh_y2'] = mu2, var2, y2
+    o['gh_hetero'] = RF.ghdiag(Hetero(input_dim=np.array([0, 1])).pllik, mu2, var2, y2)
+    save('g22_mice_ghdiag', **o)
+
+    # ---- G23: emulator.nllik on a Poisson-likelihood DGP
+    np.random.seed(31)
+    rng = np.random.default_rng(31)
+    n = 20
+    X = rng.uniform(size=(n, 2))
+    Yc = rng.poisson(np.exp(1.0 + np.sin(3 * X[:, 0]) + X[:, 1]))[:, None].astype(float)
+    layers = combine([kernel(length=np.array([1.0]), name='sexp') for _ in range(2)],
+                     [kernel(length=np.array([1.0]), name='sexp', scale_est=True, connect=np.arange(2))],
+                     [Poisson(input_dim=np.array([0]))])
+    model = dgp(X, Yc, layers)
+    for layer in model.all_layer:
+        for nd in layer:
+            if nd.type == 'gp':
+                nd.para_path = np.atleast_2d(np.concatenate((nd.scale, nd.length, nd.nugget)))
+    model.N = 1
+    est = model.estimate(burnin=0)
+    emu = emulator(est, N=2)
+    o = {'n_imp': np.array(len(emu.all_layer_set))}
+    for s_, al in enumerate(emu.all_layer_set):
+        o.update(dump_structure([l for l in al if l[0].type == 'gp'], 's%d_' % s_))
+    xt = rng.uniform(size=(8, 2)); yt = rng.poisson(3.0, size=(8, 1)).astype(float)
+    avg, per = emu.nllik(xt, yt)
+    o.update(xt=xt, yt=yt, avg=np.array(avg), per=per, X=X, Y=Yc)
+    save('g23_nllik_poisson', **o)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch', 'export', 'counts', 'categorical']
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch', 'export', 'counts', 'categorical', 'multitile']
     if 'kernel' in which:
         gen_kernel_cases()
     if 'fmvn' in which:
@@ -735,3 +849,5 @@ if __name__ == '__main__':
         gen_counts()
     if 'categorical' in which:
         gen_categorical()
+    if 'multitile' in which:
+        gen_multitile()

@@ -47,17 +47,19 @@ def build_structure(d, pre, eng):
     return layers
 
 
-@pytest.mark.parametrize('tag', ['sexp', 'matern', 'deep'])
+@pytest.mark.parametrize('tag', ['sexp', 'matern', 'deep', 'matern200'])
 @pytest.mark.parametrize('batch', [1, 3, 8])
 def test_ess_trajectory_matches_reference(eng, golden, tag, batch):
-    """imputer.sample(burnin=2) with the reference's own draws: same accepted latents, and the
-    speculative batches consume exactly the uniforms the sequential sampler consumed."""
+    """imputer.sample with the reference's own draws: same accepted latents, and the speculative batches consume
+    exactly the uniforms the sequential sampler consumed.  The two-layer recordings run through the device-resident
+    accept / shrink loop (dgpamd_ess_queue); 'matern200' is n = 200 (four 64-wide tiles per matrix, global input
+    connected: panel / bulk tasks and the flag hand-offs of the factorisation are all on the path)."""
     from dgp_amd.imputation import imputer, DrawStream
     d = golden('g5_ess_' + tag)
     layers = build_structure(d, 'pre_', eng)
     draws = DrawStream(z=list(d['z']), u=list(d['u']))
     imp = imputer(layers, block=True, draws=draws, engine=eng, batch=batch)
-    imp.sample(burnin=2)
+    imp.sample(burnin=1 if tag == 'matern200' else 2)
     assert draws.exhausted(), 'all logged draws must be consumed, no more and no fewer'
     post = build_structure(d, 'post_', eng)
     for la, lb in zip(layers, post):
@@ -82,8 +84,10 @@ def test_nodewise_ess_matches_reference(eng, golden, batch):
             close(a.input, b.input, rtol=1e-8, atol=1e-10)
 
 
-@pytest.mark.parametrize('tag', ['sexp', 'matern'])
+@pytest.mark.parametrize('tag', ['sexp', 'matern', 'matern150'])
 def test_emulator_predict_matches_reference(eng, golden, tag):
+    """emulator.predict from the reference's own imputations; 'matern150' is n = 150 (three 64-wide tiles in the
+    factorisations and inverses behind compute_stats, several row tiles in the linked-GP pair kernels)."""
     from dgp_amd.emulation import emulator
     d = golden('g9_emulator_' + tag)
     S = int(d['n_imp'])
@@ -98,17 +102,20 @@ def test_emulator_predict_matches_reference(eng, golden, tag):
         emu.latents.append([np.stack([nd.output[:, 0] for nd in layer], 1) for layer in ls[:-1]])
     emu.orders = []
     emu._stats = None
+    # means go through R^-1 y: with the default nugget 1e-6 the n = 150 correlation matrices have condition ~1e7, i.e.
+    # ~1e-8 of the O(1) outputs is the attainable agreement between two factorisations (the oracle itself is at 1e-8)
+    am = 1e-7 if tag == 'matern150' else 1e-8
     mu_s, var_s = emu.predict(d['xt'], aggregation=False)
     for s in range(S):
-        close(mu_s[s], d['mu_s'][s], rtol=1e-6, atol=1e-8)
+        close(mu_s[s], d['mu_s'][s], rtol=1e-6, atol=am)
         # variance = O(scale) terms cancelling through R^-1 (cond ~1e6): absolute tolerance 1e-6 * prior variance
         close(var_s[s], d['var_s'][s], rtol=1e-5, atol=1e-6)
     mu, var = emu.predict(d['xt'])
-    close(mu, d['mu'], rtol=1e-6, atol=1e-8)
+    close(mu, d['mu'], rtol=1e-6, atol=am)
     close(var, d['var'], rtol=1e-5, atol=1e-6)
     ml, vl = emu.predict(d['xt'], full_layer=True)
     assert len(ml) == 2 and ml[0].shape == (len(d['xt']), 2)
-    close(ml[-1], d['mu'], rtol=1e-6, atol=1e-8)
+    close(ml[-1], d['mu'], rtol=1e-6, atol=am)
 
 
 @pytest.mark.parametrize('tag', ['sexp', 'matern'])
@@ -1128,3 +1135,124 @@ def test_queued_ess_equals_host_loop(eng, nout, batch):
     close(Fq, Fh, rtol=1e-9, atol=1e-11)
     assert sq == sh, (sq, sh)   # proposals, updates, batches
     assert uq == uh
+
+
+
+def test_mice_var_ghdiag_nllik_match_reference(eng, golden):
+    """functions.mice_var / ghdiag (functions.py:233-256) and emulator.nllik (emulation.py:856-914) against values recorded
+    from the reference (g22, g23): the smoothed candidate-set variance behind metric('MICE'), the Gauss-Hermite predictive
+    likelihood, and the whole negative predicted log-likelihood of a Poisson-likelihood DGP from the reference's imputations."""
+    from dgp_amd import kernel, Poisson, Hetero
+    from dgp_amd.emulation import emulator
+    from dgp_amd.likelihood_class import ghdiag
+    g = golden('g22_mice_ghdiag')
+    emu = emulator.__new__(emulator)
+    emu.engine = eng
+    for i in range(2):
+        glob = bool(g['m%d_glob' % i])
+        nd = kernel(length=g['m%d_length' % i].copy(), scale=1.7, nugget=1e-6, name=str(g['m%d_name' % i]), input_dim=np.arange(3),
+                    connect=np.arange(2) if glob else None, engine=eng)
+        s2 = emu._mice_var(g['m%d_x' % i], g['m%d_xe' % i], nd, 1e-3)
+        close(s2, g['m%d_sigma2' % i].ravel(), rtol=1e-8)
+    close(ghdiag(Poisson(input_dim=np.array([0])).pllik, g['gh_mu'], g['gh_var'], g['gh_y']), g['gh_poisson'], rtol=1e-12)
+    close(ghdiag(Hetero(input_dim=np.array([0, 1])).pllik, g['gh_mu2'], g['gh_var2'], g['gh_y2']), g['gh_hetero'], rtol=1e-12)
+    d = golden('g23_nllik_poisson')
+    S = int(d['n_imp'])
+    est = build_structure(d, 's0_', eng) + [[Poisson(input_dim=np.array([0]))]]
+    emu = emulator.__new__(emulator)
+    emu.all_layer, emu.n_layer, emu.vecch, emu.engine = est, len(est), False, eng
+    emu.N = emu.N_total = S
+    emu.shard = False
+    emu.latents = []
+    for s_ in range(S):
+        ls = build_structure(d, 's%d_' % s_, eng)
+        emu.latents.append([np.stack([nd.output[:, 0] for nd in layer], 1) for layer in ls])
+    emu.orders = []
+    emu._stats = None
+    avg, per = emu.nllik(d['xt'], d['yt'])
+    close(per, d['per'], rtol=1e-6, atol=1e-9)
+    close(avg, d['avg'], rtol=1e-6)
+
+
+def test_lockstep_mstep_equals_per_node_maximise(eng):
+    """dgp._m_step drives scipy's L-BFGS-B core for all nodes in lock-step with batched device objectives
+    (dgp_amd.mstep, dgpamd_llik_batch); kernel.maximise() runs scipy.optimize.minimize on one node at a time like the
+    reference (kernel_class.py:516-579, dgp.py:1391-1398).  On two identical copies of a model both leave the SAME
+    para_path rows and hyper-parameters, bit for bit (same iterates, same objective values)."""
+    from dgp_amd import dgp, kernel, combine
+    rng = np.random.default_rng(12)
+    n, d = 200, 3
+    X = rng.uniform(size=(n, d))
+    f = np.sin(1.0 / ((0.7 * X[:, 0] + 0.3) * (0.7 * X[:, 1] + 0.3))) + 0.5 * X[:, 2] ** 2
+    Y = ((f - f.mean()) / f.std())[:, None]
+
+    def build():
+        layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                         [kernel(length=np.array([1.0, 0.8, 1.2, 1.0, 0.9, 1.1]), name='matern2.5', scale_est=True, nugget_est=True,
+                                 connect=np.arange(d))])
+        m = dgp(X, Y, layers, seed=4)
+        m.imp.sample(burnin=3)
+        return m
+
+    a, b = build(), build()
+    a._m_step()                                   # lock-step, batched
+    for l, layer in enumerate(b.all_layer):       # one node after another
+        for nd in layer:
+            nd.engine = b.engine
+            if l != 0:
+                nd.r2()
+            nd.maximise()
+    for la, lb in zip(a.all_layer, b.all_layer):
+        for na, nb in zip(la, lb):
+            assert np.array_equal(na.para_path, nb.para_path), (na.para_path[-1], nb.para_path[-1])
+            assert np.array_equal(na.length, nb.length) and np.array_equal(na.scale, nb.scale) and np.array_equal(na.nugget, nb.nugget)
+
+
+def test_one_si_iteration_at_bench_size_vs_oracle(eng):
+    """ONE stochastic-imputation iteration of BASELINE's configs[1] (n = 2000, d = 5, 5 + 1 Matern-2.5 nodes) against
+    the oracle with injected draws: the I-step's block update (prior draws through five n x n factors, the speculative
+    batch's twelve factorisations, the device-resident accept / shrink loop) must accept the proposal the sequential
+    sampler accepts and consume the same uniforms; the M-step's objective and gradient (K assembly, factorisation + fused
+    inverse, derivative reductions) must agree at the resulting state.  Oracle: ~0.5 s per n = 2000 log-likelihood."""
+    from oracle import dgp_oracle as O
+    from dgp_amd.imputation import DrawStream
+    import bench
+    model, X, Y = bench.build_model(2000, 5, 100, 0)
+    model.engine = eng
+    n, d = X.shape
+    rng = np.random.default_rng(77)
+    z = [rng.standard_normal(n) for _ in range(d)]
+    u = list(rng.random(40))
+    imp = model.imp
+    imp.draws = DrawStream(z=[v.copy() for v in z], u=list(u))
+    layer0, top = model.all_layer[0], model.all_layer[1][0]
+    F0 = np.stack([nd.output[:, 0] for nd in layer0], 1)
+    par = dict(length=top.length.copy(), scale=float(top.scale[0]), nugget=float(top.nugget[0]))
+    nu = np.stack([O.fmvn(float(nd.scale[0]) * O.k_matrix(nd.input, nd.length, nd.nugget[0], nd.name), z[k]) for k, nd in enumerate(layer0)], 1)
+
+    def upper(fp):
+        Xi = np.concatenate((fp[:, top.input_dim], X[:, top.connect]), 1)
+        return O.log_likelihood(Xi, Y, par['length'], par['scale'], par['nugget'], top.name)
+
+    f_ref, nprop, thetas, lls, log_y = O.ess_block_sweep(F0, nu, upper, np.log(u[0]), u[1:])
+    imp.sample(burnin=0)
+    F1 = np.stack([nd.output[:, 0] for nd in layer0], 1)
+    assert len(imp.draws._ubuf) == len(u) - (1 + nprop), 'uniforms consumed: threshold + one per proposal'
+    close(F1, f_ref, rtol=1e-8, atol=1e-10)
+    # the accepted state's log-likelihood as the device computed it (the threshold of the next update)
+    close(imp._ll_cache[0], lls[-1], rtol=1e-9)
+    # M-step objective / gradient of every node at this state
+    for l, layer in enumerate(model.all_layer):
+        for nd in layer:
+            nd.engine = eng
+            if l != 0:
+                nd.r2()
+            x = nd.log_t()
+            Xn = nd.input if nd.global_input is None else np.concatenate((nd.input, nd.global_input), 1)
+            nll_o, g_o, _ = O.nll_grad(x, Xn, nd.output, nd.name, nd.scale.copy(), nd.nugget[0], nd.nugget_est, nd.scale_est,
+                                       nd.prior_name, nd.prior_coef, getattr(nd, 'cl', None), None, None, None)
+            sc = nd.scale.copy()
+            nll, g = nd.llik(x.copy())
+            nd.scale = sc
+            close(nll, nll_o, rtol=1e-8)
+            close(g, g_o, rtol=1e-6, atol=1e-6)

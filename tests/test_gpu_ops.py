@@ -38,8 +38,9 @@ def split(eng, X, nl):
 
 
 # ---------------------------------------------------------------- a1/a2/a5/a8
-def test_kmatrix_golden(eng, golden):
-    g = golden('g1_kernel_llik')
+@pytest.mark.parametrize('fixture', ['g1_kernel_llik', 'g19_kernel_llik_n130'])
+def test_kmatrix_golden(eng, golden, fixture):
+    g = golden(fixture)
     for c in range(int(g['n_cases'])):
         d = case(g, 'c%d_' % c)
         nl = 3
@@ -73,8 +74,11 @@ def gpu_nll_grad(eng, d):
     return k
 
 
-def test_llik_and_loglik_golden(eng, golden):
-    g = golden('g1_kernel_llik')
+@pytest.mark.parametrize('fixture', ['g1_kernel_llik', 'g19_kernel_llik_n130'])
+def test_llik_and_loglik_golden(eng, golden, fixture):
+    """kernel.llik / log_likelihood_func against the reference's recorded values: 112 configurations at n = 12..21 and
+    four at n = 130 (three 64-wide tiles: panel and bulk tasks, flag hand-offs of the factorisation + fused inverse)."""
+    g = golden(fixture)
     for c in range(int(g['n_cases'])):
         d = case(g, 'c%d_' % c)
         k = gpu_nll_grad(eng, d)
@@ -84,8 +88,7 @@ def test_llik_and_loglik_golden(eng, golden):
         close(nll, d['nll'], rtol=1e-9)
         close(grad, d['grad'], rtol=1e-7, atol=1e-8)
         close(k.scale, d['scale_after'], rtol=1e-9)
-        Kf, fod = k.k_matrix(fod_eval=True)
-        close(Kf, d['K'].copy() if False else k.k_matrix(), rtol=0, atol=0)
+        Kf, fod = k.k_matrix(fod_eval=True)   # (fod is assembled in host numpy: API only, not on the hot path)
         # fod after llik(x): parameters moved to exp(x); compare against the oracle at those parameters
         from oracle import dgp_oracle as O
         X = d['X']

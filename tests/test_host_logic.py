@@ -345,3 +345,16 @@ def test_public_api_accepts_the_reference_calls():
         bad += [(fn, p) for p in ps if p not in sig]
     assert missing == moved_to_device, missing ^ moved_to_device
     assert not bad, bad
+
+
+def test_lost_handoff_is_not_a_numerical_failure():
+    """info < 0 (a bounded in-kernel spin gave up) raises DgpAmdError, which dgp.train's LinAlgError restart policy
+    (dgp.py:1402-1412) does not swallow; info > 0 stays numpy's LinAlgError."""
+    import numpy as np
+    import pytest
+    from dgp_amd.ops import raise_not_pd, DgpAmdError
+    with pytest.raises(np.linalg.LinAlgError):
+        raise_not_pd(17)
+    with pytest.raises(DgpAmdError):
+        raise_not_pd(-1)
+    assert not issubclass(DgpAmdError, np.linalg.LinAlgError)

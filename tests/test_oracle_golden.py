@@ -14,10 +14,14 @@ def close(a, b, rtol=RTOL, atol=1e-13):
     np.testing.assert_allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol)
 
 
-def kernel_cases(golden):
-    g = golden('g1_kernel_llik')
-    for c in range(int(g['n_cases'])):
-        yield c, case(g, 'c%d_' % c)
+def kernel_cases(golden, files=('g1_kernel_llik', 'g19_kernel_llik_n130')):
+    """g1: 112 configurations at n = 12..21; g19: four at n = 130 (several 64-wide tiles on the device)."""
+    c0 = 0
+    for f in files:
+        g = golden(f)
+        for c in range(int(g['n_cases'])):
+            yield c0 + c, case(g, 'c%d_' % c)
+        c0 += int(g['n_cases'])
 
 
 def test_k_matrix_and_fod(golden):
@@ -29,8 +33,9 @@ def test_k_matrix_and_fod(golden):
         close(K, d['K'])
         K2, fod = O.k_matrix_fod(d['X'], d['length'], d['nugget'][0], name, nugget_est, W)
         close(K2, d['K'])
-        assert fod.shape == d['fod'].shape
-        close(fod, d['fod'])
+        if 'fod' in d:
+            assert fod.shape == d['fod'].shape
+            close(fod, d['fod'])
 
 
 def test_loglik(golden):
@@ -78,11 +83,11 @@ def load_structure(d, pre):
     return layers
 
 
-def replay_ess(d):
-    """Replay imputer.sample(burnin=2) (imputation.py:22-119) with the logged draws."""
+def replay_ess(d, sweeps=3):
+    """Replay imputer.sample(burnin=sweeps-1) (imputation.py:22-119) with the logged draws."""
     layers = load_structure(d, 'pre_')
     z, u = list(d['z']), list(d['u'])
-    for _ in range(3):
+    for _ in range(sweeps):
         for l in range(len(layers) - 1):
             tgt, upp = layers[l], layers[l + 1]
             n, M = tgt[0]['output'].shape[0], len(tgt)
@@ -113,9 +118,9 @@ def replay_ess(d):
 
 
 @pytest.mark.parametrize('tag', ['sexp', 'matern', 'deep'])
-def test_ess_trajectory(golden, tag):
+def test_ess_trajectory(golden, tag, sweeps=3):
     d = golden('g5_ess_' + tag)
-    layers = replay_ess(d)
+    layers = replay_ess(d, sweeps)
     post = load_structure(d, 'post_')
     for la, lb in zip(layers, post):
         for a, b in zip(la, lb):
@@ -194,7 +199,7 @@ def test_vecchia_kernels(golden):
         close(lv, d['lgv_v'], rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize('tag', ['sexp', 'matern'])
+@pytest.mark.parametrize('tag', ['sexp', 'matern', 'matern150'])
 def test_emulator_predict(golden, tag):
     """emulator.predict (emulation.py:631-854) from the dumped imputed structures."""
     d = golden('g9_emulator_' + tag)
@@ -231,6 +236,8 @@ def test_emulator_predict(golden, tag):
     close(var, d['var'], rtol=1e-5, atol=2e-7)
     # dgp.estimate (dgp.py:1529-1540): mean of para_path[int(0.75 N):]
     est = load_structure(d, 'est_')
+    if 'path_l0_k0' not in d:   # (the n = 150 fixture was recorded without training)
+        return
     for l, layer in enumerate(est):
         for k, nd in enumerate(layer):
             path = d['path_l%d_k%d' % (l, k)]
@@ -315,3 +322,20 @@ def test_count_likelihoods(golden):
             close(lat[:, cols], g[pre + 'latent'][:, cols], rtol=1e-13)
             li = lat if rep is None else lat[rep]
             close(li[:, cols], g[pre + 'lik_input'][:, cols], rtol=1e-13)
+
+
+def test_mice_var_and_ghdiag_pinned(golden):
+    """functions.mice_var / ghdiag (functions.py:233-256) recorded from the reference."""
+    g = golden('g22_mice_ghdiag')
+    for i in range(2):
+        glob = bool(g['m%d_glob' % i])
+        s2 = O.mice_var(g['m%d_x' % i], g['m%d_xe' % i], np.arange(3), np.arange(2) if glob else None, str(g['m%d_name' % i]),
+                        g['m%d_length' % i], 1.7, 1e-6, 1e-3)
+        close(s2, g['m%d_sigma2' % i], rtol=1e-9)
+    close(O.ghdiag(O.poisson_pllik, g['gh_mu'], g['gh_var'], g['gh_y']), g['gh_poisson'], rtol=1e-12)
+    close(O.ghdiag(O.hetero_pllik, g['gh_mu2'], g['gh_var2'], g['gh_y2']), g['gh_hetero'], rtol=1e-12)
+
+
+def test_ess_trajectory_multitile(golden):
+    """The n = 200 recording (three Matern nodes, global input connected): four 64-wide tiles per matrix on the device."""
+    test_ess_trajectory(golden, 'matern200', sweeps=2)
