@@ -1155,7 +1155,10 @@ static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, d
     const int64_t useful = (int64_t)batch * (mt->ntask + 1 + mega_wgs_per_cu());
     if (grid > useful) grid = useful;
     if (grid < batch + 1) grid = batch + 1;
+    // algorithmic flops of the launch: n^3/3 per matrix, n^3 with the fused inverse
+    PROF_BEGIN(ctx, PROF_SYRK, (double)batch * (double)n * (double)n * (double)n * (T ? 1.0 : 1.0 / 3.0));
     hipLaunchKernelGGL(potrf_mega_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, g);
+    PROF_END(ctx, PROF_SYRK);
     if (T)
         hipLaunchKernelGGL(copy_alpha_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, ctx->stream,
                            (const double *)T, S, Np, n, stride_a);

@@ -85,6 +85,7 @@ static inline int graph_run(dgpamd_ctx *ctx, const std::array<uint64_t, 10> &key
             return body();
         }
         if (ctx->graphs.size() >= 64) {   // callers that keep changing buffers: do not let the cache grow without bound
+            (void)hipStreamSynchronize(ctx->stream);   // (the host runs ahead: a replay may still be executing)
             for (auto &kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
             ctx->graphs.clear();
         }

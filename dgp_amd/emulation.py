@@ -48,6 +48,8 @@ class emulator:
         self.shard_points = shard == 'points' and ddist.is_active()
         self.shard = False if shard == 'points' else (ddist.is_active() if shard is None else bool(shard))
         rank, world = (ddist.rank(), ddist.world()) if self.shard else (0, 1)
+        if self.shard and self.N_total < world:   # (a rank without imputations would skip the collectives the others enter)
+            raise Exception('emulator(shard=True) needs at least one imputation per rank: N = %d < %d ranks' % (self.N_total, world))
         self.N = ddist.share(self.N_total, rank, world)
         if self.shard_points and seed is None:      # all ranks must draw the same imputations: rank 0's entropy for everyone
             box = [np.random.SeedSequence().entropy]
@@ -337,6 +339,10 @@ class emulator:
             return self._predict_points(x, method, full_layer, sample_size, m, aggregation)
         if self.vecch:
             return self._predict_vecchia(x, full_layer, m, aggregation, method, sample_size)
+        if self.shard and (method == 'sampling' or not aggregation):
+            # (each rank holds its own imputations only: the per-imputation lists / draws would silently be partial)
+            raise NotImplementedError("with the imputations sharded over ranks predict() returns aggregated moments only; "
+                                      "use emulator(..., shard=False) or shard='points' for method='sampling' / aggregation=False")
         e = self.engine
         M, S = len(x), self.N
         per_layer = self._layer_moments(x)

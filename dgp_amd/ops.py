@@ -76,7 +76,22 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------ utils
+    def _enter(self):
+        """Called before every library call.  The library launches on THIS engine's stream; torch work the caller
+        queued on another current stream (a different thread, a user's torch.cuda.stream block) is ordered before it by
+        an event wait, and _chk() orders the caller's stream after the call again.  The creating thread's current
+        stream IS the engine's stream, so both are no-ops there.  Returns None (used as `_enter() or lib.f(...)`)."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self._torch_stream.cuda_stream:
+            self._torch_stream.wait_stream(cur)
+            self._foreign = cur
+        return None
+
     def _chk(self, rc):
+        f = getattr(self, '_foreign', None)
+        if f is not None:
+            self._foreign = None
+            f.wait_stream(self._torch_stream)
         if rc != 0:
             raise DgpAmdError('libdgp_amd rc=%d: %s' % (rc, lib.dgpamd_last_error(self.h).decode()))
 
@@ -85,14 +100,14 @@ class Engine:
 
     def set_linkgp_direct(self, enable):
         """Matern linked-GP J factor: reference's direct expression (True) or its separable form (default)."""
-        self._chk(lib.dgpamd_set_linkgp_direct(self.h, 1 if enable else 0))
+        self._chk(self._enter() or lib.dgpamd_set_linkgp_direct(self.h, 1 if enable else 0))
 
     def set_graphs(self, enable):
-        self._chk(lib.dgpamd_set_graphs(self.h, 1 if enable else 0))
+        self._chk(self._enter() or lib.dgpamd_set_graphs(self.h, 1 if enable else 0))
 
     def set_potrf_mode(self, mode):
         """1 (default): the factorisation is one persistent dataflow launch; 0: one launch per 64-column block step; 2: chosen per call."""
-        self._chk(lib.dgpamd_set_potrf_mode(self.h, int(mode)))
+        self._chk(self._enter() or lib.dgpamd_set_potrf_mode(self.h, int(mode)))
 
     def stream(self):
         """Context manager making this engine's HIP stream torch's current stream (so that torch's
@@ -122,31 +137,31 @@ class Engine:
 
     def event(self):
         e = C.c_void_p()
-        self._chk(lib.dgpamd_event_create(self.h, C.byref(e)))
+        self._chk(self._enter() or lib.dgpamd_event_create(self.h, C.byref(e)))
         return e
 
     def record(self, ev):
-        self._chk(lib.dgpamd_event_record(self.h, ev))
+        self._chk(self._enter() or lib.dgpamd_event_record(self.h, ev))
 
     def elapsed_ms(self, start, stop):
         ms = C.c_float()
-        self._chk(lib.dgpamd_event_elapsed_ms(self.h, start, stop, C.byref(ms)))
+        self._chk(self._enter() or lib.dgpamd_event_elapsed_ms(self.h, start, stop, C.byref(ms)))
         return float(ms.value)
 
     PROF = dict(kmatrix=1, potrf_diag=2, trsm=3, syrk=4, trtri=5, lauum=6, grad=7, linkgp_j=8, gp_quad=9)
 
     def prof_enable(self, name):
-        self._chk(lib.dgpamd_prof_enable(self.h, self.PROF[name] if name else 0))
+        self._chk(self._enter() or lib.dgpamd_prof_enable(self.h, self.PROF[name] if name else 0))
 
     def prof_event_overhead_us(self):
         v = C.c_double()
-        self._chk(lib.dgpamd_prof_event_overhead_us(self.h, C.byref(v)))
+        self._chk(self._enter() or lib.dgpamd_prof_event_overhead_us(self.h, C.byref(v)))
         return float(v.value)
 
     def prof_collect(self):
         """(launches, total_ms, algorithmic work) of the launches timed since prof_enable."""
         n, ms, w = C.c_int64(), C.c_double(), C.c_double()
-        self._chk(lib.dgpamd_prof_collect(self.h, C.byref(n), C.byref(ms), C.byref(w)))
+        self._chk(self._enter() or lib.dgpamd_prof_collect(self.h, C.byref(n), C.byref(ms), C.byref(w)))
         return int(n.value), float(ms.value), float(w.value)
 
     # --------------------------------------------------------------- kernels
@@ -179,7 +194,7 @@ class Engine:
         stride_y = 0
         if Y is not None and Y.dim() == 3:
             stride_y = Y.shape[-2] * Y.shape[-1]
-        self._chk(lib.dgpamd_kmatrix(self.h, KIND[kind], n, _dp(Xloc), ldloc, stride_loc, cmp_, Dl, _dp(Xglob), Dg,
+        self._chk(self._enter() or lib.dgpamd_kmatrix(self.h, KIND[kind], n, _dp(Xloc), ldloc, stride_loc, cmp_, Dl, _dp(Xglob), Dg,
                                      _hp(length), len(length), float(nugget), _dp(W), _dp(out), ld, stride_k,
                                      1 if full else 0, _dp(Y), n, stride_y, r, batch))
         return out
@@ -194,7 +209,7 @@ class Engine:
             work = self.potrf_workspace(n, batch)
         logdet = self.empty(batch)
         info = self.empty(batch, dtype=torch.int32)
-        self._chk(lib.dgpamd_potrf(self.h, n, _dp(A), Np * Np, batch, _dp(logdet), _dp(info), _dp(work)))
+        self._chk(self._enter() or lib.dgpamd_potrf(self.h, n, _dp(A), Np * Np, batch, _dp(logdet), _dp(info), _dp(work)))
         return logdet, info
 
     def potrf_inv(self, n, A, T, S, batch=1, work=None):
@@ -205,13 +220,13 @@ class Engine:
             work = self.potrf_workspace(n, batch)
         logdet = self.empty(batch)
         info = self.empty(batch, dtype=torch.int32)
-        self._chk(lib.dgpamd_potrf_inv(self.h, n, _dp(A), _dp(T), _dp(S), Np * Np, batch, _dp(logdet), _dp(info), _dp(work)))
+        self._chk(self._enter() or lib.dgpamd_potrf_inv(self.h, n, _dp(A), _dp(T), _dp(S), Np * Np, batch, _dp(logdet), _dp(info), _dp(work)))
         return logdet, info
 
     def aug_quad(self, n, A, batch, r):
         Np = self.padded_dim(n)
         out = self.empty(batch, r, r)
-        self._chk(lib.dgpamd_aug_quad(self.h, n, _dp(A), Np * Np, batch, r, _dp(out)))
+        self._chk(self._enter() or lib.dgpamd_aug_quad(self.h, n, _dp(A), Np * Np, batch, r, _dp(out)))
         return out
 
     def loglik(self, kind, Xloc, colmap, Xglob, length, nugget, scale, y, W=None, batch=1, A=None, ll=None, info=None):
@@ -230,7 +245,7 @@ class Engine:
         if info is None:
             info = self.empty(batch, dtype=torch.int32)
         stride_loc = n * ldloc if Xloc.dim() == 3 else 0
-        self._chk(lib.dgpamd_loglik(self.h, KIND[kind], n, _dp(Xloc), ldloc, stride_loc, cmp_, Dl, _dp(Xglob), Dg,
+        self._chk(self._enter() or lib.dgpamd_loglik(self.h, KIND[kind], n, _dp(Xloc), ldloc, stride_loc, cmp_, Dl, _dp(Xglob), Dg,
                                     _hp(length), len(length), float(nugget), _dp(W), float(scale), _dp(y), _dp(A),
                                     Np * Np, batch, _dp(ll), _dp(info), _dp(work)))
         return ll, info
@@ -242,7 +257,7 @@ class Engine:
             sc = np.repeat(sc, batch)
         if out is None:
             out = self.empty(batch, n)
-        self._chk(lib.dgpamd_trmv_lower(self.h, n, _dp(L), Np * Np, _hp(sc), _dp(z), _dp(out), batch))
+        self._chk(self._enter() or lib.dgpamd_trmv_lower(self.h, n, _dp(L), Np * Np, _hp(sc), _dp(z), _dp(out), batch))
         return out
 
     def ess_propose(self, F, NU, thetas, out=None):
@@ -251,12 +266,12 @@ class Engine:
         B = len(th)
         if out is None:
             out = self.empty(B, n, M)
-        self._chk(lib.dgpamd_ess_propose(self.h, n, M, _dp(F), _dp(NU), _hp(th), B, _dp(out)))
+        self._chk(self._enter() or lib.dgpamd_ess_propose(self.h, n, M, _dp(F), _dp(NU), _hp(th), B, _dp(out)))
         return out
 
     def potri(self, n, A, Ainv, r, work, batch=1):
         Np = self.padded_dim(n)
-        self._chk(lib.dgpamd_potri_batched(self.h, n, _dp(A), _dp(Ainv), Np * Np if batch > 1 else 0, r, batch, _dp(work)))
+        self._chk(self._enter() or lib.dgpamd_potri_batched(self.h, n, _dp(A), _dp(Ainv), Np * Np if batch > 1 else 0, r, batch, _dp(work)))
         return Ainv
 
     def grad_reduce(self, kind, Xloc, colmap, Xglob, length, nugget, nugget_est, Ainv, W=None):
@@ -268,7 +283,7 @@ class Engine:
         P = (1 if len(length) == 1 else Dl + Dg) + (1 if nugget_est else 0)
         work = self.workspace(('grad', n, P), lib.dgpamd_grad_workspace(n, P))
         out = self.empty(2 * P)
-        self._chk(lib.dgpamd_grad_reduce(self.h, KIND[kind], n, _dp(Xloc), ldloc, cmp_, Dl, _dp(Xglob), Dg, _hp(length),
+        self._chk(self._enter() or lib.dgpamd_grad_reduce(self.h, KIND[kind], n, _dp(Xloc), ldloc, cmp_, Dl, _dp(Xglob), Dg, _hp(length),
                                          len(length), float(nugget), _dp(W), 1 if nugget_est else 0, _dp(Ainv), _dp(out),
                                          _dp(work)))
         return out, P
@@ -277,7 +292,7 @@ class Engine:
         rows, cols = A.shape
         if out is None:
             out = self.empty(rows)
-        self._chk(lib.dgpamd_gemv(self.h, rows, cols, _dp(A), A.stride(0), _dp(x), _dp(out)))
+        self._chk(self._enter() or lib.dgpamd_gemv(self.h, rows, cols, _dp(A), A.stride(0), _dp(x), _dp(out)))
         return out
 
     def pinvh(self, K):
@@ -325,14 +340,14 @@ class Engine:
         torch's .cpu() for the few bytes a sampler / optimiser step returns)."""
         t = t.contiguous()
         out = np.empty(tuple(t.shape), dtype={torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64}[t.dtype])
-        self._chk(lib.dgpamd_fetch(self.h, _dp(t), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        self._chk(self._enter() or lib.dgpamd_fetch(self.h, _dp(t), out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
     def fetch_ll_info(self, ll, info):
         """(ll float64 (B,), info int32 (B,)) device tensors -> two numpy arrays with ONE synchronisation."""
         B = ll.numel()
         buf = np.empty(12 * B, dtype=np.uint8)
-        self._chk(lib.dgpamd_fetch2(self.h, _dp(ll), 8 * B, _dp(info), 4 * B, buf.ctypes.data_as(C.c_void_p)))
+        self._chk(self._enter() or lib.dgpamd_fetch2(self.h, _dp(ll), 8 * B, _dp(info), 4 * B, buf.ctypes.data_as(C.c_void_p)))
         return buf[:8 * B].view(np.float64), buf[8 * B:].view(np.int32)
 
     def ess_queue_plan(self, n, M, nodes, batch):
@@ -359,7 +374,7 @@ class Engine:
             mean = self.empty(M) if ry.dim() == 1 else self.empty(nry, M)
         if var is None:
             var = self.empty(M)
-        self._chk(lib.dgpamd_gp_predict(self.h, KIND[kind], n, M, D, _dp(x), _dp(Wtr), _hp(length), len(length), _dp(Rinv),
+        self._chk(self._enter() or lib.dgpamd_gp_predict(self.h, KIND[kind], n, M, D, _dp(x), _dp(Wtr), _hp(length), len(length), _dp(Rinv),
                                         ldr, _dp(ry), nry, float(scale), float(nugget), _dp(mean), _dp(var), _dp(work)))
         return mean, var
 
@@ -377,27 +392,27 @@ class Engine:
             var = self.empty(M)
         if drop is not None:
             assert drop.dtype == torch.int32 and drop.numel() == M and drop.is_contiguous()
-            self._chk(lib.dgpamd_linkgp_loo(self.h, KIND[kind], n, M, Dw, Dz, _dp(m), _dp(v), _dp(z), _dp(Wtr), _dp(Wg),
+            self._chk(self._enter() or lib.dgpamd_linkgp_loo(self.h, KIND[kind], n, M, Dw, Dz, _dp(m), _dp(v), _dp(z), _dp(Wtr), _dp(Wg),
                                             _hp(length), len(length), _dp(Rinv), ldr, _dp(ry), _dp(drop), float(scale),
                                             float(nugget), _dp(mean), _dp(var), _dp(work)))
             return mean, var
-        self._chk(lib.dgpamd_linkgp_predict(self.h, KIND[kind], n, M, Dw, Dz, _dp(m), _dp(v), _dp(z), _dp(Wtr), _dp(Wg),
+        self._chk(self._enter() or lib.dgpamd_linkgp_predict(self.h, KIND[kind], n, M, Dw, Dz, _dp(m), _dp(v), _dp(z), _dp(Wtr), _dp(Wg),
                                             _hp(length), len(length), _dp(Rinv), ldr, _dp(ry), float(scale),
                                             float(nugget), _dp(mean), _dp(var), _dp(work)))
         return mean, var
 
     def moments_accumulate(self, mu, var, sum_mu, sum_m2):
-        self._chk(lib.dgpamd_moments_accumulate(self.h, mu.numel(), _dp(mu), _dp(var), _dp(sum_mu), _dp(sum_m2)))
+        self._chk(self._enter() or lib.dgpamd_moments_accumulate(self.h, mu.numel(), _dp(mu), _dp(var), _dp(sum_mu), _dp(sum_m2)))
 
     def moments_finalize(self, S, sum_mu, sum_m2):
-        self._chk(lib.dgpamd_moments_finalize(self.h, sum_mu.numel(), float(S), _dp(sum_mu), _dp(sum_m2)))
+        self._chk(self._enter() or lib.dgpamd_moments_finalize(self.h, sum_mu.numel(), float(S), _dp(sum_mu), _dp(sum_m2)))
 
     # --------------------------------------------------------------- vecchia
     def nn_ordered(self, x, m):
         n, D = x.shape
         m = min(m, n - 1)
         out = self.empty(n, m + 1, dtype=torch.int64)
-        self._chk(lib.dgpamd_nn_ordered(self.h, n, D, _dp(x), m, _dp(out)))
+        self._chk(self._enter() or lib.dgpamd_nn_ordered(self.h, n, D, _dp(x), m, _dp(out)))
         return out
 
     def nn_query(self, q, x, m):
@@ -405,14 +420,14 @@ class Engine:
         n = x.shape[0]
         m = min(m, n)
         out = self.empty(M, m, dtype=torch.int64)
-        self._chk(lib.dgpamd_nn_query(self.h, M, n, D, _dp(q), _dp(x), m, _dp(out)))
+        self._chk(self._enter() or lib.dgpamd_nn_query(self.h, M, n, D, _dp(q), _dp(x), m, _dp(out)))
         return out
 
     def vecchia_llik(self, kind, X, y, NN, length, nugget, nugget_diag):
         n, D = X.shape
         length = _f64(length)
         out = self.empty(2)
-        self._chk(lib.dgpamd_vecchia_llik(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(y), _dp(NN), _hp(length),
+        self._chk(self._enter() or lib.dgpamd_vecchia_llik(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(y), _dp(NN), _hp(length),
                                           len(length), float(nugget), _dp(nugget_diag), _dp(out)))
         return out
 
@@ -421,7 +436,7 @@ class Engine:
         length = _f64(length)
         P = (1 if len(length) == 1 else D) + (1 if nugget_est else 0)
         out = self.empty(2 + 2 * P)
-        self._chk(lib.dgpamd_vecchia_nllik(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(y), _dp(NN),
+        self._chk(self._enter() or lib.dgpamd_vecchia_nllik(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(y), _dp(NN),
                                            _hp(length), len(length), float(nugget), _dp(nugget_diag),
                                            1 if nugget_est else 0, _dp(out)))
         return out, P
@@ -430,7 +445,7 @@ class Engine:
         n, D = X.shape
         length = _f64(length)
         out = self.empty(n, NN.shape[1])
-        self._chk(lib.dgpamd_vecchia_lmatrix(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(NN), _hp(length),
+        self._chk(self._enter() or lib.dgpamd_vecchia_lmatrix(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(NN), _hp(length),
                                              len(length), float(nugget), _dp(out)))
         return out
 
@@ -445,7 +460,7 @@ class Engine:
         Lrows, t = self.empty(n, mp1), self.empty(n)
         NNl = torch.empty((n, mp1), dtype=torch.int64, device=X_ord.device)
         info = torch.empty(1, dtype=torch.int32, device=X_ord.device)
-        self._chk(lib.dgpamd_vecchia_het_rows(self.h, KIND[kind], n, D, mp1 - 1, _dp(X_ord), _dp(impNN), _hp(length), len(length),
+        self._chk(self._enter() or lib.dgpamd_vecchia_het_rows(self.h, KIND[kind], n, D, mp1 - 1, _dp(X_ord), _dp(impNN), _hp(length), len(length),
                                               float(scale), _dp(gamma), _dp(y), _dp(Lrows), _dp(NNl), _dp(t), _dp(info)))
         bad = int(info.item())
         if bad:
@@ -455,7 +470,7 @@ class Engine:
     def vecchia_spsolve(self, Lmat, NN, inv_sqrt_scale, b):
         n = Lmat.shape[0]
         out = self.empty(n)
-        self._chk(lib.dgpamd_vecchia_spsolve(self.h, n, NN.shape[1] - 1, _dp(Lmat), _dp(NN), float(inv_sqrt_scale), _dp(b),
+        self._chk(self._enter() or lib.dgpamd_vecchia_spsolve(self.h, n, NN.shape[1] - 1, _dp(Lmat), _dp(NN), float(inv_sqrt_scale), _dp(b),
                                              _dp(out)))
         return out
 
@@ -465,14 +480,14 @@ class Engine:
         nrhs = b.shape[1]
         out = self.empty(nmat, nrhs, n)
         sc = self.tensor(np.asarray(inv_sqrt_scale, dtype=np.float64))
-        self._chk(lib.dgpamd_vecchia_spsolve_batch(self.h, n, mp1 - 1, nmat, nrhs, _dp(Lmat), _dp(NN), _dp(sc), _dp(b), _dp(out)))
+        self._chk(self._enter() or lib.dgpamd_vecchia_spsolve_batch(self.h, n, mp1 - 1, nmat, nrhs, _dp(Lmat), _dp(NN), _dp(sc), _dp(b), _dp(out)))
         return out
 
     def vecchia_gp(self, kind, x, w, NN, y, scale, length, nugget, nugget_diag):
         M, D = x.shape
         length = _f64(length)
         mean, var = self.empty(M), self.empty(M)
-        self._chk(lib.dgpamd_vecchia_gp(self.h, KIND[kind], M, w.shape[0], D, NN.shape[1], _dp(x), _dp(w), _dp(NN), _dp(y),
+        self._chk(self._enter() or lib.dgpamd_vecchia_gp(self.h, KIND[kind], M, w.shape[0], D, NN.shape[1], _dp(x), _dp(w), _dp(NN), _dp(y),
                                         float(scale), _hp(length), len(length), float(nugget), _dp(nugget_diag),
                                         _dp(mean), _dp(var)))
         return mean, var
@@ -482,7 +497,7 @@ class Engine:
         Dz = 0 if z is None else z.shape[1]
         length = _f64(length)
         mean, var = self.empty(M), self.empty(M)
-        self._chk(lib.dgpamd_vecchia_linkgp(self.h, KIND[kind], M, w1.shape[0], Dw, Dz, NN.shape[1], _dp(m), _dp(v), _dp(z),
+        self._chk(self._enter() or lib.dgpamd_vecchia_linkgp(self.h, KIND[kind], M, w1.shape[0], Dw, Dz, NN.shape[1], _dp(m), _dp(v), _dp(z),
                                             _dp(w1), _dp(wg), _dp(NN), _dp(y), float(scale), _hp(length), len(length),
                                             float(nugget), _dp(nugget_diag), _dp(mean), _dp(var)))
         return mean, var
@@ -548,7 +563,7 @@ class _LlikPlan:
             B = len(idx)
             nodes = (_lib.Node * B)(*[self.nodes[i] for i in idx])
         host = self.host[:B]
-        e._chk(lib.dgpamd_llik_batch(e.h, self.n, B, nodes, _dp(self.A), _dp(self.T), _dp(self.Ainv), self.stride_a, _dp(self.work),
+        e._chk(e._enter() or lib.dgpamd_llik_batch(e.h, self.n, B, nodes, _dp(self.A), _dp(self.T), _dp(self.Ainv), self.stride_a, _dp(self.work),
                                      _dp(self.gwork), _dp(self.dev_out), host.ctypes.data_as(C.c_void_p), self.stride_out))
         out = {}
         for r, i in enumerate(idx):
@@ -603,7 +618,7 @@ class _EssQueue:
         st0[4], st0[7] = cursor, 0.0 if ll is None else ll
         self.state.copy_(e.tensor(st0))
         sc = np.ascontiguousarray(np.asarray(scales, dtype=np.float64))
-        e._chk(lib.dgpamd_ess_queue(e.h, self.n, self.M, _dp(F), _dp(NU), int(NU.shape[0]), C.cast(self.nodes, C.c_void_p),
+        e._chk(e._enter() or lib.dgpamd_ess_queue(e.h, self.n, self.M, _dp(F), _dp(NU), int(NU.shape[0]), C.cast(self.nodes, C.c_void_p),
                                     sc.ctypes.data_as(C.c_void_p), self.nnodes, _dp(self.state), _dp(ud), _dp(ud[nuni:]), nuni,
                                     self.batch, int(batch_next) if batch_next else self.batch, int(max_batches),
                                     1 if compute_ll0 else 0, _dp(self.FP), _dp(self.A), _dp(self.work), _dp(self.scratch)))
@@ -644,7 +659,7 @@ class _EssPlan:
         e = self.e
         us = np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64))
         self.state[:] = (theta, lo, hi, 1.0 if pending else 0.0)
-        e._chk(lib.dgpamd_ess_update(e.h, self.n, self.M, _dp(F), _dp(NU), C.byref(self.node), float(scale), float(log_y),
+        e._chk(e._enter() or lib.dgpamd_ess_update(e.h, self.n, self.M, _dp(F), _dp(NU), C.byref(self.node), float(scale), float(log_y),
                                      self.state.ctypes.data_as(C.c_void_p), us.ctypes.data_as(C.c_void_p), len(us),
                                      self.batch, int(batch_next) if batch_next else self.batch, _dp(self.FP), _dp(self.A),
                                      _dp(self.work), _dp(self.ll), _dp(self.info), self.out.ctypes.data_as(C.c_void_p)))
