@@ -269,6 +269,30 @@ def main():
                                                 launches=p_n, avg_launch_us=1e3 * p_ms / p_n,
                                                 note='algorithmic flops = M n^2/2 x D x 30 x 2 per launch (DESIGN section 3)')
 
+    # ---- N > 1: ONE model trained by all ranks with the M-step's nodes split over them (dist.split_training; every rank
+    #      runs the same I-step from the same seed, node i is fitted by rank i mod N, one all-gather per M-step) -- the
+    #      informational strong-scaling companion of the replicas above
+    split = None
+    if world > 1:
+        dd.split_training(nodes=True)
+        shared, _, _ = build_model(args.n, args.d, 100, local)
+        k_split = max(3, min(10, args.steps))
+        for _ in range(2):
+            shared.imp.sample(burnin=args.ess_burn)
+            shared._m_step()
+        dd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k_split):
+            shared.imp.sample(burnin=args.ess_burn)
+            shared._m_step()
+        torch.cuda.synchronize()
+        dd.barrier()
+        ts = dd.allreduce_max_scalar(time.perf_counter() - t0, dev)
+        dd.split_training(nodes=False)
+        split = dict(what='one model, M-step nodes round-robin over the ranks (I-step replicated)', steps=k_split,
+                     ms_per_step=1e3 * ts / k_split, si_it_per_s=k_split / ts)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, counts, args.ess_burn)
@@ -283,7 +307,7 @@ def main():
                                    'train(ess_burn=%d): one step = one SI iteration' % (args.d, args.n, args.d, args.ess_burn),
                        'parallelism': 'replicas x%d (SI chain does not shard); predict: imputations sharded, 1 all-reduce' % world},
             'predict': pred, 'counts': counts, 'roofline': roof, 'roofline_kmatrix': roof_k,
-            'roofline_predict': (pred or {}).get('roofline_predict'), 'cpu_baseline': cpu,
+            'roofline_predict': (pred or {}).get('roofline_predict'), 'cpu_baseline': cpu, 'mstep_nodes_split': split,
             'speedup_vs_cpu_baseline': (value / world / cpu['value']) if cpu else None,
         }
         print(json.dumps(out))

@@ -15,6 +15,7 @@ import torch
 from tqdm import trange, tqdm
 
 from .kernel_class import kernel as ker, combine
+from . import dist as ddist
 from .imputation import imputer, DrawStream
 from .ops import Engine, default_engine
 from . import utils
@@ -434,6 +435,9 @@ class dgp:
         from . import mstep
         eng = self.engine
         nodes = [(l, nd) for l, layer in enumerate(self.all_layer) for nd in layer if nd.type == 'gp']
+        every = nodes
+        if ddist.nodes_split():   # this rank fits nodes rank, rank + world, ...; the fits are exchanged below
+            nodes = [nodes[i] for i in range(ddist.rank(), len(nodes), ddist.world())]
         with eng.stream():
             for l, nd in nodes:
                 nd.engine = eng
@@ -449,6 +453,16 @@ class dgp:
             for _, nd in nodes:
                 if not any(nd is d for d in dense):
                     nd.maximise()
+            if ddist.nodes_split():
+                # one all-gather per M-step: (scale, lengthscales, nugget) of the nodes every rank has fitted
+                mine = {i: (every[i][1].scale.copy(), every[i][1].length.copy(), every[i][1].nugget.copy())
+                        for i in range(ddist.rank(), len(every), ddist.world())}
+                for part in ddist.allgather_objects(mine):
+                    for i, (sc, ln, ng) in part.items():
+                        nd = every[i][1]
+                        if i % ddist.world() != ddist.rank():
+                            nd.scale, nd.length, nd.nugget = sc.copy(), ln.copy(), ng.copy()
+                            nd.add_to_path()
 
     def train(self, N=500, ess_burn=10, disable=False):
         """N iterations of stochastic EM (dgp.py:1364-1412) with the same restart policy on LinAlgError."""

@@ -1,7 +1,14 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on
 the GPU box, "gloo" in CPU tests).  The SI path shards embarrassingly over imputation
-samples; the only data-path collective is the sum of the two predictive-moment arrays
-(emulation.py:846-847 aggregated across ranks)."""
+samples; the only data-path collective of prediction is the sum of the two predictive-moment arrays
+(emulation.py:846-847 aggregated across ranks).
+
+Training one model on several GPUs (every rank holds the whole model and draws the same numbers: same seed) has two
+natural splits, both off by default and switched on with split_training():
+  * Vecchia rows (vecchia.py:164-242: the `prange` over rows): a rank evaluates the rows vecchia_rows() gives it and
+    the (quad, logdet, gradient) sums are all-reduced -- a few doubles per objective evaluation;
+  * M-step nodes (dgp.py:1455-1467: pool.map over the nodes of a layer): node i is fitted by rank i mod world, the
+    fitted (scale, lengthscales, nugget) are all-gathered once per M-step."""
 import os
 
 import torch
@@ -84,3 +91,51 @@ def barrier():
         td.barrier(device_ids=[torch.cuda.current_device()])
     else:
         td.barrier()
+
+
+_SPLIT = {'rows': False, 'nodes': False}
+
+
+def split_training(rows=None, nodes=None):
+    """Switch the Vecchia-row split and / or the M-step-node split on or off (they act only in an initialised process
+    group of more than one rank).  Returns the current settings."""
+    if rows is not None:
+        _SPLIT['rows'] = bool(rows)
+    if nodes is not None:
+        _SPLIT['nodes'] = bool(nodes)
+    return dict(_SPLIT)
+
+
+def rows_split():
+    return _SPLIT['rows'] and is_active()
+
+
+def nodes_split():
+    return _SPLIT['nodes'] and is_active()
+
+
+def vecchia_rows(n):
+    """Rows [lo, hi) of the n rows of a Vecchia likelihood this rank evaluates (all rows without the split)."""
+    return row_range(n, rank(), world()) if rows_split() else (0, n)
+
+
+def allreduce_sum_vector(t):
+    """Sum over ranks of a small device (or host) tensor; returns a tensor on the same device.  gloo reduces host
+    tensors only, so under gloo the few doubles make a round trip through the host."""
+    if not is_active():
+        return t
+    if td.get_backend() == 'nccl' or not t.is_cuda:
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return t
+    h = t.cpu()
+    td.all_reduce(h, op=td.ReduceOp.SUM)
+    return h.to(t.device)
+
+
+def allgather_objects(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small python objects: fitted hyper-parameters)."""
+    if not is_active():
+        return [obj]
+    out = [None] * world()
+    td.all_gather_object(out, obj)
+    return out

@@ -17,6 +17,7 @@ from .ops import raise_not_pd
 from scipy.optimize import minimize, Bounds
 
 from .ops import default_engine
+from . import dist as ddist
 
 _KINDS = ('sexp', 'matern2.5')
 
@@ -311,7 +312,9 @@ class kernel:
     def log_likelihood_func_vecch(self):
         """kernel_class.py:494-509 -> vecchia_llik (vecchia.py:164-180)."""
         e, s = self.engine, self._vecch_stage()
-        out = e.vecchia_llik(self.name, s['X'], s['y'], s['NN'], self.length, self.nugget[0], s['nd']).cpu().numpy()
+        lo, hi = ddist.vecchia_rows(s['NN'].shape[0])   # (all rows unless dist.split_training(rows=True) on several ranks)
+        out = e.vecchia_llik(self.name, s['X'], s['y'], s['NN'][lo:hi], self.length, self.nugget[0], s['nd'])
+        out = ddist.allreduce_sum_vector(out).cpu().numpy() if ddist.rows_split() else out.cpu().numpy()
         ll = -0.5 * (out[1] + out[0] / self.scale[0])
         if self.prior_name == 'ref':
             self.compute_cl()
@@ -329,8 +332,9 @@ class kernel:
         else:
             origin_n, rr = len(self.rep), float(self.sum_residual[0])
             s['nd'] = e.tensor(self.W_diag[self.ord])
-        o, P = e.vecchia_nllik(self.name, s['X'], s['y'], s['NN'], self.length, self.nugget[0], s['nd'], self.nugget_est)
-        o = o.cpu().numpy()
+        lo, hi = ddist.vecchia_rows(s['NN'].shape[0])
+        o, P = e.vecchia_nllik(self.name, s['X'], s['y'], s['NN'][lo:hi], self.length, self.nugget[0], s['nd'], self.nugget_est)
+        o = ddist.allreduce_sum_vector(o).cpu().numpy() if ddist.rows_split() else o.cpu().numpy()
         quad, logdet, dquad, dlogdet = o[0], o[1], o[2:2 + P].copy(), o[2 + P:].copy()
         nug = self.nugget[0]
         if self.scale_est:

@@ -424,7 +424,9 @@ class Engine:
         return out
 
     def vecchia_llik(self, kind, X, y, NN, length, nugget, nugget_diag):
-        n, D = X.shape
+        """(quad, logdet) summed over the rows of NN.  NN may be a block of rows of the neighbour array (the rows a rank
+        owns, dist.vecchia_rows): X, y and nugget_diag are indexed through its entries, so they stay whole."""
+        n, D = NN.shape[0], X.shape[1]
         length = _f64(length)
         out = self.empty(2)
         self._chk(self._enter() or lib.dgpamd_vecchia_llik(self.h, KIND[kind], n, D, NN.shape[1] - 1, _dp(X), _dp(y), _dp(NN), _hp(length),
@@ -432,7 +434,7 @@ class Engine:
         return out
 
     def vecchia_nllik(self, kind, X, y, NN, length, nugget, nugget_diag, nugget_est):
-        n, D = X.shape
+        n, D = NN.shape[0], X.shape[1]   # (rows of NN: possibly one rank's block, see vecchia_llik)
         length = _f64(length)
         P = (1 if len(length) == 1 else D) + (1 if nugget_est else 0)
         out = self.empty(2 + 2 * P)

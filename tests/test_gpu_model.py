@@ -1256,3 +1256,83 @@ def test_one_si_iteration_at_bench_size_vs_oracle(eng):
             nd.scale = sc
             close(nll, nll_o, rtol=1e-8)
             close(g, g_o, rtol=1e-6, atol=1e-6)
+
+
+def test_training_splits_two_ranks(tmp_path):
+    """The two natural multi-GPU splits of TRAINING one model (dist.split_training) on two processes (gloo
+    rendezvous, both on this GPU, same seed = same draws): Vecchia likelihood rows n/2 per rank with an all-reduce of
+    (quad, logdet, gradient) (vecchia.py:164-242), and M-step nodes round-robin with one all-gather of the fitted
+    hyper-parameters (dgp.py:1455-1467).  Both must reproduce the single-rank training: rows to 1e-10 (a different
+    summation order), nodes bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'worker.py'
+    script.write_text("""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from dgp_amd import dgp, kernel, combine, dist as dd
+dd.init_from_env('gloo')
+rng = np.random.default_rng(3)
+
+def hyper(model):
+    return np.concatenate([np.concatenate((nd.scale, nd.length, nd.nugget)) for layer in model.all_layer for nd in layer])
+
+# ---- dense model: M-step nodes split
+X = rng.uniform(size=(150, 3)); Y = np.sin(4 * X[:, [0]]) + X[:, [1]] * X[:, [2]]
+def dense(split):
+    dd.split_training(rows=False, nodes=split)
+    layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(3)],
+                     [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(3))])
+    m = dgp(X, Y, layers, seed=7)
+    m.train(N=3, ess_burn=2, disable=True)
+    return m
+a, b = dense(True), dense(False)
+assert np.array_equal(hyper(a), hyper(b)), (hyper(a), hyper(b))
+for la, lb in zip(a.all_layer, b.all_layer):
+    for na, nb in zip(la, lb):
+        assert np.array_equal(na.para_path, nb.para_path)
+
+# ---- Vecchia model: likelihood rows split.  Every objective / gradient / log-likelihood evaluation must agree with the
+# unsplit one to rounding (a different summation order); one M-step from the same state ends within the optimiser's own
+# tolerance (L-BFGS-B stops on a flat objective: 1e-16 in f moves its last iterate by ~1e-6).  Whole trainings are not
+# compared: the SI chain amplifies such differences (a flipped accept decision) like any change of rounding would.
+Xv = rng.uniform(size=(260, 2)); Yv = np.sin(5 * Xv[:, [0]]) + Xv[:, [1]] ** 2
+def vecch():
+    np.random.seed(5)   # the Vecchia ordering is drawn from numpy's global generator (as in the reference): same on every rank / run
+    layers = combine([kernel(length=np.array([1.0]), name='sexp') for _ in range(2)],
+                     [kernel(length=np.array([1.0]), name='sexp', scale_est=True, connect=np.arange(2))])
+    return dgp(Xv, Yv, layers, seed=9, vecchia=True, m=8)
+dd.split_training(rows=False, nodes=False)
+c, d = vecch(), vecch()
+for l, layer in enumerate(c.all_layer):
+    for nd in layer:
+        nd.engine = c.engine
+        if l != 0:
+            nd.r2()
+        x, sc = nd.log_t(), nd.scale.copy()
+        dd.split_training(rows=False)
+        f0, g0 = nd.llik_vecch(x.copy()); s0 = nd.scale.copy(); nd.scale = sc.copy()
+        l0 = nd.log_likelihood_func_vecch()
+        dd.split_training(rows=True)
+        f1, g1 = nd.llik_vecch(x.copy()); s1 = nd.scale.copy(); nd.scale = sc.copy()
+        l1 = nd.log_likelihood_func_vecch()
+        np.testing.assert_allclose(f1, f0, rtol=1e-12); np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(s1, s0, rtol=1e-12); np.testing.assert_allclose(l1, l0, rtol=1e-12)
+dd.split_training(rows=True)
+np.random.seed(11); c._m_step()
+dd.split_training(rows=False)
+np.random.seed(11); d._m_step()
+np.testing.assert_allclose(hyper(c), hyper(d), rtol=1e-4, atol=1e-8)
+dd.barrier()
+print('rank', dd.rank(), 'ok')
+""" % root)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29549', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK='0'),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert 'ok' in o

@@ -122,6 +122,21 @@ for M in (7, 8, 1):
     assert got.shape == (M, 3) and np.array_equal(got, full)
 np.testing.assert_allclose(mu.numpy(), g['mu'], rtol=1e-12, atol=1e-14)
 np.testing.assert_allclose(var.numpy(), g['var'], rtol=1e-9, atol=1e-14)
+# the two training splits (dist.split_training): Vecchia rows -> row blocks + sum of the (quad, logdet, gradient) vector;
+# M-step nodes -> node i on rank i mod world + one all-gather of the fitted hyper-parameters
+assert dd.vecchia_rows(11) == (0, 11) and not dd.rows_split() and not dd.nodes_split()
+dd.split_training(rows=True, nodes=True)
+assert dd.rows_split() and dd.nodes_split()
+lo, hi = dd.vecchia_rows(11)
+assert (lo, hi) == ((0, 6) if dd.rank() == 0 else (6, 11))
+rows = np.arange(11 * 4, dtype=float).reshape(11, 4)
+part = dd.allreduce_sum_vector(torch.from_numpy(rows[lo:hi].sum(0)))
+assert np.array_equal(part.numpy(), rows.sum(0))
+fits = {i: (np.array([1.0 + i]), np.array([0.5 * i, 2.0]), np.array([1e-6])) for i in range(dd.rank(), 5, 2)}
+parts = dd.allgather_objects(fits)
+merged = {k: v for p_ in parts for k, v in p_.items()}
+assert sorted(merged) == [0, 1, 2, 3, 4] and merged[3][1][0] == 1.5
+dd.split_training(rows=False, nodes=False)
 dd.barrier()
 print('rank', dd.rank(), 'ok')
 ''' % (ROOT, ROOT))
