@@ -673,7 +673,6 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
             logdet += v;
         }
         if (k + 1 == g.nbk) break;
-        if (__hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // (a lost hand-off ends the launch)
         // ---- the next block's inputs from the workers: A[k+1][k] and A[k+1][k+1] with the panels <= k-1 applied ----
         if (!ready) {
             const int32_t *addr = nullptr;
@@ -681,6 +680,7 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
             if (tid == 0) { addr = ver + (k + 1) * g.nbk + k; nd = need.x; }
             if (tid == 1) { addr = ver + (k + 1) * g.nbk + k + 1; nd = need.y; }
             wg_wait_flags<true>(addr, nd, 100 + k, &g.sync->status, tid);
+            if (__hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // (a lost hand-off ends the launch)
         }
         if (tr) tr[16 * k + 3] = wall_clock64();
         double *Pg = A + ((int64_t)(k + 1) * 64) * ld + (int64_t)k * 64;

@@ -55,3 +55,15 @@ for i in range(len(w)):
     gap = w[i + 1][0] - w[i][4] if i + 1 < len(w) and w[i + 1][0] > 0 else float('nan')
     print('%3d %5s %d | %5.1f  %5.1f  %5.1f  %5.1f | %5.1f   %5.1f' % (i, kinds.get(code & 15, '?'), (code >> 8) & 255, w[i][1] - w[i][0], w[i][2] - w[i][1],
                                                               w[i][3] - w[i][2], w[i][4] - w[i][3], w[i][4] - w[i][0], gap))
+tot = {'wait': 0.0, 'compute': 0.0, 'store': 0.0, 'publish': 0.0, 'gap': 0.0}
+nt = 0
+for i in range(len(w)):
+    if w[i][0] == 0:
+        break
+    nt += 1
+    tot['wait'] += w[i][1] - w[i][0]; tot['compute'] += w[i][2] - w[i][1]; tot['store'] += w[i][3] - w[i][2]; tot['publish'] += w[i][4] - w[i][3]
+    if i + 1 < len(w) and w[i + 1][0] > 0:
+        tot['gap'] += w[i + 1][0] - w[i][4]
+span = w[nt - 1][4] - w[0][0] if nt else 0.0
+print('this worker: %d tasks over %.1f us: ' % (nt, span) + ', '.join('%s %.1f%%' % (k, 100 * v / span) for k, v in tot.items()))
+print('first task pulled %.1f us after the chain started, last published %.1f us after' % (w[0][0] - t[0][0], w[nt - 1][4] - t[0][0]))
