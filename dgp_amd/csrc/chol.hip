@@ -1018,13 +1018,19 @@ static int get_tasks(dgpamd_ctx *ctx, int nbk, bool inv, TaskTable *&out) {
 // `applied` panels so far, `visits` so far.  Differences: no chain tasks (the chain workgroups run on their own); the
 // first panel tile A[k+1][k] gets its last worker visit as a plain update (the chain does the solve); what the chain
 // waits for is produced one block step ahead of the rest (look-ahead, see below).
+// Panels per visit of a trailing A / T tile and of a K^-1 tile (measured at n = 2000, tools/gpu_lazy_sweep.py: 6 / 6 against
+// the per-step kernel's 4 / 2 gives potrf -7 % at 12 matrices, potrf_inv -11 % at 6; the deeper visits run the tile engine at
+// a higher rate and the look-ahead tasks keep the chain's inputs current whatever the depth).  DGPAMD_MEGA_LAZY / _SLAZY
+// override (tuning only).
+#define MEGA_LAZY 6
+#define MEGA_SLAZY 6
 struct MegaTable {
     MTask *dev = nullptr;
     int2 *need_dev = nullptr;
     int ntask = 0;
 };
 
-static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::vector<int2> &need) {
+static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::vector<int2> &need, int lazy, int slazy) {
     const int nb2 = nbk * nbk;
     std::vector<int> appliedA(nb2, 0), visitsA(nb2, 0), appliedT(nb2, 0), visitsT(nb2, 0), visitsS(nb2, 0);
     if (inv)
@@ -1056,7 +1062,7 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
         emit(make_task(T_SOLVE, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap), visitsA[i * nbk + k]++, 1, k);
         appliedA[i * nbk + k] = k;
     };
-    const int nl = nbk + (inv ? 2 : 0);
+    const int nl = nbk + (inv ? slazy : 0);
     for (int k = 0; k < nl; ++k) {
         if (k < nbk) {
             // LOOK-AHEAD: what the chain picks up after factoring block k+1 -- A[k+2][k+1] and A[k+2][k+2] with the panels
@@ -1086,20 +1092,20 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
                     appliedT[q * nbk + k] = k;
                 }
             // lazy bulk: columns k+1, k+1+LAZY, ... below the diagonal; diagonal tiles one block step ahead of that
-            for (int j = k + 2; j < nbk; j += LAZY) updA(j, j, k);
-            for (int j = k + 1; j < nbk; j += LAZY)
+            for (int j = k + 2; j < nbk; j += lazy) updA(j, j, k);
+            for (int j = k + 1; j < nbk; j += lazy)
                 for (int i = j + 1; i < nbk; ++i) updA(i, j, k);
             if (inv)
-                for (int j = k + 1; j < nbk; j += LAZY)
+                for (int j = k + 1; j < nbk; j += lazy)
                     for (int q = 0; q <= k - 1; ++q) updT(q, j, k);
         }
-        if (inv)   // S[q][q'] += Pt_q Pt_q'^T for the panels (k-2, k-1), rows q = k-2, k-4, ...
-            for (int q = k - 2; q >= 0; q -= 2) {
-                const int nkb = (k - 1 < nbk ? k : nbk) - (k - 2);
+        if (inv)   // S[q][q'] += Pt_q Pt_q'^T for the panels (k-slazy .. k-1), rows q = k-slazy, k-2 slazy, ...
+            for (int q = k - slazy; q >= 0; q -= slazy) {
+                const int nkb = (k - 1 < nbk ? k : nbk) - (k - slazy);
                 if (nkb <= 0) continue;
-                const int mask = (k - 2 + nkb - 1 == nbk - 1) ? 1 : 0;
+                const int mask = (k - slazy + nkb - 1 == nbk - 1) ? 1 : 0;
                 for (int q2 = 0; q2 <= q; ++q2)
-                    emit(make_task(T_STORE, q == k - 2, 1, mask, BUF_S, q, q2, BUF_T, q, BUF_T, q2, k - 2, nkb), visitsS[q * nbk + q2]++, 0, 0);
+                    emit(make_task(T_STORE, q == k - slazy, 1, mask, BUF_S, q, q2, BUF_T, q, BUF_T, q2, k - slazy, nkb), visitsS[q * nbk + q2]++, 0, 0);
             }
     }
 }
@@ -1110,7 +1116,9 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, MegaTable *&out) {
     if (!mt.dev) {
         std::vector<MTask> tasks;
         std::vector<int2> need;
-        build_mega_tasks(nbk, inv, tasks, need);
+        const char *lz = getenv("DGPAMD_MEGA_LAZY"), *sz = getenv("DGPAMD_MEGA_SLAZY");
+        const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : MEGA_LAZY, slazy = sz && atoi(sz) > 0 ? atoi(sz) : MEGA_SLAZY;
+        build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy);
         mt.ntask = (int)tasks.size();
         HIP_TRY(ctx, hipMalloc((void **)&mt.dev, (tasks.size() + 1) * sizeof(MTask)));
         HIP_TRY(ctx, hipMemcpy(mt.dev, tasks.data(), tasks.size() * sizeof(MTask), hipMemcpyHostToDevice));

@@ -25,3 +25,9 @@ nr = len(rounds) - len(rounds) // 3
 print('mean span kmatrix..grad_final %.1f us, gaps inside %.1f us' % (tot / nr / 1e3, gaps / nr / 1e3))
 for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     print('%-30s %6.1f us per round (%4.1f launches x %6.1f us)' % (n, t / nr / 1e3, c / nr, t / c / 1e3))
+# turn-around between consecutive rounds of one M-step: grad_final end -> next kmatrix_multi start (D2H copy, host, H2D copy)
+ta = [b[0][0] - a[-1][1] for a, b in zip(rounds, rounds[1:]) if b[0][0] - a[-1][1] < 1e6]
+if ta:
+    ta.sort()
+    print('turn-around between rounds: median %.1f us, mean %.1f us, p90 %.1f us (%d gaps)'
+          % (ta[len(ta) // 2] / 1e3, sum(ta) / len(ta) / 1e3, ta[int(len(ta) * 0.9)] / 1e3, len(ta)))
