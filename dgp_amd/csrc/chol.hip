@@ -1146,7 +1146,7 @@ static size_t mega_sync_bytes(int64_t nbk, int batch) {
 }
 
 static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, double *S, int64_t stride_a, int batch,
-                             double *logdet, int32_t *info, double *ws, void *syncmem, const MegaTable *mt) {
+                             double *logdet, int32_t *info, double *ws, void *syncmem, const MegaTable *mt, bool no_post = false) {
     const int64_t Np = padded_dim(n);
     const int nbk = (int)(Np / 64);
     HIP_TRY(ctx, hipMemsetAsync(syncmem, 0, mega_sync_bytes(nbk, batch), ctx->stream));
@@ -1167,7 +1167,7 @@ static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, d
     PROF_BEGIN(ctx, PROF_SYRK, (double)batch * (double)n * (double)n * (double)n * (T ? 1.0 : 1.0 / 3.0));
     hipLaunchKernelGGL(potrf_mega_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, g);
     PROF_END(ctx, PROF_SYRK);
-    if (T)
+    if (T && !no_post)
         hipLaunchKernelGGL(copy_alpha_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, ctx->stream,
                            (const double *)T, S, Np, n, stride_a);
     LAUNCH_CHECK(ctx);
@@ -1235,7 +1235,7 @@ __global__ void potrf_copy_out_kernel(const double *ld_ws, const int32_t *info_w
 }
 
 int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
-              double *ws, double *T, double *S) {
+              double *ws, double *T, double *S, PotrfPost *post) {
     // One launch per 64-column block step with a static shape: replayed as one hipGraph.  The graph writes
     // logdet/info into the workspace tail (fixed addresses -> the cached graph does not depend on where the
     // caller wants them); a tiny kernel outside the graph copies them out.
@@ -1253,8 +1253,15 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
         if (rc) return rc;
         (void)mega_wgs_per_cu();
         void *syncmem = reinterpret_cast<char *>(ws) + mega_sync_offset(n, batch);
-        rc = potrf_mega_launch(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, syncmem, mt);
+        rc = potrf_mega_launch(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, syncmem, mt, post != nullptr);
         if (rc) return rc;
+        if (post) {
+            post->pending = 1;
+            post->ld_ws = ld_ws;
+            post->info_ws = info_ws;
+            post->status = &reinterpret_cast<MegaSync *>(syncmem)->status;
+            return DGPAMD_OK;
+        }
         hipLaunchKernelGGL(potrf_copy_out_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)ld_ws,
                            (const int32_t *)info_ws, logdet, info, batch, (const int32_t *)&reinterpret_cast<MegaSync *>(syncmem)->status);
         LAUNCH_CHECK(ctx);

@@ -33,6 +33,7 @@ struct dgpamd_ctx {
     int potrf_mode;                                   // 1: factorisation as one persistent dataflow launch; 0: one launch per block step
     long long *trace;                                 // device buffer for in-kernel timestamps (diagnostics), or null
     double *pinned;                                   // small pinned staging buffer for result copies (lazy)
+    unsigned long long host_seq;                      // sequence number of the last result a kernel published into `pinned`
     char *devargs, *hostargs;                         // argument arrays of the multi-node launches (device / pinned host)
     size_t devargs_bytes;
     size_t pinned_bytes;
@@ -190,8 +191,17 @@ int build_kmat_args(dgpamd_ctx *ctx, KmatArgs &a, int kind, int64_t n, const dou
                     int64_t stride_loc, const int32_t *colmap_h, int Dl, const double *Xglob, int Dg,
                     const double *length_h, int nlen, double nugget, const double *W, double *K, int64_t ldk,
                     int64_t stride_k, int full, const double *Y, int64_t ldy, int64_t stride_y, int r, int batch);
+// When `post` is given and the factorisation ran as the one-launch kernel, its two tiny follow-up launches (results out of
+// the workspace, -alpha into row n of the inverse) are left to the caller, who folds them into a kernel of its own:
+// post->pending = 1 and the pointers say where the results are.
+struct PotrfPost {
+    int pending = 0;
+    const double *ld_ws = nullptr;
+    const int32_t *info_ws = nullptr;
+    const int32_t *status = nullptr;
+};
 int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
-              double *ws, double *T = nullptr, double *S = nullptr);   // T, S: fused inverse (dgpamd_potrf_inv)
+              double *ws, double *T = nullptr, double *S = nullptr, PotrfPost *post = nullptr);   // T, S: fused inverse (dgpamd_potrf_inv)
 size_t potrf_ws_doubles(int64_t n, int batch);
 int ensure_pinned(dgpamd_ctx *ctx, size_t bytes);   // grow the context's pinned staging buffer
 int ensure_devargs(dgpamd_ctx *ctx, size_t bytes);  // grow the device / pinned argument arrays

@@ -345,6 +345,34 @@ __global__ void llik_pack_kernel(const double *logdet, const int32_t *info, cons
     }
 }
 
+// The same with the one-launch factorisation's two follow-ups folded in (PotrfPost): results out of the workspace (a lost
+// hand-off becomes info = -1), -alpha = column n of T into row n of the inverse.
+__global__ void llik_post_kernel(const double *T, double *S, const double *A, int64_t ld, int64_t stride_a, int64_t n,
+                                 const double *ld_ws, const int32_t *info_ws, const int32_t *status, double *logdet, int32_t *info,
+                                 double *out, int64_t stride_out) {
+    const int b = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) S[(int64_t)b * stride_a + n * ld + j] = T[(int64_t)b * stride_a + j * ld + n];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double l = ld_ws[b];
+        const int32_t f = *status ? -1 : info_ws[b];
+        logdet[b] = l;
+        info[b] = f;
+        out[b * stride_out] = l;
+        out[b * stride_out + 1] = -A[(int64_t)b * stride_a + n * ld + n];
+        out[b * stride_out + 2] = (double)f;
+    }
+}
+
+// Results straight into pinned host memory, then a sequence word: the host spins on it (microseconds) instead of sleeping in
+// a stream synchronisation (tens of microseconds to wake up), once per round of the lock-step M-step.
+__global__ void publish_host_kernel(const double *src, double *host, int nd, unsigned long long *flag, unsigned long long seq) {
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) host[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T,
                                  double *Ainv, int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
                                  int64_t stride_out) {
@@ -358,7 +386,7 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     const size_t need = (size_t)batch * (sizeof(KmatArgs) + sizeof(GradMulti));
     int rc = ensure_devargs(ctx, need);
     if (rc) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the previous call's argument copy has been consumed
+    // (the previous call's argument copy has been consumed: every call ends with the stream drained)
     KmatArgs *ka = reinterpret_cast<KmatArgs *>(ctx->hostargs);
     GradMulti *ga = reinterpret_cast<GradMulti *>(ctx->hostargs + (size_t)batch * sizeof(KmatArgs));
     const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
@@ -393,21 +421,46 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     if (rc) return rc;
     double *logdet = dev_out + (int64_t)batch * stride_out;
     int32_t *info = reinterpret_cast<int32_t *>(logdet + batch);
-    rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, T, Ainv);   // factor + inverse, one sweep
+    PotrfPost post;
+    rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, T, Ainv, &post);   // factor + inverse, one sweep
     if (rc) return rc;
-    hipLaunchKernelGGL(llik_pack_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)logdet,
-                       (const int32_t *)info, (const double *)A, Np, stride_a, n, dev_out, stride_out, batch);
+    if (post.pending)
+        hipLaunchKernelGGL(llik_post_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, ctx->stream, (const double *)T,
+                           Ainv, (const double *)A, Np, stride_a, n, post.ld_ws, post.info_ws, post.status, logdet, info, dev_out,
+                           stride_out);
+    else
+        hipLaunchKernelGGL(llik_pack_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)logdet,
+                           (const int32_t *)info, (const double *)A, Np, stride_a, n, dev_out, stride_out, batch);
     {
         const size_t shm = ((size_t)2 * Dmax * 64 + 4 * 2 * Pmax) * sizeof(double);
         hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(ntiles, 1, batch), dim3(256), shm, ctx->stream, gd);
         hipLaunchKernelGGL(grad_final_multi_kernel, dim3(2 * Pmax, batch), dim3(256), 0, ctx->stream, gd, ntiles);
         LAUNCH_CHECK(ctx);
     }
-    const size_t bytes = (size_t)batch * stride_out * sizeof(double);
-    rc = ensure_pinned(ctx, bytes);
+    const int nd = (int)(batch * stride_out);
+    const size_t bytes = (size_t)nd * sizeof(double);
+    rc = ensure_pinned(ctx, bytes + 64);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, dev_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long *flag = reinterpret_cast<unsigned long long *>(ctx->pinned + (ctx->pinned_bytes / sizeof(double) - 1));
+    *flag = 0;   // (the stream is drained: nobody else touches the staging buffer now)
+    const unsigned long long seq = ++ctx->host_seq;
+    hipLaunchKernelGGL(publish_host_kernel, dim3(1), dim3(128), 0, ctx->stream, (const double *)dev_out, ctx->pinned, nd, flag, seq);
+    LAUNCH_CHECK(ctx);
+    // spin on the sequence word; now and then make sure the stream is still alive (a fault would leave the word unwritten)
+    for (unsigned long long it = 1;; ++it) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        __builtin_ia32_pause();
+        if ((it & 0xfffff) == 0) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {   // everything ran: the word is there, or this memory is not coherent -- settle it the slow way
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+                    HIP_TRY(ctx, hipMemcpy(ctx->pinned, dev_out, bytes, hipMemcpyDeviceToHost));
+                break;
+            }
+            if (q != hipErrorNotReady) HIP_TRY(ctx, q);
+        }
+    }
     memcpy(host_out, ctx->pinned, bytes);
     return DGPAMD_OK;
 }

@@ -447,6 +447,10 @@ class dgp:
                     nd.r2()
             dense = [nd for _, nd in nodes if not nd.vecch] if mstep._HAVE_CORE else []
             if dense:
+                pre = self.imp.stage_for_mstep() if getattr(self, 'imp', None) is not None else {}
+                for nd in dense:
+                    if id(nd) in pre:
+                        nd._prestaged = pre[id(nd)]
                 self.last_mstep = mstep.maximise_lockstep(eng, dense, self)
             else:
                 self.last_mstep = None

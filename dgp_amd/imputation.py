@@ -159,18 +159,36 @@ class imputer:
         st['_engine'] = None
         st['_factor_cache'] = {}
         st['_ess_plans'] = {}
-        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache'):   # device state: rebuilt by the next sample()
+        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh'):   # device state: rebuilt by the next sample()
             st.pop(key, None)
         return st
 
     # ------------------------------------------------------------------ device state
+    def _dev_const(self, key, arr):
+        """Device copy of a host array that rarely changes (inputs, observed outputs): uploaded again only when the host
+        values differ from the ones uploaded last (the numpy attributes stay the source of truth, as in the reference)."""
+        arr = np.ascontiguousarray(arr, dtype=float)
+        cache = self.__dict__.setdefault('_const', {})
+        hit = cache.get(key)
+        if hit is not None and hit[0].shape == arr.shape and np.array_equal(hit[0], arr):
+            return hit[1]
+        t = self.engine.tensor(arr)
+        cache[key] = (arr.copy(), t)
+        return t
+
     def _attach(self):
-        e = self.engine
         L = len(self.all_layer)
-        self.F = []
+        # latents: what _detach wrote to the nodes is still on the device unless somebody changed the numpy side since
+        Fh = self.__dict__.get('_Fh', {})
+        old = self.__dict__.get('F', None)
+        F = []
         for l in range(L - 1):
             cols = [np.asarray(nd.output, dtype=float).reshape(-1) for nd in self.all_layer[l]]
-            self.F.append(e.tensor(np.stack(cols, 1)))
+            host = np.stack(cols, 1)
+            keep = old is not None and l < len(old) and l in Fh and Fh[l].shape == host.shape and np.array_equal(Fh[l], host)
+            F.append(old[l] if keep else self.engine.tensor(host))
+        self.F = F
+        self._Fh = {}
         self._glob = {}
         self._yy = {}
         self._x0 = {}
@@ -178,18 +196,20 @@ class imputer:
             for k, nd in enumerate(self.all_layer[l]):
                 if nd.type != 'gp':
                     continue
-                self._glob[(l, k)] = None if nd.global_input is None else e.tensor(nd.global_input)
+                self._glob[(l, k)] = None if nd.global_input is None else self._dev_const(('g', l, k), nd.global_input)
                 if l == 0:
-                    self._x0[k] = e.tensor(nd.input)
+                    self._x0[k] = self._dev_const(('x', k), nd.input)
                 if l == L - 1:
-                    self._yy[k] = e.tensor(np.asarray(nd.output, dtype=float).reshape(-1))
+                    self._yy[k] = self._dev_const(('y', k), np.asarray(nd.output, dtype=float).reshape(-1))
         self._ll_cache = {}
 
     def _detach(self):
         """Refresh the numpy attributes the reference's sampler mutates (imputation.py:94,109)."""
         L = len(self.all_layer)
+        self._Fh = {}
         for l in range(L - 1):
             Fh = self.F[l].cpu().numpy()
+            self._Fh[l] = Fh
             for k, nd in enumerate(self.all_layer[l]):
                 nd.output[:, 0] = Fh[:, k]
             for nd in self.all_layer[l + 1]:
@@ -197,6 +217,39 @@ class imputer:
                     nd.input = Fh[nd.rep, :][:, nd.input_dim]
                 else:
                     nd.input = Fh[:, nd.input_dim]
+
+    def stage_for_mstep(self):
+        """Device views of every dense GP node's (input, global input, output) in the state the last sample() left --
+        what kernel._stage() would upload from the numpy attributes _detach has just written, without the round trip
+        through the host (24 small uploads per M-step at the bench shape).  {id(node): dict}; nodes with replicates,
+        Vecchia nodes and likelihood nodes are left to their own staging."""
+        out = {}
+        if not self.__dict__.get('_Fh') or self.__dict__.get('F') is None:   # (no sample() yet, or state dropped by pickling)
+            return out
+        L = len(self.all_layer)
+        Fh = self._Fh
+        for l in range(L):
+            for k, nd in enumerate(self.all_layer[l]):
+                if nd.type != 'gp' or nd.vecch or nd.rep is not None:
+                    continue
+                # (valid only while the numpy attributes still hold what _detach wrote / what was uploaded)
+                const = self.__dict__.get('_const', {})
+                y_ok = np.array_equal(np.asarray(nd.output, dtype=float).reshape(-1),
+                                      Fh[l][:, k] if l < L - 1 else const.get(('y', k), (None,))[0])
+                g_ok = nd.global_input is None or np.array_equal(nd.global_input, const.get(('g', l, k), (None,))[0])
+                if l == 0:
+                    x_ok = np.array_equal(nd.input, const.get(('x', k), (None,))[0])
+                    Xl = self._x0[k]
+                else:
+                    idx = np.asarray(nd.input_dim)
+                    x_ok = np.array_equal(nd.input, Fh[l - 1][:, idx])
+                    src = self.F[l - 1]
+                    Xl = src if (len(idx) == src.shape[1] and np.array_equal(idx, np.arange(src.shape[1]))) \
+                        else src[:, torch.as_tensor(idx, device=src.device)].contiguous()
+                if not (y_ok and g_ok and x_ok):
+                    continue
+                out[id(nd)] = dict(Xl=Xl, Xg=self._glob[(l, k)], y=self._node_y(l, k), W=None)
+        return out
 
     def _node_input(self, l, k, nd):
         """(Xloc tensor, colmap) of GP node k in layer l in the current state."""

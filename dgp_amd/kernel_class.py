@@ -92,6 +92,10 @@ class kernel:
 
     def _stage(self):
         """Upload the node's current numpy state (inputs, output, replicate weights)."""
+        pre = self.__dict__.pop('_prestaged', None)   # (device views handed over by the imputer: dgp._m_step)
+        if pre is not None:
+            self._staged = pre
+            return pre
         e = self.engine
         s = dict(Xl=e.tensor(self.input), Xg=None if self.global_input is None else e.tensor(self.global_input),
                  y=e.tensor(np.asarray(self.output, dtype=float).reshape(-1)),

@@ -12,4 +12,4 @@ for _ in range(5):
     model.imp.sample(burnin=10); model._m_step()
 torch.cuda.synchronize()
 pr.disable()
-st = pstats.Stats(pr); st.sort_stats('tottime').print_stats(28)
+st = pstats.Stats(pr); st.sort_stats('cumtime').print_stats(60)
