@@ -85,6 +85,8 @@ class kernel:
         st['_engine'] = None
         st['_staged'] = None
         st['_stats'] = None
+        st.pop('_r2_cache', None)
+        st.pop('_prestaged', None)
         return st
 
     def _X(self):
@@ -137,15 +139,29 @@ class kernel:
             self.cl = (X.max(0) - X.min(0)) / n_out ** (1 / len(self.length))
 
     def r2(self, overwritten=False):
-        """R2 of the linear regression of `input` on `global_input` (kernel_class.py:227-243)."""
+        """R2 of the linear regression of `input` on `global_input` (kernel_class.py:227-243).  The design matrix is a
+        constant of the node, so its rank test and an orthonormal basis of its column space are kept between calls
+        (the reference redoes two SVD ranks and an SVD least-squares fit per M-step); the residual sums are
+        |y - Q Q'y|^2, which is what lstsq returns for a full-column-rank design."""
         if self.global_input is None:
             return
         G = self.global_input
-        Xd = np.concatenate((G, np.ones((len(G), 1))), axis=1)
-        if np.linalg.matrix_rank(G) == np.linalg.matrix_rank(Xd):
-            Xd = G
+        sig = (id(G), G.shape, float(G[0, 0]), float(G[-1, -1]), float(G.sum()))
+        hit = self.__dict__.get('_r2_cache')
+        if hit is None or hit[0] != sig:
+            Xd = np.concatenate((G, np.ones((len(G), 1))), axis=1)
+            if np.linalg.matrix_rank(G) == np.linalg.matrix_rank(Xd):
+                Xd = G
+            Q = None
+            if Xd.shape[0] > Xd.shape[1] and np.linalg.matrix_rank(Xd) == Xd.shape[1]:
+                Q = np.linalg.qr(Xd)[0]
+            hit = self._r2_cache = (sig, Xd, Q)
+        _, Xd, Q = hit
         if Xd.shape[0] == Xd.shape[1]:
             resid = np.zeros(self.input.shape[1])
+        elif Q is not None:
+            r = self.input - Q @ (Q.T @ self.input)
+            resid = np.einsum('ij,ij->j', r, r)
         else:
             resid = np.linalg.lstsq(Xd, self.input, rcond=None)[1]
         rsq = 1 - resid / (len(self.input) * np.var(self.input, axis=0))

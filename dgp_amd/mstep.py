@@ -125,16 +125,16 @@ def maximise_lockstep(engine, nodes, cache):
             plans[n].set(pos, nd.length, nd.nugget[0])
             todo.setdefault(n, []).append((pos, i))
         host = {}
-        with engine.stream():
-            for n, lst in todo.items():
-                res = plans[n].run([pos for pos, _ in lst])
-                for pos, i in lst:
-                    host[i] = res[pos]
+        for n, lst in todo.items():   # (inside the engine's stream context entered once below, not once per round)
+            res = plans[n].run([pos for pos, _ in lst])
+            for pos, i in lst:
+                host[i] = res[pos]
         evals[0] += len(req)
         return [nodes[i]._llik_finish(host[i]) for i, _ in req]
 
     try:
-        rounds = minimize_lockstep(problems, evaluate)
+        with engine.stream():
+            rounds = minimize_lockstep(problems, evaluate)
     finally:
         for nd in nodes:
             nd._in_maximise = False

@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""Kernel sequences around the idle gaps of one (previous -> next) kernel pair in a rocprofv3 --kernel-trace CSV.
-usage: analyze_context.py <dir> <prev substring> <next substring> [min gap us]"""
+"""Kernel sequences around the long idle gaps of a rocprofv3 --kernel-trace CSV (second half of the trace).
+usage: analyze_context.py <dir> [min gap us]"""
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
-ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][-36:]) for r in csv.DictReader(open(f))))
-a, b = sys.argv[2], sys.argv[3]
-ming = float(sys.argv[4]) * 1e3 if len(sys.argv) > 4 else 20e3
-seqs = collections.Counter()
-for i in range(3, len(ev) - 3):
-    if a in ev[i][2] and b in ev[i + 1][2] and ev[i + 1][0] - ev[i][1] > ming:
-        seqs[' | '.join(e[2] for e in ev[i - 3:i + 1]) + '  ==gap==>  ' + ' | '.join(e[2] for e in ev[i + 1:i + 4])] += 1
-for s, c in seqs.most_common(8):
-    print(c, 'x', s)
+ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].split('<')[0][-30:]) for r in csv.DictReader(open(f))))
+ev = ev[len(ev) // 2:]
+ming = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 150e3
+seqs = collections.defaultdict(lambda: [0, 0.0])
+for i in range(4, len(ev) - 4):
+    g = ev[i + 1][0] - ev[i][1]
+    if g > ming:
+        key = ' | '.join(e[2] for e in ev[i - 3:i + 1]) + '  ==>  ' + ' | '.join(e[2] for e in ev[i + 1:i + 5])
+        seqs[key][0] += 1
+        seqs[key][1] += g
+for s, (c, t) in sorted(seqs.items(), key=lambda kv: -kv[1][1])[:12]:
+    print('%3d x %7.1f us   %s' % (c, t / c / 1e3, s))
