@@ -106,7 +106,15 @@ __device__ __forceinline__ double dcoef(double df) {
     if (KIND == DGPAMD_SEXP) return 2.0 * df * df;
     double r = fabs(df);
     double e1 = fma(r, SQRT5, 1.0), e2 = (5.0 / 3.0) * r * r;
-    return e2 * e1 / (e1 + e2);
+    // e1 + e2 >= 1: the hardware reciprocal and two Newton rounds (<= 1 ulp) instead of the IEEE division sequence, which
+    // was most of this kernel's instructions (five divisions per matrix entry)
+    const double d = e1 + e2;
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    return e2 * e1 * x;
 }
 
 template <int KIND>
