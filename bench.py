@@ -191,7 +191,7 @@ def main():
         engines = [eng]
         for e in engines:
             e.prof_enable(args.prof_kernel)
-        for _ in range(max(1, min(2, args.steps))):
+        for _ in range(max(1, min(4, args.steps))):
             step()
         tot_n, tot_ms, tot_w = 0, 0.0, 0.0
         for e in engines:
@@ -220,7 +220,8 @@ def main():
                                           'kernel in separate rocprofv3 --pmc passes of `%s` (an earlier run, not this one)' % pj.get('command', '?'))
             roof.update(launches=tot_n, avg_launch_us=1e3 * tot_ms / tot_n, work_per_launch=tot_w / tot_n,
                         event_pair_overhead_us=ev_us, avg_launch_us_if_event_overhead_removed=1e3 * corrected_ms / tot_n,
-                        note='algorithmic flops = n^3/3 per matrix (n^3 with the fused inverse), SURVEY 8(d); under full f64 MFMA '
+                        note='algorithmic flops = n^3/3 per matrix (n^3 with the fused inverse), SURVEY 8(d); speculative batches '
+                             'whose predicate turned them into no-ops are not counted (neither work nor time); under full f64 MFMA '
                              'load the chip holds ~1.85 of its 2.4 GHz, i.e. ~60 of the 78.6 TFLOP/s datasheet peak are attainable')
     # K assembly against the HBM roofline on the same steps (its own pass: one kernel class is timed at a time)
     roof_k = None

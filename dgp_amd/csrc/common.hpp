@@ -27,6 +27,8 @@ struct dgpamd_ctx {
     int prof_class;                                   // PROF_* being timed (0 = off)
     double prof_work;                                 // algorithmic flops (or bytes) of the timed launches
     std::vector<hipEvent_t> prof_events;              // start/stop pairs
+    std::vector<double> prof_pair_work;               // algorithmic work of each pair
+    std::vector<char> prof_pair_pred;                 // 1: the launch was predicated (ctx->pred set): it may have done nothing
     int use_graphs;                                   // replay static launch sequences as hipGraphs
     int linkgp_direct;                                // 1: evaluate the Matern J factor in the reference's direct form
     const int32_t *pred;                              // device word: kernels launched while it is set return at once when it is non-zero (dgpamd_ess_queue)
@@ -104,7 +106,8 @@ static inline int graph_run(dgpamd_ctx *ctx, const std::array<uint64_t, 10> &key
             if (hipEventCreate(&e0__) == hipSuccess) {                        \
                 (void)hipEventRecord(e0__, (ctx)->stream);                    \
                 (ctx)->prof_events.push_back(e0__);                           \
-                (ctx)->prof_work += (double)(work);                           \
+                (ctx)->prof_pair_work.push_back((double)(work));              \
+                (ctx)->prof_pair_pred.push_back((ctx)->pred ? 1 : 0);         \
             }                                                                 \
         }                                                                     \
     } while (0)

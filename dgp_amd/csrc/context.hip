@@ -146,6 +146,8 @@ extern "C" int dgpamd_prof_enable(dgpamd_ctx *ctx, int kernel_class) {
     if (!ctx || kernel_class < 0 || kernel_class > PROF_GP_QUAD) return DGPAMD_BAD_ARG;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     ctx->prof_events.clear();
+    ctx->prof_pair_work.clear();
+    ctx->prof_pair_pred.clear();
     ctx->prof_work = 0.0;
     ctx->prof_class = kernel_class;
     return DGPAMD_OK;
@@ -177,18 +179,26 @@ extern "C" int dgpamd_prof_event_overhead_us(dgpamd_ctx *ctx, double *us_h) {
 extern "C" int dgpamd_prof_collect(dgpamd_ctx *ctx, int64_t *launches_h, double *total_ms_h, double *work_h) {
     if (!ctx || !launches_h || !total_ms_h || !work_h) return DGPAMD_BAD_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    double total = 0.0;
+    double total = 0.0, work = 0.0;
     const size_t pairs = ctx->prof_events.size() / 2;
+    int64_t counted = 0;
     for (size_t i = 0; i < pairs; ++i) {
         float ms = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+        // a predicated launch that found its predicate set did nothing (an empty event pair reads ~5 us, such a launch
+        // 6-8, the smallest real one of the bench 25): neither its time nor the work it would have done is counted
+        if (i < ctx->prof_pair_pred.size() && ctx->prof_pair_pred[i] && ms < 0.012f) continue;
         total += ms;
+        work += i < ctx->prof_pair_work.size() ? ctx->prof_pair_work[i] : 0.0;
+        ++counted;
     }
-    *launches_h = (int64_t)pairs;
+    *launches_h = counted;
     *total_ms_h = total;
-    *work_h = ctx->prof_work;
+    *work_h = work;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     ctx->prof_events.clear();
+    ctx->prof_pair_work.clear();
+    ctx->prof_pair_pred.clear();
     ctx->prof_work = 0.0;
     ctx->prof_class = PROF_NONE;
     return DGPAMD_OK;

@@ -16,9 +16,11 @@ python3 tools/gpu_mega_trace.py 2000 6 inv > "$O/phase_trace_b6inv.txt" 2>&1
 python3 tools/gpu_mega_trace.py 2000 12 > "$O/phase_trace_b12.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $BENCH > "$O/prof_stats.log" 2>&1
 python3 tools/summarize_rocprof.py /tmp/prof_stats python3 $BENCH > "$O/bench_kernel_stats.txt" 2>&1
-python3 tools/analyze_gaps.py /tmp/prof_stats 30 > "$O/idle_gaps.txt" 2>&1
-python3 tools/analyze_round.py /tmp/prof_stats >> "$O/idle_gaps.txt" 2>&1
-python3 tools/analyze_context.py /tmp/prof_stats 120 >> "$O/idle_gaps.txt" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_train -- python3 $BENCH --no-predict > "$O/prof_train.log" 2>&1
+echo "# rocprofv3 --kernel-trace -- python3 $BENCH --no-predict ; tools/analyze_gaps.py (last 70 % of the trace), analyze_round.py, analyze_context.py" > "$O/idle_gaps.txt"
+python3 tools/analyze_gaps.py /tmp/prof_train 30 >> "$O/idle_gaps.txt" 2>&1
+python3 tools/analyze_round.py /tmp/prof_train >> "$O/idle_gaps.txt" 2>&1
+python3 tools/analyze_context.py /tmp/prof_train 120 >> "$O/idle_gaps.txt" 2>&1
 head -4 "$O/idle_gaps.txt"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_fetch --output-format csv -- python3 $BENCH > "$O/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_write --output-format csv -- python3 $BENCH > "$O/pmc_write.log" 2>&1
