@@ -525,9 +525,10 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
 #define MEGA_SPIN_LIMIT (1 << 20)   // polls of ~1 us: a lost hand-off gives up after about a second
 
 struct MegaSync {   // zeroed by a memset node ahead of every launch; the version words follow it
-    int32_t qhead;                  // queue head
+    int32_t qhead;                  // (unused)
     int32_t status;                 // 0, or the code of the first spin that gave up
-    int32_t pad[14];
+    int32_t ghead[8];               // queue head of each group of matrices (see MegaArgs::ngroups)
+    int32_t pad[6];
     int32_t wflag[DGPAMD_MAXB];     // per matrix: blocks factored (W_k is readable for k < wflag)
     int32_t cukey[DGPAMD_MAXB];     // per matrix: CU of its chain workgroup (cu_key())
 };
@@ -552,6 +553,10 @@ struct MegaArgs {
     int32_t *info;
     long long *trace;
     const int32_t *pred;     // null, or a device word: the launch does nothing when it is non-zero
+    int ngroups;             // The matrices are dealt into this many groups (matrix b: group b % ngroups), the XCDs as well
+                             // (XCD x: group x % ngroups; 1, 2, 4 or 8), and a worker takes the tasks of its own group's
+                             // matrices first: every XCD has its own L2, so with one queue for all a panel tile was fetched
+                             // into all eight of them (PMC: ~4x the algorithmic HBM-side traffic at 12 matrices).
 };
 
 // Write-through (sc1) store of an accumulator tile, 16 bytes per lane: neighbouring lanes hold neighbouring columns of the
@@ -759,20 +764,34 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
     const int64_t ld = g.ld;
     const int64_t rem_last = g.n - (int64_t)(g.nbk - 1) * 64;
     const int ncol_last = rem_last > 0 ? (int)rem_last : 0;
-    const int total = g.ntask * batch;
     // debug (dgpamd_debug_trace): the first 80 tasks of one worker, 5 stamps each, from trace[2048]: pulled, inputs ready,
     // computed, stored, published (+ the task's kind / panels in the sixth word)
     long long *wst = (g.trace && tid == 0 && (int)blockIdx.x == batch + 40) ? g.trace + 2048 : nullptr;
     int nst = 0;
+    // this workgroup's group of matrices: those of its XCD's group first, then -- when that queue is empty -- the others'
+    const int G = g.ngroups;
+    const int home = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) % G;   // HW_REG_XCC_ID
+    int grp = home, tried = 0;
+    auto group_size = [&](int gi) { return (batch - gi + G - 1) / G; };
     // The pull of the NEXT task is issued when a task's arithmetic is done and lands while its tile is stored and
     // published (an agent-scope atomic plus the descriptor read are several microseconds under load).
-    if (tid == 0) bc[1] = __hip_atomic_fetch_add(&g.sync->qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) bc[1] = __hip_atomic_fetch_add(&g.sync->ghead[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         __syncthreads();
-        const int q = __builtin_amdgcn_readfirstlane(bc[1]);
+        int q = __builtin_amdgcn_readfirstlane(bc[1]);
         __syncthreads();
-        if (q >= total) break;
-        const int slot = q / batch, b = q - slot * batch;
+        int nbg = group_size(grp);
+        while (q >= g.ntask * nbg) {   // this group's queue is empty: on to the next one (all empty: done)
+            if (++tried >= G) break;
+            grp = grp + 1 == G ? 0 : grp + 1;
+            nbg = group_size(grp);
+            if (tid == 0) bc[1] = __hip_atomic_fetch_add(&g.sync->ghead[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            q = __builtin_amdgcn_readfirstlane(bc[1]);
+            __syncthreads();
+        }
+        if (tried >= G) break;
+        const int slot = q / nbg, b = grp + G * (q - slot * nbg);
         const MTask mt = g.tasks[slot];
         long long *st = (wst && nst < 80) ? wst + 8 * nst++ : nullptr;
         if (st) { st[0] = wall_clock64(); st[5] = (mt.a.x & 15) | ((mt.a.w >> 16) << 8) | ((long long)slot << 16); }
@@ -792,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         const int newver = fin ? VER_FINAL : need_c + 1;
         int qn = 0;
         auto pull_next = [&]() {
-            if (tid == 0) qn = __hip_atomic_fetch_add(&g.sync->qhead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) qn = __hip_atomic_fetch_add(&g.sync->ghead[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto finish = [&]() {   // drain (the tile's stores and the pull), publish, hand the next task to the loop's head
             wg_publish(vC, newver, tid);
@@ -1158,6 +1177,15 @@ static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, d
     g.sync = reinterpret_cast<MegaSync *>(syncmem);
     g.ver = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(syncmem) + sizeof(MegaSync));
     g.logdet = logdet; g.info = info; g.trace = ctx->trace; g.pred = ctx->pred;
+    {
+        const char *eg = getenv("DGPAMD_MEGA_GROUPS");
+        // (measured at n = 2000, tools/gpu_lazy_sweep.py: uneven groups are fine -- an XCD whose own queue has run out takes
+        // from the others -- so odd batches use two groups as well: potrf_inv -10 % at 3 matrices, -7 % at 6, -12 % at 12)
+        int G = eg ? atoi(eg) : (batch % 8 == 0 ? 8 : batch % 4 == 0 ? 4 : batch >= 2 ? 2 : 1);
+        if (G != 1 && G != 2 && G != 4 && G != 8) G = 1;
+        while (G > batch) G >>= 1;
+        g.ngroups = G;
+    }
     // every workgroup resident at once (not needed for progress, but a queued worker would only start late)
     int64_t grid = (int64_t)mega_wgs_per_cu() * ctx->num_cu;
     const int64_t useful = (int64_t)batch * (mt->ntask + 1 + mega_wgs_per_cu());

@@ -13,7 +13,7 @@ from dgp_amd.ops import Engine
 eng = Engine(0)
 n = 2000; Np = eng.padded_dim(n)
 ev0, ev1 = eng.event(), eng.event()
-for B in (1, 3, 6, 12):
+for B in [int(v) for v in os.environ.get("BLIST", "1,3,6,12").split(",")]:
     r = np.random.default_rng(B)
     X = eng.tensor(r.uniform(size=(B, n, 5))); G = eng.tensor(r.uniform(size=(n, 5))); y = eng.tensor(r.normal(size=n))
     work = eng.potrf_workspace(n, B)
