@@ -1039,8 +1039,8 @@ static int get_tasks(dgpamd_ctx *ctx, int nbk, bool inv, TaskTable *&out) {
 // waits for is produced one block step ahead of the rest (look-ahead, see below).
 // Panels per visit of a trailing A / T tile and of a K^-1 tile (measured at n = 2000, tools/gpu_lazy_sweep.py: 6 / 6 against
 // the per-step kernel's 4 / 2 gives potrf -7 % at 12 matrices, potrf_inv -11 % at 6; the deeper visits run the tile engine at
-// a higher rate and the look-ahead tasks keep the chain's inputs current whatever the depth).  DGPAMD_MEGA_LAZY / _SLAZY
-// override (tuning only).
+// a higher rate and the look-ahead tasks keep the chain's inputs current whatever the depth); get_mega_tasks goes deeper for
+// the tile-engine-bound calls.
 #define MEGA_LAZY 6
 #define MEGA_SLAZY 6
 struct MegaTable {
@@ -1129,14 +1129,18 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
     }
 }
 
-static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, MegaTable *&out) {
-    static std::map<std::pair<dgpamd_ctx *, std::pair<int, int>>, MegaTable> cache;
-    MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0}}];
+static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTable *&out) {
+    // panels per visit: 6 / 6; with the fused inverse and five or more matrices -- tile-engine-bound calls -- 8 per trailing
+    // and 12 per K^-1 tile (potrf_inv at 6 matrices 1.31 -> 1.19 ms, at 12 2.43 -> 2.31; at 1-3 matrices, where the chains
+    // bound the time, the deeper tasks delay them: 0.57 -> 0.65 ms).  DGPAMD_MEGA_LAZY / _SLAZY override (tuning only).
+    const char *lz = getenv("DGPAMD_MEGA_LAZY"), *sz = getenv("DGPAMD_MEGA_SLAZY");
+    const bool deep = inv && batch >= 5;
+    const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : (deep ? 8 : MEGA_LAZY), slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? 12 : MEGA_SLAZY);
+    static std::map<std::pair<dgpamd_ctx *, std::array<int, 4>>, MegaTable> cache;
+    MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy}}];
     if (!mt.dev) {
         std::vector<MTask> tasks;
         std::vector<int2> need;
-        const char *lz = getenv("DGPAMD_MEGA_LAZY"), *sz = getenv("DGPAMD_MEGA_SLAZY");
-        const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : MEGA_LAZY, slazy = sz && atoi(sz) > 0 ? atoi(sz) : MEGA_SLAZY;
         build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy);
         mt.ntask = (int)tasks.size();
         HIP_TRY(ctx, hipMalloc((void **)&mt.dev, (tasks.size() + 1) * sizeof(MTask)));
@@ -1277,7 +1281,7 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     const bool mega = ctx->potrf_mode == 1 || (ctx->potrf_mode == 2 && batch <= (T ? 4 : 8)) || (ctx->pred && ctx->potrf_mode != 0);
     if (mega) {
         MegaTable *mt = nullptr;
-        int rc = get_mega_tasks(ctx, (int)nbk, T != nullptr, mt);   // (uploads the table on first use)
+        int rc = get_mega_tasks(ctx, (int)nbk, T != nullptr, batch, mt);   // (uploads the table on first use)
         if (rc) return rc;
         (void)mega_wgs_per_cu();
         void *syncmem = reinterpret_cast<char *>(ws) + mega_sync_offset(n, batch);
