@@ -113,6 +113,7 @@ def main():
     ap.add_argument('--imputations', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-predict', action='store_true')
+    ap.add_argument('--no-split-leg', action='store_true', help='N > 1: skip the informational leg that trains one model with the M-step nodes split over the ranks')
     ap.add_argument('--prof-kernel', default='syrk',
                     help="kernel class timed with HIP events for the roofline ('syrk' = the fused block-step kernel "
                          "of the factorisation, the dominant kernel; 'lauum', 'trtri', 'kmatrix', ...)")
@@ -274,25 +275,30 @@ def main():
     #      runs the same I-step from the same seed, node i is fitted by rank i mod N, one all-gather per M-step) -- the
     #      informational strong-scaling companion of the replicas above
     split = None
-    if world > 1:
-        dd.split_training(nodes=True)
-        shared, _, _ = build_model(args.n, args.d, 100, local)
-        k_split = max(3, min(10, args.steps))
-        for _ in range(2):
-            shared.imp.sample(burnin=args.ess_burn)
-            shared._m_step()
-        dd.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(k_split):
-            shared.imp.sample(burnin=args.ess_burn)
-            shared._m_step()
-        torch.cuda.synchronize()
-        dd.barrier()
-        ts = dd.allreduce_max_scalar(time.perf_counter() - t0, dev)
-        dd.split_training(nodes=False)
-        split = dict(what='one model, M-step nodes round-robin over the ranks (I-step replicated)', steps=k_split,
-                     ms_per_step=1e3 * ts / k_split, si_it_per_s=k_split / ts)
+    if world > 1 and not args.no_split_leg:
+        # (informational: a failure here must not cost the run its result line)
+        try:
+            dd.split_training(nodes=True)
+            shared, _, _ = build_model(args.n, args.d, 100, local)
+            k_split = max(3, min(10, args.steps))
+            for _ in range(2):
+                shared.imp.sample(burnin=args.ess_burn)
+                shared._m_step()
+            dd.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k_split):
+                shared.imp.sample(burnin=args.ess_burn)
+                shared._m_step()
+            torch.cuda.synchronize()
+            dd.barrier()
+            ts = dd.allreduce_max_scalar(time.perf_counter() - t0, dev)
+            split = dict(what='one model, M-step nodes round-robin over the ranks (I-step replicated)', steps=k_split,
+                         ms_per_step=1e3 * ts / k_split, si_it_per_s=k_split / ts)
+        except Exception as exc:   # noqa: BLE001
+            split = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
+        finally:
+            dd.split_training(nodes=False)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -40,7 +40,8 @@ def init_from_env(backend=None):
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-    td.init_process_group(backend=backend)
+    import datetime
+    td.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=int(os.environ.get('DGPAMD_DIST_TIMEOUT', '300'))))
 
 
 def allreduce_sum(*tensors):

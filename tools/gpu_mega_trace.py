@@ -61,7 +61,10 @@ for i in range(len(w)):
     if w[i][0] == 0:
         break
     nt += 1
-    tot['wait'] += w[i][1] - w[i][0]; tot['compute'] += w[i][2] - w[i][1]; tot['store'] += w[i][3] - w[i][2]; tot['publish'] += w[i][4] - w[i][3]
+    if min(w[i][1], w[i][2], w[i][3]) > 0:   # (a T[k][k] = W_k^T task only stamps its two ends: all of it counts as store)
+        tot['wait'] += w[i][1] - w[i][0]; tot['compute'] += w[i][2] - w[i][1]; tot['store'] += w[i][3] - w[i][2]; tot['publish'] += w[i][4] - w[i][3]
+    else:
+        tot['store'] += w[i][4] - w[i][0]
     if i + 1 < len(w) and w[i + 1][0] > 0:
         tot['gap'] += w[i + 1][0] - w[i][4]
 span = w[nt - 1][4] - w[0][0] if nt else 0.0
