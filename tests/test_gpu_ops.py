@@ -133,7 +133,10 @@ def test_potrf_potri_sizes(eng, name, n):
     close(-Ai[n, :n], alpha, rtol=1e-7, atol=1e-8 * np.abs(alpha).max())
 
 
-@pytest.mark.parametrize('n,B', [(10, 2), (64, 1), (65, 1), (200, 3), (333, 5), (1000, 2), (2000, 1), (1984, 1)])
+# (five or more matrices: the deeper task table -- 8 / 12 panels per visit, more than the block count at the small sizes --
+#  and two to eight XCD groups, even and uneven)
+@pytest.mark.parametrize('n,B', [(10, 2), (64, 1), (65, 1), (200, 3), (333, 5), (1000, 2), (2000, 1), (1984, 1),
+                                 (300, 16), (520, 7), (700, 6), (1300, 5), (200, 12), (900, 8)])
 def test_potrf_inv_one_sweep(eng, n, B):
     """dgpamd_potrf_inv: factor, L^-T, K^-1 (lower tiles) and -alpha from ONE sweep, against LAPACK."""
     import torch
