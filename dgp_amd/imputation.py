@@ -208,7 +208,7 @@ class imputer:
         L = len(self.all_layer)
         self._Fh = {}
         for l in range(L - 1):
-            Fh = self.F[l].cpu().numpy()
+            Fh = self.engine.fetch(self.F[l])   # (pinned staging: ~10x cheaper than torch's pageable .cpu() for 80 KB)
             self._Fh[l] = Fh
             for k, nd in enumerate(self.all_layer[l]):
                 nd.output[:, 0] = Fh[:, k]

@@ -11,6 +11,8 @@ tr(K^-1 dK_p) and y^T K^-1 dK_p K^-1 y from one inverse and fused in-flight
 reductions instead of one n x n solve per parameter; `compute_stats` keeps
 R^-1 / R^-1 y on the device and never materialises Psexp.
 """
+import math
+
 import numpy as np
 from numpy.linalg import LinAlgError
 from .ops import raise_not_pd
@@ -264,6 +266,33 @@ class kernel:
         n = len(self.output)
         P = (len(host) - 3) // 2
         self._raise_if_not_pd(host[-1])
+        if self.rep is None and self.prior_name in (None, 'ga', 'inv_ga') and P <= 2:
+            # the same arithmetic in the same order on python floats (this runs once per node and L-BFGS-B round between
+            # two device calls: a dozen numpy calls on one- and two-element arrays were most of the host's turn-around)
+            logdet, YKinvY = float(host[0]), float(host[1])
+            if self.scale_est:
+                sc = YKinvY / n
+                self.scale = np.array([sc])
+                nll = 0.5 * (logdet + n * math.log(sc))
+            else:
+                sc = float(self.scale[0])
+                nll = 0.5 * (logdet + YKinvY / sc)
+            g = [0.5 * float(host[2 + p]) - (0.5 * float(host[2 + P + p])) / sc for p in range(P)]
+            if self.prior_name is not None:
+                c0, c1 = float(self.prior_coef[0]), float(self.prior_coef[1])
+                xs = [float(v) for v in self.length] + ([float(self.nugget[0])] if self.nugget_est else [])
+                if len(xs) == P:
+                    if self.prior_name == 'ga':
+                        lp = [c0 * math.log(x) - c1 * x for x in xs]
+                        fod = [c0 - c1 * x for x in xs]
+                    else:
+                        lp = [-c0 * math.log(x) - c1 / x for x in xs]
+                        fod = [-c0 + c1 / x for x in xs]
+                    nll = nll - (lp[0] if P == 1 else lp[0] + lp[1])
+                    g = [g[p] - fod[p] for p in range(P)]
+                    return np.array([nll]), np.array(g)
+            else:
+                return np.array([nll]), np.array(g)
         logdet, YKinvY, tr, ykky = host[0], host[1], host[2:2 + P], host[2 + P:2 + 2 * P]
         P1, P2 = -0.5 * tr, 0.5 * ykky
         rep = self.rep is not None
