@@ -234,7 +234,10 @@ def main():
             ach = k_w / (k_ms * 1e-3) / 1e9
             roof_k = dict(bound='hbm', kernel='kmatrix_kernel (lower tiles of the batched augmented buffers, as the training path assembles them)',
                           achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=None, launches=k_n,
-                          avg_launch_us=1e3 * k_ms / k_n, bytes_per_launch=k_w / k_n)
+                          avg_launch_us=1e3 * k_ms / k_n, bytes_per_launch=k_w / k_n,
+                          note='this kernel is f64-VALU-bound, not HBM-bound: 71 VALU instructions per Matern entry (22 of them the '
+                               'double-precision exp), 0.73 of the VALU issue peak (profiles/r02_pmc_valu_mfma_counters.txt); the HBM '
+                               'fraction is reported because the contract asks for it')
     kernel_class.kernel._llik_finish = orig_finish
 
     # ---- prediction leg: emulator with the imputations sharded over the ranks --------------------
