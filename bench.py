@@ -114,6 +114,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-predict', action='store_true')
     ap.add_argument('--no-split-leg', action='store_true', help='N > 1: skip the informational leg that trains one model with the M-step nodes split over the ranks')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="process-group backend for N > 1; 'gloo' lets several ranks share one GPU (functional check of the "
+                         "multi-rank path on a one-GPU box: LOCAL_RANK modulo the device count)")
     ap.add_argument('--prof-kernel', default='syrk',
                     help="kernel class timed with HIP events for the roofline ('syrk' = the fused block-step kernel "
                          "of the factorisation, the dominant kernel; 'lauum', 'trtri', 'kmatrix', ...)")
@@ -141,9 +144,11 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1:
-        dd.init_from_env('nccl')
+        dd.init_from_env(args.backend)
+    if args.backend == 'gloo':
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local) if args.backend == 'nccl' else None   # (gloo reduces host tensors)
 
     model, X, Y = build_model(args.n, args.d, 100 + rank, local)
     eng = model.engine
@@ -262,11 +267,13 @@ def main():
         tp = dd.allreduce_max_scalar(time.perf_counter() - t0, dev if world > 1 else None)
         pred = dict(points=args.predict_points, imputations=args.imputations * world, imputations_per_rank=args.imputations, seconds=tp,
                     pts_per_s=args.predict_points / tp, point_imputations_per_s=args.predict_points * args.imputations * world / tp, finite=bool(np.all(np.isfinite(mu)) and np.all(np.isfinite(var))))
-        if rank == 0 and args.prof_kernel != 'none':
+        if args.prof_kernel != 'none':
             # the linked-GP pair kernel (the prediction leg's dominant kernel) against the f64 MFMA roofline, same call again
-            eng.prof_enable('linkgp_j')
+            # (by EVERY rank: predict ends in a collective; only rank 0 brackets its launches)
+            if rank == 0:
+                eng.prof_enable('linkgp_j')
             emu.predict(xt)
-            p_n, p_ms, p_w = eng.prof_collect()
+            p_n, p_ms, p_w = eng.prof_collect() if rank == 0 else (0, 0.0, 0.0)
             if p_n:
                 ach = p_w / (p_ms * 1e-3) / 1e12
                 pred['roofline_predict'] = dict(bound='mfma', kernel='linkgp_Jsep_kernel (Matern pair phase: record dot products on f64 MFMA)',
