@@ -645,6 +645,7 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
     long long *tr = (g.trace && b == 0 && tid == 0) ? g.trace : nullptr;
     __builtin_amdgcn_s_setprio(3);
     if (tid == 0) __hip_atomic_store(&g.sync->cukey[b], cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tr) __hip_atomic_store(&g.trace[5999], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Tile64 D;
     load_cb_lower(D.v, A, ld, wave, lane, scratch);
     __syncthreads();   // (scratch and the factor's LDS share Bs)
@@ -794,6 +795,10 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         const int slot = q / nbg, b = grp + G * (q - slot * nbg);
         const MTask mt = g.tasks[slot];
         long long *st = (wst && nst < 80) ? wst + 8 * nst++ : nullptr;
+        // debug: every worker adds its waiting / arithmetic / remaining time to 100-us buckets of the launch (trace[6000..6095])
+        const bool agg = g.trace != nullptr && tid == 0;
+        long long a0 = 0, a1 = 0, a2 = 0;
+        if (agg) a0 = wall_clock64();
         if (st) { st[0] = wall_clock64(); st[5] = (mt.a.x & 15) | ((mt.a.w >> 16) << 8) | ((long long)slot << 16); }
         const int4 tk = mt.a;
         const int post = tk.x & 15, first = (tk.x >> 4) & 1, plus = (tk.x >> 5) & 1, mask_last = (tk.x >> 6) & 1;
@@ -817,6 +822,21 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
             wg_publish(vC, newver, tid);
             if (tid == 0) bc[1] = qn;
             if (st) st[4] = wall_clock64();
+            if (agg) {
+                const long long a4 = wall_clock64(), t00 = g.trace[5999];
+                long long bk = t00 > 0 ? (a0 - t00) / 10000 : 0;
+                bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
+                if (a1 == 0) a1 = a2 = a0;   // (a task without separate phases: all of it counts as the rest)
+                atomicAdd((unsigned long long *)g.trace + 6000 + bk, (unsigned long long)(a1 - a0));
+                atomicAdd((unsigned long long *)g.trace + 6032 + bk, (unsigned long long)(a2 - a1));
+                atomicAdd((unsigned long long *)g.trace + 6064 + bk, (unsigned long long)(a4 - a2));
+                // ... and by kind of task: [buffer A / T / S][update, solve]: waiting, arithmetic, rest, count (trace[6100..6123])
+                const int kd = 4 * (2 * bufC + (post == T_SOLVE ? 1 : 0));
+                atomicAdd((unsigned long long *)g.trace + 6100 + kd, (unsigned long long)(a1 - a0));
+                atomicAdd((unsigned long long *)g.trace + 6101 + kd, (unsigned long long)(a2 - a1));
+                atomicAdd((unsigned long long *)g.trace + 6102 + kd, (unsigned long long)(a4 - a2));
+                atomicAdd((unsigned long long *)g.trace + 6103 + kd, 100ull);
+            }
         };
 
         if (post == T_TDIAG) {   // T[k][k] = W_k^T, rows of the carried right-hand sides zeroed
@@ -843,11 +863,13 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
             wg_wait_flags<true>(addr, nd, 1000 + slot % 1000, &g.sync->status, tid);
         }
         if (st) st[1] = wall_clock64();
+        if (agg) a1 = wall_clock64();
         Tile64 acc;
         tile_update<true>(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
                           g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
                           mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
         if (st) st[2] = wall_clock64();
+        if (agg) a2 = wall_clock64();
         if (post == T_STORE) {
             pull_next();
             store_acc_sc1(acc.v, C, ld, crow, ccol);
@@ -1037,19 +1059,21 @@ static int get_tasks(dgpamd_ctx *ctx, int nbk, bool inv, TaskTable *&out) {
 // `applied` panels so far, `visits` so far.  Differences: no chain tasks (the chain workgroups run on their own); the
 // first panel tile A[k+1][k] gets its last worker visit as a plain update (the chain does the solve); what the chain
 // waits for is produced one block step ahead of the rest (look-ahead, see below).
-// Panels per visit of a trailing A / T tile and of a K^-1 tile (measured at n = 2000, tools/gpu_lazy_sweep.py: 6 / 6 against
-// the per-step kernel's 4 / 2 gives potrf -7 % at 12 matrices, potrf_inv -11 % at 6; the deeper visits run the tile engine at
-// a higher rate and the look-ahead tasks keep the chain's inputs current whatever the depth); get_mega_tasks goes deeper for
-// the tile-engine-bound calls.
-#define MEGA_LAZY 6
-#define MEGA_SLAZY 6
+// Panels per visit of a trailing A / T tile and of a K^-1 tile, and where the cadence starts (see build_mega_tasks).  The
+// per-step kernel's 4 / 2 / next column against 8 / 8 / three columns on gives potrf -12 % at 6 matrices and -13 % at 12,
+// potrf_inv -19 % at 6: deeper visits run the tile engine at a higher rate, and a column whose last bulk visit lies three
+// block steps before its solves does not have those solves queue up behind a 40-us task.
+#define MEGA_LAZY 8
+#define MEGA_SLAZY 8
+#define MEGA_NEAR 2
 struct MegaTable {
     MTask *dev = nullptr;
     int2 *need_dev = nullptr;
     int ntask = 0;
 };
 
-static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::vector<int2> &need, int lazy, int slazy) {
+static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::vector<int2> &need, int lazy, int slazy,
+                             int near = 0, int lag = 0, int xcatch = 0) {
     const int nb2 = nbk * nbk;
     std::vector<int> appliedA(nb2, 0), visitsA(nb2, 0), appliedT(nb2, 0), visitsT(nb2, 0), visitsS(nb2, 0);
     if (inv)
@@ -1081,7 +1105,7 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
         emit(make_task(T_SOLVE, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap), visitsA[i * nbk + k]++, 1, k);
         appliedA[i * nbk + k] = k;
     };
-    const int nl = nbk + (inv ? slazy : 0);
+    const int nl = nbk + (inv ? slazy + lag : 0);
     for (int k = 0; k < nl; ++k) {
         if (k < nbk) {
             // LOOK-AHEAD: what the chain picks up after factoring block k+1 -- A[k+2][k+1] and A[k+2][k+2] with the panels
@@ -1102,6 +1126,7 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
                 if (i == k + 3) {
                     updA(k + 3, k + 3, k + 1);
                     updA(k + 3, k + 2, k + 1);
+                    if (xcatch) updA(k + 3, k + 1, k + 1);   // (the next look-ahead solve then has no panel left to apply)
                 }
             }
             if (inv)
@@ -1111,37 +1136,48 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
                     appliedT[q * nbk + k] = k;
                 }
             // lazy bulk: columns k+1, k+1+LAZY, ... below the diagonal; diagonal tiles one block step ahead of that
-            for (int j = k + 2; j < nbk; j += lazy) updA(j, j, k);
-            for (int j = k + 1; j < nbk; j += lazy)
-                for (int i = j + 1; i < nbk; ++i) updA(i, j, k);
-            if (inv)
-                for (int j = k + 1; j < nbk; j += lazy)
-                    for (int q = 0; q <= k - 1; ++q) updT(q, j, k);
-        }
-        if (inv)   // S[q][q'] += Pt_q Pt_q'^T for the panels (k-slazy .. k-1), rows q = k-slazy, k-2 slazy, ...
-            for (int q = k - slazy; q >= 0; q -= slazy) {
-                const int nkb = (k - 1 < nbk ? k : nbk) - (k - slazy);
-                if (nkb <= 0) continue;
-                const int mask = (k - slazy + nkb - 1 == nbk - 1) ? 1 : 0;
-                for (int q2 = 0; q2 <= q; ++q2)
-                    emit(make_task(T_STORE, q == k - slazy, 1, mask, BUF_S, q, q2, BUF_T, q, BUF_T, q2, k - slazy, nkb), visitsS[q * nbk + q2]++, 0, 0);
+            // (near: the cadence's first column is k+1+near -- a column's last bulk visit is then 1+near block steps before its
+            //  solves, which do not queue up behind it; lag: the bulk applies the panels < k-lag only, i.e. nothing that the
+            //  solves of the previous `lag` block steps are still producing.  The solves apply what is left: 1+near+lag panels.)
+            const int kl = k - lag;
+            if (kl > 0) {
+                for (int j = k + 2 + near; j < nbk; j += lazy) updA(j, j, kl);
+                for (int j = k + 1 + near; j < nbk; j += lazy)
+                    for (int i = j + 1; i < nbk; ++i) updA(i, j, kl);
+                if (inv)
+                    for (int j = k + 1 + near; j < nbk; j += lazy)
+                        for (int q = 0; q <= kl - 1; ++q) updT(q, j, kl);
             }
+        }
+        if (inv) {   // S[q][q'] += Pt_q Pt_q'^T for the panels (ks-slazy .. ks-1), ks = k - lag, rows q = ks-slazy, ks-2 slazy, ...
+            const int ks = k - lag;
+            for (int q = ks - slazy; q >= 0; q -= slazy) {
+                const int nkb = (ks - 1 < nbk ? ks : nbk) - (ks - slazy);
+                if (nkb <= 0) continue;
+                const int mask = (ks - slazy + nkb - 1 == nbk - 1) ? 1 : 0;
+                for (int q2 = 0; q2 <= q; ++q2)
+                    emit(make_task(T_STORE, q == ks - slazy, 1, mask, BUF_S, q, q2, BUF_T, q, BUF_T, q2, ks - slazy, nkb), visitsS[q * nbk + q2]++, 0, 0);
+            }
+        }
     }
 }
 
 static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTable *&out) {
-    // panels per visit: 6 / 6; with the fused inverse and five or more matrices -- tile-engine-bound calls -- 8 per trailing
-    // and 12 per K^-1 tile (potrf_inv at 6 matrices 1.31 -> 1.19 ms, at 12 2.43 -> 2.31; at 1-3 matrices, where the chains
-    // bound the time, the deeper tasks delay them: 0.57 -> 0.65 ms).  DGPAMD_MEGA_LAZY / _SLAZY override (tuning only).
+    // Panels per visit: 8 (trailing and K^-1 tiles; 12 for the K^-1 tiles of calls with the fused inverse and eight or more
+    // matrices), and the cadence starts three columns to the right of the chain (near = 2).  Measured at n = 2000
+    // (tools/gpu_lazy_sweep.py, profiles/r02_mega_table_sweeps.txt).  DGPAMD_MEGA_LAZY / _SLAZY / _NEAR / _LAG / _XCATCH
+    // override (tuning only).
     const char *lz = getenv("DGPAMD_MEGA_LAZY"), *sz = getenv("DGPAMD_MEGA_SLAZY");
-    const bool deep = inv && batch >= 5;
-    const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : (deep ? 8 : MEGA_LAZY), slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? 12 : MEGA_SLAZY);
-    static std::map<std::pair<dgpamd_ctx *, std::array<int, 4>>, MegaTable> cache;
-    MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy}}];
+    const bool deep = inv && batch >= 8;
+    const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : MEGA_LAZY, slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? 12 : MEGA_SLAZY);
+    const char *en = getenv("DGPAMD_MEGA_NEAR"), *el = getenv("DGPAMD_MEGA_LAG"), *ex = getenv("DGPAMD_MEGA_XCATCH");
+    const int near = en ? atoi(en) : MEGA_NEAR, lag = el ? atoi(el) : 0, xcatch = ex ? atoi(ex) : 0;
+    static std::map<std::pair<dgpamd_ctx *, std::array<int, 7>>, MegaTable> cache;
+    MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy, near, lag, xcatch}}];
     if (!mt.dev) {
         std::vector<MTask> tasks;
         std::vector<int2> need;
-        build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy);
+        build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy, near, lag, xcatch);
         mt.ntask = (int)tasks.size();
         HIP_TRY(ctx, hipMalloc((void **)&mt.dev, (tasks.size() + 1) * sizeof(MTask)));
         HIP_TRY(ctx, hipMemcpy(mt.dev, tasks.data(), tasks.size() * sizeof(MTask), hipMemcpyHostToDevice));

@@ -70,3 +70,20 @@ for i in range(len(w)):
 span = w[nt - 1][4] - w[0][0] if nt else 0.0
 print('this worker: %d tasks over %.1f us: ' % (nt, span) + ', '.join('%s %.1f%%' % (k, 100 * v / span) for k, v in tot.items()))
 print('first task pulled %.1f us after the chain started, last published %.1f us after' % (w[0][0] - t[0][0], w[nt - 1][4] - t[0][0]))
+
+# pool-wide time split per 100 us of the launch (every worker's tasks, bucketed by the task's start)
+aw, ac, ar = raw[6000:6032], raw[6032:6064], raw[6064:6096]
+print('all workers, us per 100-us bucket of task start time: waiting for inputs | arithmetic | store / W wait / publish')
+for i in range(32):
+    tot = aw[i] + ac[i] + ar[i]
+    if tot > 0:
+        print('%4d-%4d us: %9.0f %9.0f %9.0f   (%4.1f%% / %4.1f%% / %4.1f%%)' % (100 * i, 100 * i + 100, aw[i], ac[i], ar[i], 100 * aw[i] / tot, 100 * ac[i] / tot, 100 * ar[i] / tot))
+T = aw.sum() + ac.sum() + ar.sum()
+if T > 0:
+    print('total worker time %.0f us: waiting %.1f%%, arithmetic %.1f%%, rest %.1f%%' % (T, 100 * aw.sum() / T, 100 * ac.sum() / T, 100 * ar.sum() / T))
+names = ['A update', 'A solve', 'T update', 'T solve', 'K^-1 update', '-']
+print('by kind of task: count | mean waiting, arithmetic, rest (us) | share of all worker time')
+for i, nm in enumerate(names):
+    w_, c_, r_, n_ = raw[6100 + 4 * i:6104 + 4 * i]
+    if n_ > 0:
+        print('%-12s %6d | %6.1f %6.1f %6.1f | %4.1f%%' % (nm, n_, w_ / n_, c_ / n_, r_ / n_, 100 * (w_ + c_ + r_) / T))
