@@ -60,6 +60,7 @@ SIGNATURES = {
     'dgpamd_potrf_workspace': (_z, [_l, _i]),
     'dgpamd_potrf': (_i, [_p, _l, _p, _l, _i, _p, _p, _p]),
     'dgpamd_aug_quad': (_i, [_p, _l, _p, _l, _i, _i, _p]),
+    'dgpamd_loglik_finish': (_i, [_p, _l, _p, _l, _i, _p, _d, _p]),
     'dgpamd_loglik': (_i, [_p, _i, _l, _p, _l, _l, _p, _i, _p, _i, _p, _i, _d, _p, _d, _p, _p, _l, _i, _p, _p, _p]),
     'dgpamd_trmv_lower': (_i, [_p, _l, _p, _l, _p, _p, _p, _i]),
     'dgpamd_ess_propose': (_i, [_p, _l, _i, _p, _p, _p, _i, _p]),

@@ -75,6 +75,19 @@ extern "C" int dgpamd_loglik(dgpamd_ctx *ctx, int kind, int64_t n, const double 
     return DGPAMD_OK;
 }
 
+// The closing arithmetic of a5 alone, for buffers factored elsewhere (e.g. as extra matrices of another batched call):
+// ll[b] = -0.5 (n log scale + logdet[b] + y'K^-1y / scale), y'K^-1y = -corner of the augmented buffer.
+extern "C" int dgpamd_loglik_finish(dgpamd_ctx *ctx, int64_t n, const double *A, int64_t stride_a, int batch, const double *logdet,
+                                    double scale, double *ll) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || !A || !logdet || !ll) BAD_ARG(ctx, "null pointer or n <= 0");
+    if (batch <= 0 || batch > 64) BAD_ARG(ctx, "need 1 <= batch <= 64");
+    if (!(scale > 0.0)) BAD_ARG(ctx, "scale must be positive");
+    hipLaunchKernelGGL(loglik_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, A, padded_dim(n), stride_a, n, logdet, scale, ll, batch);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
 // ---------------------------------------------------------------------------
 // a8  derivative reductions of kernel.llik (kernel_class.py:414-427) without
 //     ever storing dK:  tr_p = sum Kinv o dK_p ,  quad_p = alpha^T dK_p alpha.

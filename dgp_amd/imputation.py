@@ -20,6 +20,8 @@ Randomness: one numpy Generator for fmvn's normals and one for the uniforms (the
 reference also uses two streams: numba's for randn, numpy's global for uniform);
 both can be injected for deterministic replay.
 """
+import os
+
 import numpy as np
 from numpy.linalg import LinAlgError
 from .ops import raise_not_pd
@@ -300,7 +302,10 @@ class imputer:
         layer, upper = self.all_layer[0], self.all_layer[1]
         if any(nd.type != 'gp' or nd.vecch for nd in layer) or any(nd.type != 'gp' or nd.vecch or nd.prior_name == 'ref' for nd in upper):
             return 0, None
+        if self._ll_cache.get(0) is None:   # the first threshold's log-likelihood: factored together with the prior's matrices
+            self._want_ll0 = list(enumerate(upper))
         nu = self._prior_draws_ahead(sweeps)   # (sweeps, n, M)
+        self.__dict__.pop('_want_ll0', None)
         if nu is None:
             return 0, None
         e = self.engine
@@ -349,7 +354,10 @@ class imputer:
     def _layer_factors(self, l, dense):
         """Cholesky factors of the dense nodes `dense` of layer l in ONE batched buffer (stride Np^2) so that the draws
         are a single batched triangular product; the buffer is reused while inputs and hyper-parameters are unchanged
-        (first layer: the whole I-step and beyond; deeper layers: their inputs change every sweep)."""
+        (first layer: the whole I-step and beyond; deeper layers: their inputs change every sweep).
+        If self._want_ll0 lists the GP nodes above layer 0 whose log-likelihood of the CURRENT latents the sampler needs
+        next (the first slice threshold of an I-step, imputation.py:70-78), their matrices ride along as extra members of the
+        same batched factorisation -- one launch instead of two chain-bound ones -- and the sum lands in self._ll_cache[0]."""
         e = self.engine
         layer = self.all_layer[l]
         n = self.F[l].shape[0]
@@ -358,17 +366,30 @@ class imputer:
                       id(layer[k].input) if l == 0 else None) for k in dense)
         hit = self._factor_cache.get(l)
         if l != 0 or hit is None or hit[0] != sigs:
-            buf = hit[1] if hit is not None and hit[1].shape[0] == len(dense) else e.empty(len(dense), Np, Np)
+            extra = self.__dict__.pop('_want_ll0', None) if l == 0 else None
+            extra = extra if extra and len(dense) + len(extra) <= 64 and all(len(nd.output) == n for _, nd in extra) else []
+            nb = len(dense) + len(extra)
+            buf = hit[1] if hit is not None and hit[1].shape[0] == nb else e.empty(nb, Np, Np)
             for j, k in enumerate(dense):
                 nd = layer[k]
                 Xl, cm = self._node_input(l, k, nd)
                 e.kmatrix(nd.name, Xl, cm, self._glob[(l, k)], nd.length, nd.nugget[0], out=buf[j], full=False)
-            for c0 in range(0, len(dense), 64):
-                nb = min(64, len(dense) - c0)
-                _, info = e.potrf(n, buf[c0:c0 + nb], batch=nb)
-                info = info.cpu().numpy()
-                if info.any():
-                    raise_not_pd(int(info[info != 0][0]))
+            for j, (k, nd) in enumerate(extra):   # K of an upper node at the current latents, its output riding along
+                Xl, cm = self._node_input(1, k, nd)
+                e.kmatrix(nd.name, Xl, cm, self._glob[(1, k)], nd.length, nd.nugget[0],
+                          W=None if nd.rep is None else e.tensor(nd.W_diag), out=buf[len(dense) + j], full=False, Y=self._node_y(1, k))
+            lls = []
+            for c0 in range(0, nb, 64):
+                n1 = min(64, nb - c0)
+                logdet, info = e.potrf(n, buf[c0:c0 + n1], batch=n1)
+                for j, (k, nd) in enumerate(extra):
+                    lls.append(e.loglik_finish(n, buf[len(dense) + j], logdet[len(dense) + j:len(dense) + j + 1], nd.scale[0]))
+                got = e.fetch(torch.cat([info.to(torch.float64)] + lls))   # one synchronisation for both
+                if got[:n1].any():
+                    bad = got[:n1]
+                    raise_not_pd(int(bad[bad != 0][0]))
+                if extra:
+                    self._ll_cache[0] = float(got[n1:].sum())
             self._factor_cache[l] = (sigs, buf)
         return self._factor_cache[l][1]
 

@@ -229,6 +229,13 @@ class Engine:
         self._chk(self._enter() or lib.dgpamd_aug_quad(self.h, n, _dp(A), Np * Np, batch, r, _dp(out)))
         return out
 
+    def loglik_finish(self, n, A, logdet, scale, batch=1):
+        """ll (batch,) of buffers assembled with their y row and factored by another call (dgpamd_loglik_finish)."""
+        Np = self.padded_dim(n)
+        ll = self.empty(batch)
+        self._chk(self._enter() or lib.dgpamd_loglik_finish(self.h, n, _dp(A), Np * Np, batch, _dp(logdet), float(scale), _dp(ll)))
+        return ll
+
     def loglik(self, kind, Xloc, colmap, Xglob, length, nugget, scale, y, W=None, batch=1, A=None, ll=None, info=None):
         """Batched ESS target (kernel_class.py:481-492).  Returns (ll, info) device tensors (no sync)."""
         n, ldloc = Xloc.shape[-2], Xloc.shape[-1]

@@ -128,6 +128,12 @@ int dgpamd_set_potrf_mode(dgpamd_ctx *ctx, int mode);
  * y_q^T K^-1 y_q'  (= -corner).                                               */
 int dgpamd_aug_quad(dgpamd_ctx *ctx, int64_t n, const double *A, int64_t stride_a, int batch, int r, double *quad);
 
+/* The closing arithmetic of dgpamd_loglik (kernel_class.py:486-488) for buffers that were assembled with their y row and
+ * factored by another call (e.g. as extra matrices of a batched dgpamd_potrf):
+ * ll[b] = -0.5 (n log scale + logdet[b] + y'K^-1y / scale). */
+int dgpamd_loglik_finish(dgpamd_ctx *ctx, int64_t n, const double *A, int64_t stride_a, int batch, const double *logdet,
+                         double scale, double *ll);
+
 /* Dense row-major matrix-vector product out = A x (rows x cols, leading dimension ld): the K alpha + u step of the
  * heteroskedastic exact-posterior draw (likelihood_class.py:184-243), where K is a full kernel matrix. */
 int dgpamd_gemv(dgpamd_ctx *ctx, int64_t rows, int64_t cols, const double *A, int64_t ld, const double *x, double *out);
