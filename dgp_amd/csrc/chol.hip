@@ -1073,9 +1073,10 @@ struct MegaTable {
 };
 
 static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::vector<int2> &need, int lazy, int slazy,
-                             int near = 0, int lag = 0, int xcatch = 0) {
+                             int near = 0, int lag = 0, int xcatch = 0, int stail = 0) {
     const int nb2 = nbk * nbk;
-    std::vector<int> appliedA(nb2, 0), visitsA(nb2, 0), appliedT(nb2, 0), visitsT(nb2, 0), visitsS(nb2, 0);
+    std::vector<int> appliedA(nb2, 0), visitsA(nb2, 0), appliedT(nb2, 0), visitsT(nb2, 0), visitsS(nb2, 0), appliedS(nbk, 0);
+    for (int q = 0; q < nbk; ++q) appliedS[q] = q;   // row q of K^-1 sums the panels kb >= q
     if (inv)
         for (int q = 0; q < nbk; ++q)
             for (int j = 0; j < nbk; ++j) appliedT[q * nbk + j] = q;   // T[q][j] sums the panels kb >= q
@@ -1105,7 +1106,7 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
         emit(make_task(T_SOLVE, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap), visitsA[i * nbk + k]++, 1, k);
         appliedA[i * nbk + k] = k;
     };
-    const int nl = nbk + (inv ? slazy + lag : 0);
+    const int nl = nbk + (inv ? 1 + lag : 0);   // (one more pass flushes what is left of K^-1)
     for (int k = 0; k < nl; ++k) {
         if (k < nbk) {
             // LOOK-AHEAD: what the chain picks up after factoring block k+1 -- A[k+2][k+1] and A[k+2][k+2] with the panels
@@ -1149,14 +1150,23 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
                         for (int q = 0; q <= kl - 1; ++q) updT(q, j, kl);
             }
         }
-        if (inv) {   // S[q][q'] += Pt_q Pt_q'^T for the panels (ks-slazy .. ks-1), ks = k - lag, rows q = ks-slazy, ks-2 slazy, ...
+        if (inv) {
+            // S[q][q'] += Pt_q Pt_q'^T: row q is visited when `slazy` panels are pending (rows q = k - slazy, k - 2 slazy, ... at
+            // block step k).  With `stail` (up to three matrices: the chains bound the time) the threshold shrinks towards the end
+            // with the block steps that are left, so that when the last chain has finished every K^-1 tile lacks one or two
+            // panels, not eight: the tail after the chains is one round of short tasks behind the last column's solves
+            // (potrf_inv of one matrix 0.57 -> 0.55 ms, of three 0.77 -> 0.75; with more matrices the extra shallow tasks cost more than the tail).
             const int ks = k - lag;
-            for (int q = ks - slazy; q >= 0; q -= slazy) {
-                const int nkb = (ks - 1 < nbk ? ks : nbk) - (ks - slazy);
-                if (nkb <= 0) continue;
-                const int mask = (ks - slazy + nkb - 1 == nbk - 1) ? 1 : 0;
+            const int left = nbk - ks;   // block steps until the flush
+            const int thr = ks >= nbk ? 1 : (stail && left < slazy ? (left > 1 ? left : 1) : slazy);
+            for (int q = 0; q <= ks - 1 && q < nbk; ++q) {
+                const int upto = ks < nbk ? ks : nbk;
+                if (upto - appliedS[q] < thr) continue;
+                const int ap = appliedS[q], nkb = upto - ap;
+                const int mask = (upto - 1 == nbk - 1) ? 1 : 0;
                 for (int q2 = 0; q2 <= q; ++q2)
-                    emit(make_task(T_STORE, q == ks - slazy, 1, mask, BUF_S, q, q2, BUF_T, q, BUF_T, q2, ks - slazy, nkb), visitsS[q * nbk + q2]++, 0, 0);
+                    emit(make_task(T_STORE, ap == q, 1, mask, BUF_S, q, q2, BUF_T, q, BUF_T, q2, ap, nkb), visitsS[q * nbk + q2]++, 0, 0);
+                appliedS[q] = upto;
             }
         }
     }
@@ -1171,13 +1181,14 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTab
     const bool deep = inv && batch >= 8;
     const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : MEGA_LAZY, slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? 12 : MEGA_SLAZY);
     const char *en = getenv("DGPAMD_MEGA_NEAR"), *el = getenv("DGPAMD_MEGA_LAG"), *ex = getenv("DGPAMD_MEGA_XCATCH");
-    const int near = en ? atoi(en) : MEGA_NEAR, lag = el ? atoi(el) : 0, xcatch = ex ? atoi(ex) : 0;
+    const char *es = getenv("DGPAMD_MEGA_STAIL");
+    const int near = en ? atoi(en) : MEGA_NEAR, lag = el ? atoi(el) : 0, xcatch = (ex ? atoi(ex) : 0) + 2 * (es ? atoi(es) : (inv && batch <= 3 ? 1 : 0));
     static std::map<std::pair<dgpamd_ctx *, std::array<int, 7>>, MegaTable> cache;
     MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy, near, lag, xcatch}}];
     if (!mt.dev) {
         std::vector<MTask> tasks;
         std::vector<int2> need;
-        build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy, near, lag, xcatch);
+        build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy, near, lag, xcatch & 1, xcatch >> 1);
         mt.ntask = (int)tasks.size();
         HIP_TRY(ctx, hipMalloc((void **)&mt.dev, (tasks.size() + 1) * sizeof(MTask)));
         HIP_TRY(ctx, hipMemcpy(mt.dev, tasks.data(), tasks.size() * sizeof(MTask), hipMemcpyHostToDevice));
