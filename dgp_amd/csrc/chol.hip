@@ -1173,13 +1173,12 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
 }
 
 static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTable *&out) {
-    // Panels per visit: 8 (trailing and K^-1 tiles; 12 for the K^-1 tiles of calls with the fused inverse and eight or more
-    // matrices), and the cadence starts three columns to the right of the chain (near = 2).  Measured at n = 2000
-    // (tools/gpu_lazy_sweep.py, profiles/r02_mega_table_sweeps.txt).  DGPAMD_MEGA_LAZY / _SLAZY / _NEAR / _LAG / _XCATCH
-    // override (tuning only).
+    // Panels per visit: 8 (trailing and K^-1 tiles), 10 from six matrices on; the cadence starts three columns to the right
+    // of the chain (near = 2).  Measured at n = 2000 (tools/gpu_lazy_sweep.py, profiles/r02_mega_table_sweeps.txt).
+    // DGPAMD_MEGA_LAZY / _SLAZY / _NEAR / _LAG / _XCATCH / _STAIL override (tuning only).
     const char *lz = getenv("DGPAMD_MEGA_LAZY"), *sz = getenv("DGPAMD_MEGA_SLAZY");
-    const bool deep = inv && batch >= 8;
-    const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : MEGA_LAZY, slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? 12 : MEGA_SLAZY);
+    const bool deep = batch >= 6;
+    const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : (deep ? 10 : MEGA_LAZY), slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? 10 : MEGA_SLAZY);
     const char *en = getenv("DGPAMD_MEGA_NEAR"), *el = getenv("DGPAMD_MEGA_LAG"), *ex = getenv("DGPAMD_MEGA_XCATCH");
     const char *es = getenv("DGPAMD_MEGA_STAIL");
     const int near = en ? atoi(en) : MEGA_NEAR, lag = el ? atoi(el) : 0, xcatch = (ex ? atoi(ex) : 0) + 2 * (es ? atoi(es) : (inv && batch <= 3 ? 1 : 0));
