@@ -35,6 +35,7 @@ struct dgpamd_ctx {
     int potrf_mode;                                   // 1: factorisation as one persistent dataflow launch; 0: one launch per block step
     long long *trace;                                 // device buffer for in-kernel timestamps (diagnostics), or null
     double *pinned;                                   // small pinned staging buffer for result copies (lazy)
+    int args_inflight;                                // 1 while a copy of `hostargs` may still be running (a call left early)
     unsigned long long host_seq;                      // sequence number of the last result a kernel published into `pinned`
     char *devargs, *hostargs;                         // argument arrays of the multi-node launches (device / pinned host)
     size_t devargs_bytes;

@@ -35,6 +35,7 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;
     ctx->host_seq = 0;
+    ctx->args_inflight = 0;
     ctx->devargs = ctx->hostargs = nullptr;
     ctx->devargs_bytes = 0;
     // NULL = the device's default (null) stream, which is also torch's default current stream

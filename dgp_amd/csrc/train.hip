@@ -407,7 +407,8 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     const size_t need = (size_t)batch * (sizeof(KmatArgs) + sizeof(GradMulti));
     int rc = ensure_devargs(ctx, need);
     if (rc) return rc;
-    // (the previous call's argument copy has been consumed: every call ends with the stream drained)
+    // (the previous call's argument copy has been consumed: every call ends with the stream drained -- unless it left early)
+    if (ctx->args_inflight) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     KmatArgs *ka = reinterpret_cast<KmatArgs *>(ctx->hostargs);
     GradMulti *ga = reinterpret_cast<GradMulti *>(ctx->hostargs + (size_t)batch * sizeof(KmatArgs));
     const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
@@ -435,6 +436,7 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
         g.partial = reinterpret_cast<double *>(reinterpret_cast<char *>(grad_work) + (size_t)b * gw);
         ga[b].out = dev_out + b * stride_out + 3;
     }
+    ctx->args_inflight = 1;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->devargs, ctx->hostargs, need, hipMemcpyHostToDevice, ctx->stream));
     const KmatArgs *kd = reinterpret_cast<const KmatArgs *>(ctx->devargs);
     const GradMulti *gd = reinterpret_cast<const GradMulti *>(ctx->devargs + (size_t)batch * sizeof(KmatArgs));
@@ -482,6 +484,7 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
             if (q != hipErrorNotReady) HIP_TRY(ctx, q);
         }
     }
+    ctx->args_inflight = 0;
     memcpy(host_out, ctx->pinned, bytes);
     return DGPAMD_OK;
 }
