@@ -161,13 +161,39 @@ __device__ __forceinline__ void grad_reduce_body(const GradArgs &a) {
     __syncthreads();
 
     double s[4][4], pr[4][4];
+    double num[4][4];   // shared lengthscale, Matern: sum_d e1_d e2_d prod_{d' != d} q_d'  (so that c K = num exp(-sqrt5 s), see below)
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             s[p][q] = 0.0;
             pr[p][q] = 1.0;
+            num[p][q] = 0.0;
         }
+    if (a.shared_len && KIND != DGPAMD_SEXP) {
+        // ONE pass for an isotropic Matern node: the derivative coefficient of dimension d is e1 e2 / q with q = e1 + e2 the
+        // same polynomial that K's product runs over, so sum_d c_d K = [sum_d e1_d e2_d prod_{d' != d} q_d'] exp(-sqrt5 s):
+        // a two-term recurrence beside the product, no division, no second pass (157 -> ~90 VALU instructions per entry).
+        for (int d = 0; d < D; ++d) {
+            double xi[4], xj[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                xi[p] = XiT[d * 64 + ty + 16 * p];
+                xj[p] = XjT[d * 64 + tx + 16 * p];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double r = fabs(xi[p] - xj[q]);
+                    const double qd_ = fma(r, fma(r, 5.0 / 3.0, SQRT5), 1.0);   // = e1 + e2, as corr_accum_matern forms it
+                    const double e1 = fma(r, SQRT5, 1.0), e2 = (5.0 / 3.0) * r * r;
+                    num[p][q] = fma(num[p][q], qd_, e1 * e2 * pr[p][q]);
+                    pr[p][q] *= qd_;
+                    s[p][q] += r;
+                }
+        }
+    } else
     for (int d = 0; d < D; ++d) {
         double xi[4], xj[4];
 #pragma unroll
@@ -203,7 +229,12 @@ __device__ __forceinline__ void grad_reduce_body(const GradArgs &a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t gj = j0 + tx + 16 * q;
-            double kv = (KIND == DGPAMD_SEXP) ? exp(-s[p][q]) : pr[p][q] * exp(-SQRT5 * s[p][q]);
+            // K_ij -- or, with one shared lengthscale, directly c_ij K_ij (sexp: c = sum_d 2 df^2 = 2 s; Matern: num / prod)
+            double kv;
+            if (KIND == DGPAMD_SEXP)
+                kv = (a.shared_len ? 2.0 * s[p][q] : 1.0) * exp(-s[p][q]);
+            else
+                kv = (a.shared_len ? num[p][q] : pr[p][q]) * exp(-SQRT5 * s[p][q]);
             const bool in = gi < n && gj < n;
             double kinv = in ? a.Ainv[gi * a.ld + gj] : 0.0;
             if (!in || gi == gj) kv = 0.0;
@@ -217,24 +248,15 @@ __device__ __forceinline__ void grad_reduce_body(const GradArgs &a) {
         }
     }
     const int npl = a.shared_len ? 1 : D;
-    if (a.shared_len) {
+    if (a.shared_len) {   // (the weights already carry the coefficient)
         double tr = 0.0, qd = 0.0;
-        for (int d = 0; d < D; ++d) {
-            double xi[4], xj[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                xi[p] = XiT[d * 64 + ty + 16 * p];
-                xj[p] = XjT[d * 64 + tx + 16 * p];
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tr += w1[p][q];
+                qd += w2[p][q];
             }
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    double c = dcoef<KIND>(xi[p] - xj[q]);
-                    tr = fma(c, w1[p][q], tr);
-                    qd = fma(c, w2[p][q], qd);
-                }
-        }
         tr = wave_sum(tr);
         qd = wave_sum(qd);
         if (lane == 0) {
