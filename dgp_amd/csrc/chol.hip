@@ -1215,10 +1215,11 @@ static size_t mega_sync_bytes(int64_t nbk, int batch) {
 }
 
 static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, double *S, int64_t stride_a, int batch,
-                             double *logdet, int32_t *info, double *ws, void *syncmem, const MegaTable *mt, bool no_post = false) {
+                             double *logdet, int32_t *info, double *ws, void *syncmem, const MegaTable *mt, bool no_post = false,
+                             bool sync_cleared = false) {
     const int64_t Np = padded_dim(n);
     const int nbk = (int)(Np / 64);
-    HIP_TRY(ctx, hipMemsetAsync(syncmem, 0, mega_sync_bytes(nbk, batch), ctx->stream));
+    if (!sync_cleared) HIP_TRY(ctx, hipMemsetAsync(syncmem, 0, mega_sync_bytes(nbk, batch), ctx->stream));
     MegaArgs g;
     g.buf[BUF_A] = A; g.buf[BUF_T] = T; g.buf[BUF_S] = S;
     g.ws = ws; g.ld = Np; g.stride_a = stride_a; g.stride_ws = (int64_t)nbk * 4096; g.n = n; g.nbk = nbk; g.batch = batch;
@@ -1312,8 +1313,23 @@ __global__ void potrf_copy_out_kernel(const double *ld_ws, const int32_t *info_w
     }
 }
 
+static bool potrf_uses_mega(const dgpamd_ctx *ctx, int batch, bool inv) {
+    // mode 2: whichever is faster for the call (measured at n = 2000, profiles/r02_potrf_modes.txt): the one persistent
+    // launch while the pivot chains bound the time (few matrices), the per-step launches (four workgroups per CU) when
+    // the bulk does.
+    return ctx->potrf_mode == 1 || (ctx->potrf_mode == 2 && batch <= (inv ? 4 : 8)) || (ctx->pred && ctx->potrf_mode != 0);
+}
+
+void potrf_sync_area(dgpamd_ctx *ctx, int64_t n, int batch, bool inv, double *ws, int32_t **ptr, int *words) {
+    *ptr = nullptr;
+    *words = 0;
+    if (!potrf_uses_mega(ctx, batch, inv)) return;
+    *ptr = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ws) + mega_sync_offset(n, batch));
+    *words = (int)(mega_sync_bytes(padded_dim(n) / 64, batch) / sizeof(int32_t));
+}
+
 int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
-              double *ws, double *T, double *S, PotrfPost *post) {
+              double *ws, double *T, double *S, PotrfPost *post, bool sync_cleared) {
     // One launch per 64-column block step with a static shape: replayed as one hipGraph.  The graph writes
     // logdet/info into the workspace tail (fixed addresses -> the cached graph does not depend on where the
     // caller wants them); a tiny kernel outside the graph copies them out.
@@ -1321,17 +1337,14 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
     double *ld_ws = ws + (size_t)batch * nbk * 4096 + DGPAMD_MAXB;
     int32_t *info_ws = reinterpret_cast<int32_t *>(ws + (size_t)batch * nbk * 4096 + 2 * DGPAMD_MAXB);
     int32_t *flags = info_ws + DGPAMD_MAXB;
-    // mode 2: whichever is faster for the call (measured at n = 2000, profiles/r02_potrf_modes.txt): the one persistent
-    // launch while the pivot chains bound the time (few matrices), the per-step launches (four workgroups per CU) when
-    // the bulk does.
-    const bool mega = ctx->potrf_mode == 1 || (ctx->potrf_mode == 2 && batch <= (T ? 4 : 8)) || (ctx->pred && ctx->potrf_mode != 0);
+    const bool mega = potrf_uses_mega(ctx, batch, T != nullptr);
     if (mega) {
         MegaTable *mt = nullptr;
         int rc = get_mega_tasks(ctx, (int)nbk, T != nullptr, batch, mt);   // (uploads the table on first use)
         if (rc) return rc;
         (void)mega_wgs_per_cu();
         void *syncmem = reinterpret_cast<char *>(ws) + mega_sync_offset(n, batch);
-        rc = potrf_mega_launch(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, syncmem, mt, post != nullptr);
+        rc = potrf_mega_launch(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, syncmem, mt, post != nullptr, sync_cleared);
         if (rc) return rc;
         if (post) {
             post->pending = 1;

@@ -188,6 +188,8 @@ struct KmatArgs {
     int64_t ldy, stride_y;
     int r;
     const int32_t *pred;   // null, or a device word: the launch does nothing when it is non-zero
+    int32_t *zero_ptr;     // null, or words to clear on the way (the factorisation's synchronisation block: saves its memset launch)
+    int zero_words;
 };
 int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch);
 int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatArgs *host_args, int count);   // same n / mode
@@ -205,7 +207,11 @@ struct PotrfPost {
     const int32_t *status = nullptr;
 };
 int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
-              double *ws, double *T = nullptr, double *S = nullptr, PotrfPost *post = nullptr);   // T, S: fused inverse (dgpamd_potrf_inv)
+              double *ws, double *T = nullptr, double *S = nullptr, PotrfPost *post = nullptr, bool sync_cleared = false);
+// The words run_potrf would clear before its launch for this call (null / 0: none -- the per-step launches clear their own
+// flags inside their graph): a kernel that runs just before on the same stream may clear them instead (KmatArgs::zero_ptr)
+// and pass sync_cleared = true.
+void potrf_sync_area(dgpamd_ctx *ctx, int64_t n, int batch, bool inv, double *ws, int32_t **ptr, int *words);   // T, S: fused inverse (dgpamd_potrf_inv)
 size_t potrf_ws_doubles(int64_t n, int batch);
 int ensure_pinned(dgpamd_ctx *ctx, size_t bytes);   // grow the context's pinned staging buffer
 int ensure_devargs(dgpamd_ctx *ctx, size_t bytes);  // grow the device / pinned argument arrays

@@ -148,6 +148,8 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
 template <int KIND>
 __global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
     if (a.pred && *a.pred) return;   // (a speculative batch that an earlier one has made unnecessary: dgpamd_ess_queue)
+    if (a.zero_ptr && blockIdx.z == 0)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.zero_words; i += gridDim.x * 256) a.zero_ptr[i] = 0;
     kmatrix_body<KIND>(a, blockIdx.z);
 }
 
@@ -155,6 +157,8 @@ __global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
 // read from an argument array in device memory (uniform addresses: scalar loads).
 __global__ __launch_bounds__(256) void kmatrix_multi_kernel(const KmatArgs *args) {
     const KmatArgs &a = args[blockIdx.z];
+    if (a.zero_ptr)   // (set in one node's arguments only)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.zero_words; i += gridDim.x * 256) a.zero_ptr[i] = 0;
     if (a.kp.kind == DGPAMD_SEXP)
         kmatrix_body<DGPAMD_SEXP>(a, 0);
     else
@@ -213,6 +217,8 @@ int build_kmat_args(dgpamd_ctx *ctx, KmatArgs &a, int kind, int64_t n, const dou
     int rc = fill_kern_params(ctx, a.kp, kind, colmap_h, Dl, Dg, length_h, nlen, nugget);
     if (rc) return rc;
     a.pred = nullptr;
+    a.zero_ptr = nullptr;
+    a.zero_words = 0;
     a.n = n;
     a.Xloc = Xloc;
     a.ldloc = ldloc;

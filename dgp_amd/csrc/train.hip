@@ -63,11 +63,12 @@ extern "C" int dgpamd_loglik(dgpamd_ctx *ctx, int kind, int64_t n, const double 
     int rc = build_kmat_args(ctx, a, kind, n, Xloc, ldloc, stride_loc, colmap_h, Dl, Xglob, Dg, length_h, nlen, nugget,
                              W, A, Np, stride_a, 0, y, n, 0, 1, batch);
     if (rc) return rc;
+    double *ws = (double *)work;
+    potrf_sync_area(ctx, n, batch, false, ws, &a.zero_ptr, &a.zero_words);   // (cleared by the assembly kernel on the way)
     rc = launch_kmatrix(ctx, a, batch);
     if (rc) return rc;
-    double *ws = (double *)work;
     double *logdet = ws + (size_t)batch * (Np / 64) * 4096;
-    rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, ws);
+    rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, ws, nullptr, nullptr, nullptr, a.zero_ptr != nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(loglik_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, A, Np, stride_a, n, logdet, scale, ll,
                        batch);
@@ -458,6 +459,8 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
         g.partial = reinterpret_cast<double *>(reinterpret_cast<char *>(grad_work) + (size_t)b * gw);
         ga[b].out = dev_out + b * stride_out + 3;
     }
+    potrf_sync_area(ctx, n, batch, true, (double *)work, &ka[0].zero_ptr, &ka[0].zero_words);   // (node 0's blocks clear it)
+    const bool cleared = ka[0].zero_ptr != nullptr;
     ctx->args_inflight = 1;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->devargs, ctx->hostargs, need, hipMemcpyHostToDevice, ctx->stream));
     const KmatArgs *kd = reinterpret_cast<const KmatArgs *>(ctx->devargs);
@@ -467,7 +470,7 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     double *logdet = dev_out + (int64_t)batch * stride_out;
     int32_t *info = reinterpret_cast<int32_t *>(logdet + batch);
     PotrfPost post;
-    rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, T, Ainv, &post);   // factor + inverse, one sweep
+    rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, T, Ainv, &post, cleared);   // factor + inverse, one sweep
     if (rc) return rc;
     if (post.pending)
         hipLaunchKernelGGL(llik_post_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, ctx->stream, (const double *)T,
@@ -721,9 +724,10 @@ static int ess_queue_logliks(dgpamd_ctx *ctx, int64_t n, int M, const double *X,
         int rc = build_kmat_args(ctx, a, nd.kind, n, X, M, stride_x, (const int32_t *)nd.colmap, nd.Dl, nd.Xglob, nd.Dg, nd.length,
                                  nd.nlen, nd.nugget, nd.W, A, Np, Np * Np, 0, nd.y, n, 0, 1, B);
         if (rc) return rc;
+        potrf_sync_area(ctx, n, B, false, ws, &a.zero_ptr, &a.zero_words);
         rc = launch_kmatrix(ctx, a, B);
         if (rc) return rc;
-        rc = run_potrf(ctx, n, A, Np * Np, B, sc->logdet, sc->info, ws);
+        rc = run_potrf(ctx, n, A, Np * Np, B, sc->logdet, sc->info, ws, nullptr, nullptr, nullptr, a.zero_ptr != nullptr);
         if (rc) return rc;
         hipLaunchKernelGGL(ess_node_ll_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)A, Np, Np * Np, n,
                            scales_h[k], B, k == 0 ? 1 : 0, sc);
