@@ -663,17 +663,31 @@ __global__ __launch_bounds__(256) void ess_propose_dev_kernel(const double *F, c
         FP[(int64_t)b * count + i] = F[i] * c + NU[i] * s;
 }
 // log-likelihood of one upper node for every proposal of the batch, summed over the nodes (imputation.py:91-106)
+// log-likelihood of one upper node for every proposal of the batch, summed over the nodes (imputation.py:91-106).  The
+// factorisation's results come straight from its workspace when it ran as the one-launch kernel (ld_ws / info_ws / status:
+// PotrfPost; null: sc->logdet / sc->info hold them); `st` non-null (the last node of a batch): the decision follows in the
+// same launch.
+__device__ void ess_decide(double *st, EssScratch *sc);
 __global__ void ess_node_ll_kernel(const double *A, int64_t ld, int64_t stride_a, int64_t n, double scale, int B, int first,
-                                   EssScratch *sc) {
+                                   EssScratch *sc, const double *ld_ws, const int32_t *info_ws, const int32_t *status, double *st) {
     const int b = threadIdx.x;
-    if (sc->done || b >= B) return;
-    const double quad = -A[(int64_t)b * stride_a + n * ld + n];
-    const double ll = -0.5 * ((double)n * log(scale) + sc->logdet[b] + quad / scale);
-    sc->ll[b] = (first ? 0.0 : sc->ll[b]) + ll;
-    sc->infomax[b] = first ? sc->info[b] : (sc->infomax[b] ? sc->infomax[b] : sc->info[b]);
+    if (sc->done) return;
+    if (b < B) {
+        const double logdet = ld_ws ? ld_ws[b] : sc->logdet[b];
+        const int32_t info = ld_ws ? ((status && *status) ? -1 : info_ws[b]) : sc->info[b];
+        const double quad = -A[(int64_t)b * stride_a + n * ld + n];
+        const double ll = -0.5 * ((double)n * log(scale) + logdet + quad / scale);
+        sc->ll[b] = (first ? 0.0 : sc->ll[b]) + ll;
+        sc->infomax[b] = first ? info : (sc->infomax[b] ? sc->infomax[b] : info);
+    }
+    if (st) {
+        __threadfence_block();
+        __syncthreads();
+        if (b == 0) ess_decide(st, sc);
+    }
 }
-__global__ void ess_decide_kernel(double *st, EssScratch *sc) {
-    if (threadIdx.x || sc->done) return;
+__device__ void ess_decide(double *st, EssScratch *sc) {
+    if (sc->done) return;
     const int nb = sc->nb;
     int cur = (int)st[ES_CURSOR];
     st[ES_BATCHES] += 1.0;
@@ -714,7 +728,7 @@ extern "C" size_t dgpamd_ess_queue_scratch(void) { return (sizeof(EssScratch) + 
 
 // all upper nodes' log-likelihoods of the B candidate blocks X (B x n x M; stride 0: one block) into sc->ll / infomax
 static int ess_queue_logliks(dgpamd_ctx *ctx, int64_t n, int M, const double *X, int64_t stride_x, int B, const dgpamd_node *nodes,
-                             const double *scales_h, int nnodes, double *A, void *work, EssScratch *sc) {
+                             const double *scales_h, int nnodes, double *A, void *work, EssScratch *sc, double *st_decide) {
     const int64_t Np = padded_dim(n);
     double *ws = (double *)work;
     for (int k = 0; k < nnodes; ++k) {
@@ -727,10 +741,13 @@ static int ess_queue_logliks(dgpamd_ctx *ctx, int64_t n, int M, const double *X,
         potrf_sync_area(ctx, n, B, false, ws, &a.zero_ptr, &a.zero_words);
         rc = launch_kmatrix(ctx, a, B);
         if (rc) return rc;
-        rc = run_potrf(ctx, n, A, Np * Np, B, sc->logdet, sc->info, ws, nullptr, nullptr, nullptr, a.zero_ptr != nullptr);
+        PotrfPost post;   // (the factorisation's results are read where they are: no copy-out launch)
+        rc = run_potrf(ctx, n, A, Np * Np, B, sc->logdet, sc->info, ws, nullptr, nullptr, &post, a.zero_ptr != nullptr);
         if (rc) return rc;
         hipLaunchKernelGGL(ess_node_ll_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)A, Np, Np * Np, n,
-                           scales_h[k], B, k == 0 ? 1 : 0, sc);
+                           scales_h[k], B, k == 0 ? 1 : 0, sc, post.pending ? post.ld_ws : nullptr,
+                           post.pending ? post.info_ws : nullptr, post.pending ? post.status : nullptr,
+                           k == nnodes - 1 ? st_decide : nullptr);
     }
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
@@ -754,7 +771,7 @@ extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, co
     int rc;
     HIP_TRY(ctx, hipMemsetAsync(sc, 0, sizeof(EssScratch), ctx->stream));
     if (compute_ll0) {   // log-likelihood of the current state (imputation.py:70-78): the first threshold's base
-        rc = ess_queue_logliks(ctx, n, M, F, 0, 1, nodes, scales_h, nnodes, A, work, sc);
+        rc = ess_queue_logliks(ctx, n, M, F, 0, 1, nodes, scales_h, nnodes, A, work, sc, nullptr);
         if (rc) return rc;
         hipLaunchKernelGGL(ess_set_ll_kernel, dim3(1), dim3(64), 0, ctx->stream, state, (const EssScratch *)sc);
     }
@@ -768,10 +785,9 @@ extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, co
                                count, (const EssScratch *)sc);
             // every launch is predicated on the update being open (the first batch: on the queue not having stopped)
             ctx->pred = &sc->done;
-            rc = ess_queue_logliks(ctx, n, M, FP, count, B, nodes, scales_h, nnodes, A, work, sc);
+            rc = ess_queue_logliks(ctx, n, M, FP, count, B, nodes, scales_h, nnodes, A, work, sc, state);   // (decides as well)
             ctx->pred = nullptr;
             if (rc) return rc;
-            hipLaunchKernelGGL(ess_decide_kernel, dim3(1), dim3(64), 0, ctx->stream, state, sc);
             hipLaunchKernelGGL(ess_accept_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, F, (const double *)FP, count,
                                (const EssScratch *)sc);
         }
