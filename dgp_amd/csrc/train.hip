@@ -614,8 +614,12 @@ struct EssScratch {   // device scratch of one queue (dgpamd_ess_queue_scratch b
 };
 #define ESS_TWO_PI 6.283185307179586
 
-__global__ void ess_begin_kernel(double *st, const double *u, const double *logu, int nuni, EssScratch *sc) {
+__device__ void ess_prepare(double *st, const double *u, int nuni, int B, EssScratch *sc);
+// Opens update number `upd` of the queue: closes the previous one first (not accepted within its queued batches: status 3,
+// what ess_end_kernel does after the last update), draws the threshold and the first angle, and prepares the first batch.
+__global__ void ess_begin_kernel(double *st, const double *u, const double *logu, int nuni, EssScratch *sc, int upd, int B) {
     if (threadIdx.x) return;
+    if (upd > 0 && !sc->done && st[ES_STATUS] == 0.0) st[ES_STATUS] = 3.0;
     sc->acc = -1;
     sc->nb = 0;
     if (st[ES_STATUS] != 0.0) { sc->done = 1; sc->halt = 1; return; }   // an earlier update of the queue has stopped it
@@ -627,10 +631,10 @@ __global__ void ess_begin_kernel(double *st, const double *u, const double *logu
     st[ES_CURSOR] = cur + 2;
     sc->done = 0;
     sc->halt = 0;
+    ess_prepare(st, u, nuni, B, sc);
 }
 // the angles of the next speculative batch: theta, then what consecutive rejections would produce (imputation.py:115-119)
-__global__ void ess_prepare_kernel(double *st, const double *u, int nuni, int B, EssScratch *sc) {
-    if (threadIdx.x) return;
+__device__ void ess_prepare(double *st, const double *u, int nuni, int B, EssScratch *sc) {
     sc->acc = -1;
     sc->nb = 0;
     if (sc->done) return;
@@ -653,6 +657,10 @@ __global__ void ess_prepare_kernel(double *st, const double *u, int nuni, int B,
     for (int b = nb; b < B; ++b) sc->th[b] = sc->th[nb - 1];   // (unused slots: a valid angle keeps their matrices harmless)
     for (int b = 0; b < B; ++b) { sc->cs[b] = cos(sc->th[b]); sc->sn[b] = sin(sc->th[b]); }
     sc->nb = nb;
+}
+__global__ void ess_prepare_kernel(double *st, const double *u, int nuni, int B, EssScratch *sc) {
+    if (threadIdx.x) return;
+    ess_prepare(st, u, nuni, B, sc);
 }
 __global__ __launch_bounds__(256) void ess_propose_dev_kernel(const double *F, const double *NU, double *FP, int64_t count,
                                                               const EssScratch *sc) {
@@ -777,10 +785,10 @@ extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, co
     }
     for (int u = 0; u < nupd; ++u) {
         const double *NUu = NU + (int64_t)u * count;
-        hipLaunchKernelGGL(ess_begin_kernel, dim3(1), dim3(64), 0, ctx->stream, state, uniforms, log_uniforms, nuni, sc);
+        hipLaunchKernelGGL(ess_begin_kernel, dim3(1), dim3(64), 0, ctx->stream, state, uniforms, log_uniforms, nuni, sc, u, batch_first);
         for (int j = 0; j < max_batches; ++j) {
             const int B = j == 0 ? batch_first : batch_next;
-            hipLaunchKernelGGL(ess_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, state, uniforms, nuni, B, sc);
+            if (j > 0) hipLaunchKernelGGL(ess_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, state, uniforms, nuni, B, sc);
             hipLaunchKernelGGL(ess_propose_dev_kernel, dim3((unsigned)blocks, B), dim3(256), 0, ctx->stream, (const double *)F, NUu, FP,
                                count, (const EssScratch *)sc);
             // every launch is predicated on the update being open (the first batch: on the queue not having stopped)
@@ -791,7 +799,7 @@ extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, co
             hipLaunchKernelGGL(ess_accept_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, F, (const double *)FP, count,
                                (const EssScratch *)sc);
         }
-        hipLaunchKernelGGL(ess_end_kernel, dim3(1), dim3(64), 0, ctx->stream, state, sc);
+        if (u == nupd - 1) hipLaunchKernelGGL(ess_end_kernel, dim3(1), dim3(64), 0, ctx->stream, state, sc);
     }
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
