@@ -1351,6 +1351,7 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
             post->ld_ws = ld_ws;
             post->info_ws = info_ws;
             post->status = &reinterpret_cast<MegaSync *>(syncmem)->status;
+            post->spare = &reinterpret_cast<MegaSync *>(syncmem)->pad[0];
             return DGPAMD_OK;
         }
         hipLaunchKernelGGL(potrf_copy_out_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)ld_ws,

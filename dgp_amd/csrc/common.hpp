@@ -205,6 +205,7 @@ struct PotrfPost {
     const double *ld_ws = nullptr;
     const int32_t *info_ws = nullptr;
     const int32_t *status = nullptr;
+    int32_t *spare = nullptr;   // a word of the (cleared) synchronisation block that the factorisation does not use
 };
 int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch, double *logdet, int32_t *info,
               double *ws, double *T = nullptr, double *S = nullptr, PotrfPost *post = nullptr, bool sync_cleared = false);

@@ -107,6 +107,7 @@ struct GradArgs {
     int64_t ld;
     int shared_len, nugget_est, P;
     double *partial;
+    const double *alpha_col;   // null: -alpha is row n of Ainv; else -alpha_i = alpha_col[i * ld] (column n of L^-T, dgpamd_potrf_inv)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -220,8 +221,8 @@ __device__ __forceinline__ void grad_reduce_body(const GradArgs &a) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         int64_t gi = i0 + ty + 16 * p, gj = j0 + tx + 16 * p;
-        ai[p] = gi < n ? -arow[gi] : 0.0;
-        aj[p] = gj < n ? -arow[gj] : 0.0;
+        ai[p] = gi < n ? -(a.alpha_col ? a.alpha_col[gi * a.ld] : arow[gi]) : 0.0;
+        aj[p] = gj < n ? -(a.alpha_col ? a.alpha_col[gj * a.ld] : arow[gj]) : 0.0;
     }
     double trn = 0.0, qn = 0.0;
 #pragma unroll
@@ -330,17 +331,57 @@ __global__ __launch_bounds__(256) void grad_final_kernel(const double *partial, 
     if (tid == 0) out[idx] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-__global__ __launch_bounds__(256) void grad_final_multi_kernel(const GradMulti *args, int ntiles) {
+// What the LAST block of grad_final_multi_kernel does when the round's other small launches are folded into it (the
+// one-launch factorisation ran): the factorisation's results out of its workspace into every node's row of dev_out, then all
+// rows into pinned host memory and the sequence word the host spins on.
+struct LlikFinish {
+    int enable;
+    int32_t *counter;        // zero between launches (the last block puts it back)
+    const double *ld_ws;
+    const int32_t *info_ws, *status;
+    const double *A;
+    int64_t ld, stride_a, n;
+    double *dev_out;
+    int64_t stride_out;
+    int batch;
+    double *host;
+    unsigned long long *flag, seq;
+};
+__global__ __launch_bounds__(256) void grad_final_multi_kernel(const GradMulti *args, int ntiles, LlikFinish f) {
     __shared__ double sm[4];
+    __shared__ int last;
     const GradMulti &g = args[blockIdx.y];
     const int idx = blockIdx.x, tid = threadIdx.x, P2 = 2 * g.a.P;
-    if (idx >= P2) return;
-    double v = 0.0;
-    for (int t = tid; t < ntiles; t += 256) v += g.a.partial[(int64_t)t * P2 + idx];
-    v = wave_sum(v);
-    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    if (idx < P2) {
+        double v = 0.0;
+        for (int t = tid; t < ntiles; t += 256) v += g.a.partial[(int64_t)t * P2 + idx];
+        v = wave_sum(v);
+        if ((tid & 63) == 0) sm[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) g.out[idx] = sm[0] + sm[1] + sm[2] + sm[3];
+    }
+    if (!f.enable) return;
+    if (tid == 0) {
+        __threadfence();
+        last = atomicAdd(f.counter, 1) == (int)(gridDim.x * gridDim.y) - 1;
+    }
     __syncthreads();
-    if (tid == 0) g.out[idx] = sm[0] + sm[1] + sm[2] + sm[3];
+    if (!last) return;
+    __threadfence();
+    if (tid < f.batch) {
+        const int b = tid;
+        f.dev_out[b * f.stride_out] = f.ld_ws[b];
+        f.dev_out[b * f.stride_out + 1] = -f.A[(int64_t)b * f.stride_a + f.n * f.ld + f.n];
+        f.dev_out[b * f.stride_out + 2] = (double)(*f.status ? -1 : f.info_ws[b]);
+    }
+    if (tid == 0) *f.counter = 0;
+    __threadfence();
+    __syncthreads();
+    const int nd = (int)(f.batch * f.stride_out);
+    for (int i = tid; i < nd; i += 256) f.host[i] = __hip_atomic_load(f.dev_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(f.flag, f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 extern "C" size_t dgpamd_grad_workspace(int64_t n, int nparam) {
@@ -363,6 +404,7 @@ extern "C" int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n, const do
     a.shared_len = (nlen == 1); a.nugget_est = nugget_est ? 1 : 0;
     a.P = (nlen == 1 ? 1 : D) + a.nugget_est;
     a.partial = (double *)work;
+    a.alpha_col = nullptr;
     const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
     size_t shm = ((size_t)2 * D * 64 + 4 * 2 * a.P) * sizeof(double);
     if (kind == DGPAMD_SEXP)
@@ -457,10 +499,13 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
         g.shared_len = (nd.nlen == 1); g.nugget_est = nd.nugget_est ? 1 : 0;
         g.P = (nd.nlen == 1 ? 1 : nd.Dl + nd.Dg) + g.nugget_est;
         g.partial = reinterpret_cast<double *>(reinterpret_cast<char *>(grad_work) + (size_t)b * gw);
+        g.alpha_col = nullptr;
         ga[b].out = dev_out + b * stride_out + 3;
     }
     potrf_sync_area(ctx, n, batch, true, (double *)work, &ka[0].zero_ptr, &ka[0].zero_words);   // (node 0's blocks clear it)
-    const bool cleared = ka[0].zero_ptr != nullptr;
+    const bool cleared = ka[0].zero_ptr != nullptr;   // = the factorisation will run as the one-launch kernel
+    if (cleared)   // (its -alpha is read where it is, column n of L^-T: no copy into the inverse's row n)
+        for (int b = 0; b < batch; ++b) ga[b].a.alpha_col = T + (int64_t)b * stride_a + n;
     ctx->args_inflight = 1;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->devargs, ctx->hostargs, need, hipMemcpyHostToDevice, ctx->stream));
     const KmatArgs *kd = reinterpret_cast<const KmatArgs *>(ctx->devargs);
@@ -472,7 +517,24 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     PotrfPost post;
     rc = run_potrf(ctx, n, A, stride_a, batch, logdet, info, (double *)work, T, Ainv, &post, cleared);   // factor + inverse, one sweep
     if (rc) return rc;
-    if (post.pending)
+    const int nd = (int)(batch * stride_out);
+    const size_t bytes = (size_t)nd * sizeof(double);
+    rc = ensure_pinned(ctx, bytes + 64);
+    if (rc) return rc;
+    unsigned long long *flag = reinterpret_cast<unsigned long long *>(ctx->pinned + (ctx->pinned_bytes / sizeof(double) - 1));
+    *flag = 0;   // (the stream is drained: nobody else touches the staging buffer now)
+    const unsigned long long seq = ++ctx->host_seq;
+    LlikFinish fin;
+    memset(&fin, 0, sizeof(fin));
+    const bool fused = post.pending && cleared;
+    if (fused) {   // results, packing and publication ride in the last block of the final reduction
+        fin.enable = 1;
+        fin.counter = post.spare;   // (zero: the synchronisation block was cleared before the factorisation)
+        fin.ld_ws = post.ld_ws; fin.info_ws = post.info_ws; fin.status = post.status;
+        fin.A = A; fin.ld = Np; fin.stride_a = stride_a; fin.n = n;
+        fin.dev_out = dev_out; fin.stride_out = stride_out; fin.batch = batch;
+        fin.host = ctx->pinned; fin.flag = flag; fin.seq = seq;
+    } else if (post.pending)
         hipLaunchKernelGGL(llik_post_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, ctx->stream, (const double *)T,
                            Ainv, (const double *)A, Np, stride_a, n, post.ld_ws, post.info_ws, post.status, logdet, info, dev_out,
                            stride_out);
@@ -482,17 +544,11 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     {
         const size_t shm = ((size_t)2 * Dmax * 64 + 4 * 2 * Pmax) * sizeof(double);
         hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(ntiles, 1, batch), dim3(256), shm, ctx->stream, gd);
-        hipLaunchKernelGGL(grad_final_multi_kernel, dim3(2 * Pmax, batch), dim3(256), 0, ctx->stream, gd, ntiles);
+        hipLaunchKernelGGL(grad_final_multi_kernel, dim3(2 * Pmax, batch), dim3(256), 0, ctx->stream, gd, ntiles, fin);
         LAUNCH_CHECK(ctx);
     }
-    const int nd = (int)(batch * stride_out);
-    const size_t bytes = (size_t)nd * sizeof(double);
-    rc = ensure_pinned(ctx, bytes + 64);
-    if (rc) return rc;
-    unsigned long long *flag = reinterpret_cast<unsigned long long *>(ctx->pinned + (ctx->pinned_bytes / sizeof(double) - 1));
-    *flag = 0;   // (the stream is drained: nobody else touches the staging buffer now)
-    const unsigned long long seq = ++ctx->host_seq;
-    hipLaunchKernelGGL(publish_host_kernel, dim3(1), dim3(128), 0, ctx->stream, (const double *)dev_out, ctx->pinned, nd, flag, seq);
+    if (!fused)
+        hipLaunchKernelGGL(publish_host_kernel, dim3(1), dim3(128), 0, ctx->stream, (const double *)dev_out, ctx->pinned, nd, flag, seq);
     LAUNCH_CHECK(ctx);
     // spin on the sequence word; now and then make sure the stream is still alive (a fault would leave the word unwritten)
     for (unsigned long long it = 1;; ++it) {
