@@ -161,7 +161,7 @@ class imputer:
         st['_engine'] = None
         st['_factor_cache'] = {}
         st['_ess_plans'] = {}
-        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh'):   # device state: rebuilt by the next sample()
+        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev'):   # device state: rebuilt by the next sample()
             st.pop(key, None)
         return st
 
@@ -510,18 +510,24 @@ class imputer:
                         FPh = FP.cpu().numpy()
                     host += self._ref_prior_terms(nd, FPh)
             elif nd.type == 'gp':
-                cm = torch.as_tensor(np.asarray(nd.input_dim), device=FP.device, dtype=torch.long)
-                od = torch.as_tensor(nd.ord, device=FP.device, dtype=torch.long)
-                NN = e.tensor(nd.NNarray, dtype=torch.int64)
-                nd_diag = e.tensor(np.ones(FP.shape[1]) if nd.rep is None else nd.W_diag)
+                # (index arrays, the 10-MB neighbour array and the nugget weights stay on the device while the node keeps them)
+                sig = (id(nd.ord), id(nd.NNarray), id(nd.input_dim), None if nd.rep is None else id(nd.W_diag), FP.shape[1])
+                hit = self.__dict__.setdefault('_vecch_dev', {}).get((l + 1, k))
+                if hit is None or hit[0] != sig:
+                    hit = (sig, (torch.as_tensor(np.asarray(nd.input_dim), device=FP.device, dtype=torch.long),
+                                 torch.as_tensor(nd.ord, device=FP.device, dtype=torch.long),
+                                 e.tensor(nd.NNarray, dtype=torch.int64),
+                                 e.tensor(np.ones(FP.shape[1]) if nd.rep is None else nd.W_diag)))
+                    self._vecch_dev[(l + 1, k)] = hit
+                cm, od, NN, nd_diag = hit[1]
                 y = self._node_y(l + 1, k)[od].contiguous()
-                outs = []
-                for b in range(B):
-                    X = FP[b][:, cm]
-                    if self._glob[(l + 1, k)] is not None:
-                        X = torch.cat((X, self._glob[(l + 1, k)]), 1)
-                    outs.append(e.vecchia_llik(nd.name, X[od].contiguous(), y, NN, nd.length, nd.nugget[0], nd_diag))
-                o = torch.stack(outs)
+                # the ordered inputs of ALL candidates in three device operations (was five small ones per candidate: the host
+                # could not keep the device busy between the row kernels)
+                Xall = FP[:, :, cm]
+                if self._glob[(l + 1, k)] is not None:
+                    Xall = torch.cat((Xall, self._glob[(l + 1, k)].unsqueeze(0).expand(B, -1, -1)), 2)
+                Xall = Xall[:, od].contiguous()
+                o = torch.stack([e.vecchia_llik(nd.name, Xall[b], y, NN, nd.length, nd.nugget[0], nd_diag) for b in range(B)])
                 dev_terms.append(-0.5 * (o[:, 1] + o[:, 0] / float(nd.scale[0])))
                 if nd.prior_name == 'ref':
                     if FPh is None:

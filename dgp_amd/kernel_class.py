@@ -89,6 +89,7 @@ class kernel:
         st['_stats'] = None
         st.pop('_r2_cache', None)
         st.pop('_prestaged', None)
+        st.pop('_vecch_cache', None)
         return st
 
     def _X(self):
@@ -351,12 +352,22 @@ class kernel:
             self.imp_NNarray = None
 
     def _vecch_stage(self):
+        """Ordered inputs / outputs, neighbour array and nugget weights on the device.  Kept between calls while nothing
+        has changed (an L-BFGS-B run evaluates the same data dozens of times; the neighbour array alone is 10 MB at
+        n = 50 000): the arrays' identities say whether they were replaced, sums whether they were written in place."""
         e = self.engine
         import torch
-        X = self._X()[self.ord]
         nd = np.ones(len(self.output)) if self.rep is None else self.W_diag
-        return dict(X=e.tensor(X), y=e.tensor(np.asarray(self.output, float).reshape(-1)[self.ord]),
-                    NN=e.tensor(self.NNarray, dtype=torch.int64), nd=e.tensor(nd))
+        sig = (id(self.input), id(self.global_input), id(self.ord), id(self.NNarray), id(nd) if self.rep is not None else None,
+               float(np.sum(self.input)), float(np.sum(self.output)), float(np.sum(self.ord[:16])), len(self.output), id(e))
+        hit = self.__dict__.get('_vecch_cache')
+        if hit is not None and hit[0] == sig:
+            return dict(hit[1])
+        X = self._X()[self.ord]
+        st = dict(X=e.tensor(X), y=e.tensor(np.asarray(self.output, float).reshape(-1)[self.ord]),
+                  NN=e.tensor(self.NNarray, dtype=torch.int64), nd=e.tensor(nd))
+        self._vecch_cache = (sig, st)
+        return dict(st)
 
     def log_likelihood_func_vecch(self):
         """kernel_class.py:494-509 -> vecchia_llik (vecchia.py:164-180)."""
