@@ -11,8 +11,6 @@ tr(K^-1 dK_p) and y^T K^-1 dK_p K^-1 y from one inverse and fused in-flight
 reductions instead of one n x n solve per parameter; `compute_stats` keeps
 R^-1 / R^-1 y on the device and never materialises Psexp.
 """
-import math
-
 import numpy as np
 from numpy.linalg import LinAlgError
 from .ops import raise_not_pd
@@ -269,12 +267,13 @@ class kernel:
         self._raise_if_not_pd(host[-1])
         if self.rep is None and self.prior_name in (None, 'ga', 'inv_ga') and P <= 2:
             # the same arithmetic in the same order on python floats (this runs once per node and L-BFGS-B round between
-            # two device calls: a dozen numpy calls on one- and two-element arrays were most of the host's turn-around)
+            # two device calls: a dozen numpy calls on one- and two-element arrays were most of the host's turn-around);
+            # the logarithms stay numpy's (its vectorised log and libm's differ in the last bit now and then)
             logdet, YKinvY = float(host[0]), float(host[1])
             if self.scale_est:
                 sc = YKinvY / n
                 self.scale = np.array([sc])
-                nll = 0.5 * (logdet + n * math.log(sc))
+                nll = 0.5 * (logdet + n * float(np.log(sc)))
             else:
                 sc = float(self.scale[0])
                 nll = 0.5 * (logdet + YKinvY / sc)
@@ -284,10 +283,10 @@ class kernel:
                 xs = [float(v) for v in self.length] + ([float(self.nugget[0])] if self.nugget_est else [])
                 if len(xs) == P:
                     if self.prior_name == 'ga':
-                        lp = [c0 * math.log(x) - c1 * x for x in xs]
+                        lp = [c0 * float(np.log(x)) - c1 * x for x in xs]
                         fod = [c0 - c1 * x for x in xs]
                     else:
-                        lp = [-c0 * math.log(x) - c1 / x for x in xs]
+                        lp = [-c0 * float(np.log(x)) - c1 / x for x in xs]
                         fod = [-c0 + c1 / x for x in xs]
                     nll = nll - (lp[0] if P == 1 else lp[0] + lp[1])
                     g = [g[p] - fod[p] for p in range(P)]

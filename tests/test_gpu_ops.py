@@ -652,3 +652,27 @@ def test_linkgp_loo_equals_oracle_refit(eng, name, n, Dz):
                                    X[keep, Dw:] if Dz else None, s2['Rinv'], s2['Rinv_y'], 1.3, length, nug, name)
         close(m1[t], mr[0], rtol=1e-8, atol=1e-10)
         close(v1[t], vr[0], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_loglik_finish_matches_loglik(eng):
+    """dgpamd_loglik_finish on buffers factored as members of another batched call == dgpamd_loglik of the same matrices
+    (bit for bit: the imputer folds the first slice threshold of an I-step into the prior factorisation this way)."""
+    import torch
+    rng = np.random.default_rng(11)
+    n, B = 333, 3
+    Np = eng.padded_dim(n)
+    X = eng.tensor(rng.uniform(size=(B, n, 4)))
+    G = eng.tensor(rng.uniform(size=(n, 2)))
+    y = eng.tensor(rng.normal(size=n))
+    ll_ref, info = eng.loglik('matern2.5', X, None, G, [0.8], 1e-5, 1.7, y, batch=B)
+    A = eng.empty(B + 2, Np, Np)
+    for b in range(B):
+        eng.kmatrix('matern2.5', X[b], None, G, [0.8], 1e-5, out=A[b + 2], full=False, Y=y)
+    for b in range(2):   # two unrelated matrices ahead of them in the same call (no y row)
+        eng.kmatrix('sexp', X[b], None, G, [0.5], 1e-4, out=A[b], full=False)
+    logdet, info2 = eng.potrf(n, A, batch=B + 2)
+    ll = torch.cat([eng.loglik_finish(n, A[b + 2], logdet[b + 2:b + 3], 1.7) for b in range(B)])
+    eng.sync()
+    assert not npy(info).any() and not npy(info2).any()
+    assert np.array_equal(npy(ll), npy(ll_ref))

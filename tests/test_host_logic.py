@@ -373,3 +373,45 @@ def test_lost_handoff_is_not_a_numerical_failure():
     with pytest.raises(DgpAmdError):
         raise_not_pd(-1)
     assert not issubclass(DgpAmdError, np.linalg.LinAlgError)
+
+
+def test_llik_finish_scalar_path_is_bit_identical():
+    """kernel._llik_finish has a python-float path for the common case (no replicates, gamma / inverse-gamma or no prior, one
+    or two parameters) that must reproduce the general numpy path bit for bit -- both feed L-BFGS-B, whose iterates the
+    lock-step M-step promises to leave unchanged."""
+    import inspect
+    import textwrap
+    import types
+    from dgp_amd import kernel_class as kc
+    src = textwrap.dedent(inspect.getsource(kc.kernel._llik_finish))
+    general = src.replace("if self.rep is None and self.prior_name in (None, 'ga', 'inv_ga') and P <= 2:", "if False:")
+    assert general != src
+    ns = {}
+    exec("import numpy as np, math\n" + general, ns)
+    rng = np.random.default_rng(3)
+
+    class Node:
+        pass
+    for trial in range(600):
+        a = Node()
+        a.output = np.zeros((int(rng.integers(5, 3000)), 1))
+        a.rep = None
+        a.prior_name = [None, 'ga', 'inv_ga'][trial % 3]
+        a.prior_coef = rng.uniform(0.5, 3, size=2)
+        a.scale_est = bool(trial % 2)
+        a.scale = np.array([rng.uniform(0.1, 5)])
+        a.nugget_est = bool((trial // 2) % 2)
+        a.length = np.array([rng.uniform(0.1, 5)])
+        a.nugget = np.array([rng.uniform(1e-8, 1e-2)])
+        a._raise_if_not_pd = lambda v: None
+        b = Node()
+        b.__dict__.update({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in a.__dict__.items()})
+        for o in (a, b):
+            for nm in ('log_prior', 'log_prior_fod', 'gfod'):
+                setattr(o, nm, types.MethodType(getattr(kc.kernel, nm), o))
+        P = 1 + int(a.nugget_est)
+        host = np.concatenate(([rng.normal() * 100, rng.uniform(1, 5000)], rng.normal(size=2 * P) * 50, [0.0]))
+        fa, ga = kc.kernel._llik_finish(a, host)
+        fb, gb = ns['_llik_finish'](b, host)
+        assert np.array_equal(np.ravel(fa), np.ravel(fb)) and np.array_equal(np.ravel(ga), np.ravel(gb))
+        assert np.array_equal(np.ravel(a.scale), np.ravel(b.scale))
