@@ -104,7 +104,7 @@ def cpu_baseline(model, counts, ess_burn):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=120)   # ~5.5 s of timed region: long enough for the driver's SMI sampler
+    ap.add_argument('--steps', type=int, default=150)   # ~5.5 s of timed region: long enough for the driver's SMI sampler
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--n', type=int, default=2000)
     ap.add_argument('--d', type=int, default=5)
