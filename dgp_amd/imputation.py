@@ -304,7 +304,7 @@ class imputer:
             return 0, None
         if self._ll_cache.get(0) is None:   # the first threshold's log-likelihood: factored together with the prior's matrices
             self._want_ll0 = list(enumerate(upper))
-        nu = self._prior_draws_ahead(sweeps)   # (sweeps, n, M)
+        nu = self._prior_draws_ahead(sweeps, prefetch=False)   # (sweeps, n, M); the next call's normals are started below
         self.__dict__.pop('_want_ll0', None)
         if nu is None:
             return 0, None
@@ -328,6 +328,8 @@ class imputer:
             us = self.draws.uniform_peek((sweeps - first) * per)
             cur = self._ll_cache.get(0)
             plan.queue(F, nu[first:], scales, us, 0, cur, cur is None, self.batch_next, self.queue_max_batches)
+            if first == 0:   # the next call's normals: generated by a background thread while this one waits in fetch()
+                self.draws.prefetch(sweeps * M * n)   # (started only now: it would fight the launches above for the interpreter)
             st = plan.fetch()   # the one synchronisation of the queue (of the whole I-step unless an update was left open)
             status, done = int(st['status']), int(st['updates'])
             self.draws.uniform_take(int(st['cursor']))
@@ -393,7 +395,7 @@ class imputer:
             self._factor_cache[l] = (sigs, buf)
         return self._factor_cache[l][1]
 
-    def _prior_draws_ahead(self, sweeps):
+    def _prior_draws_ahead(self, sweeps, prefetch=True):
         """Layer 0's prior draws for all `sweeps` sweeps of a sample() call at once: its factors depend only on X and
         the hyper-parameters, so the normals of every sweep are uploaded in one copy and the triangular products are
         queued back to back.  Consumes the normal stream in the order the sequential loop would as long as layer 0 is
@@ -419,7 +421,8 @@ class imputer:
             else:
                 Z = np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)])
             xs = self._vecchia_draws(0, list(range(M)), e.tensor(np.ascontiguousarray(Z.transpose(1, 0, 2))))   # (M, sweeps, n)
-            self.draws.prefetch(sweeps * M * n)
+            if prefetch:
+                self.draws.prefetch(sweeps * M * n)
             return xs.permute(1, 2, 0).contiguous()
         buf = self._layer_factors(0, list(range(M)))
         if self.draws._z is None:
@@ -431,7 +434,8 @@ class imputer:
         out = e.empty(sweeps, M, n)
         for s_ in range(sweeps):
             e.trmv_lower(n, buf, scales, Zd[s_], batch=M, out=out[s_])
-        self.draws.prefetch(sweeps * M * n)   # the next call's normals, generated while the device works
+        if prefetch:
+            self.draws.prefetch(sweeps * M * n)   # the next call's normals, generated while the device works
         return out.transpose(1, 2).contiguous()
 
     def _prior_draw(self, l, cols=None):
