@@ -676,3 +676,29 @@ def test_loglik_finish_matches_loglik(eng):
     eng.sync()
     assert not npy(info).any() and not npy(info2).any()
     assert np.array_equal(npy(ll), npy(ll_ref))
+
+
+@pytest.mark.gpu
+def test_one_launch_factorisation_random_shapes_repeatable(eng):
+    """Random sizes / batch sizes / with and without the inverse through the one-launch kernel, several launches each on the
+    same buffers: info == 0 and a bitwise identical log-determinant every time (a stale tile read or a lost hand-off between
+    the kernel's workgroups would show here); the short version of tools/gpu_mega_stress.py."""
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        n = int(rng.choice([64, 65, 130, 333, 640, 1000, 1280]))
+        B = int(rng.choice([1, 2, 3, 5, 6, 8, 12, 16]))
+        inv = bool(rng.integers(2))
+        Np = eng.padded_dim(n)
+        X = eng.tensor(rng.uniform(size=(B, n, 3)))
+        y = eng.tensor(rng.normal(size=n))
+        A, T, S = eng.empty(B, Np, Np), eng.empty(B, Np, Np), eng.empty(B, Np, Np)
+        work = eng.potrf_workspace(n, B)
+        ref = None
+        for rep in range(4):
+            eng.kmatrix('matern2.5', X, None, None, [0.6], 1e-5, out=A, full=False, Y=y, batch=B)
+            ld, info = eng.potrf_inv(n, A, T, S, batch=B, work=work) if inv else eng.potrf(n, A, batch=B, work=work)
+            ldh, ih = eng.fetch(ld), eng.fetch(info)
+            assert not ih.any(), (n, B, inv, ih)
+            if ref is None:
+                ref = ldh.copy()
+            assert np.array_equal(ldh, ref), (n, B, inv, rep)
