@@ -20,8 +20,6 @@ Randomness: one numpy Generator for fmvn's normals and one for the uniforms (the
 reference also uses two streams: numba's for randn, numpy's global for uniform);
 both can be injected for deterministic replay.
 """
-import os
-
 import numpy as np
 from numpy.linalg import LinAlgError
 from .ops import raise_not_pd
@@ -161,7 +159,7 @@ class imputer:
         st['_engine'] = None
         st['_factor_cache'] = {}
         st['_ess_plans'] = {}
-        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev'):   # device state: rebuilt by the next sample()
+        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_adopt', '_adopt_ll'):   # device state: rebuilt by the next sample()
             st.pop(key, None)
         return st
 
@@ -188,6 +186,8 @@ class imputer:
             cols = [np.asarray(nd.output, dtype=float).reshape(-1) for nd in self.all_layer[l]]
             host = np.stack(cols, 1)
             keep = old is not None and l < len(old) and l in Fh and Fh[l].shape == host.shape and np.array_equal(Fh[l], host)
+            if not keep:
+                self.__dict__.pop('_adopt_ll', None)   # (the latents are not the ones the M-step saw)
             F.append(old[l] if keep else self.engine.tensor(host))
         self.F = F
         self._Fh = {}
@@ -220,12 +220,69 @@ class imputer:
                 else:
                     nd.input = Fh[:, nd.input_dim]
 
+    def adopt_from_mstep(self, nd, Aslot, host):
+        """Called by the lock-step M-step when a node's optimiser has ended, with the factored buffer and the host results of
+        its last evaluation -- which is at the node's final hyper-parameters.  For a dense first-layer node that factor IS
+        the prior factor the next I-step draws with (K depends on the fixed inputs and the hyper-parameters only): it is
+        copied into the factor cache (33 MB on the device) instead of being recomputed.  For a node of the last layer of a
+        two-layer model, -0.5 (n log s + logdet + y'K^-1y / s) is the log-likelihood of the current latents under the new
+        hyper-parameters: the base of the next I-step's first slice threshold.  Both save the I-step its opening
+        factorisation launch."""
+        if nd.type != 'gp' or nd.vecch or nd.rep is not None or self.__dict__.get('F') is None:
+            return
+        L = len(self.all_layer)
+        for l, layer in enumerate(self.all_layer):
+            for k, cand in enumerate(layer):
+                if cand is not nd:
+                    continue
+                e = self.engine
+                n = len(nd.output)
+                if l == 0:
+                    M = len(layer)
+                    Np = e.padded_dim(n)
+                    st = self.__dict__.setdefault('_adopt', {})
+                    buf = st.get('buf')
+                    if buf is None or buf.shape[0] < M or tuple(buf.shape[1:]) != (Np, Np):
+                        hit = self._factor_cache.get(0)
+                        ok = hit is not None and hit[1].shape[0] >= M and tuple(hit[1].shape[1:]) == (Np, Np)
+                        buf = hit[1] if ok else e.empty(M, Np, Np)
+                        st.clear()
+                        st['buf'] = buf
+                        self._factor_cache.pop(0, None)   # (its buffer is being rewritten)
+                    buf[k].copy_(Aslot)
+                    st[k] = (k, nd.name, tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), id(nd.input))
+                    if all(j in st for j in range(M)):
+                        self._factor_cache[0] = (tuple(st[j] for j in range(M)), buf)
+                elif l == L - 1 and L == 2 and nd.prior_name != 'ref':
+                    s_ = float(nd.scale[0])
+                    ll = -0.5 * (n * float(np.log(s_)) + float(host[0]) + float(host[1]) / s_)
+                    sig = (tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), s_)
+                    self.__dict__.setdefault('_adopt_ll', {})[k] = (ll, sig)
+                return
+
+    def _adopted_ll0(self):
+        """Sum of the upper nodes' log-likelihoods handed over by the M-step, if it is still valid (same latents -- _attach
+        drops it when they were re-uploaded -- and same hyper-parameters); used once."""
+        got = self.__dict__.pop('_adopt_ll', None)
+        upper = self.all_layer[1]
+        if not got or len(got) != len(upper):
+            return None
+        tot = 0.0
+        for k, nd in enumerate(upper):
+            ll, sig = got[k]
+            if sig != (tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), float(nd.scale[0])):
+                return None
+            tot += ll
+        return tot
+
     def stage_for_mstep(self):
         """Device views of every dense GP node's (input, global input, output) in the state the last sample() left --
         what kernel._stage() would upload from the numpy attributes _detach has just written, without the round trip
         through the host (24 small uploads per M-step at the bench shape).  {id(node): dict}; nodes with replicates,
         Vecchia nodes and likelihood nodes are left to their own staging."""
         out = {}
+        self.__dict__.pop('_adopt', None)
+        self.__dict__.pop('_adopt_ll', None)
         if not self.__dict__.get('_Fh') or self.__dict__.get('F') is None:   # (no sample() yet, or state dropped by pickling)
             return out
         L = len(self.all_layer)
@@ -302,7 +359,11 @@ class imputer:
         layer, upper = self.all_layer[0], self.all_layer[1]
         if any(nd.type != 'gp' or nd.vecch for nd in layer) or any(nd.type != 'gp' or nd.vecch or nd.prior_name == 'ref' for nd in upper):
             return 0, None
-        if self._ll_cache.get(0) is None:   # the first threshold's log-likelihood: factored together with the prior's matrices
+        if self._ll_cache.get(0) is None:   # the first threshold's log-likelihood: handed over by the M-step if it can be ...
+            v = self._adopted_ll0()
+            if v is not None:
+                self._ll_cache[0] = v
+        if self._ll_cache.get(0) is None:   # ... else factored together with the prior's matrices
             self._want_ll0 = list(enumerate(upper))
         nu = self._prior_draws_ahead(sweeps, prefetch=False)   # (sweeps, n, M); the next call's normals are started below
         self.__dict__.pop('_want_ll0', None)

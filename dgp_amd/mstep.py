@@ -73,15 +73,21 @@ class _Problem:
                 return False
 
 
-def minimize_lockstep(problems, evaluate):
+def minimize_lockstep(problems, evaluate, on_finish=None):
     """Run several independent L-BFGS-B minimisations in lock-step from ONE thread: every round, all runs that want an
     objective value get it from one call evaluate([(index, x), ...]) -> [(f, g), ...].  Each run sees exactly the
     sequence of points scipy.optimize.minimize(method='L-BFGS-B') would give it (same core, same options)."""
     if not _HAVE_CORE:
         raise RuntimeError('scipy L-BFGS-B core not available')
     rounds = 0
+    told = set()
     while True:
         want = [i for i, p in enumerate(problems) if not p.finished and p.advance()]
+        if on_finish is not None:   # (before the next round's launches reuse the buffers of the runs that have just ended)
+            for i, p in enumerate(problems):
+                if p.finished and i not in told:
+                    told.add(i)
+                    on_finish(i)
         if not want:
             return rounds
         out = evaluate([(i, problems[i].x.copy()) for i in want])
@@ -127,14 +133,26 @@ def maximise_lockstep(engine, nodes, cache):
         host = {}
         for n, lst in todo.items():   # (inside the engine's stream context entered once below, not once per round)
             res = plans[n].run([pos for pos, _ in lst])
-            for pos, i in lst:
+            for r, (pos, i) in enumerate(lst):
                 host[i] = res[pos]
+                last[i] = (n, r, res[pos])   # where this node's factor is now: row r of the run's buffers
         evals[0] += len(req)
         return [nodes[i]._llik_finish(host[i]) for i, _ in req]
 
+    last = {}
+    imp = getattr(cache, 'imp', None)
+
+    def on_finish(i):
+        # The reference keeps the hyper-parameters of the LAST evaluation (kernel_class.py:516-579 discards minimize's
+        # result; llik() has updated the node), so the factorisation of that evaluation is the one the next I-step needs:
+        # the prior factor of a first-layer node, the log-likelihood of the current latents for a node of the last layer.
+        if imp is not None and i in last and hasattr(imp, 'adopt_from_mstep'):
+            n, r, host = last[i]
+            imp.adopt_from_mstep(nodes[i], plans[n].factor_view(r), host)
+
     try:
         with engine.stream():
-            rounds = minimize_lockstep(problems, evaluate)
+            rounds = minimize_lockstep(problems, evaluate, on_finish)
     finally:
         for nd in nodes:
             nd._in_maximise = False

@@ -562,6 +562,12 @@ class _LlikPlan:
         self.lengths[b][:] = length
         self.nodes[b].nugget = float(nugget)
 
+    def factor_view(self, r):
+        """The augmented buffer of row r of the LAST run() as an (Np, Np) float64 tensor: after the sweep its lower tiles
+        hold the Cholesky factor of that node's K (rows < n), exactly what dgpamd_potrf leaves."""
+        Np = self.e.padded_dim(self.n)
+        return self.A[r * self.stride_a * 8:(r + 1) * self.stride_a * 8].view(torch.float64).view(Np, Np)
+
     def run(self, idx):
         """Evaluate the nodes listed in idx (positions in the plan); returns {position: host vector
         [logdet, y'K^-1y, tr.., quad.., info]} in kernel._llik_device's layout."""
