@@ -454,8 +454,16 @@ class dgp:
                 self.last_mstep = mstep.maximise_lockstep(eng, dense, self)
             else:
                 self.last_mstep = None
+            # Vecchia nodes whose optimiser needs no callback: lock-step as well (one synchronisation per round, not one per
+            # node and evaluation)
+            vlock = [nd for _, nd in nodes if nd.vecch and mstep._HAVE_CORE and not ddist.rows_split()
+                     and not (nd.target == 'gp' and len(nd.length) != 1)]
+            if len(vlock) > 1:
+                mstep.maximise_lockstep_vecch(eng, vlock)
+            else:
+                vlock = []
             for _, nd in nodes:
-                if not any(nd is d for d in dense):
+                if not any(nd is d for d in dense) and not any(nd is d for d in vlock):
                     nd.maximise()
             if ddist.nodes_split():
                 # one all-gather per M-step: (scale, lengthscales, nugget) of the nodes every rank has fitted

@@ -384,16 +384,30 @@ class kernel:
         """kernel_class.py:451-479 -> vecchia_nllik (vecchia.py:182-242); the closing scale_est /
         replicate algebra (vecchia.py:224-241) runs here on the reduced sums."""
         self.update(x)
-        e, s = self.engine, self._vecch_stage()
+        o, P = self._llik_vecch_device()
+        o = ddist.allreduce_sum_vector(o).cpu().numpy() if ddist.rows_split() else o.cpu().numpy()
+        return self._llik_vecch_finish(o, P)
+
+    def _llik_vecch_device(self):
+        """The device part of llik_vecch at the node's current hyper-parameters: (sums on the device, P), no synchronisation
+        (the lock-step M-step queues several nodes' evaluations before it fetches them all)."""
+        e = self.engine
+        s = self.__dict__.get('_vecch_fixed') if getattr(self, '_in_maximise', False) else None   # (staged once per optimiser run)
+        if s is None:
+            s = self._vecch_stage()
+        if self.rep is not None:
+            s = dict(s)
+            s['nd'] = e.tensor(self.W_diag[self.ord])
+        lo, hi = ddist.vecchia_rows(s['NN'].shape[0])
+        return e.vecchia_nllik(self.name, s['X'], s['y'], s['NN'][lo:hi], self.length, self.nugget[0], s['nd'], self.nugget_est)
+
+    def _llik_vecch_finish(self, o, P):
+        """The closing scale_est / replicate algebra of llik_vecch (vecchia.py:224-241) on the reduced sums (host)."""
         n = len(self.output)
         if self.rep is None:
             origin_n, rr = n, -1.0
         else:
             origin_n, rr = len(self.rep), float(self.sum_residual[0])
-            s['nd'] = e.tensor(self.W_diag[self.ord])
-        lo, hi = ddist.vecchia_rows(s['NN'].shape[0])
-        o, P = e.vecchia_nllik(self.name, s['X'], s['y'], s['NN'][lo:hi], self.length, self.nugget[0], s['nd'], self.nugget_est)
-        o = ddist.allreduce_sum_vector(o).cpu().numpy() if ddist.rows_split() else o.cpu().numpy()
         quad, logdet, dquad, dlogdet = o[0], o[1], o[2:2 + P].copy(), o[2 + P:].copy()
         nug = self.nugget[0]
         if self.scale_est:

@@ -1208,6 +1208,43 @@ def test_lockstep_mstep_equals_per_node_maximise(eng):
             assert np.array_equal(na.length, nb.length) and np.array_equal(na.scale, nb.scale) and np.array_equal(na.nugget, nb.nugget)
 
 
+def test_lockstep_vecchia_mstep_equals_per_node_maximise(eng):
+    """The Vecchia nodes of a layer are fitted in lock-step too (dgp_amd.mstep.maximise_lockstep_vecch: every round's
+    vecchia_nllik evaluations queued back to back, one fetch); kernel.maximise() fits one node at a time like the
+    reference (kernel_class.py:516-579 with llik_vecch).  Same para_path rows and hyper-parameters, bit for bit."""
+    from dgp_amd import dgp, kernel, combine
+    rng = np.random.default_rng(21)
+    n, d = 500, 3
+    X = rng.uniform(size=(n, d))
+    f = np.sin(4 * X[:, 0]) * np.cos(3 * X[:, 1]) + 0.5 * X[:, 2]
+    Y = ((f - f.mean()) / f.std())[:, None]
+
+    def build():
+        np.random.seed(9)
+        layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                         [kernel(length=np.array([1.0]), name='sexp', scale_est=True, nugget_est=True, connect=np.arange(d))])
+        m = dgp(X, Y, layers, vecchia=True, m=12, seed=4)
+        m.imp.sample(burnin=2)
+        return m
+
+    a, b = build(), build()
+    for la, lb in zip(a.all_layer, b.all_layer):
+        for na, nb in zip(la, lb):
+            assert np.array_equal(na.output, nb.output) and np.array_equal(na.input, nb.input)
+    a._m_step()                                   # lock-step over the Vecchia nodes of each layer
+    for l, layer in enumerate(b.all_layer):       # one node after another
+        for nd in layer:
+            nd.engine = b.engine
+            if l != 0:
+                nd.r2()
+            nd.maximise()
+    for la, lb in zip(a.all_layer, b.all_layer):
+        for na, nb in zip(la, lb):
+            assert na.para_path.shape[0] == 2
+            assert np.array_equal(na.para_path, nb.para_path), (na.para_path[-1], nb.para_path[-1])
+            assert np.array_equal(na.length, nb.length) and np.array_equal(na.scale, nb.scale) and np.array_equal(na.nugget, nb.nugget)
+
+
 def test_one_si_iteration_at_bench_size_vs_oracle(eng):
     """ONE stochastic-imputation iteration of BASELINE's configs[1] (n = 2000, d = 5, 5 + 1 Matern-2.5 nodes) against
     the oracle with injected draws: the I-step's block update (prior draws through five n x n factors, the speculative

@@ -70,8 +70,17 @@ elif which == 'cfg4train':
     t = time.perf_counter(); model = dgp(X, Y, vecchia=True, m=m, seed=1); sync()
     print('cfg4train n=%d: construct (warm start + NN + 11 sweeps) %.1f s' % (n, time.perf_counter() - t), flush=True)
     its = int(os.environ.get('ITERS', '3'))
+    spent, inner = [0.0], model._m_step
+
+    def timed_m_step(*a, **k):
+        sync(); t0 = time.perf_counter()
+        r = inner(*a, **k)
+        sync(); spent[0] += time.perf_counter() - t0
+        return r
+    model._m_step = timed_m_step
     t = time.perf_counter(); model.train(N=its, ess_burn=10, disable=True); sync(); dt = time.perf_counter() - t
-    print('cfg4train: %d SI iterations %.1f s -> %.3f it/s; stats %s' % (its, dt, its / dt, model.imp.stats), flush=True)
+    print('cfg4train: %d SI iterations %.1f s -> %.3f it/s (M-steps %.0f ms each, the rest %.0f ms); stats %s'
+          % (its, dt, its / dt, 1e3 * spent[0] / its, 1e3 * (dt - spent[0]) / its, model.imp.stats), flush=True)
     t = time.perf_counter(); emu = emulator(model.estimate(burnin=0), N=2, seed=3); sync()
     print('cfg4train: emulator(N=2) %.1f s' % (time.perf_counter() - t), flush=True)
     xt = rng.uniform(size=(2000, d))
