@@ -9,6 +9,7 @@
 #include "linkfun.hpp"
 
 #include <math.h>
+#include <utility>
 
 #define VW 64   // threads per item (one wave)
 
@@ -423,8 +424,9 @@ struct VRowArgs {
     const double *X, *y, *nugget_diag;
     const int64_t *NN;
     int nugget_est, P;
-    double *partial;  // [n][2 + 2P] (LLIK: [n][2])
+    double *partial;  // [batch][n][2 + 2P] (LLIK: [batch][n][2])
     double *Lmat;     // [n][m+1]
+    int64_t x_stride; // doubles between the input sets of a batch (blockIdx.y); LLIK only
 };
 
 // gather the row's conditioning block (ascending index, self last) into LDS; returns its size
@@ -532,17 +534,333 @@ __global__ __launch_bounds__(VW) void vecchia_row_kernel(VRowArgs a) {
     }
 }
 
-// deterministic column sums of partial[n][w] -> out[w]
-__global__ __launch_bounds__(256) void colsum_kernel(const double *partial, int64_t n, int w, double *out) {
-    __shared__ double sm[4];
+// ---------------------------------------------------------------------------
+// The same three per-row computations for conditioning sets of at most 31 points (m <= 30: the default m = 25), held in
+// REGISTERS: FOUR rows of the likelihood per wave, one 16-lane DPP row each.  Lane t of a group owns rows t and 16 + t of
+// the (m+2) x (m+1) block (the right-hand side rides as row m+1).  Column j of the factor is normalised in place and
+// every trailing entry takes  a[r][c] -= l[r] * l[c]  in ONE v_fmac_f64_dpp whose first operand is read from lane
+// c mod 16 of the group (row_newbcast) -- no LDS round trips, no shuffles and no barriers inside the factorisation.
+// (The LDS version above spends its time on three barriers and a dependent LDS read-modify-write chain per column with
+// 40 % of the lanes idle; a version with 32-wide ds_bpermute shuffles was bound by the LDS pipe: 2.9x slower than this.)
+// The block itself is assembled with its m(m+1)/2 entries spread evenly over the group and handed over through LDS
+// once.  Sets shorter than the compiled size (the first m rows; sizes between the compiled ones) are padded IN FRONT
+// with identity rows, so that "self" is always the last slot and the loop bounds are compile-time constants.
+// ---------------------------------------------------------------------------
+#define VR_MAXB 31
+
+__device__ __forceinline__ void tri_decode_small(int t, int &r, int &c) {   // t < 2^16: float is plenty
+    int b = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((b + 1) * (b + 2) / 2 <= t) ++b;
+    while (b * (b + 1) / 2 > t) --b;
+    r = b;
+    c = t - b * (b + 1) / 2;
+}
+
+__device__ __forceinline__ double hsum16(double v) {   // sum over the 16 lanes of a group, in every lane of it
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+    return v;
+}
+
+// 1/sqrt(d) and sqrt(d): hardware estimate + two Newton rounds + one correction of the root (a few ulp)
+__device__ __forceinline__ void rsqrt_sqrt(double d, double &inv, double &sd) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    double e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    double r = d * y;
+    r = fma(0.5 * y, fma(-r, r, d), r);
+    inv = y;
+    sd = r;
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// value of lane C of the caller's 16-lane group (s_nop 1: a DPP source written by the previous VALU needs two wait states)
+template <int C>
+__device__ __forceinline__ double group_bcast(const double &v) {
+    double out;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(v), "i"(C));
+    return out;
+}
+// acc += (lane C's src) * mul
+template <int C>
+__device__ __forceinline__ void fmac_bcast(double &acc, const double &src, const double &mul) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "i"(C));
+}
+
+static size_t vrow4_lds(int BS, int D, bool grad) {
+    const size_t asz = (size_t)(BS + 1) * (BS + 2) / 2 + (grad ? (size_t)BS * (BS - 1) / 2 : 0);
+    return 4 * (asz + (size_t)BS * D + 2 * 32) * sizeof(double);
+}
+
+template <int KIND, int MODE, int BS>
+__global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
+    extern __shared__ double lds[];
+    constexpr int rows = BS + 1;                      // block rows, then the right-hand side as row BS
+    constexpr int T2 = BS * (BS - 1) / 2;
+    constexpr int asz = rows * (rows + 1) / 2 + (MODE == V_NLLIK ? T2 : 0);
+    constexpr int NBB = BS > 16 ? BS : 16;            // columns kept for the second row of a lane
+#define AT(r, c) ((r) * ((r) + 1) / 2 + (c))
+    const int mp1 = a.m + 1, D = a.vp.D;
+    const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
+    double *A = lds + (size_t)g * asz;                                   // packed lower triangle (+ K itself for the gradient)
+    double *Kp = A + rows * (rows + 1) / 2;
+    double *xs = lds + (size_t)4 * asz + (size_t)g * BS * D;             // [BS][D] scaled inputs
+    double *V = lds + (size_t)4 * asz + (size_t)4 * BS * D + (size_t)g * 64;   // [2][32] u, alpha
+    const int64_t i = (int64_t)blockIdx.x * 4 + g;
+    const bool live = i < a.n;
+    const double *X = a.X + (MODE == V_LLIK ? (int64_t)blockIdx.y * a.x_stride : 0);
+    double *partial = a.partial;
+    if (MODE == V_LLIK) partial += (int64_t)blockIdx.y * a.n * 2;
+
+    // conditioning set: the valid entries of the row come first; slot R <- entry b-1-(R-pad)  (ascending, self last).
+    // One load of the row, the reversal by shuffle; then every slot fetches its own point (inputs, output, nugget
+    // weight) with all loads in flight together: two memory latencies in all before the arithmetic starts.
+    const int nn0 = (live && t < mp1) ? (int)a.NN[i * mp1 + t] : -1;
+    const int nn1 = (live && 16 + t < mp1) ? (int)a.NN[i * mp1 + 16 + t] : -1;
+    const unsigned m0 = (unsigned)(__ballot(nn0 >= 0) >> (16 * g)) & 0xffffu, m1 = (unsigned)(__ballot(nn1 >= 0) >> (16 * g)) & 0xffffu;
+    const int b = __popc(m0) + __popc(m1);
+    const int pad = BS - b;
+    int my[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int R = 16 * h + t, src = b - 1 - (R - pad);
+        const int g0 = __shfl(nn0, src & 15, 16), g1 = __shfl(nn1, src & 15, 16);
+        my[h] = (R >= pad && R < BS) ? ((src & 16) ? g1 : g0) : -1;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int R = 16 * h + t;
+        double yv = 0.0, ndv = 1.0;
+        if (MODE != V_LMAT && my[h] >= 0) {
+            yv = a.y[my[h]];
+            ndv = a.nugget_diag[my[h]];
+        }
+        const double *xrow = X + (int64_t)(my[h] >= 0 ? my[h] : 0) * D;
+        for (int d0 = 0; d0 < D; d0 += 8) {
+            double x8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x8[q] = (my[h] >= 0 && d0 + q < D) ? xrow[d0 + q] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (R < BS && d0 + q < D) xs[R * D + d0 + q] = x8[q] * a.vp.inv_len[d0 + q];
+        }
+        if (R < BS) {
+            A[AT(R, R)] = my[h] >= 0 ? 1.0 + a.vp.nugget * ndv : 1.0;
+            if (MODE != V_LMAT) A[AT(BS, R)] = yv;
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < T2; e += 16) {
+        int r, c;
+        tri_decode_small(e, r, c);
+        ++r;   // strictly lower: (r, c), r > c; pads come first
+        const double v = c >= pad ? corr_pts<KIND>(xs + r * D, xs + c * D, D) : 0.0;
+        A[AT(r, c)] = v;
+        if (MODE == V_NLLIK) Kp[e] = v;   // the correlation itself, kept for the derivative sums
+    }
+    __syncthreads();
+
+    double ra[16], rb[NBB];   // rows t and 16 + t
+#pragma unroll
+    for (int c = 0; c < 16; ++c) ra[c] = (c <= t && c < BS && t <= BS) ? A[AT(t, c)] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NBB; ++c) rb[c] = (c < BS && 16 + t <= BS && c <= 16 + t) ? A[AT(16 + t, c < BS ? c : 0)] : 0.0;
+
+    double sd_last = 1.0, w_last = 0.0;
+    static_for<BS>([&](auto J) {
+        constexpr int j = J;
+        double d = j < 16 ? group_bcast<(j & 15)>(ra[j & 15]) : group_bcast<(j & 15)>(rb[j < NBB ? j : 0]);
+        if (!(d > 0.0)) d = 1.0;
+        double inv, sd;
+        rsqrt_sqrt(d, inv, sd);
+        double la = 0.0, lb, nla = 0.0, nlb;
+        if constexpr (j < 16) {
+            la = ra[j] * inv;   // (lane j: d * inv = the diagonal of the factor)
+            ra[j] = la;
+            nla = -la;
+        }
+        lb = rb[j] * inv;
+        rb[j] = lb;
+        nlb = -lb;
+        asm volatile("s_nop 1" : "+v"(nla), "+v"(nlb));   // (DPP sources just written)
+        static_for<BS>([&](auto Cc) {
+            constexpr int c = Cc;
+            if constexpr (c > j) {
+                if constexpr (c < 16) {
+                    fmac_bcast<(c & 15)>(ra[c & 15], nla, la);
+                    if constexpr (BS >= 16) fmac_bcast<(c & 15)>(rb[c], nla, lb);
+                } else {
+                    fmac_bcast<(c & 15)>(rb[c], nlb, lb);
+                }
+            }
+        });
+        if constexpr (j == BS - 1) {
+            sd_last = sd;
+            w_last = BS < 16 ? la : lb;   // (in the right-hand-side row's lane: (L^-1 y)_last)
+        }
+    });
+    constexpr int WL = BS & 15;   // lane of the right-hand-side row BS (second row of the lane when BS >= 16)
+
+    if (MODE == V_LLIK) {
+        if (t == WL && live) {
+            partial[i * 2] = w_last * w_last;            // vecchia.py:177
+            partial[i * 2 + 1] = 2.0 * log(sd_last);     // vecchia.py:178
+        }
+        return;
+    }
+    // the factor (and w) back to LDS for the transposed solves
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (c <= t && c < BS && t <= BS) A[AT(t, c)] = ra[c];
+#pragma unroll
+    for (int c = 0; c < BS; ++c)
+        if (16 + t <= BS && c <= 16 + t) A[AT(16 + t, c)] = rb[c];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int R = 16 * h + t;
+        if (R < BS) {
+            V[R] = (R == BS - 1) ? 1.0 : 0.0;
+            if (MODE == V_NLLIK) V[32 + R] = A[AT(BS, R)];
+        }
+    }
+    // x <- L^-T x, column-oriented; pads decouple (identity rows in front)
+    for (int c = BS - 1; c >= 0; --c) {
+        __syncthreads();
+        if (t < (MODE == V_NLLIK ? 2 : 1)) V[t * 32 + c] /= A[AT(c, c)];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int R = 16 * h + t;
+            if (R < c) {
+                const double lcr = A[AT(c, R)];
+                V[R] = fma(-lcr, V[c], V[R]);
+                if (MODE == V_NLLIK) V[32 + R] = fma(-lcr, V[32 + c], V[32 + R]);
+            }
+        }
+    }
+    __syncthreads();
+    if (MODE == V_LMAT) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int R = 16 * h + t;
+            if (R < mp1 && live) a.Lmat[i * mp1 + R] = V[BS - 1 - R];   // reversed, self first; pads give the trailing zeros
+        }
+        return;
+    }
+    // vecchia.py:216-219 restated: t_last = u^T dK u ; s = alpha^T dK u
+    const int P = a.P, npl = (a.vp.nlen == 1) ? 1 : D;
+    const double wl = __shfl(w_last, WL, 16);
+    double *out = partial + i * (2 + 2 * P);
+    if (t == 0 && live) {
+        out[0] = wl * wl;
+        out[1] = 2.0 * log(sd_last);
+    }
+    const double *u = V, *al = V + 32;
+    for (int k = 0; k < npl; ++k) {
+        double tl = 0.0, sm = 0.0;
+        for (int e = t; e < T2; e += 16) {
+            int r, c;
+            tri_decode_small(e, r, c);
+            ++r;
+            const double kv = Kp[e];
+            double cf = 0.0;
+            if (a.vp.nlen == 1)
+                for (int d = 0; d < D; ++d) cf += dcoef_v<KIND>(xs[r * D + d] - xs[c * D + d]);
+            else
+                cf = dcoef_v<KIND>(xs[r * D + k] - xs[c * D + k]);
+            const double dk = cf * kv;
+            tl = fma(2.0 * dk, u[r] * u[c], tl);
+            sm = fma(dk, al[r] * u[c] + al[c] * u[r], sm);
+        }
+        tl = hsum16(tl);
+        sm = hsum16(sm);
+        if (t == 0 && live) {
+            out[2 + k] = 2.0 * sm * wl - tl * wl * wl;
+            out[2 + P + k] = tl;
+        }
+    }
+    if (a.nugget_est) {   // dK/dlog eta = diag(nugget * nugget_diag)   vecchia.py:329-332
+        double tl = 0.0, sm = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int R = 16 * h + t;
+            if (R < BS && my[h] >= 0) {
+                const double dk = a.vp.nugget * a.nugget_diag[my[h]];
+                tl = fma(dk, u[R] * u[R], tl);
+                sm = fma(dk, al[R] * u[R], sm);
+            }
+        }
+        tl = hsum16(tl);
+        sm = hsum16(sm);
+        if (t == 0 && live) {
+            out[2 + npl] = 2.0 * sm * wl - tl * wl * wl;
+            out[2 + P + npl] = tl;
+        }
+    }
+#undef AT
+}
+
+template <int KIND, int MODE, int BS>
+static int launch_vrow4_nb(dgpamd_ctx *ctx, VRowArgs &a, int batch) {
+    const size_t shm = vrow4_lds(BS, a.vp.D, MODE == V_NLLIK);
+    int rc = set_lds(ctx, (const void *)vecchia_row4_kernel<KIND, MODE, BS>, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((vecchia_row4_kernel<KIND, MODE, BS>), dim3((unsigned)((a.n + 3) / 4), (unsigned)batch), dim3(64), shm,
+                       ctx->stream, a);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+template <int KIND, int MODE>
+static int launch_vrow4(dgpamd_ctx *ctx, VRowArgs &a, int batch) {
+    const int nb = a.m + 1;   // compiled sizes: every fourth, and 26 (the default m = 25) exactly
+    if (nb <= 4) return launch_vrow4_nb<KIND, MODE, 4>(ctx, a, batch);
+    if (nb <= 8) return launch_vrow4_nb<KIND, MODE, 8>(ctx, a, batch);
+    if (nb <= 12) return launch_vrow4_nb<KIND, MODE, 12>(ctx, a, batch);
+    if (nb <= 16) return launch_vrow4_nb<KIND, MODE, 16>(ctx, a, batch);
+    if (nb <= 20) return launch_vrow4_nb<KIND, MODE, 20>(ctx, a, batch);
+    if (nb <= 24) return launch_vrow4_nb<KIND, MODE, 24>(ctx, a, batch);
+    if (nb <= 26) return launch_vrow4_nb<KIND, MODE, 26>(ctx, a, batch);
+    if (nb <= 28) return launch_vrow4_nb<KIND, MODE, 28>(ctx, a, batch);
+    return launch_vrow4_nb<KIND, MODE, VR_MAXB>(ctx, a, batch);
+}
+
+// deterministic column sums of partial[batch][n][w] -> out[batch][w]  (grid: w x batch)
+__global__ __launch_bounds__(1024) void colsum_kernel(const double *partial, int64_t n, int w, double *out) {
+    __shared__ double sm[16];
     const int c = blockIdx.x, tid = threadIdx.x;
-    double v = 0.0;
-    for (int64_t r = tid; r < n; r += 256) v += partial[r * w + c];
+    partial += (int64_t)blockIdx.y * n * w;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    int64_t r = tid;
+    for (; r + 3072 < n; r += 4096) {   // four loads in flight per thread
+        v0 += partial[r * w + c];
+        v1 += partial[(r + 1024) * w + c];
+        v2 += partial[(r + 2048) * w + c];
+        v3 += partial[(r + 3072) * w + c];
+    }
+    for (; r < n; r += 1024) v0 += partial[r * w + c];
+    double v = (v0 + v1) + (v2 + v3);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((tid & 63) == 0) sm[tid >> 6] = v;
     __syncthreads();
-    if (tid == 0) out[c] = sm[0] + sm[1] + sm[2] + sm[3];
+    if (tid == 0) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += sm[q];
+        out[(int64_t)blockIdx.y * w + c] = t;
+    }
 }
 
 static size_t vrow_lds(int m, int D) {
@@ -551,16 +869,24 @@ static size_t vrow_lds(int m, int D) {
 }
 
 template <int MODE>
-static int launch_vrow(dgpamd_ctx *ctx, VRowArgs &a) {
+static int launch_vrow(dgpamd_ctx *ctx, VRowArgs &a, int batch = 1) {
+    const char *env = getenv("DGPAMD_VECCHIA_LDS");   // (1: the LDS version for every size -- the tests compare the two)
+    if (a.m + 1 <= VR_MAXB && !(env && atoi(env)))   // register-resident factorisation, two rows per wave
+        return a.vp.kind == DGPAMD_SEXP ? launch_vrow4<DGPAMD_SEXP, MODE>(ctx, a, batch) : launch_vrow4<DGPAMD_MATERN25, MODE>(ctx, a, batch);
     const size_t shm = vrow_lds(a.m, a.vp.D);
     const void *fn = a.vp.kind == DGPAMD_SEXP ? (const void *)vecchia_row_kernel<DGPAMD_SEXP, MODE>
                                               : (const void *)vecchia_row_kernel<DGPAMD_MATERN25, MODE>;
     int rc = set_lds(ctx, fn, shm);
     if (rc) return rc;
-    if (a.vp.kind == DGPAMD_SEXP)
-        hipLaunchKernelGGL((vecchia_row_kernel<DGPAMD_SEXP, MODE>), dim3((unsigned)a.n), dim3(VW), shm, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((vecchia_row_kernel<DGPAMD_MATERN25, MODE>), dim3((unsigned)a.n), dim3(VW), shm, ctx->stream, a);
+    VRowArgs one = a;
+    for (int bb = 0; bb < batch; ++bb) {   // (LDS version: one launch per input set)
+        if (a.vp.kind == DGPAMD_SEXP)
+            hipLaunchKernelGGL((vecchia_row_kernel<DGPAMD_SEXP, MODE>), dim3((unsigned)a.n), dim3(VW), shm, ctx->stream, one);
+        else
+            hipLaunchKernelGGL((vecchia_row_kernel<DGPAMD_MATERN25, MODE>), dim3((unsigned)a.n), dim3(VW), shm, ctx->stream, one);
+        one.X += a.x_stride;
+        one.partial += a.n * 2;
+    }
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }
@@ -572,24 +898,31 @@ static int with_partials(dgpamd_ctx *ctx, size_t bytes, double **p) {
     return DGPAMD_OK;
 }
 
-extern "C" int dgpamd_vecchia_llik(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, const double *y,
-                                   const int64_t *NNarray, const double *length_h, int nlen, double nugget,
-                                   const double *nugget_diag, double *out_llik) {
+extern "C" int dgpamd_vecchia_llik_batch(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, int64_t x_stride,
+                                         int batch, const double *y, const int64_t *NNarray, const double *length_h, int nlen,
+                                         double nugget, const double *nugget_diag, double *out_llik) {
     if (!ctx) return DGPAMD_BAD_ARG;
-    if (n <= 0 || m < 0 || !X || !y || !NNarray || !nugget_diag || !out_llik) BAD_ARG(ctx, "bad arguments");
+    if (n <= 0 || m < 0 || batch <= 0 || batch > 65535 || !X || !y || !NNarray || !nugget_diag || !out_llik)
+        BAD_ARG(ctx, "bad arguments");
     VRowArgs a;
     int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, nugget);
     if (rc) return rc;
     a.n = n; a.m = m; a.X = X; a.y = y; a.nugget_diag = nugget_diag; a.NN = NNarray; a.nugget_est = 0; a.P = 0;
-    a.Lmat = nullptr;
-    rc = with_partials(ctx, (size_t)n * 2 * sizeof(double), &a.partial);
+    a.Lmat = nullptr; a.x_stride = x_stride;
+    rc = with_partials(ctx, (size_t)batch * n * 2 * sizeof(double), &a.partial);
     if (rc) return rc;
-    rc = launch_vrow<V_LLIK>(ctx, a);
+    rc = launch_vrow<V_LLIK>(ctx, a, batch);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3(2), dim3(256), 0, ctx->stream, (const double *)a.partial, n, 2, out_llik);
+    hipLaunchKernelGGL(colsum_kernel, dim3(2, (unsigned)batch), dim3(1024), 0, ctx->stream, (const double *)a.partial, n, 2, out_llik);
     HIP_TRY(ctx, hipFreeAsync(a.partial, ctx->stream));
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_vecchia_llik(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, const double *y,
+                                   const int64_t *NNarray, const double *length_h, int nlen, double nugget,
+                                   const double *nugget_diag, double *out_llik) {
+    return dgpamd_vecchia_llik_batch(ctx, kind, n, D, m, X, 0, 1, y, NNarray, length_h, nlen, nugget, nugget_diag, out_llik);
 }
 
 extern "C" int dgpamd_vecchia_nllik(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X,
@@ -602,13 +935,13 @@ extern "C" int dgpamd_vecchia_nllik(dgpamd_ctx *ctx, int kind, int64_t n, int D,
     if (rc) return rc;
     a.n = n; a.m = m; a.X = X; a.y = y; a.nugget_diag = nugget_diag; a.NN = NNarray; a.nugget_est = nugget_est ? 1 : 0;
     a.P = (nlen == 1 ? 1 : D) + a.nugget_est;
-    a.Lmat = nullptr;
+    a.Lmat = nullptr; a.x_stride = 0;
     const int w = 2 + 2 * a.P;
     rc = with_partials(ctx, (size_t)n * w * sizeof(double), &a.partial);
     if (rc) return rc;
     rc = launch_vrow<V_NLLIK>(ctx, a);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3(w), dim3(256), 0, ctx->stream, (const double *)a.partial, n, w, out_nllik);
+    hipLaunchKernelGGL(colsum_kernel, dim3(w), dim3(1024), 0, ctx->stream, (const double *)a.partial, n, w, out_nllik);
     HIP_TRY(ctx, hipFreeAsync(a.partial, ctx->stream));
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
@@ -623,7 +956,7 @@ extern "C" int dgpamd_vecchia_lmatrix(dgpamd_ctx *ctx, int kind, int64_t n, int 
     int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, nugget);
     if (rc) return rc;
     a.n = n; a.m = m; a.X = X; a.y = nullptr; a.nugget_diag = nullptr; a.NN = NNarray; a.nugget_est = 0; a.P = 0;
-    a.partial = nullptr; a.Lmat = Lmat;
+    a.partial = nullptr; a.Lmat = Lmat; a.x_stride = 0;
     return launch_vrow<V_LMAT>(ctx, a);
 }
 

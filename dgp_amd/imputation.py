@@ -592,7 +592,7 @@ class imputer:
                 if self._glob[(l + 1, k)] is not None:
                     Xall = torch.cat((Xall, self._glob[(l + 1, k)].unsqueeze(0).expand(B, -1, -1)), 2)
                 Xall = Xall[:, od].contiguous()
-                o = torch.stack([e.vecchia_llik(nd.name, Xall[b], y, NN, nd.length, nd.nugget[0], nd_diag) for b in range(B)])
+                o = e.vecchia_llik_batch(nd.name, Xall, y, NN, nd.length, nd.nugget[0], nd_diag)
                 dev_terms.append(-0.5 * (o[:, 1] + o[:, 0] / float(nd.scale[0])))
                 if nd.prior_name == 'ref':
                     if FPh is None:

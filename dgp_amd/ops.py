@@ -440,6 +440,16 @@ class Engine:
                                           len(length), float(nugget), _dp(nugget_diag), _dp(out)))
         return out
 
+    def vecchia_llik_batch(self, kind, Xall, y, NN, length, nugget, nugget_diag):
+        """vecchia_llik for the B input sets Xall (B, n_points, D) at once: (B, 2) sums, one row launch + one reduction."""
+        B, D = Xall.shape[0], Xall.shape[2]
+        length = _f64(length)
+        out = self.empty(B, 2)
+        self._chk(self._enter() or lib.dgpamd_vecchia_llik_batch(self.h, KIND[kind], NN.shape[0], D, NN.shape[1] - 1, _dp(Xall),
+                                                                 Xall.stride(0), B, _dp(y), _dp(NN), _hp(length), len(length),
+                                                                 float(nugget), _dp(nugget_diag), _dp(out)))
+        return out
+
     def vecchia_nllik(self, kind, X, y, NN, length, nugget, nugget_diag, nugget_est):
         n, D = NN.shape[0], X.shape[1]   # (rows of NN: possibly one rank's block, see vecchia_llik)
         length = _f64(length)

@@ -336,6 +336,12 @@ int dgpamd_nn_query(dgpamd_ctx *ctx, int64_t M, int64_t n, int D, const double *
 int dgpamd_vecchia_llik(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, const double *y,
                         const int64_t *NNarray, const double *length_h, int nlen, double nugget,
                         const double *nugget_diag, double *out_llik);
+/* The same for `batch` input sets at once (the candidate blocks of one speculative ESS batch, imputation.py:91-106
+ * called once per proposal): X holds them x_stride doubles apart, y / NNarray / nugget_diag are shared; out_llik
+ * (device, batch x 2 doubles).  One row launch and one reduction for the whole batch. */
+int dgpamd_vecchia_llik_batch(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, int64_t x_stride,
+                              int batch, const double *y, const int64_t *NNarray, const double *length_h, int nlen,
+                              double nugget, const double *nugget_diag, double *out_llik);
 int dgpamd_vecchia_nllik(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, const double *y,
                          const int64_t *NNarray, const double *length_h, int nlen, double nugget,
                          const double *nugget_diag, int nugget_est, double *out_nllik);

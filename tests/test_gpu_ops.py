@@ -424,6 +424,36 @@ def test_vecchia_kernels_golden(eng, golden):
         close(npy(lv), d['lgv_v'], rtol=1e-6, atol=1e-8)
 
 
+@pytest.mark.parametrize('name', ['sexp', 'matern2.5'])
+def test_vecchia_row_kernels_register_and_lds_versions_agree(eng, name, monkeypatch):
+    """Conditioning sets of up to 31 points take the register-resident two-rows-per-wave kernel, larger ones (and
+    DGPAMD_VECCHIA_LDS=1) the LDS kernel the golden vectors were first pinned on: same sums, gradients and sparse-factor
+    rows to rounding over ragged first rows, odd n, isotropic / ARD lengthscales, nugget weights, and a batch of inputs."""
+    import torch
+    rng = np.random.default_rng(31)
+    for n, D, m, ard, nugget_est in [(301, 3, 6, False, True), (777, 8, 25, False, False), (500, 5, 30, True, True), (64, 1, 12, False, True),
+                                     (40, 2, 30, True, False)]:
+        X = rng.uniform(size=(n, D))
+        y = np.sin(3 * X[:, 0]) + 0.1 * rng.normal(size=n)
+        ln = rng.uniform(0.4, 1.2, size=D) if ard else np.array([0.7])
+        w = rng.uniform(0.5, 2.0, size=n)
+        dX, dy, dw = eng.tensor(X), eng.tensor(y), eng.tensor(w)
+        NN = eng.nn_ordered(eng.tensor(X / ln), m)
+        XB = eng.tensor(np.stack([X, X + 0.01 * rng.normal(size=X.shape), rng.uniform(size=X.shape)]))
+        got = {}
+        for lds in ('0', '1'):
+            monkeypatch.setenv('DGPAMD_VECCHIA_LDS', lds)
+            o, P = eng.vecchia_nllik(name, dX, dy, NN, ln, 1e-3, dw, nugget_est)
+            got[lds] = (npy(eng.vecchia_llik(name, dX, dy, NN, ln, 1e-3, dw)), npy(o), npy(eng.vecchia_lmatrix(name, dX, NN, ln, 1e-3)),
+                        npy(eng.vecchia_llik_batch(name, XB, dy, NN, ln, 1e-3, dw)))
+        for a, b in zip(got['0'], got['1']):
+            close(a, b, rtol=1e-9, atol=1e-9 * np.abs(b).max())
+        monkeypatch.setenv('DGPAMD_VECCHIA_LDS', '0')
+        close(got['0'][3][0], got['0'][0], rtol=1e-14)       # batch member 0 is the single evaluation
+        for j in range(3):                                   # and every member equals its own single evaluation
+            close(got['0'][3][j], npy(eng.vecchia_llik(name, XB[j], dy, NN, ln, 1e-3, dw)), rtol=1e-14)
+
+
 def test_vecchia_spsolve_long_chain(eng):
     """Rows span many 1024-row windows and deep in-window dependency chains."""
     from oracle import dgp_oracle as O
