@@ -548,6 +548,21 @@ __global__ __launch_bounds__(VW) void vecchia_row_kernel(VRowArgs a) {
 // ---------------------------------------------------------------------------
 #define VR_MAXB 31
 
+// (r, c) of the strictly-lower entry e = (r-1) r / 2 + c, r > c, packed r | c << 8: the same for every block size, read
+// per lane from the constant cache's neighbour L1 instead of being decoded with a square root and two fix-up loops
+struct TriTable {
+    unsigned short rc[VR_MAXB * (VR_MAXB - 1) / 2 + 32];
+};
+static constexpr TriTable make_tri_table() {
+    TriTable t{};
+    int e = 0;
+    for (int r = 1; r < VR_MAXB; ++r)
+        for (int c = 0; c < r; ++c) t.rc[e++] = (unsigned short)(r | (c << 8));
+    for (; e < VR_MAXB * (VR_MAXB - 1) / 2 + 32; ++e) t.rc[e] = (unsigned short)(1 | (0 << 8));
+    return t;
+}
+__device__ const TriTable g_tri = make_tri_table();
+
 __device__ __forceinline__ void tri_decode_small(int t, int &r, int &c) {   // t < 2^16: float is plenty
     int b = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
     while ((b + 1) * (b + 2) / 2 <= t) ++b;
@@ -600,7 +615,7 @@ __device__ __forceinline__ void fmac_bcast(double &acc, const double &src, const
 
 static size_t vrow4_lds(int BS, int D, bool grad) {
     const size_t asz = (size_t)(BS + 1) * (BS + 2) / 2 + (grad ? (size_t)BS * (BS - 1) / 2 : 0);
-    return 4 * (asz + (size_t)BS * D + 2 * 32) * sizeof(double);
+    return 4 * (asz + (size_t)BS * (D | 1) + 2 * 32) * sizeof(double);
 }
 
 template <int KIND, int MODE, int BS>
@@ -611,12 +626,12 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
     constexpr int asz = rows * (rows + 1) / 2 + (MODE == V_NLLIK ? T2 : 0);
     constexpr int NBB = BS > 16 ? BS : 16;            // columns kept for the second row of a lane
 #define AT(r, c) ((r) * ((r) + 1) / 2 + (c))
-    const int mp1 = a.m + 1, D = a.vp.D;
+    const int mp1 = a.m + 1, D = a.vp.D, DP = D | 1;   // (odd row stride: the rows of a group on distinct LDS banks)
     const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
     double *A = lds + (size_t)g * asz;                                   // packed lower triangle (+ K itself for the gradient)
     double *Kp = A + rows * (rows + 1) / 2;
-    double *xs = lds + (size_t)4 * asz + (size_t)g * BS * D;             // [BS][D] scaled inputs
-    double *V = lds + (size_t)4 * asz + (size_t)4 * BS * D + (size_t)g * 64;   // [2][32] u, alpha
+    double *xs = lds + (size_t)4 * asz + (size_t)g * BS * DP;             // [BS][D] scaled inputs
+    double *V = lds + (size_t)4 * asz + (size_t)4 * BS * DP + (size_t)g * 64;   // [2][32] u, alpha
     const int64_t i = (int64_t)blockIdx.x * 4 + g;
     const bool live = i < a.n;
     const double *X = a.X + (MODE == V_LLIK ? (int64_t)blockIdx.y * a.x_stride : 0);
@@ -653,7 +668,7 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
             for (int q = 0; q < 8; ++q) x8[q] = (my[h] >= 0 && d0 + q < D) ? xrow[d0 + q] : 0.0;
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (R < BS && d0 + q < D) xs[R * D + d0 + q] = x8[q] * a.vp.inv_len[d0 + q];
+                if (R < BS && d0 + q < D) xs[R * DP + d0 + q] = x8[q] * a.vp.inv_len[d0 + q];
         }
         if (R < BS) {
             A[AT(R, R)] = my[h] >= 0 ? 1.0 + a.vp.nugget * ndv : 1.0;
@@ -661,13 +676,47 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
         }
     }
     __syncthreads();
-    for (int e = t; e < T2; e += 16) {
-        int r, c;
-        tri_decode_small(e, r, c);
-        ++r;   // strictly lower: (r, c), r > c; pads come first
-        const double v = c >= pad ? corr_pts<KIND>(xs + r * D, xs + c * D, D) : 0.0;
-        A[AT(r, c)] = v;
-        if (MODE == V_NLLIK) Kp[e] = v;   // the correlation itself, kept for the derivative sums
+    // strictly lower entries (r, c), r > c, two per lane and pass: their 4 x 8 coordinates are read from LDS together
+    // (the dimension loop of corr_pts waits for LDS once per coordinate: with two waves per SIMD nothing hides that)
+    for (int e0 = t; e0 < T2; e0 += 32) {
+        const int e1 = e0 + 16 < T2 ? e0 + 16 : e0;
+        const int q0 = g_tri.rc[e0], q1 = g_tri.rc[e1];
+        const int r0 = q0 & 255, c0 = q0 >> 8, r1 = q1 & 255, c1 = q1 >> 8;
+        const double *pa0 = xs + r0 * DP, *pb0 = xs + c0 * DP, *pa1 = xs + r1 * DP, *pb1 = xs + c1 * DP;
+        double s0 = 0.0, p0 = 1.0, s1 = 0.0, p1 = 1.0;
+        for (int d0 = 0; d0 < D; d0 += 8) {
+            double u0[8], v0[8], u1[8], v1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int d = d0 + q < D ? d0 + q : D - 1;   // (past the end: the last coordinate against itself below)
+                u0[q] = pa0[d];
+                v0[q] = pb0[d];
+                u1[q] = pa1[d];
+                v1[q] = pb1[d];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool in = d0 + q < D;
+                const double f0 = in ? u0[q] - v0[q] : 0.0, f1 = in ? u1[q] - v1[q] : 0.0;   // (0: neutral for both kernels)
+                if (KIND == DGPAMD_SEXP) {
+                    corr_accum_sexp(f0, s0);
+                    corr_accum_sexp(f1, s1);
+                } else {
+                    corr_accum_matern(f0, p0, s0);
+                    corr_accum_matern(f1, p1, s1);
+                }
+            }
+        }
+        double k0 = (KIND == DGPAMD_SEXP) ? exp(-s0) : p0 * exp(-SQRT5 * s0);
+        double k1 = (KIND == DGPAMD_SEXP) ? exp(-s1) : p1 * exp(-SQRT5 * s1);
+        if (c0 < pad) k0 = 0.0;   // pads come first
+        if (c1 < pad) k1 = 0.0;
+        A[e0 + r0] = k0;   // AT(r, c) = e + r
+        A[e1 + r1] = k1;
+        if (MODE == V_NLLIK) {   // the correlation itself, kept for the derivative sums
+            Kp[e0] = k0;
+            Kp[e1] = k1;
+        }
     }
     __syncthreads();
 
@@ -771,15 +820,13 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
     for (int k = 0; k < npl; ++k) {
         double tl = 0.0, sm = 0.0;
         for (int e = t; e < T2; e += 16) {
-            int r, c;
-            tri_decode_small(e, r, c);
-            ++r;
+            const int qe = g_tri.rc[e], r = qe & 255, c = qe >> 8;
             const double kv = Kp[e];
             double cf = 0.0;
             if (a.vp.nlen == 1)
-                for (int d = 0; d < D; ++d) cf += dcoef_v<KIND>(xs[r * D + d] - xs[c * D + d]);
+                for (int d = 0; d < D; ++d) cf += dcoef_v<KIND>(xs[r * DP + d] - xs[c * DP + d]);
             else
-                cf = dcoef_v<KIND>(xs[r * D + k] - xs[c * D + k]);
+                cf = dcoef_v<KIND>(xs[r * DP + k] - xs[c * DP + k]);
             const double dk = cf * kv;
             tl = fma(2.0 * dk, u[r] * u[c], tl);
             sm = fma(dk, al[r] * u[c] + al[c] * u[r], sm);
