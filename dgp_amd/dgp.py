@@ -446,11 +446,14 @@ class dgp:
                 if l != 0:
                     nd.r2()
             dense = [nd for _, nd in nodes if not nd.vecch] if mstep._HAVE_CORE else []
-            if dense:
-                pre = self.imp.stage_for_mstep() if getattr(self, 'imp', None) is not None else {}
-                for nd in dense:
-                    if id(nd) in pre:
+            pre = self.imp.stage_for_mstep() if getattr(self, 'imp', None) is not None and mstep._HAVE_CORE else {}
+            for _, nd in nodes:
+                if id(nd) in pre:
+                    if nd.vecch:
+                        nd._vecch_prestaged = pre[id(nd)]
+                    elif any(nd is d for d in dense):
                         nd._prestaged = pre[id(nd)]
+            if dense:
                 self.last_mstep = mstep.maximise_lockstep(eng, dense, self)
             else:
                 self.last_mstep = None

@@ -61,8 +61,34 @@ class DrawStream:
             return out
         rest = None if buf is None else buf[self._zpos:]
         self._zbuf, self._zpos = None, 0
-        fresh = self._gz.standard_normal(count - (0 if rest is None else len(rest)))
-        return fresh if rest is None or len(rest) == 0 else np.concatenate((rest, fresh))
+        return self._fill(rest, count)
+
+    def _fill(self, rest, count):
+        """`count` normals: the unread tail `rest` of the old buffer, then fresh ones -- in page-locked host memory when a
+        device is there (the I-step uploads them: 35 MB per call at n = 50 000 with eight nodes, which from pageable
+        memory goes through the runtime's staging chunks at ~1.4 GB/s)."""
+        have = 0 if rest is None else len(rest)
+        out = None
+        if count >= (1 << 16):
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    pins = self.__dict__.setdefault('_zpin', [])
+                    if len(pins) < 2 or pins[0].numel() < count:      # two buffers in turn: the previous one may still be read
+                        pins.insert(0, torch.empty(max(count, pins[0].numel() if pins else 0), dtype=torch.float64, pin_memory=True))
+                        del pins[2:]
+                    else:
+                        pins.reverse()
+                    out = pins[0].numpy()[:count]
+            except Exception:
+                out = None
+        if out is None:
+            out = np.empty(count)
+        if have:
+            out[:have] = rest
+        if count > have:
+            self._gz.standard_normal(out=out[have:])
+        return out
 
     def prefetch(self, count):
         """Generate the next `count` normals on a background thread (numpy releases the GIL while filling), e.g. while
@@ -77,8 +103,7 @@ class DrawStream:
         rest = None if have == 0 else self._zbuf[self._zpos:].copy()
 
         def work():
-            fresh = self._gz.standard_normal(count - have)
-            self._zbuf = fresh if rest is None else np.concatenate((rest, fresh))
+            self._zbuf = self._fill(rest, count)
             self._zpos = 0
         self._zbuf, self._zpos = None, 0
         self._thread = threading.Thread(target=work, daemon=True)
@@ -88,6 +113,9 @@ class DrawStream:
         self._join()
         st = dict(self.__dict__)
         st['_thread'] = None
+        st.pop('_zpin', None)
+        if st.get('_zbuf') is not None:
+            st['_zbuf'] = np.array(st['_zbuf'])   # (out of the page-locked buffer)
         return st
 
     def _join(self):
@@ -289,7 +317,7 @@ class imputer:
         Fh = self._Fh
         for l in range(L):
             for k, nd in enumerate(self.all_layer[l]):
-                if nd.type != 'gp' or nd.vecch or nd.rep is not None:
+                if nd.type != 'gp' or nd.rep is not None:
                     continue
                 # (valid only while the numpy attributes still hold what _detach wrote / what was uploaded)
                 const = self.__dict__.get('_const', {})
@@ -307,7 +335,11 @@ class imputer:
                         else src[:, torch.as_tensor(idx, device=src.device)].contiguous()
                 if not (y_ok and g_ok and x_ok):
                     continue
-                out[id(nd)] = dict(Xl=Xl, Xg=self._glob[(l, k)], y=self._node_y(l, k), W=None)
+                if nd.vecch:   # (kernel._vecch_stage orders these on the device)
+                    Xg = self._glob[(l, k)]
+                    out[id(nd)] = dict(X=Xl if Xg is None else torch.cat((Xl, Xg), 1), y=self._node_y(l, k))
+                else:
+                    out[id(nd)] = dict(Xl=Xl, Xg=self._glob[(l, k)], y=self._node_y(l, k), W=None)
         return out
 
     def _node_input(self, l, k, nd):
@@ -481,7 +513,7 @@ class imputer:
                 Z = self.draws.normals(sweeps * M * n).reshape(sweeps, M, n)
             else:
                 Z = np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)])
-            xs = self._vecchia_draws(0, list(range(M)), e.tensor(np.ascontiguousarray(Z.transpose(1, 0, 2))))   # (M, sweeps, n)
+            xs = self._vecchia_draws(0, list(range(M)), e.tensor(Z).permute(1, 0, 2).contiguous())   # (M, sweeps, n)
             if prefetch:
                 self.draws.prefetch(sweeps * M * n)
             return xs.permute(1, 2, 0).contiguous()
@@ -541,12 +573,12 @@ class imputer:
             X = Xl if cm is None else Xl[:, torch.as_tensor(cm, device=Xl.device, dtype=torch.long)]
             if self._glob[(l, k)] is not None:
                 X = torch.cat((X, self._glob[(l, k)]), 1)
-            od = torch.as_tensor(nd.ord, device=X.device, dtype=torch.long)
-            NN = e.tensor(nd.NNarray, dtype=torch.int64)
+            od = nd.ord_dev()
+            NN = nd.nn_dev()
             Lms.append(e.vecchia_lmatrix(nd.name, X[od].contiguous(), NN, nd.length, nd.nugget[0]))
             NNs.append(NN)
             sc.append(1.0 / np.sqrt(nd.scale[0]))
-            rev.append(torch.as_tensor(nd.rev_ord, device=X.device, dtype=torch.long))
+            rev.append(nd.rev_ord_dev())
         xs = e.vecchia_spsolve_batch(torch.stack(Lms), torch.stack(NNs), sc, Zd.contiguous())
         return torch.stack([xs[j][:, rev[j]] for j in range(len(nodes))])
 
@@ -580,8 +612,7 @@ class imputer:
                 hit = self.__dict__.setdefault('_vecch_dev', {}).get((l + 1, k))
                 if hit is None or hit[0] != sig:
                     hit = (sig, (torch.as_tensor(np.asarray(nd.input_dim), device=FP.device, dtype=torch.long),
-                                 torch.as_tensor(nd.ord, device=FP.device, dtype=torch.long),
-                                 e.tensor(nd.NNarray, dtype=torch.int64),
+                                 nd.ord_dev(), nd.nn_dev(),
                                  e.tensor(np.ones(FP.shape[1]) if nd.rep is None else nd.W_diag)))
                     self._vecch_dev[(l + 1, k)] = hit
                 cm, od, NN, nd_diag = hit[1]

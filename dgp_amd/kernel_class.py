@@ -88,7 +88,31 @@ class kernel:
         st.pop('_r2_cache', None)
         st.pop('_prestaged', None)
         st.pop('_vecch_cache', None)
+        st.pop('_vecch_prestaged', None)
+        st.pop('_dev_cache', None)
         return st
+
+    def _dev_of(self, name, dtype=None):
+        """Device copy of one of the node's index arrays (NNarray: 10 MB at n = 50 000; ord, rev_ord), uploaded once per
+        array OBJECT: ord_nn() always binds new arrays, a strided checksum guards against writes in place."""
+        import torch
+        a = getattr(self, name)
+        cache = self.__dict__.setdefault('_dev_cache', {})
+        step = max(1, a.shape[0] // 61)
+        key = (id(a), a.shape, int(np.asarray(a[::step], dtype=np.int64).sum()), id(self.engine))
+        hit = cache.get(name)
+        if hit is None or hit[0] != key or hit[2] is not a:
+            hit = cache[name] = (key, self.engine.tensor(a, dtype=torch.int64 if dtype is None else dtype), a)
+        return hit[1]
+
+    def nn_dev(self):
+        return self._dev_of('NNarray')
+
+    def ord_dev(self):
+        return self._dev_of('ord')
+
+    def rev_ord_dev(self):
+        return self._dev_of('rev_ord')
 
     def _X(self):
         return self.input if self.global_input is None else np.concatenate((self.input, self.global_input), 1)
@@ -333,7 +357,11 @@ class kernel:
         if NNarray is None:
             e = self.engine
             Xs = (self._X() / self.length)[self.ord]
-            self.NNarray = e.nn_ordered(e.tensor(Xs), self.m).cpu().numpy()
+            dev = e.nn_ordered(e.tensor(Xs), self.m)
+            self.NNarray = dev.cpu().numpy()
+            self.__dict__.setdefault('_dev_cache', {}).pop('NNarray', None)
+            step = max(1, self.NNarray.shape[0] // 61)   # (seed the device cache: no upload of what was just computed there)
+            self._dev_cache['NNarray'] = ((id(self.NNarray), self.NNarray.shape, int(self.NNarray[::step].sum()), id(e)), dev, self.NNarray)
         else:
             self.NNarray = NNarray
         if pointer:
@@ -360,11 +388,18 @@ class kernel:
         sig = (id(self.input), id(self.global_input), id(self.ord), id(self.NNarray), id(nd) if self.rep is not None else None,
                float(np.sum(self.input)), float(np.sum(self.output)), float(np.sum(self.ord[:16])), len(self.output), id(e))
         hit = self.__dict__.get('_vecch_cache')
+        pre = self.__dict__.pop('_vecch_prestaged', None)   # (device views of input and output handed over by the imputer)
         if hit is not None and hit[0] == sig:
             return dict(hit[1])
-        X = self._X()[self.ord]
-        st = dict(X=e.tensor(X), y=e.tensor(np.asarray(self.output, float).reshape(-1)[self.ord]),
-                  NN=e.tensor(self.NNarray, dtype=torch.int64), nd=e.tensor(nd))
+        if pre is not None and self.rep is None:
+            od = self.ord_dev()
+            ones = self.__dict__.setdefault('_dev_cache', {}).get('ones')
+            if ones is None or ones.shape[0] != len(self.output) or ones.device != od.device:
+                ones = self._dev_cache['ones'] = e.tensor(nd)
+            st = dict(X=pre['X'][od].contiguous(), y=pre['y'][od].contiguous(), NN=self.nn_dev(), nd=ones)
+        else:
+            X = self._X()[self.ord]
+            st = dict(X=e.tensor(X), y=e.tensor(np.asarray(self.output, float).reshape(-1)[self.ord]), NN=self.nn_dev(), nd=e.tensor(nd))
         self._vecch_cache = (sig, st)
         return dict(st)
 
@@ -476,7 +511,8 @@ class kernel:
             fun = self.llik_vecch
             if self.target == 'gp' and len(self.length) != 1:
                 kw['callback'] = self.callback
-        self._stage()
+        if not self.vecch:   # (Vecchia objectives stage their own ordered arrays: _vecch_stage)
+            self._stage()
         self._in_maximise = True
         try:
             minimize(fun, x0, options=opts, **kw)

@@ -70,6 +70,9 @@ elif which == 'cfg4train':
     t = time.perf_counter(); model = dgp(X, Y, vecchia=True, m=m, seed=1); sync()
     print('cfg4train n=%d: construct (warm start + NN + 11 sweeps) %.1f s' % (n, time.perf_counter() - t), flush=True)
     its = int(os.environ.get('ITERS', '3'))
+    if os.environ.get('BATCH'):
+        model.imp.batch = int(os.environ['BATCH'])
+        model.imp.batch_next = int(os.environ.get('BATCH_NEXT', os.environ['BATCH']))
     spent, inner = [0.0], model._m_step
 
     def timed_m_step(*a, **k):
@@ -81,6 +84,8 @@ elif which == 'cfg4train':
     t = time.perf_counter(); model.train(N=its, ess_burn=10, disable=True); sync(); dt = time.perf_counter() - t
     print('cfg4train: %d SI iterations %.1f s -> %.3f it/s (M-steps %.0f ms each, the rest %.0f ms); stats %s'
           % (its, dt, its / dt, 1e3 * spent[0] / its, 1e3 * (dt - spent[0]) / its, model.imp.stats), flush=True)
+    if os.environ.get('TRAIN_ONLY'):
+        sys.exit(0)
     t = time.perf_counter(); emu = emulator(model.estimate(burnin=0), N=2, seed=3); sync()
     print('cfg4train: emulator(N=2) %.1f s' % (time.perf_counter() - t), flush=True)
     xt = rng.uniform(size=(2000, d))
