@@ -454,6 +454,28 @@ def test_vecchia_row_kernels_register_and_lds_versions_agree(eng, name, monkeypa
             close(got['0'][3][j], npy(eng.vecchia_llik(name, XB[j], dy, NN, ln, 1e-3, dw)), rtol=1e-14)
 
 
+def test_nn_streaming_topk_equals_store_once_kernel(eng, monkeypatch):
+    """Candidate sets of 4096 points and more in up to 16 dimensions take the streaming top-k kernels (register-resident
+    sorted lists, candidates staged once per 64 queries); DGPAMD_NN_STORE_ONCE=1 forces the store-once histogram kernel
+    the bit-exact golden comparison was first made with (=2 the streaming ones).  Same neighbour arrays, element for element: ordered (vecchia.py:
+    98-109) and query form (:20-37), ties between duplicated points broken by index, fewer candidates than neighbours in
+    the first rows, query counts that do not fill the last block of 64."""
+    rng = np.random.default_rng(17)
+    for n, D, m in [(4500, 3, 25), (6001, 8, 25), (5000, 1, 15), (4200, 12, 50), (9000, 2, 60), (4100, 5, 31)]:
+        x = rng.uniform(size=(n, D))
+        x[rng.integers(0, n, 300)] = x[rng.integers(0, n, 300)]       # duplicated points: equal distances
+        q = np.concatenate((rng.uniform(size=(333, D)), x[:40]))
+        dx, dq = eng.tensor(x), eng.tensor(q)
+        got = {}
+        for flag in ('2', '1'):   # (2: streaming at every size; by default it starts where it pays: n >= 12 000)
+            monkeypatch.setenv('DGPAMD_NN_STORE_ONCE', flag)
+            got[flag] = (npy(eng.nn_ordered(dx, m)), npy(eng.nn_query(dq, dx, m)))
+        np.testing.assert_array_equal(got['2'][0], got['1'][0])
+        np.testing.assert_array_equal(got['2'][1], got['1'][1])
+        a = got['2'][0]
+        assert a.shape == (n, m + 1) and np.array_equal(a[:, 0], np.arange(n)) and np.all(a[:5, 6:] == -1)
+
+
 def test_vecchia_spsolve_long_chain(eng):
     """Rows span many 1024-row windows and deep in-window dependency chains."""
     from oracle import dgp_oracle as O
