@@ -58,7 +58,11 @@ __device__ __forceinline__ double dcoef_v(double df) {
     if (KIND == DGPAMD_SEXP) return 2.0 * df * df;
     double r = fabs(df);
     double e1 = fma(r, SQRT5, 1.0), e2 = (5.0 / 3.0) * r * r;
-    return e2 * e1 / (e1 + e2);
+    const double den = e1 + e2;   // >= 1: hardware reciprocal + two Newton rounds instead of the ~30-instruction division
+    double x = __builtin_amdgcn_rcp(den);
+    x = fma(x, fma(-den, x, 1.0), x);
+    x = fma(x, fma(-den, x, 1.0), x);
+    return e2 * e1 * x;
 }
 
 // In-LDS right-looking Cholesky of the leading npiv columns of a `rows` x `rows` lower matrix (ld = lda).
@@ -769,6 +773,19 @@ __device__ __forceinline__ double hsum16(double v) {   // sum over the 16 lanes 
     return v;
 }
 
+// the same with four DPP rotations of the 16-lane row (every lane pairs the same values: identical sums in all lanes)
+__device__ __forceinline__ double row_allreduce_sum(double v) {
+#define ROR_ADD(CTRL)                                                                                 \
+    {                                                                                                 \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);      \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);      \
+        v += __hiloint2double(hi, lo);                                                                \
+    }
+    ROR_ADD(0x128) ROR_ADD(0x124) ROR_ADD(0x122) ROR_ADD(0x121)
+#undef ROR_ADD
+    return v;
+}
+
 // 1/sqrt(d) and sqrt(d): hardware estimate + two Newton rounds + one correction of the root (a few ulp)
 __device__ __forceinline__ void rsqrt_sqrt(double d, double &inv, double &sd) {
     double y = __builtin_amdgcn_rsq(d);
@@ -876,6 +893,8 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
         const int r0 = q0 & 255, c0 = q0 >> 8, r1 = q1 & 255, c1 = q1 >> 8;
         const double *pa0 = xs + r0 * DP, *pb0 = xs + c0 * DP, *pa1 = xs + r1 * DP, *pb1 = xs + c1 * DP;
         double s0 = 0.0, p0 = 1.0, s1 = 0.0, p1 = 1.0;
+        double cf0 = 0.0, cf1 = 0.0;   // (gradient, one shared lengthscale: sum over the dimensions of dK/dlog(l) / K)
+        const bool iso = MODE == V_NLLIK && a.vp.nlen == 1;
         for (int d0 = 0; d0 < D; d0 += 8) {
             double u0[8], v0[8], u1[8], v1[8];
 #pragma unroll
@@ -896,8 +915,16 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
                 } else {
                     corr_accum_matern(f0, p0, s0);
                     corr_accum_matern(f1, p1, s1);
+                    if (iso) {
+                        cf0 += dcoef_v<KIND>(f0);
+                        cf1 += dcoef_v<KIND>(f1);
+                    }
                 }
             }
+        }
+        if (iso && KIND == DGPAMD_SEXP) {   // dcoef = 2 df^2
+            cf0 = 2.0 * s0;
+            cf1 = 2.0 * s1;
         }
         double k0 = (KIND == DGPAMD_SEXP) ? exp(-s0) : p0 * exp(-SQRT5 * s0);
         double k1 = (KIND == DGPAMD_SEXP) ? exp(-s1) : p1 * exp(-SQRT5 * s1);
@@ -905,9 +932,9 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
         if (c1 < pad) k1 = 0.0;
         A[e0 + r0] = k0;   // AT(r, c) = e + r
         A[e1 + r1] = k1;
-        if (MODE == V_NLLIK) {   // the correlation itself, kept for the derivative sums
-            Kp[e0] = k0;
-            Kp[e1] = k1;
+        if (MODE == V_NLLIK) {   // kept for the derivative sums: dK itself with one shared lengthscale, else the correlation
+            Kp[e0] = iso ? cf0 * k0 : k0;
+            Kp[e1] = iso ? cf1 * k1 : k1;
         }
     }
     __syncthreads();
@@ -960,35 +987,48 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
         }
         return;
     }
-    // the factor (and w) back to LDS for the transposed solves
+    // x <- L^-T x for e_last (u) and for w (alpha), in registers.  As soon as x_r is known the lane that owns row r adds
+    // L[r][c] x_r to its partial sums of the columns c < r; when column c's turn comes the sum over the group's 16 lanes
+    // (four DPP rotations) closes it.  No LDS, no barrier; pads decouple (identity rows in front).
+    {
+        double accu[BS], acca[MODE == V_NLLIK ? BS : 1];
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-        if (c <= t && c < BS && t <= BS) A[AT(t, c)] = ra[c];
+        for (int c = 0; c < BS; ++c) accu[c] = 0.0;
 #pragma unroll
-    for (int c = 0; c < BS; ++c)
-        if (16 + t <= BS && c <= 16 + t) A[AT(16 + t, c)] = rb[c];
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int R = 16 * h + t;
-        if (R < BS) {
-            V[R] = (R == BS - 1) ? 1.0 : 0.0;
-            if (MODE == V_NLLIK) V[32 + R] = A[AT(BS, R)];
-        }
-    }
-    // x <- L^-T x, column-oriented; pads decouple (identity rows in front)
-    for (int c = BS - 1; c >= 0; --c) {
-        __syncthreads();
-        if (t < (MODE == V_NLLIK ? 2 : 1)) V[t * 32 + c] /= A[AT(c, c)];
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int R = 16 * h + t;
-            if (R < c) {
-                const double lcr = A[AT(c, R)];
-                V[R] = fma(-lcr, V[c], V[R]);
-                if (MODE == V_NLLIK) V[32 + R] = fma(-lcr, V[32 + c], V[32 + R]);
+        for (int c = 0; c < (MODE == V_NLLIK ? BS : 1); ++c) acca[c] = 0.0;
+        double u0 = 0.0, u1 = 0.0, a0 = 0.0, a1 = 0.0;   // x of rows t and 16 + t
+        static_for<BS>([&](auto RR) {
+            constexpr int r = BS - 1 - RR, owner = r & 15;
+            constexpr bool sb = r >= 16;
+            double diag;
+            if constexpr (sb) diag = group_bcast<owner>(rb[r]); else diag = group_bcast<owner>(ra[r & 15]);
+            double inv = __builtin_amdgcn_rcp(diag);
+            inv = fma(inv, fma(-diag, inv, 1.0), inv);
+            inv = fma(inv, fma(-diag, inv, 1.0), inv);
+            const double ur = ((r == BS - 1 ? 1.0 : 0.0) - row_allreduce_sum(accu[r])) * inv;
+            const double um = (t == owner) ? ur : 0.0;
+            if constexpr (sb) u1 += um; else u0 += um;
+            double am = 0.0;
+            if constexpr (MODE == V_NLLIK) {
+                double wr;
+                if constexpr (BS < 16) wr = group_bcast<WL>(ra[r & 15]); else wr = group_bcast<WL>(rb[r]);
+                const double ar = (wr - row_allreduce_sum(acca[r])) * inv;
+                am = (t == owner) ? ar : 0.0;
+                if constexpr (sb) a1 += am; else a0 += am;
             }
+            static_for<r>([&](auto Cc) {
+                constexpr int c = Cc;
+                double lrc;
+                if constexpr (sb) lrc = rb[c]; else lrc = ra[c & 15];
+                accu[c] = fma(lrc, um, accu[c]);
+                if constexpr (MODE == V_NLLIK) acca[c] = fma(lrc, am, acca[c]);
+            });
+        });
+        V[t] = u0;
+        if (MODE == V_NLLIK) V[32 + t] = a0;
+        if (16 + t < BS) {
+            V[16 + t] = u1;
+            if (MODE == V_NLLIK) V[48 + t] = a1;
         }
     }
     __syncthreads();
@@ -1013,18 +1053,12 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
         double tl = 0.0, sm = 0.0;
         for (int e = t; e < T2; e += 16) {
             const int qe = g_tri.rc[e], r = qe & 255, c = qe >> 8;
-            const double kv = Kp[e];
-            double cf = 0.0;
-            if (a.vp.nlen == 1)
-                for (int d = 0; d < D; ++d) cf += dcoef_v<KIND>(xs[r * DP + d] - xs[c * DP + d]);
-            else
-                cf = dcoef_v<KIND>(xs[r * DP + k] - xs[c * DP + k]);
-            const double dk = cf * kv;
+            const double dk = a.vp.nlen == 1 ? Kp[e] : dcoef_v<KIND>(xs[r * DP + k] - xs[c * DP + k]) * Kp[e];
             tl = fma(2.0 * dk, u[r] * u[c], tl);
             sm = fma(dk, al[r] * u[c] + al[c] * u[r], sm);
         }
-        tl = hsum16(tl);
-        sm = hsum16(sm);
+        tl = row_allreduce_sum(tl);
+        sm = row_allreduce_sum(sm);
         if (t == 0 && live) {
             out[2 + k] = 2.0 * sm * wl - tl * wl * wl;
             out[2 + P + k] = tl;
@@ -1041,8 +1075,8 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
                 sm = fma(dk, al[R] * u[R], sm);
             }
         }
-        tl = hsum16(tl);
-        sm = hsum16(sm);
+        tl = row_allreduce_sum(tl);
+        sm = row_allreduce_sum(sm);
         if (t == 0 && live) {
             out[2 + npl] = 2.0 * sm * wl - tl * wl * wl;
             out[2 + P + npl] = tl;
