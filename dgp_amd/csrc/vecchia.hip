@@ -809,11 +809,12 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-// value of lane C of the caller's 16-lane group (s_nop 1: a DPP source written by the previous VALU needs two wait states)
+// value of lane C of the caller's 16-lane group.  s_nop 4: a DPP source written by the previous VALU needs two wait states
+// and an EXEC written by the previous SALU (the end of a divergent region: the compiler cannot see into the asm) five.
 template <int C>
 __device__ __forceinline__ double group_bcast(const double &v) {
     double out;
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(v), "i"(C));
+    asm volatile("s_nop 4\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(v), "i"(C));
     return out;
 }
 // acc += (lane C's src) * mul
@@ -822,9 +823,9 @@ __device__ __forceinline__ void fmac_bcast(double &acc, const double &src, const
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "i"(C));
 }
 
-static size_t vrow4_lds(int BS, int D, bool grad) {
+static size_t vrow4_lds(int BS, int D, bool grad, bool solves) {
     const size_t asz = (size_t)(BS + 1) * (BS + 2) / 2 + (grad ? (size_t)BS * (BS - 1) / 2 : 0);
-    return 4 * (asz + (size_t)BS * (D | 1) + 2 * 32) * sizeof(double);
+    return 4 * (asz + (size_t)BS * (D | 1) + (solves ? 2 * 32 : 0)) * sizeof(double);   // (llik: 19.6 KB at m = 25, d = 8: 8 waves per CU)
 }
 
 template <int KIND, int MODE, int BS>
@@ -940,10 +941,11 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
     __syncthreads();
 
     double ra[16], rb[NBB];   // rows t and 16 + t
+    constexpr int LROWS = MODE == V_LMAT ? BS : BS + 1;   // (no right-hand-side row in the sparse-factor mode: nothing wrote it)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) ra[c] = (c <= t && c < BS && t <= BS) ? A[AT(t, c)] : 0.0;
+    for (int c = 0; c < 16; ++c) ra[c] = (c <= t && c < BS && t < LROWS) ? A[AT(t, c)] : 0.0;
 #pragma unroll
-    for (int c = 0; c < NBB; ++c) rb[c] = (c < BS && 16 + t <= BS && c <= 16 + t) ? A[AT(16 + t, c < BS ? c : 0)] : 0.0;
+    for (int c = 0; c < NBB; ++c) rb[c] = (c < BS && 16 + t < LROWS && c <= 16 + t) ? A[AT(16 + t, c < BS ? c : 0)] : 0.0;
 
     double sd_last = 1.0, w_last = 0.0;
     static_for<BS>([&](auto J) {
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
         lb = rb[j] * inv;
         rb[j] = lb;
         nlb = -lb;
-        asm volatile("s_nop 1" : "+v"(nla), "+v"(nlb));   // (DPP sources just written)
+        asm volatile("s_nop 4" : "+v"(nla), "+v"(nlb));   // (DPP sources just written; see group_bcast)
         static_for<BS>([&](auto Cc) {
             constexpr int c = Cc;
             if constexpr (c > j) {
@@ -991,6 +993,11 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
     // L[r][c] x_r to its partial sums of the columns c < r; when column c's turn comes the sum over the group's 16 lanes
     // (four DPP rotations) closes it.  No LDS, no barrier; pads decouple (identity rows in front).
     {
+        // (entries above the diagonal are by-products of the factorisation, possibly not finite: they meet zeros below)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) ra[c] = c <= t ? ra[c] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NBB; ++c) rb[c] = c <= 16 + t ? rb[c] : 0.0;
         double accu[BS], acca[MODE == V_NLLIK ? BS : 1];
 #pragma unroll
         for (int c = 0; c < BS; ++c) accu[c] = 0.0;
@@ -1087,7 +1094,7 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
 
 template <int KIND, int MODE, int BS>
 static int launch_vrow4_nb(dgpamd_ctx *ctx, VRowArgs &a, int batch) {
-    const size_t shm = vrow4_lds(BS, a.vp.D, MODE == V_NLLIK);
+    const size_t shm = vrow4_lds(BS, a.vp.D, MODE == V_NLLIK, MODE != V_LLIK);
     int rc = set_lds(ctx, (const void *)vecchia_row4_kernel<KIND, MODE, BS>, shm);
     if (rc) return rc;
     hipLaunchKernelGGL((vecchia_row4_kernel<KIND, MODE, BS>), dim3((unsigned)((a.n + 3) / 4), (unsigned)batch), dim3(64), shm,
@@ -1141,8 +1148,22 @@ static size_t vrow_lds(int m, int D) {
     return ((size_t)(mp1 + 1) * lda + (size_t)mp1 * D + 2 * lda) * sizeof(double) + (size_t)mp1 * sizeof(int);
 }
 
+// Debugging aid (DGPAMD_POISON_LDS=1): fill the LDS of every CU with NaNs before a row launch, so that a read of LDS the
+// kernel has not written shows up in the results whatever ran on the device before (tests/test_gpu_ops.py uses it).
+__global__ __launch_bounds__(256) void lds_poison_kernel(double *sink) {
+    extern __shared__ double lds[];
+    for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = __builtin_nan("");
+    __syncthreads();
+    if (lds[(threadIdx.x * 31) & 8191] == 1.0) sink[0] = 1.0;   // (never true: keeps the stores alive)
+}
+
 template <int MODE>
 static int launch_vrow(dgpamd_ctx *ctx, VRowArgs &a, int batch = 1) {
+    const char *poison = getenv("DGPAMD_POISON_LDS");
+    if (poison && atoi(poison)) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        hipLaunchKernelGGL(lds_poison_kernel, dim3(8 * ctx->num_cu), dim3(256), 65536, ctx->stream, (double *)a.X);
+    }
     const char *env = getenv("DGPAMD_VECCHIA_LDS");   // (1: the LDS version for every size -- the tests compare the two)
     if (a.m + 1 <= VR_MAXB && !(env && atoi(env)))   // register-resident factorisation, two rows per wave
         return a.vp.kind == DGPAMD_SEXP ? launch_vrow4<DGPAMD_SEXP, MODE>(ctx, a, batch) : launch_vrow4<DGPAMD_MATERN25, MODE>(ctx, a, batch);

@@ -1307,7 +1307,8 @@ def test_training_splits_two_ranks(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'worker.py'
     script.write_text("""
-import os, sys
+import os, sys, faulthandler
+faulthandler.dump_traceback_later(100, exit=True)   # (a stuck rank says where)
 sys.path.insert(0, %r)
 import numpy as np
 from dgp_amd import dgp, kernel, combine, dist as dd
@@ -1326,7 +1327,8 @@ def dense(split):
     m = dgp(X, Y, layers, seed=7)
     m.train(N=3, ess_burn=2, disable=True)
     return m
-a, b = dense(True), dense(False)
+a = dense(True); print('nodes split trained', flush=True)
+b = dense(False); print('unsplit trained', flush=True)
 assert np.array_equal(hyper(a), hyper(b)), (hyper(a), hyper(b))
 for la, lb in zip(a.all_layer, b.all_layer):
     for na, nb in zip(la, lb):
@@ -1358,8 +1360,10 @@ for l, layer in enumerate(c.all_layer):
         l1 = nd.log_likelihood_func_vecch()
         np.testing.assert_allclose(f1, f0, rtol=1e-12); np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(s1, s0, rtol=1e-12); np.testing.assert_allclose(l1, l0, rtol=1e-12)
+print('evaluations agree', flush=True)
 dd.split_training(rows=True)
 np.random.seed(11); c._m_step()
+print('rows split m-step done', flush=True)
 dd.split_training(rows=False)
 np.random.seed(11); d._m_step()
 np.testing.assert_allclose(hyper(c), hyper(d), rtol=1e-4, atol=1e-8)
@@ -1369,7 +1373,15 @@ print('rank', dd.rank(), 'ok')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29549', WORLD_SIZE='2')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK='0'),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=120)[0].decode())
+    except subprocess.TimeoutExpired:   # (a rank that died leaves the other waiting in a collective: end both, show what they said)
+        for p in procs:
+            p.kill()
+        outs = [p.communicate()[0].decode()[-3000:] for p in procs]
+        raise AssertionError('two-rank worker timed out:\n' + '\n----\n'.join(outs))
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'ok' in o

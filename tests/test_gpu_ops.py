@@ -431,8 +431,10 @@ def test_vecchia_row_kernels_register_and_lds_versions_agree(eng, name, monkeypa
     rows to rounding over ragged first rows, odd n, isotropic / ARD lengthscales, nugget weights, and a batch of inputs."""
     import torch
     rng = np.random.default_rng(31)
+    monkeypatch.setenv('DGPAMD_POISON_LDS', '1')   # NaNs in every CU's LDS before each row launch: nothing unwritten may be read
     for n, D, m, ard, nugget_est in [(301, 3, 6, False, True), (777, 8, 25, False, False), (500, 5, 30, True, True), (64, 1, 12, False, True),
-                                     (40, 2, 30, True, False)]:
+                                     (40, 2, 30, True, False), (260, 2, 8, False, False), (130, 2, 3, False, True), (200, 12, 17, True, True),
+                                     (333, 4, 21, False, True), (150, 3, 27, False, False)]:
         X = rng.uniform(size=(n, D))
         y = np.sin(3 * X[:, 0]) + 0.1 * rng.normal(size=n)
         ln = rng.uniform(0.4, 1.2, size=D) if ard else np.array([0.7])
