@@ -1157,12 +1157,20 @@ __global__ __launch_bounds__(256) void lds_poison_kernel(double *sink) {
     if (lds[(threadIdx.x * 31) & 8191] == 1.0) sink[0] = 1.0;   // (never true: keeps the stores alive)
 }
 
-template <int MODE>
-static int launch_vrow(dgpamd_ctx *ctx, VRowArgs &a, int batch = 1) {
+static int maybe_poison_lds(dgpamd_ctx *ctx, const double *any_device_ptr) {
     const char *poison = getenv("DGPAMD_POISON_LDS");
     if (poison && atoi(poison)) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        hipLaunchKernelGGL(lds_poison_kernel, dim3(8 * ctx->num_cu), dim3(256), 65536, ctx->stream, (double *)a.X);
+        hipLaunchKernelGGL(lds_poison_kernel, dim3(8 * ctx->num_cu), dim3(256), 65536, ctx->stream, (double *)any_device_ptr);
+    }
+    return DGPAMD_OK;
+}
+
+template <int MODE>
+static int launch_vrow(dgpamd_ctx *ctx, VRowArgs &a, int batch = 1) {
+    {
+        int prc = maybe_poison_lds(ctx, a.X);
+        if (prc) return prc;
     }
     const char *env = getenv("DGPAMD_VECCHIA_LDS");   // (1: the LDS version for every size -- the tests compare the two)
     if (a.m + 1 <= VR_MAXB && !(env && atoi(env)))   // register-resident factorisation, two rows per wave
@@ -1349,6 +1357,10 @@ extern "C" int dgpamd_vecchia_het_rows(dgpamd_ctx *ctx, int kind, int64_t n, int
                                          : (const void *)vecchia_het_rows_kernel<DGPAMD_MATERN25>;
     rc = set_lds(ctx, fn, shm);
     if (rc) return rc;
+    {
+        int prc = maybe_poison_lds(ctx, a.X);
+        if (prc) return prc;
+    }
     if (kind == DGPAMD_SEXP)
         hipLaunchKernelGGL(vecchia_het_rows_kernel<DGPAMD_SEXP>, dim3((unsigned)n), dim3(VW), shm, ctx->stream, a);
     else
@@ -1516,6 +1528,10 @@ extern "C" int dgpamd_vecchia_gp(dgpamd_ctx *ctx, int kind, int64_t M, int64_t n
     const void *fn = kind == DGPAMD_SEXP ? (const void *)vecchia_gp_kernel<DGPAMD_SEXP> : (const void *)vecchia_gp_kernel<DGPAMD_MATERN25>;
     rc = set_lds(ctx, fn, shm);
     if (rc) return rc;
+    {
+        int prc = maybe_poison_lds(ctx, a.x);
+        if (prc) return prc;
+    }
     if (kind == DGPAMD_SEXP)
         hipLaunchKernelGGL(vecchia_gp_kernel<DGPAMD_SEXP>, dim3((unsigned)M), dim3(VW), shm, ctx->stream, a);
     else
@@ -1701,6 +1717,10 @@ extern "C" int dgpamd_vecchia_linkgp(dgpamd_ctx *ctx, int kind, int64_t M, int64
                                          : (const void *)vecchia_linkgp_kernel<DGPAMD_MATERN25>;
     int rc = set_lds(ctx, fn, shm);
     if (rc) return rc;
+    {
+        int prc = maybe_poison_lds(ctx, a.y);
+        if (prc) return prc;
+    }
     if (kind == DGPAMD_SEXP)
         hipLaunchKernelGGL(vecchia_linkgp_kernel<DGPAMD_SEXP>, dim3((unsigned)M), dim3(VW), shm, ctx->stream, a);
     else
