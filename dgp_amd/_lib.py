@@ -82,6 +82,7 @@ SIGNATURES = {
     'dgpamd_moments_finalize': (_i, [_p, _l, _d, _p, _p]),
     'dgpamd_nn_ordered': (_i, [_p, _l, _i, _p, _i, _p]),
     'dgpamd_nn_query': (_i, [_p, _l, _l, _i, _p, _p, _i, _p]),
+    'dgpamd_debug_poison_lds': (_i, [_p]),
     'dgpamd_vecchia_llik': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _i, _d, _p, _p]),
     'dgpamd_vecchia_llik_batch': (_i, [_p, _i, _l, _i, _i, _p, _l, _i, _p, _p, _p, _i, _d, _p, _p]),
     'dgpamd_vecchia_nllik': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _p, _i, _d, _p, _i, _p]),

@@ -1166,6 +1166,19 @@ static int maybe_poison_lds(dgpamd_ctx *ctx, const double *any_device_ptr) {
     return DGPAMD_OK;
 }
 
+// Fill every CU's LDS with NaNs now (whatever the environment says): Engine._enter calls it before EVERY library call under
+// DGPAMD_POISON_LDS=2, which puts the whole test suite under the same check.
+extern "C" int dgpamd_debug_poison_lds(dgpamd_ctx *ctx) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    double *sink = nullptr;
+    HIP_TRY(ctx, hipMallocAsync((void **)&sink, sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(8 * ctx->num_cu), dim3(256), 65536, ctx->stream, sink);
+    HIP_TRY(ctx, hipFreeAsync(sink, ctx->stream));
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
 template <int MODE>
 static int launch_vrow(dgpamd_ctx *ctx, VRowArgs &a, int batch = 1) {
     {

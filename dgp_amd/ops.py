@@ -10,8 +10,12 @@ import ctypes as C
 import numpy as np
 import torch
 
+import os
+
 from . import _lib
 from ._lib import lib, KIND
+
+_POISON_ALL = os.environ.get('DGPAMD_POISON_LDS') == '2'   # (debugging: NaNs into every CU's LDS before every library call)
 
 
 class DgpAmdError(RuntimeError):
@@ -85,6 +89,8 @@ class Engine:
         if cur.cuda_stream != self._torch_stream.cuda_stream:
             self._torch_stream.wait_stream(cur)
             self._foreign = cur
+        if _POISON_ALL:
+            lib.dgpamd_debug_poison_lds(self.h)
         return None
 
     def _chk(self, rc):

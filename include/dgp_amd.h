@@ -327,6 +327,11 @@ int dgpamd_moments_finalize(dgpamd_ctx *ctx, int64_t count, double S, double *su
 int dgpamd_nn_ordered(dgpamd_ctx *ctx, int64_t n, int D, const double *x, int m, int64_t *NNarray);
 int dgpamd_nn_query(dgpamd_ctx *ctx, int64_t M, int64_t n, int D, const double *q, const double *x, int m, int64_t *NN);
 
+/* Debugging aid: fill the LDS of every CU with NaNs (a kernel that reads LDS it has not written then shows it in its results
+ * whatever ran before).  DGPAMD_POISON_LDS=1 does this before the Vecchia row / prediction launches, =2 makes the Python
+ * engine call this entry point before every library call. */
+int dgpamd_debug_poison_lds(dgpamd_ctx *ctx);
+
 /* ---- a19-a21  Vecchia likelihoods and sampler ---------------------------------
  * vecchia_llik vecchia.py:164-180 ; vecchia_nllik :182-242 (raw sums; the host
  * finishes the scale_est / replicate branches) ; L_matrix :409-424 ;
