@@ -187,7 +187,7 @@ class imputer:
         st['_engine'] = None
         st['_factor_cache'] = {}
         st['_ess_plans'] = {}
-        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_adopt', '_adopt_ll'):   # device state: rebuilt by the next sample()
+        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_adopt', '_adopt_ll', '_given_inputs'):   # device state: rebuilt by the next sample()
             st.pop(key, None)
         return st
 
@@ -206,12 +206,17 @@ class imputer:
         # IS that object its values cannot have changed, and the next calls skip the comparison (0.3 ms per 3 MB array, a
         # dozen of them per iteration at n = 50 000).  Views and foreign dtypes keep the comparison by value.
         owner = None
-        if isinstance(src, np.ndarray) and src.base is None and src.dtype == np.float64 and src.flags.c_contiguous:
-            try:
-                src.flags.writeable = False
-                owner = src
-            except ValueError:
-                owner = None
+        if key[0] in ('x', 'g') and isinstance(src, np.ndarray) and src.dtype == np.float64:   # (node inputs: copies the model made)
+            # (the array owns its data, or -- numpy's X[:, columns] -- is the full transposed view of an anonymous owner)
+            base = src.base
+            if base is None or (isinstance(base, np.ndarray) and base.base is None and base.size == src.size):
+                try:
+                    if base is not None:
+                        base.flags.writeable = False
+                    src.flags.writeable = False
+                    owner = src
+                except ValueError:
+                    owner = None
         cache[key] = (arr if owner is not None else arr.copy(), t, owner)
         return t
 
@@ -233,11 +238,12 @@ class imputer:
         F = []
         for l in range(L - 1):
             cols = [np.asarray(nd.output, dtype=float).reshape(-1) for nd in self.all_layer[l]]
-            host = np.stack(cols, 1)
-            keep = old is not None and l < len(old) and l in Fh and Fh[l].shape == host.shape and np.array_equal(Fh[l], host)
+            # (column by column against what _detach fetched: no (n, M) copy when nothing changed -- 2 ms at n = 50 000)
+            keep = old is not None and l < len(old) and l in Fh and Fh[l].shape == (len(cols[0]), len(cols)) and \
+                all(np.array_equal(Fh[l][:, k], c) for k, c in enumerate(cols))
             if not keep:
                 self.__dict__.pop('_adopt_ll', None)   # (the latents are not the ones the M-step saw)
-            F.append(old[l] if keep else self.engine.tensor(host))
+            F.append(old[l] if keep else self.engine.tensor(np.stack(cols, 1)))
         self.F = F
         self._Fh = {}
         self._glob = {}
@@ -263,11 +269,14 @@ class imputer:
             self._Fh[l] = Fh
             for k, nd in enumerate(self.all_layer[l]):
                 nd.output[:, 0] = Fh[:, k]
+            given = self.__dict__.setdefault('_given_inputs', {})
             for nd in self.all_layer[l + 1]:
                 if nd.rep is not None and nd.type == 'likelihood':
                     nd.input = Fh[nd.rep, :][:, nd.input_dim]
                 else:
                     nd.input = Fh[:, nd.input_dim]
+                    nd.input.flags.writeable = False   # (stage_for_mstep recognises it by identity instead of comparing 3 MB)
+                    given[id(nd)] = nd.input
 
     def adopt_from_mstep(self, nd, Aslot, host):
         """Called by the lock-step M-step when a node's optimiser has ended, with the factored buffer and the host results of
@@ -350,7 +359,8 @@ class imputer:
                     Xl = self._x0[k]
                 else:
                     idx = np.asarray(nd.input_dim)
-                    x_ok = np.array_equal(nd.input, Fh[l - 1][:, idx])
+                    mine = self.__dict__.get('_given_inputs', {}).get(id(nd))
+                    x_ok = (mine is nd.input and not nd.input.flags.writeable) or np.array_equal(nd.input, Fh[l - 1][:, idx])
                     src = self.F[l - 1]
                     Xl = src if (len(idx) == src.shape[1] and np.array_equal(idx, np.arange(src.shape[1]))) \
                         else src[:, torch.as_tensor(idx, device=src.device)].contiguous()

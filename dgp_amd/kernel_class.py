@@ -378,12 +378,21 @@ class kernel:
         else:
             self.imp_NNarray = None
 
-    def _vecch_stage(self):
+    def _vecch_stage(self, trust_pre=False):
         """Ordered inputs / outputs, neighbour array and nugget weights on the device.  Kept between calls while nothing
         has changed (an L-BFGS-B run evaluates the same data dozens of times; the neighbour array alone is 10 MB at
         n = 50 000): the arrays' identities say whether they were replaced, sums whether they were written in place."""
         e = self.engine
         import torch
+        if trust_pre and self.rep is None and self.__dict__.get('_vecch_prestaged') is not None:
+            # (lock-step M-step: the imputer has just validated these views and the result is used for this run only --
+            # no signature of the host arrays, 0.4 ms per node at n = 50 000)
+            pre = self.__dict__.pop('_vecch_prestaged')
+            od = self.ord_dev()
+            ones = self.__dict__.setdefault('_dev_cache', {}).get('ones')
+            if ones is None or ones.shape[0] != len(self.output) or ones.device != od.device:
+                ones = self._dev_cache['ones'] = e.tensor(np.ones(len(self.output)))
+            return dict(X=pre['X'][od].contiguous(), y=pre['y'][od].contiguous(), NN=self.nn_dev(), nd=ones)
         nd = np.ones(len(self.output)) if self.rep is None else self.W_diag
         sig = (id(self.input), id(self.global_input), id(self.ord), id(self.NNarray), id(nd) if self.rep is not None else None,
                float(np.sum(self.input)), float(np.sum(self.output)), float(np.sum(self.ord[:16])), len(self.output), id(e))

@@ -173,7 +173,7 @@ def maximise_lockstep_vecch(engine, nodes):
     problems = [_Problem(x0, lb, ub, opts.get('maxiter', 15000), opts.get('maxfun', 15000)) for x0, lb, ub, opts in setups]
     evals = [0]
     for nd in nodes:
-        nd._vecch_fixed = nd._vecch_stage()   # inputs, outputs, neighbours: fixed during the run
+        nd._vecch_fixed = nd._vecch_stage(trust_pre=True)   # inputs, outputs, neighbours: fixed during the run
         nd._in_maximise = True
 
     def evaluate(req):
