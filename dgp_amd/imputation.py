@@ -187,7 +187,7 @@ class imputer:
         st['_engine'] = None
         st['_factor_cache'] = {}
         st['_ess_plans'] = {}
-        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_adopt', '_adopt_ll', '_given_inputs'):   # device state: rebuilt by the next sample()
+        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_vecch_y', '_adopt', '_adopt_ll', '_given_inputs'):   # device state: rebuilt by the next sample()
             st.pop(key, None)
         return st
 
@@ -647,10 +647,18 @@ class imputer:
                                  e.tensor(np.ones(FP.shape[1]) if nd.rep is None else nd.W_diag)))
                     self._vecch_dev[(l + 1, k)] = hit
                 cm, od, NN, nd_diag = hit[1]
-                y = self._node_y(l + 1, k)[od].contiguous()
-                # the ordered inputs of ALL candidates in three device operations (was five small ones per candidate: the host
-                # could not keep the device busy between the row kernels)
-                Xall = FP[:, :, cm]
+                ysrc = self._node_y(l + 1, k)
+                if l + 1 == len(self.all_layer) - 1:   # (observed outputs: ordered once per ordering, not once per batch)
+                    yhit = self.__dict__.setdefault('_vecch_y', {}).get((l + 1, k))
+                    if yhit is None or yhit[0] is not ysrc or yhit[1] is not od:
+                        yhit = self._vecch_y[(l + 1, k)] = (ysrc, od, ysrc[od].contiguous())
+                    y = yhit[2]
+                else:
+                    y = ysrc[od].contiguous()
+                # the ordered inputs of ALL candidates in at most three device operations (was five small ones per candidate:
+                # the host could not keep the device busy between the row kernels); one when the node takes every column in order
+                ident = FP.shape[2] == len(nd.input_dim) and np.array_equal(np.asarray(nd.input_dim), np.arange(FP.shape[2]))
+                Xall = FP if ident else FP[:, :, cm]
                 if self._glob[(l + 1, k)] is not None:
                     Xall = torch.cat((Xall, self._glob[(l + 1, k)].unsqueeze(0).expand(B, -1, -1)), 2)
                 Xall = Xall[:, od].contiguous()
