@@ -1404,17 +1404,50 @@ __global__ __launch_bounds__(SPW) void spsolve_kernel(int64_t n, int mp1, const 
         x += p * n;
         if (lscales) lscale = lscales[mat];
     }
+    constexpr int WMAX = 6;   // in-window dependencies a row keeps in registers (more: re-read from the arrays)
     for (int64_t base = 0; base < n; base += SPW) {
         const int64_t i = base + tid;
         const bool active = i < n;
         rdy[tid] = 0;
         double acc = 0.0;
-        int cnt = 0;
+        int cnt = 0, nw = 0;          // nw: in-window dependencies (all of them counted, the first WMAX kept)
+        int wdep[WMAX];
+        double wl[WMAX];
+#pragma unroll
+        for (int q = 0; q < WMAX; ++q) {
+            wdep[q] = 0;
+            wl[q] = 0.0;
+        }
         if (active) {
             cnt = (int)(i + 1 < mp1 ? i + 1 : mp1);
-            for (int j = 1; j < cnt; ++j) {   // dependencies finished in earlier windows
-                const int64_t dep = NN[i * mp1 + j];
-                if (dep < base) acc = fma(L[i * mp1 + j] * lscale, ((const volatile double *)x)[dep], acc);
+            // dependencies finished in earlier windows, eight at a time: the index loads, then the eight x loads, are in
+            // flight together (one at a time the two dependent memory latencies per entry made 50 us of a window's 180);
+            // the sum runs in the order of the entries as before
+            for (int j0 = 1; j0 < cnt; j0 += 8) {
+                int64_t dep[8];
+                double lv[8], xv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = j0 + q;
+                    dep[q] = j < cnt ? NN[i * mp1 + j] : -1;
+                    lv[q] = j < cnt ? L[i * mp1 + j] * lscale : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    xv[q] = (dep[q] >= 0 && dep[q] < base) ? ((const volatile double *)x)[dep[q]] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (dep[q] >= 0 && dep[q] < base) acc = fma(lv[q], xv[q], acc);
+                    if (dep[q] >= base) {
+#pragma unroll
+                        for (int w = 0; w < WMAX; ++w)
+                            if (w == nw) {
+                                wdep[w] = (int)(dep[q] - base);
+                                wl[w] = lv[q];
+                            }
+                        ++nw;
+                    }
+                }
             }
         }
         bool done = !active;
@@ -1423,20 +1456,32 @@ __global__ __launch_bounds__(SPW) void spsolve_kernel(int64_t n, int mp1, const 
             bool fire = false;
             if (!done) {
                 fire = true;
-                for (int j = 1; j < cnt; ++j) {
-                    const int64_t dep = NN[i * mp1 + j];
-                    if (dep >= base && !rdy[dep - base]) {
-                        fire = false;
-                        break;
+                if (nw <= WMAX) {
+#pragma unroll
+                    for (int w = 0; w < WMAX; ++w)
+                        if (w < nw && !rdy[wdep[w]]) fire = false;
+                } else {
+                    for (int j = 1; j < cnt; ++j) {
+                        const int64_t dep = NN[i * mp1 + j];
+                        if (dep >= base && !rdy[dep - base]) {
+                            fire = false;
+                            break;
+                        }
                     }
                 }
             }
             double xi = 0.0;
             if (fire) {
                 double s = acc;
-                for (int j = 1; j < cnt; ++j) {
-                    const int64_t dep = NN[i * mp1 + j];
-                    if (dep >= base) s = fma(L[i * mp1 + j] * lscale, xs[dep - base], s);
+                if (nw <= WMAX) {
+#pragma unroll
+                    for (int w = 0; w < WMAX; ++w)
+                        if (w < nw) s = fma(wl[w], xs[wdep[w]], s);
+                } else {
+                    for (int j = 1; j < cnt; ++j) {
+                        const int64_t dep = NN[i * mp1 + j];
+                        if (dep >= base) s = fma(L[i * mp1 + j] * lscale, xs[dep - base], s);
+                    }
                 }
                 xi = (b[i] - s) / (L[i * mp1] * lscale);
             }
