@@ -459,8 +459,7 @@ class dgp:
                 self.last_mstep = None
             # Vecchia nodes whose optimiser needs no callback: lock-step as well (one synchronisation per round, not one per
             # node and evaluation)
-            vlock = [nd for _, nd in nodes if nd.vecch and mstep._HAVE_CORE and not ddist.rows_split()
-                     and not (nd.target == 'gp' and len(nd.length) != 1)]
+            vlock = [nd for _, nd in nodes if nd.vecch and mstep._HAVE_CORE and not (nd.target == 'gp' and len(nd.length) != 1)]
             if len(vlock) > 1:
                 mstep.maximise_lockstep_vecch(eng, vlock)
             else:

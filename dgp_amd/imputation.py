@@ -23,6 +23,7 @@ both can be injected for deterministic replay.
 import numpy as np
 from numpy.linalg import LinAlgError
 from .ops import raise_not_pd
+from . import dist as ddist
 import torch
 
 from .ops import default_engine
@@ -662,7 +663,10 @@ class imputer:
                 if self._glob[(l + 1, k)] is not None:
                     Xall = torch.cat((Xall, self._glob[(l + 1, k)].unsqueeze(0).expand(B, -1, -1)), 2)
                 Xall = Xall[:, od].contiguous()
-                o = e.vecchia_llik_batch(nd.name, Xall, y, NN, nd.length, nd.nugget[0], nd_diag)
+                lo, hi = ddist.vecchia_rows(NN.shape[0])   # (all rows unless dist.split_training(rows=True) on several ranks)
+                o = e.vecchia_llik_batch(nd.name, Xall, y, NN[lo:hi], nd.length, nd.nugget[0], nd_diag)
+                if ddist.rows_split():   # one all-reduce of the batch's 2 B sums: every rank takes the same accept decisions
+                    o = ddist.allreduce_sum_vector(o.reshape(-1)).reshape(B, 2)
                 dev_terms.append(-0.5 * (o[:, 1] + o[:, 0] / float(nd.scale[0])))
                 if nd.prior_name == 'ref':
                     if FPh is None:

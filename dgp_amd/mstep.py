@@ -12,6 +12,8 @@ device-to-host copy).  Every node sees exactly the iterates scipy.optimize.minim
 
 import numpy as np
 
+from . import dist as ddist
+
 try:   # scipy 1.15's reverse-communication L-BFGS-B core (the routine scipy.optimize.minimize itself drives)
     import scipy
     from scipy.optimize import _lbfgsb as _core
@@ -166,8 +168,9 @@ def maximise_lockstep_vecch(engine, nodes):
     """kernel.maximise() for several Vecchia GP nodes at once: the same lock-step driver, every round's objective evaluations
     (vecchia_nllik, one launch per node) queued back to back and fetched with ONE synchronisation -- the reference (and
     kernel.maximise) pays a host round trip per node and evaluation, which at n = 50 000 is two thirds of a 1-ms kernel.
-    Only for nodes whose optimiser runs without a callback (kernel_class.py:537-542: DGP nodes, isotropic GP nodes) and
-    without the rows split over ranks.  Returns (rounds, evaluations)."""
+    Only for nodes whose optimiser runs without a callback (kernel_class.py:537-542: DGP nodes, isotropic GP nodes).  With the
+    likelihood rows split over ranks (dist.split_training(rows=True)) every rank drives the same optimisers on the same
+    all-reduced sums: one collective per round.  Returns (rounds, evaluations)."""
     import torch
     setups = [nd._opt_setup() for nd in nodes]
     problems = [_Problem(x0, lb, ub, opts.get('maxiter', 15000), opts.get('maxfun', 15000)) for x0, lb, ub, opts in setups]
@@ -182,7 +185,10 @@ def maximise_lockstep_vecch(engine, nodes):
             nd = nodes[i]
             nd.update(x)
             outs.append(nd._llik_vecch_device())
-        host = engine.fetch(torch.cat([o for o, _ in outs]))
+        buf = torch.cat([o for o, _ in outs])
+        if ddist.rows_split():   # every rank evaluated its rows of every node: ONE all-reduce per round
+            buf = ddist.allreduce_sum_vector(buf)
+        host = engine.fetch(buf)
         res, at = [], 0
         for (i, _), (o, P) in zip(req, outs):
             k = o.numel()

@@ -1300,7 +1300,8 @@ def test_training_splits_two_ranks(tmp_path):
     rendezvous, both on this GPU, same seed = same draws): Vecchia likelihood rows n/2 per rank with an all-reduce of
     (quad, logdet, gradient) (vecchia.py:164-242), and M-step nodes round-robin with one all-gather of the fitted
     hyper-parameters (dgp.py:1455-1467).  Both must reproduce the single-rank training: rows to 1e-10 (a different
-    summation order), nodes bit for bit."""
+    summation order), nodes bit for bit.  The I-step runs with the rows split as well (one all-reduce per speculative batch):
+    both ranks must end with the same latents."""
     import os
     import subprocess
     import sys
@@ -1367,6 +1368,16 @@ print('rows split m-step done', flush=True)
 dd.split_training(rows=False)
 np.random.seed(11); d._m_step()
 np.testing.assert_allclose(hyper(c), hyper(d), rtol=1e-4, atol=1e-8)
+# the I-step with the rows split: every speculative batch's sums are all-reduced, so both ranks must take the same accept
+# decisions and end with the same latent layer, bit for bit
+dd.split_training(rows=True)
+c.imp.sample(burnin=2)
+Fc = np.concatenate([nd.output for nd in c.all_layer[0]], 1)
+assert np.all(np.isfinite(Fc))
+both = dd.allgather_objects(Fc.tobytes())
+assert both[0] == both[1], 'the ranks ended with different latents'
+dd.split_training(rows=False)
+print('rows split i-step agrees across ranks', flush=True)
 dd.barrier()
 print('rank', dd.rank(), 'ok')
 """ % root)
