@@ -525,6 +525,14 @@ static int launch_nn_stream(dgpamd_ctx *ctx, int64_t nq, int64_t nx, int D, cons
     // chunks of the candidate range: enough (block, chunk) items to fill the chip, at most 8192 candidates each
     int64_t chunk = (nx * nblk / 4096 + 63) / 64 * 64;
     chunk = chunk < 1024 ? 1024 : (chunk > 8192 ? 8192 : chunk);
+    // measured (n = 50 000, d = 8): every chunk starts with empty lists, so the query form -- few blocks of queries, each scanning
+    // everything -- wants long chunks (10 000 queries: 9.8 ms with 1920-candidate chunks, 4.9 ms with 8192); the ordered search
+    // has blocks enough and only gains from 16384 at the largest sizes (4.1 -> 3.7 ms at n = 50 000)
+    if (!ordered)
+        chunk = nq < 15000 ? 8192 : (nq < 40000 ? 16384 : 25024);
+    else if (nx >= 45000)
+        chunk = 16384;
+    if (const char *ce = getenv("DGPAMD_NN_CHUNK")) chunk = atoll(ce) > 0 ? (atoll(ce) + 63) / 64 * 64 : chunk;   // (tuning aid)
     const int nchunk = (int)((nx + chunk - 1) / chunk);
     const size_t items = (size_t)nblk * nchunk;
     double *sd = nullptr;
@@ -558,12 +566,13 @@ static int launch_nn(dgpamd_ctx *ctx, int64_t nq, int64_t nx, int D, const doubl
         hipLaunchKernelGGL(nn_select_kernel, dim3((unsigned)nq), dim3(256), shm, ctx->stream, nq, nx, D, q, x, m_out, ordered, out);
         return DGPAMD_OK;
     }
-    // measured crossovers (tools/gpu_nn_bench.py): the streaming kernels win the ordered search from n ~ 12 000 on (4.9x at
-    // n = 50 000) and the query form only when both sides are large (their floor is one cold-started chunk scan, ~3 ms).
+    // measured crossovers (tools/gpu_nn_bench.py): the streaming kernels win the ordered search from n ~ 12 000 on (5.8x at
+    // n = 50 000) and the query form from ~6000 queries on (1.9x at 10 000, 2.6x at 20 000 queries against 50 000 points; their
+    // floor is one cold-started chunk scan, ~4 ms).
     // DGPAMD_NN_STORE_ONCE = 1 / 2 forces the store-once / the streaming kernels (the tests compare the two).
     const char *env = getenv("DGPAMD_NN_STORE_ONCE");
     const int force = env ? atoi(env) : 0;
-    const bool pays = ordered ? nx >= 12000 : (nq >= 32768 && nx >= 20000);
+    const bool pays = ordered ? nx >= 12000 : (nq >= 6000 && nx >= 20000);
     if (D <= 16 && m_out <= 64 && nx < INT_MAX && force != 1 && (pays || force == 2))
         return D <= 8 ? launch_nn_stream_k<8>(ctx, nq, nx, D, q, x, m_out, ordered, out)
                       : launch_nn_stream_k<16>(ctx, nq, nx, D, q, x, m_out, ordered, out);
