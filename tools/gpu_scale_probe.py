@@ -88,11 +88,12 @@ elif which == 'cfg4train':
         sys.exit(0)
     t = time.perf_counter(); emu = emulator(model.estimate(burnin=0), N=2, seed=3); sync()
     print('cfg4train: emulator(N=2) %.1f s' % (time.perf_counter() - t), flush=True)
-    xt = rng.uniform(size=(2000, d))
-    ft = np.sin(3 * xt[:, 0]) * np.cos(2 * xt[:, 1]) + xt[:, 2] ** 2 + 0.3 * xt[:, 3:].sum(1)
-    t = time.perf_counter(); mu, var = emu.predict(xt, m=50); sync(); dt = time.perf_counter() - t
-    print('cfg4train: predict 2000 pts x 2 imputations %.2f s (%.0f pts/s), rmse %.3f, mem %.1f GB' % (
-        dt, 2000 / dt, np.sqrt(np.mean((mu[:, 0] - (ft - f.mean()) / f.std()) ** 2)), torch.cuda.max_memory_allocated() / 2**30))
+    for mp in [int(v) for v in os.environ.get('MPRED', '2000').split(',')]:
+        xt = rng.uniform(size=(mp, d))
+        ft = np.sin(3 * xt[:, 0]) * np.cos(2 * xt[:, 1]) + xt[:, 2] ** 2 + 0.3 * xt[:, 3:].sum(1)
+        t = time.perf_counter(); mu, var = emu.predict(xt, m=50); sync(); dt = time.perf_counter() - t
+        print('cfg4train: predict %d pts x 2 imputations %.2f s (%.0f pts/s), rmse %.3f, mem %.1f GB' % (
+            mp, dt, mp / dt, np.sqrt(np.mean((mu[:, 0] - (ft - f.mean()) / f.std()) ** 2)), torch.cuda.max_memory_allocated() / 2**30))
 else:
     n, d, m = int(os.environ.get('N', '50000')), 8, 25
     rng = np.random.default_rng(7)
