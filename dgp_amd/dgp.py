@@ -436,47 +436,80 @@ class dgp:
         eng = self.engine
         nodes = [(l, nd) for l, layer in enumerate(self.all_layer) for nd in layer if nd.type == 'gp']
         every = nodes
-        if ddist.nodes_split():   # this rank fits nodes rank, rank + world, ...; the fits are exchanged below
+        split = ddist.nodes_split()
+        if split:   # this rank fits nodes rank, rank + world, ...; the fits are exchanged below
             nodes = [nodes[i] for i in range(ddist.rank(), len(nodes), ddist.world())]
+        failure = None
         with eng.stream():
-            for l, nd in nodes:
+            for l, nd in every:   # (diagnostics on EVERY rank, also for the nodes another rank fits: identical R2 histories)
                 nd.engine = eng
                 if nd.prior_name == 'ref':
                     nd.compute_cl()
                 if l != 0:
                     nd.r2()
-            dense = [nd for _, nd in nodes if not nd.vecch] if mstep._HAVE_CORE else []
-            pre = self.imp.stage_for_mstep() if getattr(self, 'imp', None) is not None and mstep._HAVE_CORE else {}
-            for _, nd in nodes:
-                if id(nd) in pre:
-                    if nd.vecch:
-                        nd._vecch_prestaged = pre[id(nd)]
-                    elif any(nd is d for d in dense):
-                        nd._prestaged = pre[id(nd)]
-            if dense:
-                self.last_mstep = mstep.maximise_lockstep(eng, dense, self)
-            else:
-                self.last_mstep = None
-            # Vecchia nodes whose optimiser needs no callback: lock-step as well (one synchronisation per round, not one per
-            # node and evaluation)
-            vlock = [nd for _, nd in nodes if nd.vecch and mstep._HAVE_CORE and not (nd.target == 'gp' and len(nd.length) != 1)]
-            if len(vlock) > 1:
-                mstep.maximise_lockstep_vecch(eng, vlock)
-            else:
-                vlock = []
-            for _, nd in nodes:
-                if not any(nd is d for d in dense) and not any(nd is d for d in vlock):
-                    nd.maximise()
-            if ddist.nodes_split():
-                # one all-gather per M-step: (scale, lengthscales, nugget) of the nodes every rank has fitted
-                mine = {i: (every[i][1].scale.copy(), every[i][1].length.copy(), every[i][1].nugget.copy())
-                        for i in range(ddist.rank(), len(every), ddist.world())}
-                for part in ddist.allgather_objects(mine):
-                    for i, (sc, ln, ng) in part.items():
-                        nd = every[i][1]
-                        if i % ddist.world() != ddist.rank():
-                            nd.scale, nd.length, nd.nugget = sc.copy(), ln.copy(), ng.copy()
-                            nd.add_to_path()
+            try:
+                self._fit_nodes(nodes, mstep, eng)
+            except (np.linalg.LinAlgError, SystemError, RuntimeError) as exc:   # (RuntimeError: DgpAmdError, a lost hand-off)
+                if not split:
+                    raise
+                failure = exc   # rank-local: the other ranks are on their way into the collective -- join it, then fail together
+            if split:
+                self._exchange_fits(every, failure)
+
+    def _fit_nodes(self, nodes, mstep, eng):
+        dense = [nd for _, nd in nodes if not nd.vecch] if mstep._HAVE_CORE else []
+        pre = self.imp.stage_for_mstep() if getattr(self, 'imp', None) is not None and mstep._HAVE_CORE else {}
+        for _, nd in nodes:
+            if id(nd) in pre:
+                if nd.vecch:
+                    nd._vecch_prestaged = pre[id(nd)]
+                elif any(nd is d for d in dense):
+                    nd._prestaged = pre[id(nd)]
+        if dense:
+            self.last_mstep = mstep.maximise_lockstep(eng, dense, self)
+        else:
+            self.last_mstep = None
+        # Vecchia nodes whose optimiser needs no callback: lock-step as well (one synchronisation per round, not one per
+        # node and evaluation)
+        vlock = [nd for _, nd in nodes if nd.vecch and mstep._HAVE_CORE and not (nd.target == 'gp' and len(nd.length) != 1)]
+        if len(vlock) > 1:
+            mstep.maximise_lockstep_vecch(eng, vlock)
+        else:
+            vlock = []
+        for _, nd in nodes:
+            if not any(nd is d for d in dense) and not any(nd is d for d in vlock):
+                nd.maximise()
+
+    def _exchange_fits(self, every, failure):
+        """Node split: ONE equal-size all-gather of doubles per M-step.  Rank r sends, for each node it owns, the row
+        [status, scale, nugget, lengthscales...] (status 1: this rank's fits raised); afterwards every rank holds every
+        node's estimate -- or every rank raises the same LinAlgError, so that train()'s restart (dgp.py:1402-1412) happens
+        on all of them together and the models stay identical (a non-numerical failure: RuntimeError everywhere)."""
+        w, r = ddist.world(), ddist.rank()
+        width = 3 + max(len(nd.length) for _, nd in every)
+        per_rank = -(-len(every) // w)
+        mine = np.zeros((per_rank, width))
+        for slot, i in enumerate(range(r, len(every), w)):
+            nd = every[i][1]
+            mine[slot, 1], mine[slot, 2] = nd.scale[0], nd.nugget[0]
+            mine[slot, 3:3 + len(nd.length)] = nd.length
+        if failure is not None:   # 1: numerical (every rank restarts), 2: anything else (every rank gives up)
+            mine[:, 0] = 1.0 if isinstance(failure, (np.linalg.LinAlgError, SystemError)) else 2.0
+        got = ddist.allgather_vector(mine, device=getattr(self.engine, 'device', None)).reshape(w, per_rank, width)
+        bad = [q for q in range(w) if got[q, :, 0].any()]
+        if bad:
+            msg = 'M-step failed on rank(s) %s of the node split%s' % (bad, '' if failure is None else ': %s' % failure)
+            if got[:, :, 0].max() >= 2.0:
+                raise RuntimeError(msg) from failure
+            raise np.linalg.LinAlgError(msg) from failure
+        for i, (_, nd) in enumerate(every):
+            q, slot = i % w, i // w
+            if q == r:
+                continue
+            row = got[q, slot]
+            nd.scale, nd.nugget = np.atleast_1d(row[1]).copy(), np.atleast_1d(row[2]).copy()
+            nd.length = row[3:3 + len(nd.length)].copy()
+            nd.add_to_path()
 
     def train(self, N=500, ess_burn=10, disable=False):
         """N iterations of stochastic EM (dgp.py:1364-1412) with the same restart policy on LinAlgError."""

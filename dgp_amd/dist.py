@@ -98,12 +98,19 @@ _SPLIT = {'rows': False, 'nodes': False}
 
 
 def split_training(rows=None, nodes=None):
-    """Switch the Vecchia-row split and / or the M-step-node split on or off (they act only in an initialised process
-    group of more than one rank).  Returns the current settings."""
+    """Switch the Vecchia-row split OR the M-step-node split on or off (they act only in an initialised process
+    group of more than one rank).  Returns the current settings.
+    The two do not compose -- with the node split every rank fits different nodes, so the row sums of one rank's node
+    would be added to another rank's -- and asking for both raises ValueError (nothing is changed then)."""
+    new = dict(_SPLIT)
     if rows is not None:
-        _SPLIT['rows'] = bool(rows)
+        new['rows'] = bool(rows)
     if nodes is not None:
-        _SPLIT['nodes'] = bool(nodes)
+        new['nodes'] = bool(nodes)
+    if new['rows'] and new['nodes']:
+        raise ValueError('split_training: the Vecchia-row split and the M-step-node split cannot be combined '
+                         '(switch one off first: split_training(rows=False, nodes=True) or (rows=True, nodes=False))')
+    _SPLIT.update(new)
     return dict(_SPLIT)
 
 
@@ -134,9 +141,26 @@ def allreduce_sum_vector(t):
 
 
 def allgather_objects(obj):
-    """[obj of rank 0, obj of rank 1, ...] on every rank (small python objects: fitted hyper-parameters)."""
+    """[obj of rank 0, obj of rank 1, ...] on every rank (pickles through the host: diagnostics and tests only -- the
+    training and prediction paths exchange fixed-size float64 vectors, allgather_vector)."""
     if not is_active():
         return [obj]
     out = [None] * world()
     td.all_gather_object(out, obj)
     return out
+
+
+def allgather_vector(vec, device=None):
+    """(world, len(vec)) float64 array: every rank's fixed-length vector, on every rank -- ONE equal-size all-gather of
+    doubles (no pickling; a device tensor under nccl/RCCL, a host tensor under gloo)."""
+    import numpy as np
+    vec = np.ascontiguousarray(vec, dtype=np.float64).ravel()
+    if not is_active():
+        return vec[None, :].copy()
+    on_dev = td.get_backend() == 'nccl'
+    t = torch.from_numpy(vec)
+    if on_dev:
+        t = t.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
+    out = torch.empty((world(), len(vec)), dtype=torch.float64, device=t.device)
+    td.all_gather_into_tensor(out, t) if on_dev else td.all_gather(list(out.unbind(0)), t)
+    return out.cpu().numpy()

@@ -39,17 +39,17 @@ class emulator:
         self.all_layer = all_layer
         self.n_layer = len(all_layer)
         self.vecch = bool(all_layer[0][0].vecch)
-        self.engine = default_engine(device)
-        for layer in all_layer:
-            for nd in layer:
-                if nd.type == 'gp':
-                    nd.engine = self.engine
         self.N_total = int(N)
         self.shard_points = shard == 'points' and ddist.is_active()
         self.shard = False if shard == 'points' else (ddist.is_active() if shard is None else bool(shard))
         rank, world = (ddist.rank(), ddist.world()) if self.shard else (0, 1)
         if self.shard and self.N_total < world:   # (a rank without imputations would skip the collectives the others enter)
             raise Exception('emulator(shard=True) needs at least one imputation per rank: N = %d < %d ranks' % (self.N_total, world))
+        self.engine = default_engine(device)
+        for layer in all_layer:
+            for nd in layer:
+                if nd.type == 'gp':
+                    nd.engine = self.engine
         self.N = ddist.share(self.N_total, rank, world)
         if self.shard_points and seed is None:      # all ranks must draw the same imputations: rank 0's entropy for everyone
             box = [np.random.SeedSequence().entropy]
