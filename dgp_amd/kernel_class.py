@@ -452,27 +452,8 @@ class kernel:
             origin_n, rr = n, -1.0
         else:
             origin_n, rr = len(self.rep), float(self.sum_residual[0])
-        quad, logdet, dquad, dlogdet = o[0], o[1], o[2:2 + P].copy(), o[2 + P:].copy()
-        nug = self.nugget[0]
-        if self.scale_est:
-            if n == origin_n:
-                scale = quad / n
-                nll = 0.5 * (logdet + n * np.log(scale))
-                g = 0.5 * (dlogdet - dquad / scale)
-            else:
-                scale = (quad + rr / nug) / origin_n
-                nll = 0.5 * (logdet + origin_n * np.log(scale))
-                g = 0.5 * (dlogdet - dquad / scale)
-                if self.nugget_est:
-                    nll += 0.5 * (origin_n - n) * np.log(nug)
-                    g[-1] += 0.5 * (-rr / (scale * nug) + (origin_n - n))
-        else:
-            scale = self.scale[0]
-            nll = 0.5 * (logdet + quad / scale)
-            g = 0.5 * (dlogdet - dquad / scale)
-            if n != origin_n and self.nugget_est:
-                nll += 0.5 * (rr / (nug * scale) + (origin_n - n) * np.log(nug))
-                g[-1] += 0.5 * (-rr / (scale * nug) + (origin_n - n))
+        from .vecchia import nllik_close
+        nll, g, scale = nllik_close(o, P, n, origin_n, rr, self.scale[0], self.nugget[0], self.scale_est, self.nugget_est)
         self.scale = np.atleast_1d(scale)
         nll = np.atleast_1d(nll)
         if self.prior_name is not None:

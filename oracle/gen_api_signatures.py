@@ -11,6 +11,11 @@ CLASSES = {'dgp.py': ['dgp'], 'gp.py': ['gp'], 'emulation.py': ['emulator'], 'ke
            'linkgp.py': ['container', 'lgp'], 'synthetic.py': ['path'],
            'likelihood_class.py': ['Poisson', 'Hetero', 'NegBin', 'Categorical', 'ZIP', 'ZINB']}
 FUNCS = {'kernel_class.py': ['combine'], 'utils.py': ['write', 'read', 'summary', 'nb_seed', 'set_thread', 'get_thread']}
+# the njit "operator API" (SURVEY.md 8(b)): module -> functions whose ORDERED parameter lists dgp_amd.functions /
+# dgp_amd.vecchia reproduce (positional calls must keep working)
+OPERATORS = {'functions.py': ['gp', 'link_gp', 'fmvn', 'update_f'],
+             'vecchia.py': ['get_pred_nn', 'nn', 'forward_solve_sp', 'vecchia_llik', 'vecchia_nllik', 'L_matrix', 'gp_vecch',
+                            'link_gp_vecch']}
 
 
 def params(fn):
@@ -32,6 +37,10 @@ def main():
         for node in tree.body:
             if isinstance(node, ast.FunctionDef) and node.name in names:
                 out['functions'][node.name] = params(node)
+    out['operators'] = {}
+    for f, names in OPERATORS.items():
+        tree = ast.parse(open(os.path.join(REF, f)).read())
+        out['operators'][f[:-3]] = {node.name: params(node) for node in tree.body if isinstance(node, ast.FunctionDef) and node.name in names}
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', 'api_signatures.json')
     with open(dst, 'w') as fh:
         json.dump(out, fh, indent=1, sort_keys=True)

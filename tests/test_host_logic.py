@@ -463,6 +463,23 @@ def test_public_api_accepts_the_reference_calls():
     assert not bad, bad
 
 
+def test_operator_api_shims_keep_the_reference_argument_lists():
+    """dgp_amd.functions / dgp_amd.vecchia (the njit operator API of SURVEY.md 8(b)): every function the reference's
+    callers import exists under the same name and takes the reference's parameters in the reference's ORDER (read from its
+    sources by oracle/gen_api_signatures.py), so positional calls keep working; the only addition is a trailing
+    keyword `engine`.  Parsed with ast: importing the modules needs a HIP device."""
+    import ast
+    import json
+    api = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'api_signatures.json')))['operators']
+    assert set(api) == {'functions', 'vecchia'}
+    for mod, funcs in api.items():
+        tree = ast.parse(open(os.path.join(ROOT, 'dgp_amd', mod + '.py')).read())
+        have = {n.name: [a.arg for a in n.args.args] for n in tree.body if isinstance(n, ast.FunctionDef)}
+        for fn, ps in funcs.items():
+            assert fn in have, (mod, fn)
+            assert have[fn][:len(ps)] == ps and have[fn][len(ps):] == ['engine'], (mod, fn, have[fn], ps)
+
+
 def test_lost_handoff_is_not_a_numerical_failure():
     """info < 0 (a bounded in-kernel spin gave up) raises DgpAmdError, which dgp.train's LinAlgError restart policy
     (dgp.py:1402-1412) does not swallow; info > 0 stays numpy's LinAlgError."""
