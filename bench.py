@@ -56,49 +56,96 @@ def cpu_baseline(model, counts, ess_burn):
     rng = np.random.default_rng(1)
     l1, l2 = model.all_layer[0][0], model.all_layer[1][0]
     n = len(l1.output)
-    reps_f, reps_l, reps_g, passes = 3, 5, 2, 3     # three passes of ~5 s each; the MEDIAN pass is reported
+    reps_f, reps_l, reps_g = 3, 3, 2     # after one untimed call of each: ~5 s in all (the baseline must not outlast the GPU legs)
 
-    def one_pass(first):
-        t0 = None
-        for r in range(reps_f + first):   # fmvn(scale*k_matrix()) of a first-layer node   (imputation.py:63)
-            if r == first:
-                t0 = time.perf_counter()
-            O.fmvn(l1.scale[0] * O.k_matrix(l1._X(), l1.length, l1.nugget[0], l1.name), rng.standard_normal(n))
-        t_fmvn = (time.perf_counter() - t0) / reps_f
-        for r in range(reps_l + first):   # log_likelihood_func of the second-layer node   (imputation.py:76,104)
-            if r == first:
-                t0 = time.perf_counter()
-            O.log_likelihood(l2._X(), l2.output, l2.length, l2.scale, l2.nugget[0], l2.name)
-        t_ll = (time.perf_counter() - t0) / reps_l
-        t_llik = []
-        for nd in (l1, l2):       # kernel.llik: objective + gradient, one cho_solve(n x n) per parameter
-            for r in range(reps_g + first):
-                if r == first:
-                    t0 = time.perf_counter()
-                O.nll_grad(nd.log_t(), nd._X(), nd.output, nd.name, nd.scale, nd.nugget[0], nd.nugget_est, nd.scale_est,
-                           nd.prior_name, nd.prior_coef)
-            t_llik.append((time.perf_counter() - t0) / reps_g)
-        return t_fmvn, t_ll, t_llik
+    def timed(f, reps):
+        f()   # untimed: first-touch, BLAS thread pool start-up
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts
 
+    # fmvn(scale*k_matrix()) of a first-layer node (imputation.py:63); log_likelihood_func of the second-layer node
+    # (imputation.py:76,104); kernel.llik: objective + gradient, one cho_solve(n x n) per parameter
+    t_fmvn, all_f = timed(lambda: O.fmvn(l1.scale[0] * O.k_matrix(l1._X(), l1.length, l1.nugget[0], l1.name), rng.standard_normal(n)), reps_f)
+    t_ll, all_l = timed(lambda: O.log_likelihood(l2._X(), l2.output, l2.length, l2.scale, l2.nugget[0], l2.name), reps_l)
+    t_llik, all_g = [], []
+    for nd in (l1, l2):
+        t, ts = timed(lambda nd=nd: O.nll_grad(nd.log_t(), nd._X(), nd.output, nd.name, nd.scale, nd.nugget[0], nd.nugget_est, nd.scale_est,
+                                               nd.prior_name, nd.prior_coef), reps_g)
+        t_llik.append(t)
+        all_g += ts
     sweeps = ess_burn + 1
     n_l1 = len(model.all_layer[0])
-
-    def per_iteration(t_fmvn, t_ll, t_llik):
-        return (sweeps * n_l1 * t_fmvn                                       # reference refactors every sweep
+    per_iter = (sweeps * n_l1 * t_fmvn                                       # reference refactors every sweep
                 + (sweeps + counts['proposals_per_iter']) * t_ll              # threshold + proposals
                 + counts['llik_l1_per_iter'] * t_llik[0] + counts['llik_l2_per_iter'] * t_llik[1])
-
-    runs = [one_pass(1 if p == 0 else 0) for p in range(passes)]   # (one untimed call of each function before the first pass)
-    t_fmvn, t_ll, t_llik = sorted(runs, key=lambda r: per_iteration(*r))[passes // 2]
-    per_iter = per_iteration(t_fmvn, t_ll, t_llik)
-    return dict(value=1.0 / per_iter, unit='SI it/s', cores=psutil.cpu_count(logical=False), kind='port',
-                sample=('median of %d passes, each %d fmvn + %d log_likelihood_func + 2x%d llik at n=%d (%.1f s per pass, one untimed '
-                        'call of each first), scaled by the per-iteration call counts of the GPU run: %d sweeps x %d fmvn, %.1f+%d '
-                        'log-liks, %.1f/%.1f llik calls (layer 1/2); the passes gave %s it/s'
-                        % (passes, reps_f, reps_l, reps_g, n, reps_f * t_fmvn + reps_l * t_ll + reps_g * sum(t_llik), sweeps, n_l1,
-                           counts['proposals_per_iter'], sweeps, counts['llik_l1_per_iter'], counts['llik_l2_per_iter'],
-                           ', '.join('%.4f' % (1.0 / per_iteration(*r)) for r in runs))),
+    threads = None
+    try:   # what the BLAS behind numpy / scipy actually runs with ("nothing verifies the 128 threads")
+        from threadpoolctl import threadpool_info
+        threads = [dict(api=i.get('user_api'), lib=i.get('internal_api'), threads=i.get('num_threads')) for i in threadpool_info()]
+    except Exception:   # noqa: BLE001
+        pass
+    blas_threads = max([t['threads'] for t in (threads or []) if t.get('api') == 'blas'] or [psutil.cpu_count(logical=False)])
+    return dict(value=1.0 / per_iter, unit='SI it/s', cores=int(blas_threads), physical_cores=psutil.cpu_count(logical=False), kind='port',
+                threadpools=threads,
+                sample=('one untimed call, then the median of %d fmvn, %d log_likelihood_func and 2x%d llik calls at n=%d (%.1f s of timed '
+                        'CPU work), scaled by the per-iteration call counts of the GPU run: %d sweeps x %d fmvn, %.1f+%d log-liks, '
+                        '%.1f/%.1f llik calls (layer 1/2)'
+                        % (reps_f, reps_l, reps_g, n, sum(all_f) + sum(all_l) + sum(all_g), sweeps, n_l1,
+                           counts['proposals_per_iter'], sweeps, counts['llik_l1_per_iter'], counts['llik_l2_per_iter'])),
                 seconds_per_call=dict(fmvn=t_fmvn, log_likelihood_func=t_ll, llik_layer1=t_llik[0], llik_layer2=t_llik[1]))
+
+
+def strong_leg_cfg3(dd, torch, local, dev, world, n=5000, d=10, q=3, S=16, M=2048):
+    """BASELINE configs[2] shape (2-layer DGP, d=10 in / 3 out, n=5000, default structure: SExp): S imputations IN ALL,
+    sharded over the ranks (emulation.py:701-779 per imputation; one all-reduce of the two moment arrays), M test points."""
+    from dgp_amd import dgp, emulator
+    rng = np.random.default_rng(2026)
+    X = rng.uniform(size=(n, d))
+    Y = np.stack([np.sin(1.0 / ((0.7 * X[:, 0] + 0.3) * (0.7 * X[:, 1] + 0.3))) + (0.2 + 0.1 * j) * (X[:, 2 + j:] ** 2).sum(1) for j in range(q)], 1)
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    np.random.seed(1)
+    model = dgp(X, Y, seed=1, device=local)          # the same model on every rank (same seeds)
+    model.train(N=1, ess_burn=10, disable=True)
+    emu = emulator(model.estimate(burnin=0), N=S, seed=3, device=local)   # N/world imputations on this rank
+    xt = rng.uniform(size=(M, d))
+    emu.predict(xt[:64])
+    dd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mu, var = emu.predict(xt)
+    torch.cuda.synchronize()
+    dd.barrier()
+    t = dd.allreduce_max_scalar(time.perf_counter() - t0, dev)
+    return dict(what='cfg3 shape: n=%d, d=%d in / %d out, %d imputations in all over %d ranks, %d test points' % (n, d, q, S, world, M),
+                seconds=t, point_imputations_per_s=M * S / t, finite=bool(np.all(np.isfinite(mu)) and np.all(np.isfinite(var))))
+
+
+def strong_leg_cfg4(dd, torch, local, dev, world, n=50000, d=8, m=25, its=2):
+    """BASELINE configs[3] shape (Vecchia DGP, n=50000, d=8, m=25): one model trained by all ranks with the rows of
+    vecchia_llik / vecchia_nllik split over them (vecchia.py:165-242's prange; dist.split_training(rows=True))."""
+    from dgp_amd import dgp
+    rng = np.random.default_rng(7)
+    X = rng.uniform(size=(n, d))
+    f = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + X[:, 2] ** 2 + 0.3 * X[:, 3:].sum(1)
+    Y = ((f - f.mean()) / f.std())[:, None]
+    dd.split_training(nodes=False, rows=True)
+    np.random.seed(1)                                   # (the Vecchia ordering is a numpy.random.permutation: the same on every rank)
+    model = dgp(X, Y, vecchia=True, m=m, seed=1, device=local)
+    model.train(N=1, ess_burn=10, disable=True)
+    dd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.train(N=its, ess_burn=10, disable=True)
+    torch.cuda.synchronize()
+    dd.barrier()
+    t = dd.allreduce_max_scalar(time.perf_counter() - t0, dev)
+    dd.split_training(rows=False)
+    return dict(what='cfg4 shape: Vecchia DGP n=%d, d=%d, m=%d, rows split over %d ranks' % (n, d, m, world), steps=its,
+                ms_per_step=1e3 * t / its, si_it_per_s=its / t)
 
 
 def main():
@@ -109,7 +156,12 @@ def main():
     ap.add_argument('--n', type=int, default=2000)
     ap.add_argument('--d', type=int, default=5)
     ap.add_argument('--ess-burn', type=int, default=10)
-    ap.add_argument('--predict-points', type=int, default=4096)
+    ap.add_argument('--predict-points', type=int, default=16384)
+    ap.add_argument('--predict-seconds', type=float, default=3.0, help='the prediction leg repeats its predict() call until it has run this long')
+    ap.add_argument('--min-gpu-seconds', type=float, default=6.0,
+                    help='after the timed region: keep stepping (untimed) until the GPU legs have lasted this long in all, so that a '
+                         'sampler of device activity sees the device busy whatever --steps was')
+    ap.add_argument('--no-strong-legs', action='store_true', help='N > 1: skip the strong-scaling legs (cfg3 prediction with the imputations sharded, cfg4 training with the Vecchia rows split)')
     ap.add_argument('--imputations', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-predict', action='store_true')
@@ -167,6 +219,7 @@ def main():
         model.imp.sample(burnin=args.ess_burn)
         model._m_step()
 
+    t_gpu0 = time.perf_counter()
     for _ in range(args.warmup):
         step()
     calls['l1'] = calls['l2'] = 0
@@ -258,15 +311,20 @@ def main():
         emu = emulator(est, N=args.imputations * world, seed=7, device=local)
         xt = np.random.default_rng(5).uniform(size=(args.predict_points, args.d))
         emu.predict(xt[:32])   # builds the per-imputation statistics + warms the kernels
-        dd.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        mu, var = emu.predict(xt)
-        torch.cuda.synchronize()
-        dd.barrier()
-        tp = dd.allreduce_max_scalar(time.perf_counter() - t0, dev if world > 1 else None)
+        reps, tp = 0, 0.0
+        while reps == 0 or tp < args.predict_seconds:   # (every rank takes the same number of passes: the time is the max over ranks)
+            dd.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mu, var = emu.predict(xt)
+            torch.cuda.synchronize()
+            dd.barrier()
+            tp += dd.allreduce_max_scalar(time.perf_counter() - t0, dev if world > 1 else None)
+            reps += 1
+        tp /= reps
         pred = dict(points=args.predict_points, imputations=args.imputations * world, imputations_per_rank=args.imputations, seconds=tp,
-                    pts_per_s=args.predict_points / tp, point_imputations_per_s=args.predict_points * args.imputations * world / tp, finite=bool(np.all(np.isfinite(mu)) and np.all(np.isfinite(var))))
+                    passes=reps, pts_per_s=args.predict_points / tp,
+                    point_imputations_per_s=args.predict_points * args.imputations * world / tp, finite=bool(np.all(np.isfinite(mu)) and np.all(np.isfinite(var))))
         if args.prof_kernel != 'none':
             # the linked-GP pair kernel (the prediction leg's dominant kernel) against the f64 MFMA roofline, same call again
             # (by EVERY rank: predict ends in a collective; only rank 0 brackets its launches)
@@ -310,9 +368,42 @@ def main():
         finally:
             dd.split_training(nodes=False)
 
+    # ---- N > 1: strong-scaling legs on the two axes north_star names (fixed total work, so the time should fall with N):
+    #      cfg3-shaped prediction with the imputations sharded over the ranks (one all-reduce of the moments), and
+    #      cfg4-shaped Vecchia training with the likelihood rows split (one all-reduce per speculative batch / optimiser round)
+    strong = None
+    if world > 1 and not args.no_strong_legs:
+        strong = {}
+        try:
+            strong['cfg3_predict_imputations_sharded'] = strong_leg_cfg3(dd, torch, local, dev, world)
+        except Exception as exc:   # noqa: BLE001  (informational: must not cost the run its result line)
+            strong['cfg3_predict_imputations_sharded'] = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
+        try:
+            strong['cfg4_train_rows_split'] = strong_leg_cfg4(dd, torch, local, dev, world)
+        except Exception as exc:   # noqa: BLE001
+            strong['cfg4_train_rows_split'] = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
+        finally:
+            dd.split_training(rows=False, nodes=False)
+
+    # the device stays busy for at least --min-gpu-seconds in all (untimed extra iterations; replicas: no collective inside)
+    extra_steps = 0
+    while time.perf_counter() - t_gpu0 < args.min_gpu_seconds:
+        step()
+        extra_steps += 1
+    torch.cuda.synchronize()
+    gpu_leg_seconds = time.perf_counter() - t_gpu0
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, counts, args.ess_burn)
+
+    dist_info = None
+    if world > 1:   # RCCL's view of the job, in the record
+        import torch.distributed as td
+        ids = dd.allgather_vector(np.array([float(rank), float(local), float(torch.cuda.current_device())]), device=dev)
+        dist_info = dict(world_size=td.get_world_size(), backend=td.get_backend(),
+                         ranks=[dict(rank=int(r[0]), local_rank=int(r[1]), device='cuda:%d' % int(r[2])) for r in ids],
+                         device_name=torch.cuda.get_device_name(local), devices_visible=torch.cuda.device_count())
 
     if rank == 0:
         out = {
@@ -326,6 +417,8 @@ def main():
             'predict': pred, 'counts': counts, 'roofline': roof, 'roofline_kmatrix': roof_k,
             'roofline_predict': (pred or {}).get('roofline_predict'), 'cpu_baseline': cpu, 'mstep_nodes_split': split,
             'speedup_vs_cpu_baseline': (value / world / cpu['value']) if cpu else None,
+            'strong_scaling': strong, 'distributed': dist_info,
+            'gpu_legs': dict(seconds=gpu_leg_seconds, untimed_extra_steps=extra_steps),
         }
         print(json.dumps(out))
     if world > 1:

@@ -32,7 +32,8 @@ class Node(C.Structure):
     _fields_ = [('kind', C.c_int), ('Dl', C.c_int), ('Dg', C.c_int), ('nlen', C.c_int), ('nugget_est', C.c_int),
                 ('reserved', C.c_int), ('ldloc', C.c_int64), ('Xloc', C.c_void_p), ('colmap', C.c_void_p),
                 ('Xglob', C.c_void_p), ('length', C.c_void_p), ('nugget', C.c_double), ('W', C.c_void_p),
-                ('y', C.c_void_p)]
+                ('y', C.c_void_p), ('vecch_ord', C.c_void_p), ('vecch_nn', C.c_void_p), ('vecch_nd', C.c_void_p),
+                ('vecch_y', C.c_void_p), ('vecch_m', C.c_int), ('reserved2', C.c_int)]
 
 
 SIGNATURES = {
@@ -70,7 +71,9 @@ SIGNATURES = {
     'dgpamd_grad_reduce': (_i, [_p, _i, _l, _p, _l, _p, _i, _p, _i, _p, _i, _d, _p, _i, _p, _p, _p]),
     'dgpamd_ess_update': (_i, [_p, _l, _i, _p, _p, _p, _d, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     'dgpamd_ess_queue_scratch': (_z, []),
-    'dgpamd_ess_queue': (_i, [_p, _l, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    'dgpamd_ess_queue': (_i, [_p, _l, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'dgpamd_ess_queue_vwork': (_z, [_l, _i, _i]),
+    'dgpamd_ess_queue_note_info': (_i, [_p, _p, _p, _i]),
     'dgpamd_llik_batch': (_i, [_p, _l, _i, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l]),
     'dgpamd_potrf_inv': (_i, [_p, _l, _p, _p, _p, _l, _i, _p, _p, _p]),
     'dgpamd_gp_workspace': (_z, [_l, _l]),
@@ -89,6 +92,9 @@ SIGNATURES = {
     'dgpamd_vecchia_lmatrix': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _i, _d, _p]),
     'dgpamd_vecchia_spsolve': (_i, [_p, _l, _i, _p, _p, _d, _p, _p]),
     'dgpamd_vecchia_spsolve_batch': (_i, [_p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'dgpamd_vecchia_levels_bytes': (_z, [_l, _i]),
+    'dgpamd_vecchia_levels': (_i, [_p, _l, _i, _i, _p, _p]),
+    'dgpamd_vecchia_spsolve_levels': (_i, [_p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     'dgpamd_vecchia_het_rows': (_i, [_p, _i, _l, _i, _i, _p, _p, _p, _i, _d, _p, _p, _p, _p, _p, _p]),
     'dgpamd_vecchia_gp': (_i, [_p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _d, _p, _i, _d, _p, _p, _p]),
     'dgpamd_vecchia_linkgp': (_i, [_p, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _d, _p, _i, _d, _p, _p, _p]),

@@ -1181,13 +1181,18 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTab
     const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : (deep ? 10 : MEGA_LAZY), slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? 10 : MEGA_SLAZY);
     const char *en = getenv("DGPAMD_MEGA_NEAR"), *el = getenv("DGPAMD_MEGA_LAG"), *ex = getenv("DGPAMD_MEGA_XCATCH");
     const char *es = getenv("DGPAMD_MEGA_STAIL");
-    const int near = en ? atoi(en) : MEGA_NEAR, lag = el ? atoi(el) : 0, xcatch = (ex ? atoi(ex) : 0) + 2 * (es ? atoi(es) : (inv && batch <= 3 ? 1 : 0));
+    // (a task waits on 1 + 2 nkb version words, one per lane of ONE wave: the overrides are clamped so that the deepest visit --
+    //  lazy + 1 + near + lag panels -- stays within 64 flags, and build_mega_tasks' output is checked below)
+    const int near_raw = en ? atoi(en) : MEGA_NEAR, lag_raw = el ? atoi(el) : 0;
+    const int near = near_raw < 0 ? 0 : (near_raw > 3 ? 3 : near_raw), lag = lag_raw < 0 ? 0 : (lag_raw > 2 ? 2 : lag_raw), xcatch = (ex ? atoi(ex) : 0) + 2 * (es ? atoi(es) : (inv && batch <= 3 ? 1 : 0));
     static std::map<std::pair<dgpamd_ctx *, std::array<int, 7>>, MegaTable> cache;
     MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy, near, lag, xcatch}}];
     if (!mt.dev) {
         std::vector<MTask> tasks;
         std::vector<int2> need;
         build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy, near, lag, xcatch & 1, xcatch >> 1);
+        for (const MTask &t : tasks)   // wg_wait_flags polls with the 64 lanes of one wave
+            if (1 + 2 * (t.a.w >> 16) > 64) BAD_ARG(ctx, "task table: a visit applies more panels than one wave can wait for");
         mt.ntask = (int)tasks.size();
         HIP_TRY(ctx, hipMalloc((void **)&mt.dev, (tasks.size() + 1) * sizeof(MTask)));
         HIP_TRY(ctx, hipMemcpy(mt.dev, tasks.data(), tasks.size() * sizeof(MTask), hipMemcpyHostToDevice));

@@ -214,6 +214,11 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
 // and pass sync_cleared = true.
 void potrf_sync_area(dgpamd_ctx *ctx, int64_t n, int batch, bool inv, double *ws, int32_t **ptr, int *words);   // T, S: fused inverse (dgpamd_potrf_inv)
 size_t potrf_ws_doubles(int64_t n, int batch);
+// vecchia_llik for `batch` input sets into caller-provided buffers (partial: batch x n x 2 doubles, out: batch x 2 = (quad,
+// logdet) per set), no allocation; launches made while ctx->pred is set are predicated on it (dgpamd_ess_queue)
+int vecchia_llik_batch_into(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, int64_t x_stride, int batch,
+                            const double *y, const int64_t *NNarray, const double *length_h, int nlen, double nugget,
+                            const double *nugget_diag, double *partial, double *out);
 int ensure_pinned(dgpamd_ctx *ctx, size_t bytes);   // grow the context's pinned staging buffer
 int ensure_devargs(dgpamd_ctx *ctx, size_t bytes);  // grow the device / pinned argument arrays
 

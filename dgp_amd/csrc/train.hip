@@ -784,20 +784,91 @@ __global__ void ess_end_kernel(double *st, EssScratch *sc) {
 }
 __global__ void ess_set_ll_kernel(double *st, const EssScratch *sc) {
     if (threadIdx.x) return;
+    if (st[ES_STATUS] != 0.0) return;   // (a continued queue that has already stopped: its state is what the host resumes from)
     if (sc->infomax[0] != 0) { st[ES_STATUS] = 2.0; st[ES_INFO] = sc->infomax[0]; }
     st[ES_LL] = sc->ll[0];
 }
+__global__ void ess_note_info_kernel(double *st, const int32_t *info, int count) {
+    if (threadIdx.x || st[ES_STATUS] != 0.0) return;
+    for (int i = 0; i < count; ++i)
+        if (info[i] != 0) { st[ES_STATUS] = 2.0; st[ES_INFO] = info[i]; return; }
+}
+
+// ---- Vecchia nodes upstairs (kernel.log_likelihood_func_vecch, kernel_class.py:494-509) ----
+// The ordered inputs of every candidate block: out[b][i][d] = [X_b[ord[i]][colmap[d]] | Xglob[ord[i]][d - Dl]]
+struct VGatherArgs {
+    const double *X;
+    int64_t stride_x;   // doubles between the candidate blocks (0: one block)
+    int M, Dl, Dg;
+    int colmap[DGPAMD_MAXD];
+    const double *Xglob;
+    const int64_t *ord;
+    int64_t n;
+    double *out;
+    const int32_t *pred;
+};
+__global__ __launch_bounds__(256) void ess_vgather_kernel(VGatherArgs a) {
+    if (a.pred && *a.pred) return;
+    const int D = a.Dl + a.Dg, b = blockIdx.y;
+    const int64_t total = a.n * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e / D;
+        const int d = (int)(e - i * D);
+        const int64_t src = a.ord[i];
+        a.out[(int64_t)b * total + e] = d < a.Dl ? a.X[(int64_t)b * a.stride_x + src * a.M + a.colmap[d]] : a.Xglob[src * a.Dg + (d - a.Dl)];
+    }
+}
+// ... and the node's log-likelihood of every candidate from the row sums o[b] = (quad, logdet): -0.5 (logdet + quad / scale)
+__global__ void ess_vnode_ll_kernel(const double *o, double scale, int B, int first, EssScratch *sc, double *st) {
+    const int b = threadIdx.x;
+    if (sc->done) return;
+    if (b < B) {
+        const double ll = -0.5 * (o[2 * b + 1] + o[2 * b] / scale);
+        sc->ll[b] = (first ? 0.0 : sc->ll[b]) + ll;
+        if (first) sc->infomax[b] = 0;
+    }
+    if (st) {
+        __threadfence_block();
+        __syncthreads();
+        if (b == 0) ess_decide(st, sc);
+    }
+}
 
 extern "C" size_t dgpamd_ess_queue_scratch(void) { return (sizeof(EssScratch) + 15) / 16 * 16; }
+// gathered inputs (batch x n x D) + per-row partials (batch x n x 2) + the row sums (batch x 2)
+extern "C" size_t dgpamd_ess_queue_vwork(int64_t n, int D, int batch) {
+    return ((size_t)batch * n * (D + 2) + 2 * (size_t)batch + 2) * sizeof(double);
+}
 
 // all upper nodes' log-likelihoods of the B candidate blocks X (B x n x M; stride 0: one block) into sc->ll / infomax
 static int ess_queue_logliks(dgpamd_ctx *ctx, int64_t n, int M, const double *X, int64_t stride_x, int B, const dgpamd_node *nodes,
-                             const double *scales_h, int nnodes, double *A, void *work, EssScratch *sc, double *st_decide) {
+                             const double *scales_h, int nnodes, double *A, void *work, EssScratch *sc, double *st_decide, void *vwork,
+                             int vbatch) {
     const int64_t Np = padded_dim(n);
     double *ws = (double *)work;
     for (int k = 0; k < nnodes; ++k) {
         const dgpamd_node &nd = nodes[k];
         if (!(scales_h[k] > 0.0)) BAD_ARG(ctx, "scale must be positive");
+        if (nd.vecch_nn) {
+            const int D = nd.Dl + nd.Dg;
+            if (!vwork || !nd.vecch_ord || !nd.vecch_nd || !nd.vecch_y || nd.vecch_m < 0) BAD_ARG(ctx, "incomplete Vecchia node");
+            if (D <= 0 || D > DGPAMD_MAXD) BAD_ARG(ctx, "need 1 <= Dl+Dg <= DGPAMD_MAXD");
+            double *Xall = (double *)vwork, *partial = Xall + (size_t)vbatch * n * D, *osum = partial + (size_t)vbatch * n * 2;
+            VGatherArgs ga;
+            ga.X = X; ga.stride_x = stride_x; ga.M = M; ga.Dl = nd.Dl; ga.Dg = nd.Dg;
+            for (int d = 0; d < nd.Dl; ++d) ga.colmap[d] = nd.colmap ? ((const int32_t *)nd.colmap)[d] : d;
+            ga.Xglob = nd.Xglob; ga.ord = nd.vecch_ord; ga.n = n; ga.out = Xall; ga.pred = ctx->pred;
+            int64_t gb = (n * D + 255) / 256;
+            if (gb > 2048) gb = 2048;
+            hipLaunchKernelGGL(ess_vgather_kernel, dim3((unsigned)gb, B), dim3(256), 0, ctx->stream, ga);
+            int rc = vecchia_llik_batch_into(ctx, nd.kind, n, D, nd.vecch_m, Xall, n * (int64_t)D, B, nd.vecch_y, nd.vecch_nn, nd.length,
+                                             nd.nlen, nd.nugget, nd.vecch_nd, partial, osum);
+            if (rc) return rc;
+            hipLaunchKernelGGL(ess_vnode_ll_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)osum, scales_h[k], B,
+                               k == 0 ? 1 : 0, sc, k == nnodes - 1 ? st_decide : nullptr);
+            continue;
+        }
+        if (!A || !work) BAD_ARG(ctx, "dense nodes upstairs need A and work");
         KmatArgs a;
         int rc = build_kmat_args(ctx, a, nd.kind, n, X, M, stride_x, (const int32_t *)nd.colmap, nd.Dl, nd.Xglob, nd.Dg, nd.length,
                                  nd.nlen, nd.nugget, nd.W, A, Np, Np * Np, 0, nd.y, n, 0, 1, B);
@@ -820,9 +891,9 @@ static int ess_queue_logliks(dgpamd_ctx *ctx, int64_t n, int M, const double *X,
 extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double *NU, int nupd, const dgpamd_node *nodes,
                                 const double *scales_h, int nnodes, double *state, const double *uniforms, const double *log_uniforms,
                                 int nuni, int batch_first, int batch_next, int max_batches, int compute_ll0, double *FP, double *A,
-                                void *work, void *scratch) {
+                                void *work, void *scratch, void *vwork) {
     if (!ctx) return DGPAMD_BAD_ARG;
-    if (n <= 0 || M <= 0 || nupd <= 0 || nnodes <= 0 || !F || !NU || !nodes || !scales_h || !state || !FP || !A || !work || !scratch)
+    if (n <= 0 || M <= 0 || nupd <= 0 || nnodes <= 0 || !F || !NU || !nodes || !scales_h || !state || !FP || !scratch)
         BAD_ARG(ctx, "null pointer or empty block");
     if (nuni < 0 || (nuni > 0 && (!uniforms || !log_uniforms))) BAD_ARG(ctx, "bad uniform stream");
     if (batch_first <= 0 || batch_first > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch_first <= DGPAMD_MAXB");
@@ -835,7 +906,7 @@ extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, co
     int rc;
     HIP_TRY(ctx, hipMemsetAsync(sc, 0, sizeof(EssScratch), ctx->stream));
     if (compute_ll0) {   // log-likelihood of the current state (imputation.py:70-78): the first threshold's base
-        rc = ess_queue_logliks(ctx, n, M, F, 0, 1, nodes, scales_h, nnodes, A, work, sc, nullptr);
+        rc = ess_queue_logliks(ctx, n, M, F, 0, 1, nodes, scales_h, nnodes, A, work, sc, nullptr, vwork, batch_first);
         if (rc) return rc;
         hipLaunchKernelGGL(ess_set_ll_kernel, dim3(1), dim3(64), 0, ctx->stream, state, (const EssScratch *)sc);
     }
@@ -849,7 +920,7 @@ extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, co
                                count, (const EssScratch *)sc);
             // every launch is predicated on the update being open (the first batch: on the queue not having stopped)
             ctx->pred = &sc->done;
-            rc = ess_queue_logliks(ctx, n, M, FP, count, B, nodes, scales_h, nnodes, A, work, sc, state);   // (decides as well)
+            rc = ess_queue_logliks(ctx, n, M, FP, count, B, nodes, scales_h, nnodes, A, work, sc, state, vwork, batch_first);   // (decides as well)
             ctx->pred = nullptr;
             if (rc) return rc;
             hipLaunchKernelGGL(ess_accept_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, F, (const double *)FP, count,
@@ -857,6 +928,14 @@ extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, co
         }
         if (u == nupd - 1) hipLaunchKernelGGL(ess_end_kernel, dim3(1), dim3(64), 0, ctx->stream, state, sc);
     }
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_ess_queue_note_info(dgpamd_ctx *ctx, double *state, const int32_t *info, int count) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (!state || !info || count <= 0) BAD_ARG(ctx, "bad arguments");
+    hipLaunchKernelGGL(ess_note_info_kernel, dim3(1), dim3(64), 0, ctx->stream, state, info, count);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }

@@ -632,6 +632,7 @@ struct VRowArgs {
     double *partial;  // [batch][n][2 + 2P] (LLIK: [batch][n][2])
     double *Lmat;     // [n][m+1]
     int64_t x_stride; // doubles between the input sets of a batch (blockIdx.y); LLIK only
+    const int32_t *pred;   // null, or a device word: the launch does nothing when it is non-zero (dgpamd_ess_queue)
 };
 
 // gather the row's conditioning block (ascending index, self last) into LDS; returns its size
@@ -645,6 +646,7 @@ __device__ int gather_block(const int64_t *NNrow, int mp1, int *idx, int lane) {
 template <int KIND, int MODE>
 __global__ __launch_bounds__(VW) void vecchia_row_kernel(VRowArgs a) {
     extern __shared__ double lds[];
+    if (a.pred && *a.pred) return;
     const int mp1 = a.m + 1, D = a.vp.D, lda = mp1 + 2;
     double *A = lds;                         // [(mp1+1)][lda]  block + one right-hand-side row
     double *xs = A + (mp1 + 1) * lda;        // [mp1][D] scaled inputs
@@ -840,6 +842,7 @@ static size_t vrow4_lds(int BS, int D, bool grad, bool solves) {
 template <int KIND, int MODE, int BS>
 __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
     extern __shared__ double lds[];
+    if (a.pred && *a.pred) return;
     constexpr int rows = BS + 1;                      // block rows, then the right-hand side as row BS
     constexpr int T2 = BS * (BS - 1) / 2;
     constexpr int asz = rows * (rows + 1) / 2 + (MODE == V_NLLIK ? T2 : 0);
@@ -1222,6 +1225,21 @@ static int with_partials(dgpamd_ctx *ctx, size_t bytes, double **p) {
     return DGPAMD_OK;
 }
 
+int vecchia_llik_batch_into(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, int64_t x_stride, int batch,
+                            const double *y, const int64_t *NNarray, const double *length_h, int nlen, double nugget,
+                            const double *nugget_diag, double *partial, double *out) {
+    VRowArgs a;
+    int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, nugget);
+    if (rc) return rc;
+    a.n = n; a.m = m; a.X = X; a.y = y; a.nugget_diag = nugget_diag; a.NN = NNarray; a.nugget_est = 0; a.P = 0;
+    a.Lmat = nullptr; a.x_stride = x_stride; a.partial = partial; a.pred = ctx->pred;
+    rc = launch_vrow<V_LLIK>(ctx, a, batch);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3(2, (unsigned)batch), dim3(1024), 0, ctx->stream, (const double *)partial, n, 2, out);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
 extern "C" int dgpamd_vecchia_llik_batch(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, int64_t x_stride,
                                          int batch, const double *y, const int64_t *NNarray, const double *length_h, int nlen,
                                          double nugget, const double *nugget_diag, double *out_llik) {
@@ -1232,7 +1250,7 @@ extern "C" int dgpamd_vecchia_llik_batch(dgpamd_ctx *ctx, int kind, int64_t n, i
     int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, nugget);
     if (rc) return rc;
     a.n = n; a.m = m; a.X = X; a.y = y; a.nugget_diag = nugget_diag; a.NN = NNarray; a.nugget_est = 0; a.P = 0;
-    a.Lmat = nullptr; a.x_stride = x_stride;
+    a.Lmat = nullptr; a.x_stride = x_stride; a.pred = nullptr;
     rc = with_partials(ctx, (size_t)batch * n * 2 * sizeof(double), &a.partial);
     if (rc) return rc;
     rc = launch_vrow<V_LLIK>(ctx, a, batch);
@@ -1259,7 +1277,7 @@ extern "C" int dgpamd_vecchia_nllik(dgpamd_ctx *ctx, int kind, int64_t n, int D,
     if (rc) return rc;
     a.n = n; a.m = m; a.X = X; a.y = y; a.nugget_diag = nugget_diag; a.NN = NNarray; a.nugget_est = nugget_est ? 1 : 0;
     a.P = (nlen == 1 ? 1 : D) + a.nugget_est;
-    a.Lmat = nullptr; a.x_stride = 0;
+    a.Lmat = nullptr; a.x_stride = 0; a.pred = nullptr;
     const int w = 2 + 2 * a.P;
     rc = with_partials(ctx, (size_t)n * w * sizeof(double), &a.partial);
     if (rc) return rc;
@@ -1280,7 +1298,7 @@ extern "C" int dgpamd_vecchia_lmatrix(dgpamd_ctx *ctx, int kind, int64_t n, int 
     int rc = fill_vparams(ctx, a.vp, kind, D, length_h, nlen, nugget);
     if (rc) return rc;
     a.n = n; a.m = m; a.X = X; a.y = nullptr; a.nugget_diag = nullptr; a.NN = NNarray; a.nugget_est = 0; a.P = 0;
-    a.partial = nullptr; a.Lmat = Lmat; a.x_stride = 0;
+    a.partial = nullptr; a.Lmat = Lmat; a.x_stride = 0; a.pred = nullptr;
     return launch_vrow<V_LMAT>(ctx, a);
 }
 
@@ -1508,6 +1526,200 @@ __global__ __launch_bounds__(SPW) void spsolve_kernel(int64_t n, int mp1, const 
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same substitution LEVEL-SCHEDULED.  Row i depends on rows NN[i][1..] only, all earlier in the ordering; its level is
+// 1 + the highest level among them, and rows of one level are independent.  With a random ordering and m = 25 the
+// dependency DAG of n = 50 000 points is a few hundred levels deep (tens to hundreds of rows each), against 50 000 rows
+// walked in windows of 1024 above.  The schedule depends on the neighbour array only, so it is built once per array
+// (dgpamd_vecchia_levels: when the ordering is refreshed, kernel_class.py:245-277 / dgp.py:1388) and reused by every draw:
+// fmvn_sp for all nodes of a layer and all sweeps of imputer.sample (vecchia.py:133-140, imputation.py:54-63).
+// Schedule of one matrix (int32): lev[n] | order[n] | ptr[n + 1] | cursor[n + 1] | nlev.
+// ---------------------------------------------------------------------------
+static inline size_t splevel_words(int64_t n) { return (size_t)(4 * n + 3); }
+
+// levels of one matrix per workgroup: the window walk of spsolve_kernel on integers
+__global__ __launch_bounds__(SPW) void splevel_kernel(int64_t n, int mp1, const int64_t *NN, int32_t *sched, int64_t words) {
+    __shared__ int ls[SPW];
+    __shared__ int rdy[SPW];
+    __shared__ int top;
+    const int tid = threadIdx.x;
+    NN += (int64_t)blockIdx.x * n * mp1;
+    int32_t *lev = sched + (int64_t)blockIdx.x * words;
+    if (tid == 0) top = 0;
+    for (int64_t base = 0; base < n; base += SPW) {
+        const int64_t i = base + tid;
+        const bool active = i < n;
+        rdy[tid] = 0;
+        int acc = -1;
+        const int cnt = active ? (int)(i + 1 < mp1 ? i + 1 : mp1) : 0;
+        for (int j = 1; j < cnt; ++j) {
+            const int64_t dep = NN[i * mp1 + j];
+            if (dep >= 0 && dep < base) acc = max(acc, ((const volatile int32_t *)lev)[dep]);
+        }
+        bool done = !active;
+        __syncthreads();
+        while (true) {
+            bool fire = !done;
+            int l = acc;
+            if (fire)
+                for (int j = 1; j < cnt; ++j) {
+                    const int64_t dep = NN[i * mp1 + j];
+                    if (dep >= base) {
+                        if (!rdy[dep - base]) { fire = false; break; }
+                        l = max(l, ls[dep - base]);
+                    }
+                }
+            __syncthreads();
+            if (fire) {
+                ls[tid] = l + 1;
+                rdy[tid] = 1;
+                lev[i] = l + 1;
+                atomicMax(&top, l + 1);
+                done = true;
+            }
+            if (__syncthreads_and(done)) break;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) lev[4 * n + 2] = top + 1;   // nlev
+}
+// counting sort of the rows by level (the order inside a level does not matter: its rows are independent, every row's
+// sum is formed the same way wherever it sits)
+__global__ __launch_bounds__(1024) void splevel_sort_kernel(int64_t n, int32_t *sched, int64_t words) {
+    const int tid = threadIdx.x;
+    int32_t *lev = sched + (int64_t)blockIdx.x * words, *order = lev + n, *ptr = order + n, *cursor = ptr + n + 1;
+    const int nl = lev[4 * n + 2];
+    for (int64_t i = tid; i <= n; i += 1024) { ptr[i] = 0; cursor[i] = 0; }
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += 1024) atomicAdd(&ptr[lev[i] + 1], 1);   // counts, shifted by one
+    __syncthreads();
+    if (tid == 0) {   // (a few hundred levels: a serial scan)
+        int run = 0;
+        for (int l = 0; l <= nl; ++l) { run += ptr[l]; ptr[l] = run; }
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += 1024) {
+        const int l = lev[i];
+        order[ptr[l] + atomicAdd(&cursor[l], 1)] = (int32_t)i;
+    }
+}
+
+// One workgroup per (matrix, chunk of <= SPL_R right-hand sides): level by level, SPL_LANES lanes per row (128 rows per
+// pass of the 1024 threads); a lane takes the row's entries j = 1 + lane, 1 + lane + SPL_LANES, ... (up to SPL_DEPS of them
+// kept in registers; wider conditioning sets re-read the arrays) for ALL right-hand sides of the chunk, the partial sums
+// are closed by a fixed butterfly.  Three passes are in flight: the row index of pass p + 2 and the matrix entries of pass
+// p + 1 are requested together with the x values of pass p, so a pass exposes ONE memory round trip; a barrier (after the
+// stores have drained) closes every level.
+#define SPL_R 1
+#define SPL_LANES 8
+#define SPL_DEPS 4
+struct SplRow {
+    int i, cnt;                  // row (-1: none), entries in its conditioning set
+    int dep[SPL_DEPS];
+    double lv[SPL_DEPS], diag, rhs;
+};
+__global__ __launch_bounds__(1024) void spsolve_level_kernel(int64_t n, int mp1, const double *L, const int64_t *NN, const double *lscales,
+                                                             int nrhs, const double *b, double *x, const int32_t *sched, int64_t words) {
+    const int tid = threadIdx.x, lane = tid & (SPL_LANES - 1), grp = tid / SPL_LANES;
+    constexpr int RPP = 1024 / SPL_LANES;   // rows per pass
+    const int chunks = (nrhs + SPL_R - 1) / SPL_R;
+    const int mat = blockIdx.x / chunks, q0 = (blockIdx.x - mat * chunks) * SPL_R;
+    const int R = nrhs - q0 < SPL_R ? nrhs - q0 : SPL_R;
+    L += (int64_t)mat * n * mp1;
+    NN += (int64_t)mat * n * mp1;
+    b += ((int64_t)mat * nrhs + q0) * n;
+    x += ((int64_t)mat * nrhs + q0) * n;
+    const double lscale = lscales[mat];
+    const int32_t *lev = sched + (int64_t)mat * words, *order = lev + n, *ptr = order + n;
+    const int nl = lev[4 * n + 2];
+    // the passes in order: (level, first row); `adv` moves one pass on
+    struct Pos { int lv, rb, rend; };
+    auto adv = [&](Pos p) {
+        p.rb += RPP;
+        while (p.lv < nl && p.rb >= p.rend) {
+            ++p.lv;
+            if (p.lv < nl) { p.rb = ptr[p.lv]; p.rend = ptr[p.lv + 1]; }
+        }
+        return p;
+    };
+    auto row_of = [&](const Pos &p) { return (p.lv < nl && p.rb + grp < p.rend) ? order[p.rb + grp] : -1; };
+    auto entries = [&](int i) {
+        SplRow d;
+        d.i = i;
+        d.cnt = 0;
+        d.diag = 1.0;
+        d.rhs = 0.0;
+#pragma unroll
+        for (int q = 0; q < SPL_DEPS; ++q) { d.dep[q] = -1; d.lv[q] = 0.0; }
+        if (i >= 0) {
+            d.cnt = (int)((int64_t)i + 1 < mp1 ? i + 1 : mp1);
+#pragma unroll
+            for (int q = 0; q < SPL_DEPS; ++q) {
+                const int j = 1 + lane + q * SPL_LANES;
+                if (j < d.cnt) {
+                    d.dep[q] = (int)NN[(int64_t)i * mp1 + j];
+                    d.lv[q] = L[(int64_t)i * mp1 + j];
+                }
+            }
+            d.diag = L[(int64_t)i * mp1];
+            if (lane < R) d.rhs = b[(int64_t)lane * n + i];
+        }
+        return d;
+    };
+    Pos p0{0, nl > 0 ? ptr[0] : 0, nl > 0 ? ptr[1] : 0};
+    Pos p1 = adv(p0), p2 = adv(p1);
+    SplRow cur = entries(row_of(p0));
+    int i1 = row_of(p1);
+    while (p0.lv < nl) {
+        const int i2 = row_of(p2);            // index of the pass after next
+        const SplRow nxt = entries(i1);       // entries of the next pass
+        double acc[SPL_R];
+#pragma unroll
+        for (int q = 0; q < SPL_R; ++q) acc[q] = 0.0;
+        if (cur.i >= 0) {
+#pragma unroll
+            for (int e = 0; e < SPL_DEPS; ++e)
+                if (cur.dep[e] >= 0) {
+                    const double lv_ = cur.lv[e] * lscale;
+#pragma unroll
+                    for (int q = 0; q < SPL_R; ++q)
+                        if (q < R) acc[q] = fma(lv_, __hip_atomic_load(x + (int64_t)q * n + cur.dep[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), acc[q]);
+                }
+            for (int j = 1 + lane + SPL_DEPS * SPL_LANES; j < cur.cnt; j += SPL_LANES) {   // (m + 1 > 1 + SPL_DEPS * SPL_LANES only)
+                const int64_t dep = NN[(int64_t)cur.i * mp1 + j];
+                if (dep >= 0) {
+                    const double lv_ = L[(int64_t)cur.i * mp1 + j] * lscale;
+#pragma unroll
+                    for (int q = 0; q < SPL_R; ++q)
+                        if (q < R) acc[q] = fma(lv_, __hip_atomic_load(x + (int64_t)q * n + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), acc[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < SPL_R; ++q) {
+            double v = acc[q];
+#pragma unroll
+            for (int off = SPL_LANES / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, SPL_LANES);
+            acc[q] = v;
+        }
+        if (cur.i >= 0 && lane < R) {
+            double sm = 0.0;
+#pragma unroll
+            for (int q = 0; q < SPL_R; ++q)
+                if (q == lane) sm = acc[q];
+            __hip_atomic_store(x + (int64_t)lane * n + cur.i, (cur.rhs - sm) / (cur.diag * lscale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (p1.lv != p0.lv) {   // the level ends with this pass: its x must be in memory before anybody reads it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        cur = nxt;
+        i1 = i2;
+        p0 = p1; p1 = p2; p2 = adv(p2);
+    }
+}
+
 extern "C" int dgpamd_vecchia_spsolve(dgpamd_ctx *ctx, int64_t n, int m, const double *Lmat, const int64_t *NNarray,
                                       double inv_sqrt_scale, const double *b, double *x) {
     if (!ctx) return DGPAMD_BAD_ARG;
@@ -1525,6 +1737,30 @@ extern "C" int dgpamd_vecchia_spsolve_batch(dgpamd_ctx *ctx, int64_t n, int m, i
     if (n <= 0 || m < 0 || nmat <= 0 || nrhs <= 0 || !Lmat || !NNarray || !inv_sqrt_scale || !b || !x) BAD_ARG(ctx, "bad arguments");
     hipLaunchKernelGGL(spsolve_kernel, dim3((unsigned)(nmat * nrhs)), dim3(SPW), 0, ctx->stream, n, m + 1, Lmat, NNarray, 1.0,
                        inv_sqrt_scale, nrhs, b, x);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" size_t dgpamd_vecchia_levels_bytes(int64_t n, int nmat) { return (size_t)nmat * splevel_words(n) * sizeof(int32_t); }
+
+extern "C" int dgpamd_vecchia_levels(dgpamd_ctx *ctx, int64_t n, int m, int nmat, const int64_t *NNarray, void *sched) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || m < 0 || nmat <= 0 || !NNarray || !sched) BAD_ARG(ctx, "bad arguments");
+    const int64_t words = (int64_t)splevel_words(n);
+    hipLaunchKernelGGL(splevel_kernel, dim3((unsigned)nmat), dim3(SPW), 0, ctx->stream, n, m + 1, NNarray, (int32_t *)sched, words);
+    hipLaunchKernelGGL(splevel_sort_kernel, dim3((unsigned)nmat), dim3(1024), 0, ctx->stream, n, (int32_t *)sched, words);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_vecchia_spsolve_levels(dgpamd_ctx *ctx, int64_t n, int m, int nmat, int nrhs, const double *Lmat,
+                                             const int64_t *NNarray, const double *inv_sqrt_scale, const double *b, double *x,
+                                             const void *sched) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (n <= 0 || m < 0 || nmat <= 0 || nrhs <= 0 || !Lmat || !NNarray || !inv_sqrt_scale || !b || !x || !sched) BAD_ARG(ctx, "bad arguments");
+    const int chunks = (nrhs + SPL_R - 1) / SPL_R;
+    hipLaunchKernelGGL(spsolve_level_kernel, dim3((unsigned)(nmat * chunks)), dim3(1024), 0, ctx->stream, n, m + 1, Lmat, NNarray,
+                       inv_sqrt_scale, nrhs, b, x, (const int32_t *)sched, (int64_t)splevel_words(n));
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }

@@ -74,12 +74,16 @@ class DrawStream:
             try:
                 import torch
                 if torch.cuda.is_available():
+                    # two page-locked buffers in turn (the previous one may still be read by an upload in flight); BOTH are
+                    # checked against this request -- after a larger request has grown one of them the other one is still
+                    # the old size (it was handed out short)
                     pins = self.__dict__.setdefault('_zpin', [])
-                    if len(pins) < 2 or pins[0].numel() < count:      # two buffers in turn: the previous one may still be read
-                        pins.insert(0, torch.empty(max(count, pins[0].numel() if pins else 0), dtype=torch.float64, pin_memory=True))
-                        del pins[2:]
-                    else:
-                        pins.reverse()
+                    if len(pins) == 2:
+                        pins.reverse()   # (pins[0] becomes the older one; `rest` may point into the other)
+                    if len(pins) < 2:
+                        pins.insert(0, torch.empty(count, dtype=torch.float64, pin_memory=True))
+                    elif pins[0].numel() < count:
+                        pins[0] = torch.empty(count, dtype=torch.float64, pin_memory=True)
                     out = pins[0].numpy()[:count]
             except Exception:
                 out = None
@@ -89,6 +93,7 @@ class DrawStream:
             out[:have] = rest
         if count > have:
             self._gz.standard_normal(out=out[have:])
+        assert len(out) == count
         return out
 
     def prefetch(self, count):
@@ -171,6 +176,7 @@ class imputer:
         self.draws = draws if draws is not None else DrawStream()
         self._engine = engine
         self.batch = int(batch)
+        self._batch_default = int(batch) == 12   # (the queue picks its own sizes for Vecchia nodes upstairs unless the caller chose)
         self.batch_next = 4      # size of the 2nd, 3rd, ... speculative batch of an update: after a rejected batch the
                                  # bracket is narrow and acceptance is near (measured: I-step -7% against 12 throughout)
         self._factor_cache = {}
@@ -188,7 +194,7 @@ class imputer:
         st['_engine'] = None
         st['_factor_cache'] = {}
         st['_ess_plans'] = {}
-        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_vecch_y', '_adopt', '_adopt_ll', '_given_inputs'):   # device state: rebuilt by the next sample()
+        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_vecch_y', '_adopt', '_adopt_ll', '_given_inputs', '_sp_levels'):   # device state: rebuilt by the next sample()
             st.pop(key, None)
         return st
 
@@ -389,6 +395,9 @@ class imputer:
         """ESS-within-Gibbs over the layers (imputation.py:22-42)."""
         self._attach()
         n_layer = len(self.all_layer)
+        if n_layer > 2 and self._sample_queued_deep(burnin + 1):   # every sweep of every hidden layer queued on the device
+            self._detach()
+            return
         first, ahead = self._sample_queued(burnin + 1) if n_layer == 2 else (0, None)   # sweeps done without host round trips
         if first > burnin:
             self._detach()
@@ -421,13 +430,13 @@ class imputer:
         if not self.block or not getattr(self, 'queued', True):
             return 0, None
         layer, upper = self.all_layer[0], self.all_layer[1]
-        if any(nd.type != 'gp' or nd.vecch for nd in layer) or any(nd.type != 'gp' or nd.vecch or nd.prior_name == 'ref' for nd in upper):
+        if not self._queue_applies(0):
             return 0, None
         if self._ll_cache.get(0) is None:   # the first threshold's log-likelihood: handed over by the M-step if it can be ...
             v = self._adopted_ll0()
             if v is not None:
                 self._ll_cache[0] = v
-        if self._ll_cache.get(0) is None:   # ... else factored together with the prior's matrices
+        if self._ll_cache.get(0) is None and not any(nd.vecch for nd in layer + upper):   # ... else factored together with the prior's matrices
             self._want_ll0 = list(enumerate(upper))
         nu = self._prior_draws_ahead(sweeps, prefetch=False)   # (sweeps, n, M); the next call's normals are started below
         self.__dict__.pop('_want_ll0', None)
@@ -436,23 +445,15 @@ class imputer:
         e = self.engine
         F = self.F[0]
         n, M = F.shape
-        key = tuple((tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), self._node_y(1, k).data_ptr(),
-                     None if self._glob[(1, k)] is None else self._glob[(1, k)].data_ptr()) for k, nd in enumerate(upper)) + (self.batch,)
-        hit = self._ess_plans.get('queue')
-        if hit is None or hit[0] != key:
-            nodes = [dict(kind=nd.name, colmap=np.asarray(nd.input_dim, dtype=np.int32), Xglob=self._glob[(1, k)], length=nd.length,
-                          nugget=nd.nugget[0], W=None if nd.rep is None else e.tensor(nd.W_diag), y=self._node_y(1, k))
-                     for k, nd in enumerate(upper)]
-            self._ess_plans['queue'] = hit = (key, e.ess_queue_plan(n, M, nodes, self.batch))
-        plan = hit[1]
-        bn = int(self.batch_next) if self.batch_next else self.batch
-        per = 2 + (self.batch - 1) + (self.queue_max_batches - 1) * bn + 2
+        plan = self._queue_plan(0)
+        b0, bn, qmax = self._queue_batches(0)
+        per = 2 + (b0 - 1) + (qmax - 1) * bn + 2
         scales = [float(nd.scale[0]) for nd in upper]
         first = 0
         while first < sweeps:
             us = self.draws.uniform_peek((sweeps - first) * per)
             cur = self._ll_cache.get(0)
-            plan.queue(F, nu[first:], scales, us, 0, cur, cur is None, self.batch_next, self.queue_max_batches)
+            plan.queue(F, nu[first:], scales, us, 0, cur, cur is None, bn, qmax)
             if first == 0:   # the next call's normals: generated by a background thread while this one waits in fetch()
                 self.draws.prefetch(sweeps * M * n)   # (started only now: it would fight the launches above for the interpreter)
             st = plan.fetch()   # the one synchronisation of the queue (of the whole I-step unless an update was left open)
@@ -477,6 +478,162 @@ class imputer:
                                                                  hi=float(st['hi']), pending=bool(st['pending'])))
             first += 1
         return sweeps, nu
+
+    def _queue_applies(self, l):
+        """Can the updates of hidden layer l run through dgpamd_ess_queue?  Block updates; GP nodes only, in the layer and
+        above it, without a reference prior upstairs (its constant depends on the proposal and is evaluated on the host);
+        the layer's own nodes all dense or all Vecchia; the Vecchia rows not split over ranks (that needs an all-reduce per
+        batch)."""
+        if not self.block or not getattr(self, 'queued', True) or ddist.rows_split():
+            return False
+        layer, upper = self.all_layer[l], self.all_layer[l + 1]
+        if any(nd.type != 'gp' for nd in layer) or any(nd.type != 'gp' or nd.prior_name == 'ref' for nd in upper):
+            return False
+        if len({bool(nd.vecch) for nd in layer}) != 1 or len(layer) > 64:
+            return False
+        return True
+
+    def _queue_batches(self, l):
+        """(first batch, later batches, batches queued per update) of the device queue for hidden layer l.  Dense nodes upstairs:
+        the sampler's settings (12, then 4; two batches queued) -- a factorisation batch is latency-bound, so wide batches cost
+        little.  Vecchia nodes upstairs: an evaluation is throughput-bound (0.1 ms of the whole device per candidate at
+        n = 50 000) and a queued batch costs no host round trip, so narrow batches waste fewer candidates: 6, then 3, five
+        queued (cfg4 I-step 50 -> 40 ms; profiles/r03_cfg4_vecchia.txt).  Explicit settings of the caller are kept."""
+        upper = self.all_layer[l + 1]
+        if all(nd.type == 'gp' and nd.vecch for nd in upper) and self._batch_default and self.batch == 12 and self.batch_next == 4 \
+                and self.queue_max_batches == 2:
+            return 6, 3, 5
+        return self.batch, int(self.batch_next) if self.batch_next else self.batch, self.queue_max_batches
+
+    def _queue_plan(self, l):
+        """The dgpamd_ess_queue arguments of hidden layer l (nodes of layer l+1 as the target's likelihood), rebuilt when
+        their hyper-parameters, buffers, orderings or the batch size change.  Outputs of a hidden layer upstairs live in
+        buffers of their own (`ybuf`), refreshed from the latents by _queue_refresh_y before every update."""
+        e = self.engine
+        upper = self.all_layer[l + 1]
+        n, M = self.F[l].shape
+        last = l + 1 == len(self.all_layer) - 1
+        key = tuple((tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), self._node_y(l + 1, k).data_ptr() if last else None,
+                     None if self._glob[(l + 1, k)] is None else self._glob[(l + 1, k)].data_ptr(),
+                     (id(nd.ord), id(nd.NNarray), None if nd.rep is None else id(nd.W_diag)) if nd.vecch else None)
+                    for k, nd in enumerate(upper)) + (self._queue_batches(l)[0], n, M)
+        hit = self._ess_plans.get(('queue', l))
+        if hit is None or hit[0] != key:
+            nodes, ybuf = [], {}
+            for k, nd in enumerate(upper):
+                y = self._node_y(l + 1, k) if last else e.empty(n)
+                d = dict(kind=nd.name, colmap=np.asarray(nd.input_dim, dtype=np.int32), Xglob=self._glob[(l + 1, k)], length=nd.length,
+                         nugget=nd.nugget[0], W=None if nd.rep is None else e.tensor(nd.W_diag), y=y)
+                if nd.vecch:
+                    od = nd.ord_dev()
+                    d['vecch'] = dict(ord=od, nn=nd.nn_dev(), nd=e.tensor(np.ones(n) if nd.rep is None else nd.W_diag),
+                                      y=y[od].contiguous() if last else e.empty(n))
+                if not last:
+                    ybuf[k] = (y, d['vecch']['y'] if nd.vecch else None, d['vecch']['ord'] if nd.vecch else None)
+                nodes.append(d)
+            plan = e.ess_queue_plan(n, M, nodes, self._queue_batches(l)[0])
+            plan.ybuf = ybuf
+            self._ess_plans[('queue', l)] = hit = (key, plan)
+        return hit[1]
+
+    def _queue_refresh_y(self, l, plan):
+        """The outputs of the nodes above hidden layer l are latents themselves when layer l+1 is hidden: copy the current
+        columns into the buffers the queued launches read (device copies on the engine's stream)."""
+        for k, (y, yord, od) in plan.ybuf.items():
+            col = self.F[l + 1][:, k]
+            y.copy_(col)
+            if yord is not None:
+                yord.copy_(col[od])
+
+    def _prior_draw_queued(self, l, Z, plan):
+        """_prior_draw(l) for a queue: nu (n, M) from the normals Z (M, n; device) with no host synchronisation -- a failed
+        factorisation is noted in the queue's device state (status 2) instead of raised here."""
+        e = self.engine
+        layer = self.all_layer[l]
+        n, M = self.F[l].shape
+        if layer[0].vecch:
+            return self._vecchia_draws(l, list(range(M)), Z[:, None, :].contiguous())[:, 0].t().contiguous()
+        Np = e.padded_dim(n)
+        buf = e.workspace(('qprior', l, n, M), M * Np * Np * 8)[:M * Np * Np * 8].view(torch.float64).view(M, Np, Np)
+        for k, nd in enumerate(layer):
+            Xl, cm = self._node_input(l, k, nd)
+            e.kmatrix(nd.name, Xl, cm, self._glob[(l, k)], nd.length, nd.nugget[0], out=buf[k], full=False)
+        _, info = e.potrf(n, buf, batch=M)
+        plan.note_info(info)
+        out = e.trmv_lower(n, buf, [float(nd.scale[0]) for nd in layer], Z, batch=M)
+        return out.t().contiguous()
+
+    def _sample_queued_deep(self, sweeps):
+        """sample() for a model with more than one hidden layer with every update of every sweep queued on the device
+        (imputation.py:22-119): per sweep and hidden layer -- the layer's prior draw from its CURRENT inputs (layers above
+        the first: K assembly, factorisation and triangular product queued as well), the refresh of the output buffers of the
+        nodes upstairs, ONE update through dgpamd_ess_queue continuing the shared device state -- and one fetch at the end.
+        The normals are taken from the stream in the order the host loop takes them.  An update left open (out of queued
+        batches or uniforms) is finished by the host loop and the rest is queued anew.  Returns False when a layer does not
+        qualify (the host loop then runs the whole call)."""
+        L = len(self.all_layer)
+        hidden = list(range(L - 1))
+        if not all(self._queue_applies(l) for l in hidden):
+            return False
+        e = self.engine
+        n = self.F[0].shape[0]
+        injected = self.draws._z is not None
+        # normals, in the host loop's order: layer 0 of every sweep first (one upload; _prior_draws_ahead) unless the stream is
+        # an injected one, then sweep by sweep the deeper layers
+        nu0 = None if injected else self._prior_draws_ahead(sweeps, prefetch=False)
+        Zs = {}
+        for s_ in range(sweeps):
+            for l in hidden:
+                if l == 0 and nu0 is not None:
+                    continue
+                Zs[(s_, l)] = np.stack([self.draws.normal(n) for _ in self.all_layer[l]])
+        Zdev = {key: e.tensor(z) for key, z in Zs.items()}
+        ops = [(s_, l) for s_ in range(sweeps) for l in hidden]
+        qb = {l: self._queue_batches(l) for l in hidden}
+        per = max(2 + (b0 - 1) + (qmax - 1) * bn + 2 for b0, bn, qmax in qb.values())
+        plans = {l: self._queue_plan(l) for l in hidden}
+        pos = 0
+        while pos < len(ops):
+            us = self.draws.uniform_peek((len(ops) - pos) * per)
+            lead = plans[ops[pos][1]]
+            nus = {}
+            for j in range(pos, len(ops)):
+                s_, l = ops[j]
+                plan = plans[l]
+                if plan is not lead:
+                    lead.upload_uniforms(us)
+                    plan.share_with(lead)
+                if l == 0 and nu0 is not None:
+                    nu = nu0[s_]
+                else:
+                    nu = self._prior_draw_queued(l, Zdev[(s_, l)], lead)
+                nus[j] = nu
+                self._queue_refresh_y(l, plan)
+                scales = [float(nd.scale[0]) for nd in self.all_layer[l + 1]]
+                plan.queue(self.F[l], nu[None], scales, us, 0, None, True, qb[l][1], qb[l][2], fresh=(j == pos))
+            st = lead.fetch()
+            status, done = int(st['status']), int(st['updates'])
+            self.draws.uniform_take(int(st['cursor']))
+            self.stats['proposals'] += int(st['proposals'])
+            self.stats['batches'] += int(st['batches'])
+            self.stats['updates'] += done
+            self._ll_cache = {}
+            pos += done
+            if status == 0:
+                break
+            if status == 2:
+                raise_not_pd(int(st['info']))
+            if status == 4:
+                if not us:
+                    raise RuntimeError('injected uniform stream exhausted')
+                continue
+            s_, l = ops[pos]   # the open update: finished by the host loop from the device's bracket
+            self.one_sample_block(l, nu=nus[pos], resume=dict(log_y=float(st['log_y']), theta=float(st['theta']), lo=float(st['lo']),
+                                                                hi=float(st['hi']), pending=bool(st['pending'])))
+            pos += 1
+        if nu0 is not None:
+            self.draws.prefetch(sweeps * self.F[0].shape[1] * n)
+        return True
 
     def _layer_factors(self, l, dense):
         """Cholesky factors of the dense nodes `dense` of layer l in ONE batched buffer (stride Np^2) so that the draws
@@ -611,7 +768,13 @@ class imputer:
             NNs.append(NN)
             sc.append(1.0 / np.sqrt(nd.scale[0]))
             rev.append(nd.rev_ord_dev())
-        xs = e.vecchia_spsolve_batch(torch.stack(Lms), torch.stack(NNs), sc, Zd.contiguous())
+        NNall = torch.stack(NNs)
+        # the substitutions run level-scheduled; the schedule depends on the neighbour arrays only (rebuilt when they are)
+        sig = tuple(id(layer[k].NNarray) for k in nodes)
+        hit = self.__dict__.setdefault('_sp_levels', {}).get(l)
+        if hit is None or hit[0] != sig:
+            hit = self._sp_levels[l] = (sig, e.vecchia_levels(NNall))
+        xs = e.vecchia_spsolve_levels(torch.stack(Lms), NNall, sc, Zd.contiguous(), hit[1])
         return torch.stack([xs[j][:, rev[j]] for j in range(len(nodes))])
 
     def _upper_loglik(self, l, FP, only=None):

@@ -121,7 +121,10 @@ class Engine:
         return torch.cuda.stream(self._torch_stream)
 
     def tensor(self, a, dtype=torch.float64):
-        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device, non_blocking=False)
+        a = np.ascontiguousarray(a)
+        if not a.flags.writeable:   # (the imputer freezes the input arrays it hands to the nodes: torch refuses to alias those silently)
+            a = a.copy()
+        return torch.as_tensor(a, dtype=dtype).to(self.device, non_blocking=False)
 
     def empty(self, *shape, dtype=torch.float64):
         return torch.empty(*shape, dtype=dtype, device=self.device)
@@ -508,6 +511,26 @@ class Engine:
         self._chk(self._enter() or lib.dgpamd_vecchia_spsolve_batch(self.h, n, mp1 - 1, nmat, nrhs, _dp(Lmat), _dp(NN), _dp(sc), _dp(b), _dp(out)))
         return out
 
+    def vecchia_levels(self, NN):
+        """Level schedule of the sparse forward substitution for the neighbour arrays NN (nmat, n, m+1) or (n, m+1): an int32
+        device tensor for vecchia_spsolve_levels; depends on NN only (build once per ordering)."""
+        if NN.dim() == 2:
+            NN = NN.unsqueeze(0)
+        nmat, n, mp1 = NN.shape
+        sched = torch.empty(int(lib.dgpamd_vecchia_levels_bytes(n, nmat)) // 4, dtype=torch.int32, device=self.device)
+        self._chk(self._enter() or lib.dgpamd_vecchia_levels(self.h, n, mp1 - 1, nmat, _dp(NN.contiguous()), _dp(sched)))
+        return sched
+
+    def vecchia_spsolve_levels(self, Lmat, NN, inv_sqrt_scale, b, sched):
+        """vecchia_spsolve_batch on a level schedule (vecchia_levels of the same NN)."""
+        nmat, n, mp1 = Lmat.shape
+        nrhs = b.shape[1]
+        out = self.empty(nmat, nrhs, n)
+        sc = self.tensor(np.asarray(inv_sqrt_scale, dtype=np.float64))
+        self._chk(self._enter() or lib.dgpamd_vecchia_spsolve_levels(self.h, n, mp1 - 1, nmat, nrhs, _dp(Lmat), _dp(NN), _dp(sc), _dp(b), _dp(out),
+                                                                   _dp(sched)))
+        return out
+
     def vecchia_gp(self, kind, x, w, NN, y, scale, length, nugget, nugget_diag):
         M, D = x.shape
         length = _f64(length)
@@ -605,20 +628,24 @@ class _LlikPlan:
 
 class _EssQueue:
     """Several elliptical-slice updates of one latent block queued without host synchronisation (dgpamd_ess_queue):
-    node structs, scratch and the device state are kept alive here; fetch() is the one synchronisation."""
+    node structs, scratch and the device state are kept alive here; fetch() is the one synchronisation.  Several queues
+    (the layers of a deeper model) can share one device state and one uploaded uniform stream: share_with()."""
     STATE = 16
     FIELDS = ('theta', 'lo', 'hi', 'pending', 'cursor', 'status', 'info', 'll', 'log_y', 'proposals', 'batches', 'updates')
 
     def __init__(self, eng, n, M, nodes, batch):
-        """nodes: list of dicts {kind, colmap, Xglob, length, nugget, W, y} -- the dense GP nodes of the layer above."""
+        """nodes: list of dicts {kind, colmap, Xglob, length, nugget, W, y} -- the GP nodes of the layer above; a Vecchia
+        node adds vecch = dict(ord, nn, nd, y): device tensors (ordering, neighbour array, ordered nugget weights, ordered
+        outputs; kernel_class.py:494-509)."""
         self.e, self.n, self.M, self.batch = eng, int(n), int(M), int(batch)
         Np = eng.padded_dim(n)
         self.keep = []
         arr = (_lib.Node * len(nodes))()
+        dense, Dv = False, 0
         for i, d in enumerate(nodes):
             colmap = np.ascontiguousarray(np.asarray(d['colmap'], dtype=np.int32))
             length = np.ascontiguousarray(np.asarray(d['length'], dtype=np.float64))
-            self.keep += [colmap, length, d['Xglob'], d['W'], d['y']]
+            self.keep += [colmap, length, d['Xglob'], d['W'], d['y'], d.get('vecch')]
             nd = arr[i]
             nd.kind, nd.Dl, nd.Dg = KIND[d['kind']], len(colmap), 0 if d['Xglob'] is None else d['Xglob'].shape[1]
             nd.nlen, nd.nugget_est, nd.ldloc = len(length), 0, M
@@ -627,32 +654,57 @@ class _EssQueue:
             nd.length, nd.nugget = length.ctypes.data, float(d['nugget'])
             nd.W = None if d['W'] is None else d['W'].data_ptr()
             nd.y = d['y'].data_ptr()
+            v = d.get('vecch')
+            if v is not None:
+                nd.vecch_ord, nd.vecch_nn = v['ord'].data_ptr(), v['nn'].data_ptr()
+                nd.vecch_nd, nd.vecch_y = v['nd'].data_ptr(), v['y'].data_ptr()
+                nd.vecch_m = int(v['nn'].shape[1]) - 1
+                Dv = max(Dv, nd.Dl + nd.Dg)
+            else:
+                dense = True
         self.nodes, self.nnodes = arr, len(nodes)
         self.FP = eng.workspace(('essFP', n, M, batch), batch * n * M * 8)
-        self.A = eng.workspace(('essA', n, batch), batch * Np * Np * 8)
-        self.work = eng.potrf_workspace(n, batch)
+        self.A = eng.workspace(('essA', n, batch), batch * Np * Np * 8) if dense else None
+        self.work = eng.potrf_workspace(n, batch) if dense else None
+        self.vwork = eng.workspace(('essV', n, Dv, batch), int(lib.dgpamd_ess_queue_vwork(n, Dv, batch))) if Dv else None
         self.scratch = eng.workspace(('essQ',), int(lib.dgpamd_ess_queue_scratch()))
         self.state = eng.empty(self.STATE)
         self.udev = None
 
-    def queue(self, F, NU, scales, uniforms, cursor, ll, compute_ll0, batch_next, max_batches):
-        """Queue NU.shape[0] updates (NU: (nupd, n, M) device tensor).  uniforms: the sampler's upcoming uniforms (host);
-        cursor: how many of them earlier queues of this I-step have consumed."""
+    def share_with(self, other):
+        """Continue `other`'s queue: the same device state and the same uploaded uniforms."""
+        self.state, self.udev = other.state, other.udev
+
+    def upload_uniforms(self, uniforms):
         e = self.e
-        us = np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64))
         if self.udev is None or self.udev[0] is not uniforms:
+            us = np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64))
             with np.errstate(divide='ignore'):
                 both = np.concatenate((us, np.log(us)))
             self.udev = (uniforms, e.tensor(both), len(us))
+
+    def queue(self, F, NU, scales, uniforms, cursor, ll, compute_ll0, batch_next, max_batches, fresh=True):
+        """Queue NU.shape[0] updates (NU: (nupd, n, M) device tensor).  uniforms: the sampler's upcoming uniforms (host);
+        cursor: how many of them earlier queues of this I-step have consumed.  fresh=False: the device state is the one an
+        earlier queue() of this I-step left (cursor, status and counters carry on; `cursor` and `ll` are ignored)."""
+        e = self.e
+        self.upload_uniforms(uniforms)
         ud, nuni = self.udev[1], self.udev[2]
-        st0 = np.zeros(self.STATE)
-        st0[4], st0[7] = cursor, 0.0 if ll is None else ll
-        self.state.copy_(e.tensor(st0))
+        if fresh:
+            st0 = np.zeros(self.STATE)
+            st0[4], st0[7] = cursor, 0.0 if ll is None else ll
+            self.state.copy_(e.tensor(st0))
         sc = np.ascontiguousarray(np.asarray(scales, dtype=np.float64))
         e._chk(e._enter() or lib.dgpamd_ess_queue(e.h, self.n, self.M, _dp(F), _dp(NU), int(NU.shape[0]), C.cast(self.nodes, C.c_void_p),
                                     sc.ctypes.data_as(C.c_void_p), self.nnodes, _dp(self.state), _dp(ud), _dp(ud[nuni:]), nuni,
                                     self.batch, int(batch_next) if batch_next else self.batch, int(max_batches),
-                                    1 if compute_ll0 else 0, _dp(self.FP), _dp(self.A), _dp(self.work), _dp(self.scratch)))
+                                    1 if compute_ll0 else 0, _dp(self.FP), _dp(self.A), _dp(self.work), _dp(self.scratch),
+                                    _dp(self.vwork)))
+
+    def note_info(self, info):
+        """A factorisation queued between two updates (a deeper layer's prior factors): non-zero info stops the queue."""
+        e = self.e
+        e._chk(e._enter() or lib.dgpamd_ess_queue_note_info(e.h, _dp(self.state), _dp(info), int(info.numel())))
 
     def fetch(self):
         """The ONE synchronisation: the device state as a dict."""

@@ -193,6 +193,13 @@ typedef struct {
     double nugget;
     const double *W;       /* device replicate weights or NULL */
     const double *y;       /* device, n */
+    /* Vecchia form of the node (read by dgpamd_ess_queue only; vecch_nn == NULL: dense).  kernel.log_likelihood_func_vecch
+     * kernel_class.py:494-509 = vecchia_llik (vecchia.py:165-180) on the inputs and outputs permuted by kernel.ord. */
+    const int64_t *vecch_ord;   /* device, n: the ordering (row i of the ordered arrays is point vecch_ord[i]) */
+    const int64_t *vecch_nn;    /* device, n x (vecch_m + 1): NNarray (ordered coordinates) */
+    const double *vecch_nd;     /* device, n: nugget weights in ordered coordinates (ones without replicates) */
+    const double *vecch_y;      /* device, n: the outputs in ordered coordinates */
+    int vecch_m, reserved2;
 } dgpamd_node;
 
 /* ---- a7  one elliptical-slice update of a latent block, loop and all ------------
@@ -230,13 +237,24 @@ int dgpamd_ess_update(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double
  *   uniforms / log_uniforms (device, nuni): the sampler's next uniforms and their logarithms (taken on the host so
  *     that the thresholds are bit-identical to the host loop's).
  *   FP (batch_first x n x M), A (batch_first x Np x Np), work (dgpamd_potrf_workspace(n, batch_first)),
- *   scratch (dgpamd_ess_queue_scratch() bytes): device scratch. */
+ *   scratch (dgpamd_ess_queue_scratch() bytes): device scratch.
+ *   Vecchia nodes upstairs (nodes[k].vecch_nn != NULL, kernel_class.py:494-509): every batch gathers the candidates'
+ *     ordered inputs and evaluates vecchia_llik for all of them in one row launch; vwork (dgpamd_ess_queue_vwork(n, max
+ *     Dl + Dg, batch_first) bytes, device) holds the gathered inputs and the per-row partials.  A, work may be NULL when
+ *     every node upstairs is a Vecchia node; vwork may be NULL when none is.
+ *   A queue may be continued: a later call on the same `state` that the caller has NOT zeroed carries on from its cursor,
+ *     status and counters (ll is recomputed with compute_ll0 when the target changed) -- the layers of a deeper model are
+ *     queued one update at a time this way, with one fetch of the state at the end. */
 #define DGPAMD_ESS_STATE 16
 size_t dgpamd_ess_queue_scratch(void);
+size_t dgpamd_ess_queue_vwork(int64_t n, int D, int batch);
 int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double *NU, int nupd, const dgpamd_node *nodes,
                      const double *scales_h, int nnodes, double *state, const double *uniforms, const double *log_uniforms,
                      int nuni, int batch_first, int batch_next, int max_batches, int compute_ll0, double *FP, double *A,
-                     void *work, void *scratch);
+                     void *work, void *scratch, void *vwork);
+/* Folds the `count` info words of a factorisation queued between two updates of a queue (the prior factors of a deeper
+ * layer, imputation.py:54-63) into the queue's state: the first non-zero one stops the queue with status 2. */
+int dgpamd_ess_queue_note_info(dgpamd_ctx *ctx, double *state, const int32_t *info, int count);
 
 /* ---- a8  M-step objective pieces -------------------------------------------
  * kernel.llik  kernel_class.py:403-449 restructured:
@@ -359,6 +377,16 @@ int dgpamd_vecchia_spsolve(dgpamd_ctx *ctx, int64_t n, int m, const double *Lmat
  * layer and all sweeps of imputer.sample (imputation.py:54-63) in one launch.                                   */
 int dgpamd_vecchia_spsolve_batch(dgpamd_ctx *ctx, int64_t n, int m, int nmat, int nrhs, const double *Lmat,
                                  const int64_t *NNarray, const double *inv_sqrt_scale, const double *b, double *x);
+/* The same substitution level-scheduled (rows whose dependencies are all solved run side by side: a few hundred steps
+ * instead of n).  dgpamd_vecchia_levels builds the schedule of each of the nmat neighbour arrays (it depends on the array
+ * only: once per ordering, kernel_class.py:245-277) into sched (device, dgpamd_vecchia_levels_bytes(n, nmat));
+ * dgpamd_vecchia_spsolve_levels then solves like dgpamd_vecchia_spsolve_batch (same arguments, same results up to the
+ * order of each row's sum: a fixed 32-lane butterfly instead of left to right). */
+size_t dgpamd_vecchia_levels_bytes(int64_t n, int nmat);
+int dgpamd_vecchia_levels(dgpamd_ctx *ctx, int64_t n, int m, int nmat, const int64_t *NNarray, void *sched);
+int dgpamd_vecchia_spsolve_levels(dgpamd_ctx *ctx, int64_t n, int m, int nmat, int nrhs, const double *Lmat,
+                                  const int64_t *NNarray, const double *inv_sqrt_scale, const double *b, double *x,
+                                  const void *sched);
 /* Hetero likelihood under Vecchia: rows of the sparse factor of the latent mean's conditional posterior
  * (vecchia.U_matrix :426-446 / U_matrix_sp :599-610 through kernel.ord_nn(pointer=True) kernel_class.py:268-275;
  * consumer Hetero.post_het_vecch likelihood_class.py:166-182).  X: (n x D) ORDERED inputs; impNN: (n x (m+1))

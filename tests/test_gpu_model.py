@@ -1138,6 +1138,53 @@ def test_queued_ess_equals_host_loop(eng, nout, batch):
 
 
 
+@pytest.mark.parametrize('shape', ['vecchia_top', 'vecchia_all', 'three_layers', 'three_layers_vecchia'])
+@pytest.mark.parametrize('batch', [12, 2])
+def test_queued_ess_equals_host_loop_other_shapes(eng, shape, batch):
+    """The device-resident accept / shrink loop for the model shapes round 2 left to the host loop:
+    a Vecchia node upstairs (kernel_class.py:494-509: every speculative batch gathers the candidates' ordered inputs and
+    runs vecchia_llik for all of them in one row launch), Vecchia in both layers (sparse prior draws ahead), and three
+    layers (imputation.py:22-42: per sweep and hidden layer the prior draw from the CURRENT inputs -- K assembly,
+    factorisation, triangular product queued on the device as well -- then one queued update; one fetch per I-step).
+    Same latents in every layer, same proposal / batch / update counts, the uniform stream left at the same position as
+    the host loop; batch=2 forces updates that run out of queued batches and are finished by the host."""
+    from dgp_amd import dgp, kernel, combine
+    rng = np.random.default_rng(11)
+    n, d = 260, 3
+    X = rng.uniform(size=(n, d))
+    Y = (np.sin(3 * X[:, :1]) + X[:, 1:2] ** 2)
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    deep = shape.startswith('three')
+
+    def run(queued):
+        np.random.seed(7)   # (the Vecchia orderings are numpy.random.permutation draws, kernel_class.py:255: the same in both runs)
+        ls = [[kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)]]
+        if deep:
+            ls.append([kernel(length=np.array([1.2]), name='sexp' if k else 'matern2.5', connect=np.arange(d)) for k in range(2)])
+        ls.append([kernel(length=np.array([0.8]), name='matern2.5', scale_est=True, connect=np.arange(d))])
+        vecchia = shape in ('vecchia_all', 'three_layers_vecchia')
+        model = dgp(X, Y, combine(*ls), seed=3, vecchia=vecchia, m=12)
+        if shape == 'vecchia_top':   # dense hidden layer, Vecchia node upstairs
+            top = model.all_layer[-1][0]
+            top.vecch, top.m = True, 12
+            model.imp.update_ord_nn()
+        model.imp.batch = batch
+        model.imp.batch_next = min(4, batch)
+        model.imp._batch_default = False   # (keep these sizes in the queue too: the batch counts are compared below)
+        model.imp.queued = queued
+        for _ in range(2):
+            model.imp.sample(burnin=4)
+        F = [np.stack([nd.output[:, 0] for nd in layer], 1) for layer in model.all_layer[:-1]]
+        return F, dict(model.imp.stats), model.imp.draws.uniform_peek(3)
+
+    Fq, sq, uq = run(True)
+    Fh, sh, uh = run(False)
+    for a, b in zip(Fq, Fh):
+        close(a, b, rtol=1e-9, atol=1e-11)
+    assert sq == sh, (sq, sh)   # proposals, updates, batches
+    assert uq == uh
+
+
 def test_mice_var_ghdiag_nllik_match_reference(eng, golden):
     """functions.mice_var / ghdiag (functions.py:233-256) and emulator.nllik (emulation.py:856-914) against values recorded
     from the reference (g22, g23): the smoothed candidate-set variance behind metric('MICE'), the Gauss-Hermite predictive

@@ -647,6 +647,44 @@ def test_vecchia_spsolve_batch_equals_single(eng):
         close(xb[j, 0], ref, rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize('n,m,nrhs', [(2500, 9, 4), (700, 25, 13), (40, 40, 1), (5000, 33, 2)])
+def test_vecchia_spsolve_level_schedule(eng, n, m, nrhs):
+    """The level-scheduled sparse forward substitution (dgpamd_vecchia_levels + dgpamd_vecchia_spsolve_levels: rows whose
+    dependencies are solved run side by side) against the row-by-row kernel and the oracle's forward_solve_sp
+    (vecchia.py:112-120): same solution to rounding (a row's sum is a 32-lane butterfly instead of left to right); the
+    schedule is a permutation of the rows in which every row comes after all rows it depends on, level by level; more
+    right-hand sides than one workgroup takes (13 > 12), conditioning sets wider than the 32 lanes of a row (m = 33, 40)."""
+    from oracle import dgp_oracle as O
+    import torch
+    rng = np.random.default_rng(n + m)
+    nmat = 2
+    Ls, NNs, scs = [], [], [0.8, 1.7]
+    for j in range(nmat):
+        X = rng.uniform(size=(n, 3))
+        length = np.array([0.4 + 0.2 * j, 0.6, 0.9])
+        NN = eng.nn_ordered(eng.tensor(X / length), m)
+        Ls.append(eng.vecchia_lmatrix('matern2.5' if j else 'sexp', eng.tensor(X), NN, length, 1e-3))
+        NNs.append(NN)
+    Lm, NNa = torch.stack(Ls), torch.stack(NNs)
+    b = eng.tensor(rng.normal(size=(nmat, nrhs, n)))
+    sched = eng.vecchia_levels(NNa)
+    xl = npy(eng.vecchia_spsolve_levels(Lm, NNa, scs, b, sched))
+    xb = npy(eng.vecchia_spsolve_batch(Lm, NNa, scs, b))
+    close(xl, xb, rtol=1e-10, atol=1e-12)
+    close(xl[1, 0], O.forward_solve_sp(npy(Ls[1]) * scs[1], npy(NNs[1]), npy(b[1, 0])), rtol=1e-10, atol=1e-12)
+    # the schedule itself
+    w = 4 * n + 3
+    sc = npy(sched).reshape(nmat, w)
+    for j in range(nmat):
+        lev, order, ptr, nlev = sc[j, :n], sc[j, n:2 * n], sc[j, 2 * n:3 * n + 1], sc[j, 4 * n + 2]
+        NNh = npy(NNs[j])
+        assert sorted(order.tolist()) == list(range(n))
+        assert ptr[0] == 0 and ptr[nlev] == n and np.all(np.diff(ptr[:nlev + 1]) > 0)
+        dep = np.where(NNh[:, 1:] >= 0, lev[np.maximum(NNh[:, 1:], 0)], -1).max(1) if NNh.shape[1] > 1 else np.full(n, -1)
+        assert np.array_equal(lev, dep + 1)                      # level = 1 + highest level among the dependencies
+        assert np.array_equal(np.sort(lev[order]), lev[order])   # rows in level order
+
+
 def test_linkgp_sexp_mfma_equals_direct_across_chunks(eng):
     """SExp link_gp: the MFMA pair kernel (dot-product form of the exponent) against the direct evaluation, M = 2100
     test points (two workspace chunks), incl. zero input variances; a slice against the oracle."""

@@ -73,6 +73,10 @@ elif which == 'cfg4train':
     if os.environ.get('BATCH'):
         model.imp.batch = int(os.environ['BATCH'])
         model.imp.batch_next = int(os.environ.get('BATCH_NEXT', os.environ['BATCH']))
+    if os.environ.get('QMAX'):
+        model.imp.queue_max_batches = int(os.environ['QMAX'])
+    if os.environ.get('NOQUEUE'):
+        model.imp.queued = False   # (the host-driven accept / shrink loop: one synchronisation per speculative batch)
     spent, inner = [0.0], model._m_step
 
     def timed_m_step(*a, **k):
