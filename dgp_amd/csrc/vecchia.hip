@@ -839,10 +839,9 @@ static size_t vrow4_lds(int BS, int D, bool grad, bool solves) {
     return 4 * (asz + (size_t)BS * (D | 1) + (solves ? 2 * 32 : 0)) * sizeof(double);   // (llik: 19.6 KB at m = 25, d = 8: 8 waves per CU)
 }
 
+// four rows (row block rb) of input set `by`: the body of vecchia_row4_kernel
 template <int KIND, int MODE, int BS>
-__global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
-    extern __shared__ double lds[];
-    if (a.pred && *a.pred) return;
+__device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const int64_t rowblk, const int by) {
     constexpr int rows = BS + 1;                      // block rows, then the right-hand side as row BS
     constexpr int T2 = BS * (BS - 1) / 2;
     constexpr int asz = rows * (rows + 1) / 2 + (MODE == V_NLLIK ? T2 : 0);
@@ -854,11 +853,11 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
     double *Kp = A + rows * (rows + 1) / 2;
     double *xs = lds + (size_t)4 * asz + (size_t)g * BS * DP;             // [BS][D] scaled inputs
     double *V = lds + (size_t)4 * asz + (size_t)4 * BS * DP + (size_t)g * 64;   // [2][32] u, alpha
-    const int64_t i = (int64_t)blockIdx.x * 4 + g;
+    const int64_t i = rowblk * 4 + g;
     const bool live = i < a.n;
-    const double *X = a.X + (MODE == V_LLIK ? (int64_t)blockIdx.y * a.x_stride : 0);
+    const double *X = a.X + (MODE == V_LLIK ? (int64_t)by * a.x_stride : 0);
     double *partial = a.partial;
-    if (MODE == V_LLIK) partial += (int64_t)blockIdx.y * a.n * 2;
+    if (MODE == V_LLIK) partial += (int64_t)by * a.n * 2;
 
     // conditioning set: the valid entries of the row come first; slot R <- entry b-1-(R-pad)  (ascending, self last).
     // One load of the row, the reversal by shuffle; then every slot fetches its own point (inputs, output, nugget
@@ -1104,12 +1103,34 @@ __global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
 #undef AT
 }
 
+// A workgroup (one wave) walks row blocks rb = blockIdx.x, blockIdx.x + gridDim.x, ...: the grid is capped (launch_vrow4_nb)
+// so that a launch the device-side ESS queue has predicated away costs a few thousand workgroup dispatches, not
+// n / 4 x batch of them (at n = 50 000 the no-op launches of an I-step added up to 9 ms: ~7 ns per dispatched workgroup).
+template <int KIND, int MODE, int BS>
+__global__ __launch_bounds__(64) void vecchia_row4_kernel(VRowArgs a) {
+    extern __shared__ double lds[];
+    if (a.pred && *a.pred) return;
+    const int64_t nrb = (a.n + 3) / 4;
+    for (int64_t q = blockIdx.x; q < nrb; q += gridDim.x) {
+        vrow4_body<KIND, MODE, BS>(a, lds, q, (int)blockIdx.y);
+        __syncthreads();   // (the next row block reuses the LDS)
+    }
+}
+
+#ifndef VR4_GRID
+#define VR4_GRID 2048   // row-block workgroups per input set (each walks n / 4 / 2048 row blocks)
+#endif
 template <int KIND, int MODE, int BS>
 static int launch_vrow4_nb(dgpamd_ctx *ctx, VRowArgs &a, int batch) {
     const size_t shm = vrow4_lds(BS, a.vp.D, MODE == V_NLLIK, MODE != V_LLIK);
     int rc = set_lds(ctx, (const void *)vecchia_row4_kernel<KIND, MODE, BS>, shm);
     if (rc) return rc;
-    hipLaunchKernelGGL((vecchia_row4_kernel<KIND, MODE, BS>), dim3((unsigned)((a.n + 3) / 4), (unsigned)batch), dim3(64), shm,
+    const int64_t nrb = (a.n + 3) / 4;
+    static const int64_t cap_env = getenv("DGPAMD_VR4_GRID") ? atoll(getenv("DGPAMD_VR4_GRID")) : -1;
+    // the cap applies to the launches a device-side queue may predicate away (ctx->pred set); the others keep one
+    // workgroup per row block, which the hardware balances better (llik x6 688 vs 721 us, nllik 333 vs 380 us at n = 50 000)
+    const int64_t cap = cap_env >= 0 ? (cap_env == 0 ? nrb : cap_env) : (a.pred ? VR4_GRID : nrb);
+    hipLaunchKernelGGL((vecchia_row4_kernel<KIND, MODE, BS>), dim3((unsigned)(nrb < cap ? nrb : cap), (unsigned)batch), dim3(64), shm,
                        ctx->stream, a);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;

@@ -29,6 +29,7 @@ import torch
 from .ops import default_engine
 
 TWO_PI = 2.0 * np.pi
+_NO_UPLOAD_AHEAD = bool(__import__('os').environ.get('DGPAMD_NO_UPLOAD_AHEAD'))   # (A/B switch of DrawStream.prefetch's early upload)
 
 
 class DrawStream:
@@ -85,6 +86,7 @@ class DrawStream:
                     elif pins[0].numel() < count:
                         pins[0] = torch.empty(count, dtype=torch.float64, pin_memory=True)
                     out = pins[0].numpy()[:count]
+                    self._zpin_cur = pins[0]
             except Exception:
                 out = None
         if out is None:
@@ -96,9 +98,11 @@ class DrawStream:
         assert len(out) == count
         return out
 
-    def prefetch(self, count):
+    def prefetch(self, count, engine=None):
         """Generate the next `count` normals on a background thread (numpy releases the GIL while filling), e.g. while
-        the device is busy with the M-step; normals() then hands them out in order."""
+        the device is busy with the M-step; normals() then hands them out in order.  With `engine` the thread also starts
+        their upload on a side stream (35 MB per I-step at n = 50 000 with eight nodes: 2 ms of an otherwise idle device at
+        the start of every I-step when it waits for the copy): normals_device() hands out the device copy."""
         if self._z is not None or count <= 0:
             return
         self._join()
@@ -109,17 +113,49 @@ class DrawStream:
         rest = None if have == 0 else self._zbuf[self._zpos:].copy()
 
         def work():
+            self.__dict__.pop('_zdev', None)
+            self.__dict__.pop('_zpin_cur', None)
             self._zbuf = self._fill(rest, count)
             self._zpos = 0
+            pin = self.__dict__.get('_zpin_cur')
+            if engine is not None and pin is not None and not _NO_UPLOAD_AHEAD:
+                try:
+                    torch.cuda.set_device(engine.device)
+                    side = engine.__dict__.get('_side_stream')
+                    if side is None:
+                        side = engine._side_stream = torch.cuda.Stream(engine.device)
+                    with torch.cuda.stream(side):
+                        dev = pin[:count].to(engine.device, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    self._zdev = (self._zbuf, dev, ev)
+                except Exception:   # noqa: BLE001  (the host copy is still there)
+                    self.__dict__.pop('_zdev', None)
         self._zbuf, self._zpos = None, 0
         self._thread = threading.Thread(target=work, daemon=True)
         self._thread.start()
+
+    def normals_device(self, engine, count):
+        """normals(count) as a device tensor: the copy prefetch(engine=...) started if it covers exactly these draws,
+        else an upload now.  Same draws either way."""
+        self._join()
+        hit = self.__dict__.get('_zdev')
+        buf = self._zbuf
+        if hit is not None and buf is not None and hit[0] is buf and len(buf) - self._zpos >= count:
+            lo = self._zpos
+            self._zpos += count
+            engine._torch_stream.wait_event(hit[2])
+            hit[1].record_stream(engine._torch_stream)   # (allocated on the side stream, read on the engine's)
+            return hit[1][lo:lo + count]
+        return engine.tensor(self.normals(count))
 
     def __getstate__(self):
         self._join()
         st = dict(self.__dict__)
         st['_thread'] = None
         st.pop('_zpin', None)
+        st.pop('_zdev', None)
+        st.pop('_zpin_cur', None)
         if st.get('_zbuf') is not None:
             st['_zbuf'] = np.array(st['_zbuf'])   # (out of the page-locked buffer)
         return st
@@ -455,7 +491,7 @@ class imputer:
             cur = self._ll_cache.get(0)
             plan.queue(F, nu[first:], scales, us, 0, cur, cur is None, bn, qmax)
             if first == 0:   # the next call's normals: generated by a background thread while this one waits in fetch()
-                self.draws.prefetch(sweeps * M * n)   # (started only now: it would fight the launches above for the interpreter)
+                self.draws.prefetch(sweeps * M * n, engine=e)   # (started only now: it would fight the launches above for the interpreter)
             st = plan.fetch()   # the one synchronisation of the queue (of the whole I-step unless an update was left open)
             status, done = int(st['status']), int(st['updates'])
             self.draws.uniform_take(int(st['cursor']))
@@ -632,7 +668,7 @@ class imputer:
                                                                 hi=float(st['hi']), pending=bool(st['pending'])))
             pos += 1
         if nu0 is not None:
-            self.draws.prefetch(sweeps * self.F[0].shape[1] * n)
+            self.draws.prefetch(sweeps * self.F[0].shape[1] * n, engine=e)
         return True
 
     def _layer_factors(self, l, dense):
@@ -699,25 +735,24 @@ class imputer:
         if all_vecch:
             # Vecchia: M x sweeps independent sparse forward substitutions, all in one launch
             if self.draws._z is None:
-                Z = self.draws.normals(sweeps * M * n).reshape(sweeps, M, n)
+                Zd = self.draws.normals_device(e, sweeps * M * n).view(sweeps, M, n)
             else:
-                Z = np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)])
-            xs = self._vecchia_draws(0, list(range(M)), e.tensor(Z).permute(1, 0, 2).contiguous())   # (M, sweeps, n)
+                Zd = e.tensor(np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)]))
+            xs = self._vecchia_draws(0, list(range(M)), Zd.permute(1, 0, 2).contiguous())   # (M, sweeps, n)
             if prefetch:
-                self.draws.prefetch(sweeps * M * n)
+                self.draws.prefetch(sweeps * M * n, engine=e)
             return xs.permute(1, 2, 0).contiguous()
         buf = self._layer_factors(0, list(range(M)))
         if self.draws._z is None:
-            Z = self.draws.normals(sweeps * M * n).reshape(sweeps, M, n)
+            Zd = self.draws.normals_device(e, sweeps * M * n).view(sweeps, M, n)
         else:
-            Z = np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)])
-        Zd = e.tensor(Z)
+            Zd = e.tensor(np.stack([np.stack([self.draws.normal(n) for _ in range(M)]) for _ in range(sweeps)]))
         scales = [float(nd.scale[0]) for nd in layer]
         out = e.empty(sweeps, M, n)
         for s_ in range(sweeps):
             e.trmv_lower(n, buf, scales, Zd[s_], batch=M, out=out[s_])
         if prefetch:
-            self.draws.prefetch(sweeps * M * n)   # the next call's normals, generated while the device works
+            self.draws.prefetch(sweeps * M * n, engine=e)   # the next call's normals, generated while the device works
         return out.transpose(1, 2).contiguous()
 
     def _prior_draw(self, l, cols=None):

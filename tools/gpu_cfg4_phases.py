@@ -12,6 +12,7 @@ rng = np.random.default_rng(7)
 X = rng.uniform(size=(n, d))
 f = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + X[:, 2] ** 2 + 0.3 * X[:, 3:].sum(1)
 Y = ((f - f.mean()) / f.std())[:, None]
+np.random.seed(0)
 model = dgp(X, Y, vecchia=True, m=m, seed=1)
 model.train(N=3, ess_burn=10, disable=True)
 acc = collections.defaultdict(float)
@@ -31,7 +32,7 @@ def wrap(obj, name, label=None):
 
 
 imp = model.imp
-for nm in ('_attach', '_detach', '_prior_draws_ahead', 'one_sample_block', '_vecchia_draws', '_upper_loglik', 'stage_for_mstep', 'sample'):
+for nm in ('_attach', '_detach', '_prior_draws_ahead', 'one_sample_block', '_vecchia_draws', '_upper_loglik', 'stage_for_mstep', 'sample', '_sample_queued', '_queue_plan'):
     wrap(imp, nm)
 wrap(imp.draws, 'normals', 'draws.normals')
 wrap(MS, 'maximise_lockstep_vecch')

@@ -67,6 +67,7 @@ elif which == 'cfg4train':
     X = rng.uniform(size=(n, d))
     f = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + X[:, 2] ** 2 + 0.3 * X[:, 3:].sum(1)
     Y = ((f - f.mean()) / f.std())[:, None]
+    np.random.seed(0)   # (the Vecchia ordering is a numpy.random.permutation: the same work in every run)
     t = time.perf_counter(); model = dgp(X, Y, vecchia=True, m=m, seed=1); sync()
     print('cfg4train n=%d: construct (warm start + NN + 11 sweeps) %.1f s' % (n, time.perf_counter() - t), flush=True)
     its = int(os.environ.get('ITERS', '3'))
