@@ -821,8 +821,57 @@ def gen_multitile():
     save('g23_nllik_poisson', **o)
 
 
+def gen_wellcond():
+    """G24: the objective, its gradient, the ESS target, the prediction statistics and gp / link_gp predictions of WELL-
+    CONDITIONED nodes (nugget 1e-3, n = 150: cond(K) ~ 1e5), where the build's f64 results must agree with the reference to
+    1e-10 -- the fixtures at the default nugget 1e-6 (cond ~ 1e7) cannot tell a 1e-7 kernel bug from conditioning
+    (VERDICT round 2)."""
+    rng = np.random.default_rng(2403)
+    out = {}
+    c = 0
+    for name, per_dim, d_glob, nugget_est, scale_est in (('sexp', False, 0, False, True), ('matern2.5', False, 2, True, True),
+                                                        ('sexp', True, 2, True, False), ('matern2.5', True, 0, False, False)):
+        n, d_loc, M = 150, 3, 9
+        k = make_node(rng, n, d_loc, d_glob, name, per_dim, nugget_est, scale_est, 'ga', False)
+        k.nugget = np.array([1e-3])
+        k.length = rng.uniform(0.5, 1.1, size=len(k.length))
+        # a smooth output (an output of white noise makes y'K^-1y ~ n / nugget and the objective ill-scaled)
+        Xn = node_X(k)
+        k.output = (np.sin(3 * Xn[:, :1]) + Xn[:, 1:2] ** 2 - Xn[:, 2:3] + 0.05 * rng.normal(size=(n, 1)))
+        pre = 'c%d_' % c
+        out[pre + 'X'] = Xn; out[pre + 'n_local'] = np.array(d_loc); out[pre + 'y'] = k.output.copy()
+        out[pre + 'length'] = k.length.copy(); out[pre + 'scale'] = k.scale.copy(); out[pre + 'nugget'] = k.nugget.copy()
+        out[pre + 'name'] = np.array(name)
+        out[pre + 'flags'] = np.array([per_dim, d_glob, nugget_est, False, scale_est], dtype=np.int64)
+        out[pre + 'prior_coef'] = np.asarray(k.prior_coef, float).copy()
+        out[pre + 'loglik'] = np.atleast_1d(k.log_likelihood_func()).flatten()
+        k.compute_stats()
+        out[pre + 'Rinv'] = k.Rinv.copy(); out[pre + 'Rinv_y'] = k.Rinv_y.copy()
+        x = rng.uniform(size=(M, d_loc))
+        z = rng.uniform(size=(M, d_glob)) if d_glob else None
+        m_gp, v_gp = RF.gp(x, z, k.input, k.global_input, k.Rinv, k.Rinv_y, k.scale, k.length, k.nugget, k.name)
+        out[pre + 'x'] = x
+        if z is not None:
+            out[pre + 'z'] = z
+        out[pre + 'gp_m'] = m_gp; out[pre + 'gp_v'] = v_gp
+        mm = rng.uniform(size=(M, d_loc)); vv = rng.uniform(0.001, 0.3, size=(M, d_loc))
+        vv[0, 0] = 0.0
+        lm, lv = RF.link_gp(mm, vv, z, k.input, k.global_input, k.Rinv, k.Rinv_y, getattr(k, 'R2sexp', None), getattr(k, 'Psexp', None),
+                            k.scale[0], k.length, k.nugget[0], k.name)
+        out[pre + 'lm_in'] = mm; out[pre + 'lv_in'] = vv; out[pre + 'link_m'] = lm; out[pre + 'link_v'] = lv
+        xx = k.log_t() + rng.normal(scale=0.05, size=len(k.log_t()))
+        nll, g = k.llik(xx.copy())
+        out[pre + 'x_opt'] = xx; out[pre + 'nll'] = np.atleast_1d(nll).flatten(); out[pre + 'grad'] = np.asarray(g, float).flatten()
+        out[pre + 'scale_after'] = np.atleast_1d(k.scale).flatten()
+        c += 1
+    out['n_cases'] = np.array(c)
+    save('g24_wellcond', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch', 'export', 'counts', 'categorical', 'multitile']
+    which = sys.argv[1:] or ['kernel', 'fmvn', 'ess', 'predict', 'vecchia', 'emulator', 'lgp', 'hetero', 'loo', 'hetvecch', 'export', 'counts', 'categorical', 'multitile', 'wellcond']
+    if 'wellcond' in which:
+        gen_wellcond()
     if 'kernel' in which:
         gen_kernel_cases()
     if 'fmvn' in which:

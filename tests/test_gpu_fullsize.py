@@ -131,3 +131,140 @@ def test_cfg4_vecchia_at_full_size(eng):
     ref = O.vecchia_llik(X[:k], y[:k], NN[:k], 1.0, length, 1e-4, np.ones(k), 'matern2.5')
     close(-0.5 * (sub[1] + sub[0]), ref, rtol=1e-9)
     assert sub[0] < out[0] and np.isfinite(out).all()
+
+
+def _node(eng, name, length, inp, out, glob=None, scale=1.0, scale_est=False, nugget=1e-6):
+    """A dgp_amd kernel node with its data attached (what dgp() would build)."""
+    from dgp_amd import kernel
+    nd = kernel(length=np.asarray(length, float).copy(), scale=scale, nugget=nugget, name=name, scale_est=scale_est,
+                input_dim=np.arange(inp.shape[1]), connect=None if glob is None else np.arange(glob.shape[1]), engine=eng)
+    nd.input, nd.output, nd.global_input = inp.copy(), out.reshape(-1, 1).copy(), None if glob is None else glob.copy()
+    nd.vecch = False
+    nd.D = inp.shape[1] + (0 if glob is None else glob.shape[1])
+    return nd
+
+
+def test_cfg3_block_update_at_full_size_vs_oracle(eng):
+    """BASELINE configs[2] at its own size (n = 5000, d = 10 in / 3 out, SExp): ONE block update of the hidden layer
+    (imputation.py:44-119) with injected draws against the oracle's sequential sweep -- ten prior draws through ten
+    5000 x 5000 factors, speculative batches of four, the log-likelihoods of the THREE nodes upstairs summed
+    (imputation.py:91-106), accept / shrink on the device.  Same accepted latents, the uniforms consumed one per proposal,
+    the accepted log-likelihood.  (~2 s of host LAPACK per proposal for the oracle.)"""
+    from oracle import dgp_oracle as O
+    from dgp_amd.imputation import imputer, DrawStream
+    n, d, q = 5000, 10, 3
+    rng = np.random.default_rng(2026)
+    X = rng.uniform(size=(n, d))
+    F0 = np.stack([np.sin(2.0 * X[:, k] + 0.3 * k) + 0.5 * X[:, (k + 1) % d] ** 2 for k in range(d)], 1)
+    F0 = (F0 - F0.mean(0)) / F0.std(0) + 0.05 * rng.standard_normal((n, d))
+    Y = np.stack([np.sin(1.0 / ((0.7 * X[:, 0] + 0.3) * (0.7 * X[:, 1] + 0.3))) + (0.2 + 0.1 * j) * (X[:, 2 + j:] ** 2).sum(1) for j in range(q)], 1)
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    layer0 = [_node(eng, 'sexp', [1.0 + 0.05 * k], X, F0[:, k], nugget=1e-6) for k in range(d)]
+    upper = [_node(eng, 'sexp', [1.5 + 0.2 * j], F0, Y[:, j], glob=X, scale=0.8 + 0.1 * j, scale_est=True, nugget=1e-4) for j in range(q)]
+    z = [rng.standard_normal(n) for _ in range(d)]
+    u = [1e-12] + list(rng.random(40))      # a low threshold: the update ends within a few proposals (bounds the oracle's time)
+    imp = imputer([layer0, upper], block=True, draws=DrawStream(z=[v.copy() for v in z], u=list(u)), engine=eng, batch=4)
+    imp.batch_next = 4
+    nu = np.stack([O.fmvn(float(nd.scale[0]) * O.k_matrix(X, nd.length, nd.nugget[0], nd.name), z[k]) for k, nd in enumerate(layer0)], 1)
+
+    def up(fp):
+        Xi = np.concatenate((fp, X), 1)
+        return sum(O.log_likelihood(Xi, Y[:, [j]], nd.length, float(nd.scale[0]), nd.nugget[0], nd.name) for j, nd in enumerate(upper))
+
+    f_ref, nprop, thetas, lls, log_y = O.ess_block_sweep(F0, nu, up, np.log(u[0]), u[1:])
+    imp.sample(burnin=0)
+    F1 = np.stack([nd.output[:, 0] for nd in layer0], 1)
+    assert len(imp.draws._ubuf) == len(u) - (1 + nprop), 'uniforms consumed: threshold + one per proposal'
+    assert imp.stats['proposals'] == nprop
+    close(F1, f_ref, rtol=1e-8, atol=1e-10)
+    close(imp._ll_cache[0], lls[-1], rtol=1e-9)
+
+
+def test_cfg3_sexp_link_gp_at_full_size_vs_oracle(eng):
+    """The SExp linked-GP predictor (functions.py:396-451: IJ_sexp's terms formed in flight on f64 MFMA) of a cfg3 second-
+    layer node at n = 5000 -- ten uncertain local inputs, ten deterministic global ones -- against the oracle's direct
+    evaluation for eight test points, from the SAME R^-1 and R^-1 y (uploaded), so that only the pair kernel is compared:
+    means 1e-9, variances 1e-8 of the scale."""
+    from oracle import dgp_oracle as O
+    n, Dw, Dz, M = 5000, 10, 10, 8
+    rng = np.random.default_rng(5)
+    W, Wg = rng.normal(size=(n, Dw)), rng.uniform(size=(n, Dz))
+    y = np.sin(W[:, 0]) + Wg[:, 1] ** 2 + 0.1 * rng.normal(size=n)
+    length, scale, nugget = np.array([2.5]), 1.3, 1e-4
+    st = O.compute_stats(np.concatenate((W, Wg), 1), y[:, None], length, nugget, 'sexp', Dw)
+    m, v = rng.normal(size=(M, Dw)), rng.uniform(0.01, 0.4, size=(M, Dw))
+    v[0, 0] = 0.0
+    z = rng.uniform(size=(M, Dz))
+    mo, vo = O.link_gp_predict(m, v, z, W, Wg, st['Rinv'], st['Rinv_y'], scale, length, nugget, 'sexp')
+    lm, lv = eng.linkgp_predict('sexp', eng.tensor(m), eng.tensor(v), eng.tensor(z), eng.tensor(W), eng.tensor(Wg), length,
+                                eng.tensor(st['Rinv']), n, eng.tensor(st['Rinv_y']), scale, nugget)
+    close(npy(lm), mo, rtol=1e-9, atol=1e-11)
+    close(npy(lv), vo, rtol=1e-8, atol=1e-8 * scale)
+
+
+def test_cfg5_chain_at_full_size_vs_oracle_walk(eng):
+    """BASELINE configs[4] at its own size: GP -> DGP -> GP, n = 1000 each, Matern-2.5, through the public lgp.predict
+    (linkgp.py:285-501) against the oracle's walk of the same chain -- gp at the inputs, then per imputation link_gp
+    through the DGP's two layers and through the last GP, the mixture's moments over the imputations at the end
+    (linkgp.py:495-500) -- 256 test points and two imputations on the device, the first 16 points walked by the oracle (its
+    Matern link_gp takes ~0.4 s per point and node).  (The DGP's layers are chained without a global connection: the
+    oracle has no linkgp_prediction_full; that branch is pinned on the reference's own output at small n, g10.)"""
+    from oracle import dgp_oracle as O
+    from dgp_amd.linkgp import container, lgp
+    n, M, S = 1000, 256, 2
+    rng = np.random.default_rng(9)
+    X1 = rng.uniform(size=(n, 3))
+    Y1 = np.sin(3 * X1[:, 0]) + X1[:, 1] ** 2 - X1[:, 2]
+    Y1 = (Y1 - Y1.mean()) / Y1.std()
+    Y2 = np.tanh(2 * Y1) + 0.3 * Y1 ** 2
+    Y2 = (Y2 - Y2.mean()) / Y2.std()
+    Y3 = np.cos(2 * Y2)
+    Y3 = (Y3 - Y3.mean()) / Y3.std()
+    # (nuggets that keep cond(R) ~ 1e5 with 1000 points on a line: at 1e-6 both sides lose five digits of R^-1 y to
+    #  conditioning, each in its own way, and the comparison says nothing)
+    g1 = _node(eng, 'matern2.5', [0.8, 1.2, 1.0], X1, Y1, scale=1.1, nugget=1e-3)
+    g3 = _node(eng, 'matern2.5', [1.0], Y2[:, None], Y3, scale=0.9, nugget=1e-2)
+    sets = []
+    lat = [np.tanh(1.5 * Y1) + 0.05 * rng.standard_normal(n) for _ in range(S)]     # the imputations' hidden layers
+    for s in range(S):
+        h = _node(eng, 'matern2.5', [1.1], Y1[:, None], lat[s], scale=1.0, nugget=1e-2)
+        t = _node(eng, 'matern2.5', [0.9], lat[s][:, None], Y2, scale=1.2, nugget=1e-2)
+        one = []
+        for l, st in enumerate(([[g1]], [[h], [t]], [[g3]])):
+            c = container.__new__(container)
+            c.vecch, c.local_input_idx = False, (np.array([0, 1, 2]) if l == 0 else np.array([0]))
+            if len(st) == 1:
+                c.type, c.structure = 'gp', st[0][0]
+            else:
+                c.type, c.structure = 'dgp', st
+            one.append([c])
+        sets.append(one)
+    sysm = lgp.__new__(lgp)
+    sysm.L, sysm.all_layer, sysm.num_model, sysm.all_layer_set = 3, sets[0], [1, 1], sets
+    xt = rng.uniform(size=(M, 3))
+    mu, var = sysm.predict([xt, [None], [None]])
+
+    def stats(nd):
+        Xn = nd.input if nd.global_input is None else np.concatenate((nd.input, nd.global_input), 1)
+        return O.compute_stats(Xn, nd.output, nd.length, nd.nugget[0], nd.name, nd.input.shape[1])
+
+    def link(nd, m, v):
+        st = stats(nd)
+        return O.link_gp_predict(m[:, None], v[:, None], None, nd.input, None, st['Rinv'], st['Rinv_y'], nd.scale, nd.length, nd.nugget, nd.name)
+
+    K = 16
+    s1 = stats(g1)
+    m1, v1 = O.gp_predict(xt[:K], X1, s1['Rinv'], s1['Rinv_y'], g1.scale, g1.length, g1.nugget, g1.name)
+    mus, vars_ = [], []
+    for s in range(S):
+        h, t = sets[s][1][0].structure[0][0], sets[s][1][0].structure[1][0]
+        mh, vh = link(h, m1, v1)
+        mt, vt = link(t, mh, vh)
+        m3s, v3s = link(g3, mt, vt)
+        mus.append(m3s)
+        vars_.append(v3s)
+    m3 = np.mean(mus, 0)
+    v3 = np.mean([a ** 2 + b for a, b in zip(mus, vars_)], 0) - m3 ** 2
+    assert mu[0].shape == (M, 1) and np.all(np.isfinite(mu[0])) and np.all(var[0] > -1e-10)
+    close(mu[0][:K, 0], m3, rtol=1e-6, atol=1e-8)
+    close(var[0][:K, 0], v3, rtol=1e-5, atol=1e-7)

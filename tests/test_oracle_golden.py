@@ -339,3 +339,31 @@ def test_mice_var_and_ghdiag_pinned(golden):
 def test_ess_trajectory_multitile(golden):
     """The n = 200 recording (three Matern nodes, global input connected): four 64-wide tiles per matrix on the device."""
     test_ess_trajectory(golden, 'matern200', sweeps=2)
+
+
+def test_wellconditioned_fixture_at_1e10(golden):
+    """g24 (nugget 1e-3, n = 150, cond(K) ~ 1e5): the oracle reproduces the reference's objective, gradient, ESS target,
+    prediction statistics and gp / link_gp predictions to 1e-10 -- the tolerance SURVEY 8(c) states, which the fixtures at the
+    default nugget cannot carry."""
+    g = golden('g24_wellcond')
+    for c in range(int(g['n_cases'])):
+        d = case(g, 'c%d_' % c)
+        name, nl = str(d['name']), int(d['n_local'])
+        ll = O.log_likelihood(d['X'], d['y'], d['length'], d['scale'], d['nugget'][0], name)
+        close(ll, d['loglik'][0], rtol=1e-10)
+        nll, gr, sc = O.nll_grad(d['x_opt'], d['X'], d['y'], name, d['scale'], d['nugget'][0], bool(d['flags'][2]), bool(d['flags'][4]),
+                                 'ga', d['prior_coef'])
+        close(nll, d['nll'][0], rtol=1e-10)
+        close(gr, d['grad'], rtol=1e-10, atol=1e-10 * np.abs(d['grad']).max())
+        close(sc, d['scale_after'][0], rtol=1e-10)
+        st = O.compute_stats(d['X'], d['y'], d['length'], d['nugget'][0], name, nl)
+        close(st['Rinv_y'], d['Rinv_y'], rtol=1e-10, atol=1e-10 * np.abs(d['Rinv_y']).max())
+        x = d['x'] if 'z' not in d else np.concatenate((d['x'], d['z']), 1)
+        m, v = O.gp_predict(x, d['X'], d['Rinv'], d['Rinv_y'], d['scale'], d['length'], d['nugget'], name)
+        close(m, d['gp_m'], rtol=1e-10, atol=1e-12)
+        close(v, d['gp_v'], rtol=1e-10, atol=1e-10 * d['scale'][0])   # (a difference of O(scale) terms: absolute in units of the scale)
+        W, Wg = d['X'][:, :nl], d['X'][:, nl:]
+        lm, lv = O.link_gp_predict(d['lm_in'], d['lv_in'], d.get('z'), W, Wg if 'z' in d else None, d['Rinv'], d['Rinv_y'],
+                                   d['scale'], d['length'], d['nugget'], name)
+        close(lm, d['link_m'], rtol=1e-10, atol=1e-12)
+        close(lv, d['link_v'], rtol=1e-8, atol=1e-10 * d['scale'][0])   # (Jd-based Matern J: SURVEY 8(c) states 1e-8)
