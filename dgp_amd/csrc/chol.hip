@@ -29,9 +29,14 @@ __device__ __forceinline__ void diag_logdet(DiagShared &sh, int ncol, int k, int
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (tid == 0) {
-            logdet[b] = (k == 0 ? 0.0 : logdet[b]) + v;
-            if (k == 0) info[b] = 0;
-            if (bad && info[b] == 0) info[b] = k * 64 + bad;
+            // (device-scope accesses: the words are read-modified by the chain workgroups of consecutive launches, which run
+            //  on whatever XCD the dispatcher picks, and the workspace address they live at holds other data -- diagonal-block
+            //  inverses -- under another batch size's layout: no per-XCD L2 line of an earlier use may serve them)
+            const double ld0 = k == 0 ? 0.0 : __hip_atomic_load(logdet + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(logdet + b, ld0 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int inf = k == 0 ? 0 : __hip_atomic_load(info + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bad && inf == 0) inf = k * 64 + bad;
+            __hip_atomic_store(info + b, inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -732,8 +737,8 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
         if (tr) tr[16 * k + 5] = wall_clock64();
     }
     if (tid == 0) {
-        g.logdet[b] = logdet;
-        g.info[b] = info;
+        __hip_atomic_store(g.logdet + b, logdet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g.info + b, info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1313,8 +1318,9 @@ __global__ void potrf_copy_out_kernel(const double *ld_ws, const int32_t *info_w
                                       const int32_t *status) {
     const int b = threadIdx.x;
     if (b < batch) {
-        logdet[b] = ld_ws[b];
-        info[b] = (status && *status) ? -1 : info_ws[b];
+        logdet[b] = __hip_atomic_load(ld_ws + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int st = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        info[b] = st ? -1 : __hip_atomic_load(info_ws + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

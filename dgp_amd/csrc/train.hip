@@ -370,9 +370,10 @@ __global__ __launch_bounds__(256) void grad_final_multi_kernel(const GradMulti *
     __threadfence();
     if (tid < f.batch) {
         const int b = tid;
-        f.dev_out[b * f.stride_out] = f.ld_ws[b];
+        f.dev_out[b * f.stride_out] = __hip_atomic_load(f.ld_ws + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         f.dev_out[b * f.stride_out + 1] = -f.A[(int64_t)b * f.stride_a + f.n * f.ld + f.n];
-        f.dev_out[b * f.stride_out + 2] = (double)(*f.status ? -1 : f.info_ws[b]);
+        f.dev_out[b * f.stride_out + 2] = (double)(__hip_atomic_load(f.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                        ? -1 : __hip_atomic_load(f.info_ws + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     if (tid == 0) *f.counter = 0;
     __threadfence();
@@ -440,8 +441,9 @@ __global__ void llik_post_kernel(const double *T, double *S, const double *A, in
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) S[(int64_t)b * stride_a + n * ld + j] = T[(int64_t)b * stride_a + j * ld + n];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double l = ld_ws[b];
-        const int32_t f = *status ? -1 : info_ws[b];
+        const double l = __hip_atomic_load(ld_ws + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t f = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              ? -1 : __hip_atomic_load(info_ws + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         logdet[b] = l;
         info[b] = f;
         out[b * stride_out] = l;
@@ -737,8 +739,10 @@ __global__ void ess_node_ll_kernel(const double *A, int64_t ld, int64_t stride_a
     const int b = threadIdx.x;
     if (sc->done) return;
     if (b < B) {
-        const double logdet = ld_ws ? ld_ws[b] : sc->logdet[b];
-        const int32_t info = ld_ws ? ((status && *status) ? -1 : info_ws[b]) : sc->info[b];
+        const double logdet = ld_ws ? __hip_atomic_load(ld_ws + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : sc->logdet[b];
+        const int32_t info = ld_ws ? ((status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                          ? -1 : __hip_atomic_load(info_ws + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                   : sc->info[b];
         const double quad = -A[(int64_t)b * stride_a + n * ld + n];
         const double ll = -0.5 * ((double)n * log(scale) + logdet + quad / scale);
         sc->ll[b] = (first ? 0.0 : sc->ll[b]) + ll;
