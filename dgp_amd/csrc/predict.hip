@@ -481,6 +481,30 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
 // test point the 64 x 64 x Dw products of a tile are a handful of v_mfma_f64_16x16x4 (accumulated on top of base_ij,
 // which sits in the accumulator layout), and the VALU work per pair drops from 3 Dw + exp to 2 adds + exp.  The row /
 // column terms and the A operand of test point t+1 are staged (double buffered in LDS) while t is evaluated.
+// exp(x) for x <= ~1 (the pair loop's arguments are -(a sum of squares)): x = k ln 2 + r, |r| <= ln 2 / 2, a degree-12 Taylor
+// polynomial in r (remainder 1.7e-16 relative) and v_ldexp -- 18 VALU instructions, no branches, no table (the library's exp
+// is 27 with its special cases; a 64-entry table version read LDS beside the MFMA operand reads and was slower).  Results
+// below 2^-1022 flush through ldexp's own underflow; NaN propagates.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;               // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);            // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);            // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);            // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);            // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);            // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);            // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);            // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);            // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);            // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)fmax(k, -1100.0));
+}
+
 __global__ __launch_bounds__(256, 3) void linkgp_Jsexp_kernel(LinkArgs a) {
     extern __shared__ double lds[];
     const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
@@ -493,9 +517,9 @@ __global__ __launch_bounds__(256, 3) void linkgp_Jsexp_kernel(LinkArgs a) {
     double *tz = tv + TCH * Dw;           // [TCH][Dz]
     double *red = tz + TCH * Dz;          // [TCH][4]
     double *U = red + TCH * 4;            // [2][64][LDU]  A operand of a test point: 2 c1_k (w_ik - 2 m_k)
-    double *R = U + 2 * 64 * LDU;         // [2][64] row terms
-    double *S = R + 2 * 64;               // [2][64] column terms
-    double *ilg = S + 2 * 64;             // [Dz] reciprocal lengthscales of the global dimensions
+    double *R = U + 2 * 64 * LDU;         // [2][4][64] row terms (one partial per staging wave)
+    double *S = R + 2 * 4 * 64;           // [2][4][64] column terms
+    double *ilg = S + 2 * 4 * 64;         // [Dz] reciprocal lengthscales of the global dimensions
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -555,39 +579,57 @@ __global__ __launch_bounds__(256, 3) void linkgp_Jsexp_kernel(LinkArgs a) {
         tv[idx] = 1.0 / (8.0 * tv[idx] + 2.0 * l * l);
         tm[idx] = 2.0 * tm[idx];
     }
-    // staging of test point t: 128 point tasks (64 row points: A operand + row term; 64 column points: column term)
-    // on the even threads, so that the four waves share them evenly
+    // staging of test point t by ALL threads: lane = point (row point p of the row block, column point p of the column block),
+    // wave q = the dimensions k = q, q + 4, ... (local) and g = q, q + 4, ... (global).  Every wave writes its own partial
+    // row / column terms (R, S: [buf][4][64]); the readers add the four.  All LDS reads of a wave's share are issued before
+    // the arithmetic (fixed unroll of SX passes, predicated): one LDS latency per stage instead of one per dimension -- the
+    // former staging (128 threads, a loop over all dimensions per point) cost more cycles per test point than the 16
+    // exponentials of the pair phase.
+    constexpr int SX = 4;   // passes: up to 16 local and 16 global dimensions in registers; beyond that the loops below
     auto stage = [&](int t, int buf) {
-        if (tid & 1) return;
-        const int task = tid >> 1;
+        const int p = lane, q = wave;
         const double *c1 = tv + t * Dw, *m2 = tm + t * Dw, *zt = tz + t * Dz;
-        if (task < 64) {
-            double rr = 0.0;
-            double *u = U + (buf * 64 + task) * LDU;
-            for (int k = 0; k < Dw; ++k) {
-                const double wi = WiT[k * 64 + task] - m2[k], cw = c1[k] * wi;
-                u[k] = 2.0 * cw;
-                rr = fma(cw, wi, rr);
-            }
-            for (int k = Dw; k < KP; ++k) u[k] = 0.0;
-            for (int g = 0; g < Dz; ++g) {
-                const double di = (WiT[(Dw + g) * 64 + task] - zt[g]) * ilg[g];
-                rr = fma(di, di, rr);
-            }
-            R[buf * 64 + task] = rr;
-        } else {
-            const int j = task - 64;
-            double ss = 0.0;
-            for (int k = 0; k < Dw; ++k) {
-                const double wj = WjT[k * 64 + j];
-                ss = fma(c1[k] * wj, wj, ss);
-            }
-            for (int g = 0; g < Dz; ++g) {
-                const double dj = (WjT[(Dw + g) * 64 + j] - zt[g]) * ilg[g];
-                ss = fma(dj, dj, ss);
-            }
-            S[buf * 64 + j] = ss;
+        double wi[SX], wj[SX], ck[SX], mk[SX], gi_[SX], gj_[SX], zg[SX], lg[SX];
+#pragma unroll
+        for (int x = 0; x < SX; ++x) {
+            const int k = q + 4 * x, g = q + 4 * x;
+            const bool ok = k < Dw, og = g < Dz;
+            wi[x] = ok ? WiT[k * 64 + p] : 0.0;
+            wj[x] = ok ? WjT[k * 64 + p] : 0.0;
+            ck[x] = ok ? c1[k] : 0.0;
+            mk[x] = ok ? m2[k] : 0.0;
+            gi_[x] = og ? WiT[(Dw + g) * 64 + p] : 0.0;
+            gj_[x] = og ? WjT[(Dw + g) * 64 + p] : 0.0;
+            zg[x] = og ? zt[g] : 0.0;
+            lg[x] = og ? ilg[g] : 0.0;
         }
+        double rr = 0.0, ss = 0.0;
+        double *u = U + (buf * 64 + p) * LDU;
+#pragma unroll
+        for (int x = 0; x < SX; ++x) {
+            const int k = q + 4 * x;
+            const double d = wi[x] - mk[x], cw = ck[x] * d;
+            if (k < KP) u[k] = 2.0 * cw;   // (k >= Dw: ck = 0 -> the zero padding of the MFMA k-steps)
+            rr = fma(cw, d, rr);
+            ss = fma(ck[x] * wj[x], wj[x], ss);
+            const double di = (gi_[x] - zg[x]) * lg[x], dj = (gj_[x] - zg[x]) * lg[x];
+            rr = fma(di, di, rr);
+            ss = fma(dj, dj, ss);
+        }
+        for (int k = q + 4 * SX; k < KP; k += 4) {   // (more than 16 local dimensions)
+            const double c = k < Dw ? c1[k] : 0.0, d = (k < Dw ? WiT[k * 64 + p] : 0.0) - (k < Dw ? m2[k] : 0.0), cw = c * d;
+            const double w2 = k < Dw ? WjT[k * 64 + p] : 0.0;
+            u[k] = 2.0 * cw;
+            rr = fma(cw, d, rr);
+            ss = fma(c * w2, w2, ss);
+        }
+        for (int g = q + 4 * SX; g < Dz; g += 4) {
+            const double di = (WiT[(Dw + g) * 64 + p] - zt[g]) * ilg[g], dj = (WjT[(Dw + g) * 64 + p] - zt[g]) * ilg[g];
+            rr = fma(di, di, rr);
+            ss = fma(dj, dj, ss);
+        }
+        R[(buf * 4 + q) * 64 + p] = rr;
+        S[(buf * 4 + q) * 64 + p] = ss;
     };
     __syncthreads();
     if (nt > 0) stage(0, 0);
@@ -606,15 +648,213 @@ __global__ __launch_bounds__(256, 3) void linkgp_Jsexp_kernel(LinkArgs a) {
         }
         double rr[4], acc = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rr[r] = R[buf * 64 + mrow + 4 * r];
+        for (int r = 0; r < 4; ++r) {
+            const double *Rq = R + buf * 256 + mrow + 4 * r;
+            rr[r] = (Rq[0] + Rq[64]) + (Rq[128] + Rq[192]);
+        }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const double ss = S[buf * 64 + 16 * tt + mcol];
+            const double *Sq = S + buf * 256 + 16 * tt + mcol;
+            const double ss = (Sq[0] + Sq[64]) + (Sq[128] + Sq[192]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = fma(Cr[tt][r], exp(-(e[tt][r] + rr[r] + ss)), acc);
+            for (int r = 0; r < 4; ++r) acc = fma(Cr[tt][r], exp_nonpos(-(e[tt][r] + rr[r] + ss)), acc);
         }
         acc = wave_sum_p(acc);
         if (lane == 0) red[t * 4 + wave] = acc;
+    }
+    __syncthreads();
+    if (tid < nt)
+        a.partial[(int64_t)blockIdx.x * a.Mc + (tbase - a.t0) + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
+}
+
+// ---- SExp J, second form: per-(test point, training point) records + a pair loop without LDS -------------------------
+// The exponent of pair (i, j) at test point t is  base_ij + sum_k u_ik(t) w_jk + rr_i(t) + ss_j(t)  (see above).  The t-
+// dependent per-point quantities -- u (Dw values), rr, ss -- are computed ONCE per (t, point) by sexp_records_kernel
+// instead of once per tile pair inside the pair kernel (where that staging was a quarter of its VALU instructions), and the
+// two additive terms ride in the MFMA as two more k-columns:  A_i = [u_i | rr_i | 1 | 0..],  B_j = [w_j ; 1 ; ss_j ; 0..]
+// (k padded to a multiple of 4).  The B operand's rows are t-independent except the ss row, so a lane keeps its B fragments
+// in REGISTERS for all test points of the chunk and the lanes that hold the ss row load theirs from the records; the A
+// fragments of a test point are three or four 8-byte loads per lane from the records (L2 / Infinity Cache resident: the
+// grid runs the tiles of a test chunk back to back), prefetched one test point ahead.  The MFMA's C input is base_ij, its
+// output the whole exponent: per pair the VALU work is the exponential and one multiply-add.  No LDS traffic, no barrier
+// in the loop over test points.  For Dw <= 14 (four k-steps); wider nodes keep linkgp_Jsexp_kernel.
+__global__ __launch_bounds__(256) void sexp_records_kernel(LinkArgs a, int KPA) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tt = blockIdx.y, t = a.t0 + tt;
+    if (i >= a.npad || t >= a.M) return;
+    double *ra = a.recs + (tt * a.npad + i) * KPA;
+    double rr = 0.0, ss = 0.0;
+    if (i < a.n) {
+        for (int k = 0; k < a.Dw; ++k) {
+            const double l = a.len[k], c1 = 1.0 / (8.0 * a.v[t * a.Dw + k] + 2.0 * l * l), w = a.W[i * a.Dw + k];
+            const double d = w - 2.0 * a.m[t * a.Dw + k], cw = c1 * d;
+            ra[k] = 2.0 * cw;
+            rr = fma(cw, d, rr);
+            ss = fma(c1 * w, w, ss);
+        }
+        // (a point sees the same global-input term in its row and in its column role; added in the first form's order)
+        for (int g = 0; g < a.Dz; ++g) {
+            const double di = (a.Wg[i * a.Dz + g] - a.z[t * a.Dz + g]) * (1.0 / a.len[a.Dw + g]);
+            rr = fma(di, di, rr);
+            ss = fma(di, di, ss);
+        }
+    } else {
+        for (int k = 0; k < a.Dw; ++k) ra[k] = 0.0;
+    }
+    ra[a.Dw] = rr;
+    ra[a.Dw + 1] = 1.0;
+    for (int k = a.Dw + 2; k < KPA; ++k) ra[k] = 0.0;
+    a.gfac[tt * a.npad + i] = ss;
+}
+
+// exp(-x) for x >= ~-1 (see exp_nonpos), with full-rate instructions only: the rounding to the nearest integer is the
+// "1.5 * 2^52" addition (the integer then sits in the low word of the sum: no v_rndne / v_cvt), the scaling by 2^k a
+// multiplication by a double whose exponent field is written with integer arithmetic (no v_ldexp).  On gfx950 v_rndne_f64,
+// v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of v_fma_f64's rate: three of them cost as much as the twelve
+// multiply-adds of the polynomial (PMC: 31 VALU instructions per pair but 78 % of the issue cycles).  k is clamped at -1022:
+// arguments beyond ~708 give ~1e-308 instead of 0, which the weights multiply into nothing.
+__device__ __forceinline__ double exp_negated(double x) {
+    const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+    const double kf = fma(x, -1.44269504088896338700e+00, MAGIC);
+    const double k = kf - MAGIC;
+    double r = fma(k, -6.93147180369123816490e-01, -x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;
+    p = fma(p, r, 2.50521083854417187751e-08);
+    p = fma(p, r, 2.75573192239858906526e-07);
+    p = fma(p, r, 2.75573192239858906526e-06);
+    p = fma(p, r, 2.48015873015873015873e-05);
+    p = fma(p, r, 1.98412698412698412698e-04);
+    p = fma(p, r, 1.38888888888888888889e-03);
+    p = fma(p, r, 8.33333333333333333333e-03);
+    p = fma(p, r, 4.16666666666666666667e-02);
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int ki = __double2loint(kf);               // k as a two's-complement integer
+    ki = ki < -1022 ? -1022 : ki;
+    return p * __hiloint2double((ki + 1023) << 20, 0);
+}
+
+#define SX_KS 4   // k-steps held in registers: Dw + 2 <= 16
+// KS = k-steps (compile time: no branches in the loop over test points).  The MFMAs of test point t + 1 are issued between
+// the four column-tile groups of test point t's exponentials.  The loop is unrolled by two so that the exponent tiles of
+// consecutive test points alternate between two register sets without copies.
+#define TCH2 128   // test points per workgroup of the second SExp form: the tile's weights and base exponents (a 32-KB tile of
+                   // R^-1 read, 16 x Dw LDS reads per lane) are set up once per TCH2 test points -- at 32 that was 40 % of the run time
+template <int KS>
+__global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
+    extern __shared__ double lds[];
+    constexpr int KPA = 4 * KS;
+    const int Dw = a.Dw;
+    double *WiT = lds;                    // [Dw][64]
+    double *WjT = WiT + Dw * 64;          // [Dw][64]
+    double *red = WjT + Dw * 64;          // [TCH2][4]
+    int bi, bj;
+    tri_decode(blockIdx.x, bi, bj);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
+    const int64_t tbase = a.t0 + (int64_t)blockIdx.y * TCH2, tt0 = (int64_t)blockIdx.y * TCH2;
+    int nt = TCH2;
+    if (tbase + nt > a.M) nt = (int)(a.M - tbase);
+    if (tbase + nt > a.t0 + a.Mc) nt = (int)(a.t0 + a.Mc - tbase);
+    for (int idx = tid; idx < 64 * Dw; idx += 256) {
+        const int row = idx / Dw, d = idx - row * Dw;
+        const int64_t gi = i0 + row, gj = j0 + row;
+        WiT[d * 64 + row] = gi < n ? a.W[gi * Dw + d] : 0.0;
+        WjT[d * 64 + row] = gj < n ? a.W[gj * Dw + d] : 0.0;
+    }
+    __syncthreads();
+    const int mrow = 16 * wave + (lane >> 4), mcol = lane & 15, kq = lane >> 4, mi = lane & 15;
+    const int ksS = (Dw + 1) >> 2, kqS = (Dw + 1) & 3;
+    const bool dyn = kq == kqS;   // this lane's B fragment of k-step ksS is the ss row
+    const double wt = (bi == bj) ? 1.0 : 2.0;
+    d4 Cr[4], base[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = i0 + mrow + 4 * r, gj = j0 + 16 * tt + mcol;
+            Cr[tt][r] = (gi < n && gj < n) ? wt * (a.ry[gi] * a.ry[gj] - a.scale * a.Rinv[gi * a.ldr + gj]) : 0.0;
+            double b = 0.0;   // t-independent part: sum_k (w_ik - w_jk)^2 / (2 l_k^2)
+            for (int k = 0; k < Dw; ++k) {
+                const double d = WiT[k * 64 + mrow + 4 * r] - WjT[k * 64 + 16 * tt + mcol];
+                b = fma(d * d, 1.0 / (2.0 * a.len[k] * a.len[k]), b);
+            }
+            base[tt][r] = b;
+        }
+    // static B fragments: B[k][j], k = 4 ks + kq, j = 16 tt + mi (the ss row's lanes get theirs per test point)
+    double bst[KS][4];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int k = 4 * ks + kq;
+            bst[ks][tt] = k < Dw ? WjT[k * 64 + 16 * tt + mi] : (k == Dw ? 1.0 : 0.0);
+        }
+    const double *recA = a.recs + (tt0 * a.npad + i0 + 16 * wave + mi) * KPA + kq;   // + t * npad * KPA + 4 ks
+    const double *recS = a.gfac + tt0 * a.npad + j0 + mi;                               // + t * npad + 16 tt
+    const int64_t strA = a.npad * KPA, strS = a.npad;
+    struct Frag { double av[KS], bd[4]; };
+    auto fetch = [&](int t) {
+        Frag f;
+        t = t < nt ? t : nt - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) f.av[ks] = recA[t * strA + 4 * ks];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) f.bd[tt] = dyn ? recS[t * strS + 16 * tt] : 0.0;
+        return f;
+    };
+    // one k-step of test point f's exponent tiles into `en` (four independent MFMAs)
+    auto kstep = [&](const Frag &f, int ks, d4 (&en)[4]) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const double bv = (ks == ksS && dyn) ? f.bd[tt] : bst[ks][tt];
+            en[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[ks], bv, ks == 0 ? base[tt] : en[tt], 0, 0, 0);
+        }
+    };
+    // exponentials of column tile g of `e`, weights Cr
+    auto group = [&](const d4 (&e)[4], int g, double &acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = fma(Cr[g][r], exp_negated(e[g][r]), acc);
+    };
+    // test point t from `e`, while test point t + 1 (fragments f1) goes into `en`; f2 <- fragments of t + 2
+    auto step = [&](int t, const d4 (&e)[4], d4 (&en)[4], const Frag &f1, Frag &f2) {
+        f2 = fetch(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        double acc = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // k-step g of the NEXT test point (four independent MFMAs) and the four exponentials of column tile g of THIS one
+            // in one scheduling region, the scheduler asked for  MFMA, ~20 VALU, MFMA, ~20 VALU, ...  (inside the VALU slots the
+            // four exponentials still interleave; a barrier after every exponential serialised their dependent chains: 4x
+            // slower).  Measured: the f64 MFMA and the f64 VALU work do NOT overlap on gfx950 whatever the order -- the run time
+            // is the sum of the two (41 ms = 29 without the products + 12; 78.6 TFLOP/s is the matrix AND the vector f64 peak:
+            // one set of double-precision units) -- so the order only keeps the products' operands off the critical path.
+            if (g < KS) kstep(f1, g, en);
+            group(e, g, acc);
+            if (g < KS) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 21, 0);   // the VALU instructions of about one exponential
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc = wave_sum_p(acc);
+        if (lane == 0) red[t * 4 + wave] = acc;
+    };
+    if (nt > 0) {
+        Frag fa = fetch(0), fb = fetch(1), fc;
+        d4 e0[4], e1[4];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kstep(fa, ks, e0);
+        for (int t = 0; t < nt; t += 2) {
+            step(t, e0, e1, fb, fc);        // t from e0; t + 1 -> e1 (fragments fb); fc <- t + 2
+            if (t + 1 < nt) step(t + 1, e1, e0, fc, fb);   // t + 1 from e1; t + 2 -> e0 (fragments fc); fb <- t + 3
+        }
     }
     __syncthreads();
     if (tid < nt)
@@ -928,7 +1168,8 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
     const bool sep = (kind == DGPAMD_MATERN25) && !direct;
     a.recs = a.partial + (int64_t)ntiles * Mc;
     a.npad = (int64_t)nb * 64;
-    if (sep && Mc > MC_SEP) Mc = MC_SEP;   // records of one chunk: Mc*Dw*npad*224 B
+    const bool sx2 = (kind == DGPAMD_SEXP) && !direct && Dw + 2 <= 16;
+    if ((sep || sx2) && Mc > MC_SEP) Mc = MC_SEP;   // records of one chunk: Mc*Dw*npad*224 B (Matern), Mc*npad*(Dw+3..6)*8 B (SExp)
     a.Mc = Mc;
     a.gfac = a.recs + Mc * (int64_t)Dw * a.npad * REC;
     const int DT = Dw + Dz;
@@ -951,9 +1192,22 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
                 hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_SEXP, true>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else if (direct) {
                 hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_SEXP, false>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
+            } else if (Dw + 2 <= 4 * SX_KS && !getenv("DGPAMD_SEXP_FORM1")) {
+                const int KPA = (Dw + 2 + 3) & ~3;
+                const size_t shm2 = ((size_t)2 * Dw * 64 + TCH2 * 4) * sizeof(double);
+                const unsigned tb2 = (unsigned)((mc + TCH2 - 1) / TCH2);
+                hipLaunchKernelGGL(sexp_records_kernel, dim3((unsigned)((a.npad + 255) / 256), (unsigned)mc), dim3(256), 0, ctx->stream, a, KPA);
+                PROF_BEGIN(ctx, PROF_LINKGP_J, (double)mc * (double)n * (double)(n + 1) * 0.5);   // pair evaluations (one exponential each)
+                switch (KPA / 4) {
+                    case 1: hipLaunchKernelGGL(linkgp_Jsexp2_kernel<1>, dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a); break;
+                    case 2: hipLaunchKernelGGL(linkgp_Jsexp2_kernel<2>, dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a); break;
+                    case 3: hipLaunchKernelGGL(linkgp_Jsexp2_kernel<3>, dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a); break;
+                    default: hipLaunchKernelGGL(linkgp_Jsexp2_kernel<4>, dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a); break;
+                }
+                PROF_END(ctx, PROF_LINKGP_J);
             } else {
                 const int KP = (Dw + 3) & ~3, LDU = KP + 2;
-                const size_t shm_s = ((size_t)2 * DT * 64 + (size_t)KP * LDK + (size_t)TCH * (2 * Dw + Dz) + TCH * 4 + 2 * 64 * LDU + 4 * 64 + Dz) * sizeof(double);
+                const size_t shm_s = ((size_t)2 * DT * 64 + (size_t)KP * LDK + (size_t)TCH * (2 * Dw + Dz) + TCH * 4 + 2 * 64 * LDU + 16 * 64 + Dz) * sizeof(double);
                 if (shm_s > 48 * 1024)
                     HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsexp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_s));
                 hipLaunchKernelGGL(linkgp_Jsexp_kernel, dim3(ntiles, tb), dim3(256), shm_s, ctx->stream, a);

@@ -20,12 +20,43 @@ moment arrays precedes the finalisation (RCCL over xGMI on the GPU box).
 import contextlib
 import copy
 
+import collections
+import os
+
 import numpy as np
 import torch
 
 from .imputation import imputer, DrawStream
 from .ops import default_engine
 from . import dist as ddist
+
+
+class _LazyPer:
+    """The per-imputation prediction statistics of a linked GP node (R^-1, R^-1 y, its inputs: kernel_class.py:735-764 for
+    every imputation, emulation.py:43), built when first asked for and kept while the emulator's byte budget allows.
+    The reference holds all of them; at BASELINE configs[2]'s size -- 50 imputations x 3 nodes, n = 5000 -- that is 31 GB of
+    inverses of which a predict() call uses each exactly once, and rebuilding one costs ~30 ms against the seconds its pair
+    kernel runs.  Budget: DGPAMD_STATS_GB (default 16); smaller models never evict."""
+
+    def __init__(self, owner, key, build, nbytes):
+        self.owner, self.key, self.build, self.nbytes = owner, key, build, int(nbytes)
+
+    def __getitem__(self, s):
+        o = self.owner
+        ck = self.key + (int(s),)
+        hit = o._per_cache.get(ck)
+        if hit is not None:
+            o._per_cache.move_to_end(ck)
+            return hit
+        budget = float(os.environ.get('DGPAMD_STATS_GB', '16')) * 2 ** 30
+        while o._per_cache and o._per_bytes + self.nbytes > budget:
+            _, old = o._per_cache.popitem(last=False)
+            o._per_bytes -= old['_bytes']
+        item = self.build(int(s))
+        item['_bytes'] = self.nbytes
+        o._per_cache[ck] = item
+        o._per_bytes += self.nbytes
+        return item
 
 
 class emulator:
@@ -104,6 +135,8 @@ class emulator:
         st = dict(self.__dict__)
         st['engine'] = None       # device context and statistics are rebuilt after unpickling (utils.write / read)
         st['_stats'] = None
+        st.pop('_per_cache', None)
+        st.pop('_per_bytes', None)
         return st
 
     def __setstate__(self, st):
@@ -151,10 +184,10 @@ class emulator:
                 Xg = None if nd.global_input is None else e.tensor(nd.global_input)
                 W = None if nd.rep is None else e.tensor(nd.W_diag)
 
-                def ys(s):
+                def ys(s, l=l, k=k):   # (defaults: the closures below are called after this loop has moved on)
                     return self.latents[s][l][:, k] if l < self.n_layer - 1 else Yall[k]
 
-                def factor(Xl, Y):
+                def factor(Xl, Y, nd=nd, n=n, Np=Np, Xg=Xg, W=W):
                     A = e.workspace(('emuA', n), Np * Np * 8)
                     Ainv = e.empty(Np, Np)
                     e.kmatrix(nd.name, Xl, None, Xg, nd.length, nd.nugget[0], W=W, out=A, full=False, Y=Y)
@@ -178,13 +211,14 @@ class emulator:
                         rys.append(ry)
                     stats[(l, k)] = dict(shared=True, Rinv=Rinv, ld=Np, ry=torch.cat(rys), n=n, Wall=e.tensor(nd._X()))
                 else:
-                    per = []
-                    for s in range(S):
+                    def build(s, l=l, nd=nd, factor=factor, ys=ys):
                         Xin = self.latents[s][l - 1][:, nd.input_dim]
                         Rinv, ry = factor(e.tensor(Xin), e.tensor(ys(s)[None, :]))
-                        per.append(dict(Rinv=Rinv, ry=ry[0].contiguous(), W=e.tensor(Xin)))
-                    stats[(l, k)] = dict(shared=False, per=per, ld=Np, n=n, Wg=Xg)
+                        return dict(Rinv=Rinv, ry=ry[0].contiguous(), W=e.tensor(Xin))
+                    stats[(l, k)] = dict(shared=False, per=_LazyPer(self, (l, k), build, Np * Np * 8), ld=Np, n=n, Wg=Xg)
         self._stats = stats
+        self._per_cache = collections.OrderedDict()
+        self._per_bytes = 0
 
     def _layer_moments(self, x):
         """Per layer the (mean, variance) of every node at the rows of x for every imputation held by this rank, as
