@@ -298,6 +298,31 @@ def main():
                                'fraction is reported because the contract asks for it')
     kernel_class.kernel._llik_finish = orig_finish
 
+    # ---- K assembly alone against the HBM roofline, cache-defeating: full symmetric n = 5000, D = 10 (cfg3's node shape),
+    #      200 MB per matrix, three output buffers in turn (600 MB > the 256-MB Infinity Cache), HIP events on the engine's stream
+    roof_ks = None
+    if rank == 0 and args.prof_kernel != 'none':
+        roof_ks = {}
+        nk, Dk = 5000, 10
+        Xk = eng.tensor(np.random.default_rng(3).uniform(size=(nk, Dk)))
+        outs = [eng.empty(nk, nk) for _ in range(3)]
+        ev0, ev1 = eng.event(), eng.event()
+        for name in ('sexp', 'matern2.5'):
+            for o in outs:
+                eng.kmatrix(name, Xk, None, None, np.full(Dk, 0.9), 1e-6, out=o, full=True)
+            reps = 30
+            eng.record(ev0)
+            for r in range(reps):
+                eng.kmatrix(name, Xk, None, None, np.full(Dk, 0.9), 1e-6, out=outs[r % 3], full=True)
+            eng.record(ev1)
+            torch.cuda.synchronize()
+            ms = eng.elapsed_ms(ev0, ev1) / reps
+            nbytes = 8.0 * nk * nk + 8.0 * nk * Dk
+            roof_ks[name] = dict(bound='hbm', kernel='kmatrix_kernel<%s> (full symmetric, n=%d, D=%d, 3 x 200 MB outputs in turn)' % (name, nk, Dk),
+                                 achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s', frac=nbytes / ms / 1e6 / HBM_PEAK_GBS,
+                                 avg_launch_us=1e3 * ms, bytes_per_launch=nbytes, traffic=None)
+        del outs
+
     # ---- prediction leg: emulator with the imputations sharded over the ranks --------------------
     pred = None
     if not args.no_predict:
@@ -414,7 +439,7 @@ def main():
             'config': {'workload': 'configs[1]: 2-layer DGP, d=%d in / 1 out, n=%d, Matern-2.5, %d+1 GP nodes, '
                                    'train(ess_burn=%d): one step = one SI iteration' % (args.d, args.n, args.d, args.ess_burn),
                        'parallelism': 'replicas x%d (SI chain does not shard); predict: imputations sharded, 1 all-reduce' % world},
-            'predict': pred, 'counts': counts, 'roofline': roof, 'roofline_kmatrix': roof_k,
+            'predict': pred, 'counts': counts, 'roofline': roof, 'roofline_kmatrix': roof_k, 'roofline_kmatrix_standalone': roof_ks,
             'roofline_predict': (pred or {}).get('roofline_predict'), 'cpu_baseline': cpu, 'mstep_nodes_split': split,
             'speedup_vs_cpu_baseline': (value / world / cpu['value']) if cpu else None,
             'strong_scaling': strong, 'distributed': dist_info,

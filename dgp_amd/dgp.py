@@ -150,123 +150,109 @@ class dgp:
             return KernelPCA(n_components=num_kernel, kernel='sigmoid').fit_transform(In)
         return np.concatenate((In, In[:, np.random.choice(d, num_kernel - d)]), 1)
 
+    # ---- warm starts of the latents under a count likelihood (dgp.py:327-566): moment estimates per replicated site.
+    #      Pinned on the reference's own values (tests/golden/g17_count_likelihoods.npz).
+    _TINY, _RATE_FLOOR, _ZI_LO, _ZI_HI = 1e-12, 1e-6, 1e-4, 0.99
+
+    def _site_sums(self, y, G):
+        """(count, sum y, sum y^2, number of zeros) per input site."""
+        idx = np.asarray(self.indices)
+        tally = lambda w=None: np.bincount(idx, weights=w, minlength=G)
+        return tally().astype(float), tally(y), tally(y * y), tally((y == 0).astype(float))
+
+    @staticmethod
+    def _dispersion(mean, var, fallback=None, eps=1e-8):
+        """Method of moments for Var = mu + sigma mu^2; where it fails (non-positive, not finite) the fallback."""
+        sig = (var - mean) / (mean ** 2 + eps)
+        if fallback is None:
+            return sig
+        sig = np.where(np.isfinite(sig) & (sig > 0.0), sig, fallback)
+        return np.clip(sig, 1e-3, 10.0)
+
+    @staticmethod
+    def _site_variance(cnt, s1, s2, default):
+        """Unbiased within-site variance where a site has replicates, else `default`."""
+        out = np.array(default, dtype=float, copy=True)
+        rep = cnt > 1
+        out[rep] = (s2[rep] - s1[rep] ** 2 / cnt[rep]) / (cnt[rep] - 1.0)
+        return out
+
+    @classmethod
+    def _zero_excess_logit(cls, p_zero, q_zero):
+        """logit of the share of zeros beyond what the count model explains: (p0 - q0) / (1 - q0), kept inside (0, 1)."""
+        pi = np.clip(np.where(p_zero <= q_zero, 0.0, (p_zero - q_zero) / np.maximum(1.0 - q_zero, 1e-8)), 0.0, cls._ZI_HI)
+        pi = np.clip(pi, cls._ZI_LO, 1.0 - cls._ZI_LO)
+        return pi, np.log(pi / (1.0 - pi))
+
+    @classmethod
+    def _zero_excess_global(cls, y):
+        """The same from the whole sample (no replicates): a scalar logit."""
+        p0 = ((y == 0).sum() + 0.5) / (len(y) + 1.0)
+        mu = y.mean()
+        if mu <= 0:
+            pi = p0
+        else:
+            q0 = np.exp(-max(mu, cls._RATE_FLOOR))
+            pi = 0.0 if q0 >= 1.0 - 1e-8 else np.clip((p0 - q0) / (1.0 - q0), 0.0, cls._ZI_HI)
+        pi = np.clip(pi, cls._ZI_LO, 1.0 - cls._ZI_LO)
+        return np.log(pi / (1.0 - pi))
+
     def _count_warm_start(self, l):
-        """Initial latents of the layer feeding a lone Poisson / NegBin likelihood (dgp.py:327-336,526-566), or None:
-        log of the (site-pooled) counts + 1/2; NegBin's log-dispersion from the method of moments
-        Var = mu + sigma mu^2 per replicated site (clipped to [1e-3, 10], global estimate where that fails)."""
+        """Initial latents of the layer feeding a lone Poisson / NegBin / ZIP / ZINB likelihood (dgp.py:327-566), or None:
+        log of the (site-pooled) counts + 1/2; a log-dispersion from the method of moments per replicated site; the logit
+        of the zero excess over a Poisson with the observed mean."""
         if l != self.n_layer - 2 or len(self.all_layer[l + 1]) != 1:
             return None
         name = getattr(self.all_layer[l + 1][0], 'name', None)
         if name not in ('Poisson', 'NegBin', 'ZIP', 'ZINB'):
             return None
         y = self.Y.flatten()
-        G = self.X.shape[0]
-        M = len(self.all_layer[l])
-        if name == 'ZIP':
-            return self._zip_warm_start(y, G, M)
+        G, M = self.X.shape[0], len(self.all_layer[l])
+        pooled = self.indices is not None
+        Out = np.empty((G, M))
+        if name in ('Poisson', 'NegBin'):
+            if pooled:
+                cnt, s1, s2, _ = self._site_sums(y, G)
+                mu = (s1 + .5) / cnt
+            else:
+                mu = y + .5
+            if name == 'Poisson':
+                return np.log(mu + self._TINY).reshape(G, 1) if pooled else np.log(self.Y + .5 + self._TINY)
+            Out[:, 0] = np.log(mu + self._TINY)
+            glob = max(self._dispersion(y.mean(), y.var(ddof=1)), 1e-3)
+            if pooled:
+                Out[:, 1] = np.log(self._dispersion(mu, self._site_variance(cnt, s1, s2, mu), glob))
+            elif M > 1:   # (the reference leaves this latent uninitialised without replicates, dgp.py:528-531: here the global estimate)
+                Out[:, 1:] = np.log(glob)
+            return Out
+        # zero-inflated: ZIP = (log rate, logit pi), ZINB = (log mean, log dispersion, logit pi)
+        zi = 1 if name == 'ZIP' else 2
         if name == 'ZINB':
-            return self._zinb_warm_start(y, G, M)
-        if name == 'Poisson':
-            if self.indices is None:
-                return np.log(self.Y + .5 + 1e-12)
-            cnt = np.bincount(self.indices, minlength=G)
-            return np.log((np.bincount(self.indices, weights=y, minlength=G) + .5) / cnt + 1e-12).reshape(-1, 1)
-        Out = np.empty((G, M))
-        if self.indices is None:
-            Out[:, 0] = np.log(y + .5 + 1e-12)     # (the dispersion latent starts wherever the buffer is, as in the reference:
-            if M > 1:                               #  dgp.py:528-531 fills the first column only -- here: log of the global estimate)
-                mm, vv = y.mean(), y.var(ddof=1)
-                Out[:, 1:] = np.log(max((vv - mm) / (mm ** 2 + 1e-8), 1e-3))
+            ym = y.mean()
+            glob = min(max(self._dispersion(ym, y.var(ddof=1)) if y.size > 1 else 1.0, 1e-3), 10.0)
+        if not pooled:
+            Out[:, 0] = np.log(np.maximum(y + 0.5, self._RATE_FLOOR) + self._TINY)
+            if name == 'ZINB':
+                Out[:, 1] = np.log(glob)
+            Out[:, zi] = self._zero_excess_global(y)
             return Out
-        eps = 1e-8
-        mm, vv = y.mean(), y.var(ddof=1)
-        sig_glob = max((vv - mm) / (mm ** 2 + eps), 1e-3)
-        cnt = np.bincount(self.indices, minlength=G).astype(float)
-        s1 = np.bincount(self.indices, weights=y, minlength=G)
-        s2 = np.bincount(self.indices, weights=y * y, minlength=G)
-        mu = (s1 + .5) / cnt
-        Out[:, 0] = np.log(mu + 1e-12)
-        var_hat = mu.copy()
-        mk = cnt > 1
-        var_hat[mk] = (s2[mk] - s1[mk] ** 2 / cnt[mk]) / (cnt[mk] - 1.0)
-        sig = (var_hat - mu) / (mu ** 2 + eps)
-        sig[(~np.isfinite(sig)) | (sig <= 0.0)] = sig_glob
-        Out[:, 1] = np.log(np.clip(sig, 1e-3, 10.0))
-        return Out
-
-    def _zip_warm_start(self, y, G, M):
-        """(log rate, logit of the zero-inflation probability) for a ZIP likelihood (dgp.py:337-410): the share of zeros
-        beyond what a Poisson with the observed mean explains, globally without replicates and per site with them."""
-        Out = np.empty((G, M))
-        lam_floor, pi_min, pi_max = 1e-6, 1e-4, 0.99
-        if self.indices is None:
-            Out[:, 0] = np.log(np.maximum(y + 0.5, lam_floor) + 1e-12)
-            p0 = ((y == 0).sum() + 0.5) / (len(y) + 1.0)
-            mu = y.mean()
-            if mu <= 0:
-                pi0 = p0
-            else:
-                q0 = np.exp(-max(mu, lam_floor))
-                pi0 = 0.0 if q0 >= 1.0 - 1e-8 else np.clip((p0 - q0) / (1.0 - q0), 0.0, pi_max)
-            pi0 = np.clip(pi0, pi_min, 1.0 - pi_min)
-            Out[:, 1] = np.log(pi0 / (1.0 - pi0))
+        cnt, s1, s2, zeros = self._site_sums(y, G)
+        raw = s1 / np.maximum(cnt, 1.0)
+        p_zero = (zeros + 0.1) / (cnt + 0.2)
+        rate0 = raw.copy()
+        rate0[raw == 0.0] = y[y > 0].mean() if np.any(y > 0) else 1.0
+        rate0 = np.maximum(rate0, self._RATE_FLOOR)
+        pi, logit = self._zero_excess_logit(p_zero, np.exp(-rate0))
+        Out[:, zi] = logit
+        if name == 'ZIP':
+            pi_raw = np.clip(np.where(p_zero <= np.exp(-rate0), 0.0, (p_zero - np.exp(-rate0)) / np.maximum(1.0 - np.exp(-rate0), 1e-8)),
+                             0.0, self._ZI_HI)   # (before the lower clip: the rate is deflated by the unclipped share)
+            rate = np.maximum(np.where(raw == 0.0, rate0, raw / np.maximum(1.0 - pi_raw, 1e-3)), self._RATE_FLOOR)
+            Out[:, 0] = np.log(rate + self._TINY)
             return Out
-        idx = np.asarray(self.indices)
-        n_g = np.bincount(idx, minlength=G)
-        mu_g = np.bincount(idx, weights=y, minlength=G) / np.maximum(n_g, 1)
-        p0_g = (np.bincount(idx, weights=(y == 0).astype(float), minlength=G) + 0.1) / (n_g + 0.2)
-        pos = y > 0
-        lam0 = mu_g.copy()
-        lam0[mu_g == 0.0] = y[pos].mean() if np.any(pos) else 1.0
-        lam0 = np.maximum(lam0, lam_floor)
-        q = np.exp(-lam0)
-        pi_g = np.clip(np.where(p0_g <= q, 0.0, (p0_g - q) / np.maximum(1.0 - q, 1e-8)), 0.0, pi_max)
-        lam = np.maximum(np.where(mu_g == 0.0, lam0, mu_g / np.maximum(1.0 - pi_g, 1e-3)), lam_floor)
-        pi_g = np.clip(pi_g, pi_min, 1.0 - pi_min)
-        Out[:, 0] = np.log(lam + 1e-12)
-        Out[:, 1] = np.log(pi_g / (1.0 - pi_g))
-        return Out
-
-    def _zinb_warm_start(self, y, G, M):
-        """(log mean, log dispersion, logit zero-inflation) for a ZINB likelihood (dgp.py:411-525): NegBin's moment
-        estimates plus ZIP's zero-excess estimate (against a Poisson with the raw mean)."""
-        Out = np.empty((G, M))
-        lam_floor, pi_min, pi_max, eps = 1e-6, 1e-4, 0.99, 1e-8
-        y_mean = y.mean()
-        sig_glob = (y.var(ddof=1) - y_mean) / (y_mean ** 2 + eps) if y.size > 1 else 1.0
-        sig_glob = min(max(sig_glob, 1e-3), 10.0)
-        if self.indices is None:
-            Out[:, 0] = np.log(np.maximum(y + 0.5, lam_floor) + 1e-12)
-            Out[:, 1] = np.log(sig_glob)
-            p0 = ((y == 0).sum() + 0.5) / (len(y) + 1.0)
-            if y_mean <= 0:
-                pi0 = p0
-            else:
-                q0 = np.exp(-max(y_mean, lam_floor))
-                pi0 = 0.0 if q0 >= 1.0 - 1e-8 else np.clip((p0 - q0) / (1.0 - q0), 0.0, pi_max)
-            pi0 = np.clip(pi0, pi_min, 1.0 - pi_min)
-            Out[:, 2] = np.log(pi0 / (1.0 - pi0))
-            return Out
-        idx = np.asarray(self.indices)
-        cnt = np.bincount(idx, minlength=G).astype(float)
-        s1 = np.bincount(idx, weights=y, minlength=G)
-        s2 = np.bincount(idx, weights=y * y, minlength=G)
-        mu_g = (s1 + 0.5) / np.maximum(cnt, 1.0)
-        Out[:, 0] = np.log(mu_g + 1e-12)
-        var_hat = mu_g.copy()
-        mk = cnt > 1
-        var_hat[mk] = (s2[mk] - s1[mk] ** 2 / cnt[mk]) / (cnt[mk] - 1.0)
-        sig = (var_hat - mu_g) / (mu_g ** 2 + eps)
-        sig[(~np.isfinite(sig)) | (sig <= 0.0)] = sig_glob
-        Out[:, 1] = np.log(np.clip(sig, 1e-3, 10.0))
-        p0_g = (np.bincount(idx, weights=(y == 0).astype(float), minlength=G) + 0.1) / (cnt + 0.2)
-        mu_raw = s1 / np.maximum(cnt, 1.0)
-        lam0 = mu_raw.copy()
-        lam0[mu_raw == 0.0] = y[y > 0].mean() if np.any(y > 0) else 1.0
-        q = np.exp(-np.maximum(lam0, lam_floor))
-        pi_g = np.clip(np.where(p0_g <= q, 0.0, (p0_g - q) / np.maximum(1.0 - q, 1e-8)), 0.0, pi_max)
-        pi_g = np.clip(pi_g, pi_min, 1.0 - pi_min)
-        Out[:, 2] = np.log(pi_g / (1.0 - pi_g))
+        mu = (s1 + 0.5) / np.maximum(cnt, 1.0)
+        Out[:, 0] = np.log(mu + self._TINY)
+        Out[:, 1] = np.log(self._dispersion(mu, self._site_variance(cnt, s1, s2, mu), glob))
         return Out
 
     def _layer_warm_start(self, l, In, num_kernel):

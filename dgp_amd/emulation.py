@@ -328,6 +328,25 @@ class emulator:
         neighbours, kernel_class.py:603-619,647-664).  Returns numpy (S, M, K) pairs per layer."""
         M, S = len(x), self.N
         layers = [[] for _ in self.all_layer]
+        # Conditioning sets are searched once per GROUP of nodes that must get the same ones: nodes of a layer with the same
+        # input columns and ONE shared lengthscale see the same points in the same (distance, index) order whatever the
+        # lengthscale's value (a uniform scaling; the reference itself shares orderings between such siblings in training,
+        # imputation.py:245-262) -- and in the first layer also across imputations, whose inputs are the same X.  At
+        # BASELINE configs[3] (8 + 1 nodes, 2 imputations) that is 3 searches instead of 18, which were 60 % of a large
+        # Vecchia prediction.  DGPAMD_NN_SHARE=0 searches per node like the reference (vecchia.py:20-40 per gp_prediction).
+        share = os.environ.get('DGPAMD_NN_SHARE', '1') != '0'
+        nn_sets = {}
+
+        def hand_over(nd, l, s_, xq):
+            if not share or nd.loo_state:
+                return
+            iso = len(nd.length) == 1
+            key = (l, None if l == 0 else s_, tuple(np.asarray(nd.input_dim).tolist()),
+                   None if nd.connect is None else tuple(np.asarray(nd.connect).tolist()), 'iso' if iso else tuple(nd.length.tolist()), m)
+            if key not in nn_sets:
+                nn_sets[key] = nd._pred_nn(xq, nd._X())
+            nd._nn_given = nn_sets[key]
+
         for s in range(S):
             al = self._structure(s)
             m_in = v_in = None
@@ -346,9 +365,13 @@ class emulator:
                         continue
                     z = None if nd.connect is None else x[:, nd.connect]
                     if l == 0:
-                        mo[:, k], vo[:, k] = nd.gp_prediction(x[:, nd.input_dim], z)
+                        xq = x[:, nd.input_dim]
+                        hand_over(nd, l, s, xq if z is None else np.concatenate((xq, z), 1))
+                        mo[:, k], vo[:, k] = nd.gp_prediction(xq, z)
                     else:
-                        mo[:, k], vo[:, k] = nd.linkgp_prediction(m_in[:, nd.input_dim], v_in[:, nd.input_dim], z)
+                        mq = m_in[:, nd.input_dim]
+                        hand_over(nd, l, s, mq if z is None else np.concatenate((mq, z), 1))
+                        mo[:, k], vo[:, k] = nd.linkgp_prediction(mq, v_in[:, nd.input_dim], z)
                 m_in, v_in = mo, vo
                 layers[l].append((mo, vo))
         return [(np.stack([a for a, _ in L]), np.stack([b for _, b in L])) for L in layers]

@@ -572,6 +572,9 @@ class kernel:
         row k, emulation.py:90-143)."""
         e = self.engine
         n = len(w)
+        given = self.__dict__.pop('_nn_given', None)   # (handed over by the emulator: a sibling's search, see _layer_moments_vecchia)
+        if given is not None and given.shape[0] == len(x):
+            return given
         if self.pred_m >= n:
             import torch
             NN = ((torch.arange(n, device=e.device)[None, :] + torch.arange(len(x), device=e.device)[:, None]) % n).contiguous()
