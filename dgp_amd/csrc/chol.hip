@@ -712,7 +712,20 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
                     for (int r = 0; r < 4; ++r) Bs[(16 * I + lu + 4 * r) * LDM + 16 * (wave & 1) + lm] = (I >= wave) ? winv.v[I][r] : 0.0;
             }
             __syncthreads();
-            mfma_tile<OP_MK, OP_MK>(As, Bs, P, wave, lane, 1.0);
+            // W_k = L_kk^-1 is LOWER triangular: column tile t of P = A W_k^T takes the 16-blocks kb <= t of the sum only
+            // (40 instead of 64 MFMAs per wave: the f64 MFMA runs at the vector rate on gfx950, so the skipped zeros are time)
+            {
+                const vlds_double *Ap = (const vlds_double *)As, *Bp = (const vlds_double *)Bs;
+                const int m_ = lane & 15, kk_ = lane >> 4;
+#pragma unroll
+                for (int k0 = 0; k0 < KC; k0 += 4) {
+                    const int kb = 2 * h + (k0 >> 4);
+                    const double av = Ap[(16 * wave + m_) * LDM + k0 + kk_];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (t >= kb) P[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bp[(16 * t + m_) * LDM + k0 + kk_], P[t], 0, 0, 0);
+                }
+            }
         }
         if (tr) tr[16 * k + 4] = wall_clock64();
         store_acc_sc1(P, Pg, ld, crow, ccol);

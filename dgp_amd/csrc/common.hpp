@@ -164,6 +164,36 @@ __device__ __forceinline__ void corr_accum_matern(double d, double &prod, double
     s += r;
 }
 
+// exp(-x) for x >= ~-1 (the arguments of the correlation functions and of the linked-GP pair loop are sums of squares / distances), with full-rate instructions only: the rounding to the nearest integer is the
+// "1.5 * 2^52" addition (the integer then sits in the low word of the sum: no v_rndne / v_cvt), the scaling by 2^k a
+// multiplication by a double whose exponent field is written with integer arithmetic (no v_ldexp).  On gfx950 v_rndne_f64,
+// v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of v_fma_f64's rate: three of them cost as much as the twelve
+// multiply-adds of the polynomial (PMC: 31 VALU instructions per pair but 78 % of the issue cycles).  k is clamped at -1022:
+// arguments beyond ~708 give ~1e-308 instead of 0, which the weights multiply into nothing.
+__device__ __forceinline__ double exp_negated(double x) {
+    const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+    const double kf = fma(x, -1.44269504088896338700e+00, MAGIC);
+    const double k = kf - MAGIC;
+    double r = fma(k, -6.93147180369123816490e-01, -x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;
+    p = fma(p, r, 2.50521083854417187751e-08);
+    p = fma(p, r, 2.75573192239858906526e-07);
+    p = fma(p, r, 2.75573192239858906526e-06);
+    p = fma(p, r, 2.48015873015873015873e-05);
+    p = fma(p, r, 1.98412698412698412698e-04);
+    p = fma(p, r, 1.38888888888888888889e-03);
+    p = fma(p, r, 8.33333333333333333333e-03);
+    p = fma(p, r, 4.16666666666666666667e-02);
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int ki = __double2loint(kf);               // k as a two's-complement integer
+    ki = ki < -1022 ? -1022 : ki;
+    return p * __hiloint2double((ki + 1023) << 20, 0);
+}
+
 // lower-triangle tile index t -> (bi, bj), bi >= bj, t = bi(bi+1)/2 + bj
 __device__ __forceinline__ void tri_decode(int t, int &bi, int &bj) {
     int b = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);

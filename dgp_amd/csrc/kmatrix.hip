@@ -17,7 +17,6 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     const int D = a.kp.Dl + a.kp.Dg;
     double *XiT = lds;            // [D][64]
     double *XjT = lds + D * 64;   // [D][64]
-    double *TT = lds + 2 * D * 64;   // [64][65] transposition buffer for the mirrored tile (full mode only)
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int tid = threadIdx.x;
@@ -78,7 +77,7 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            v[p][q] = (KIND == DGPAMD_SEXP) ? exp(-s[p][q]) : pr[p][q] * exp(-SQRT5 * s[p][q]);
+            v[p][q] = (KIND == DGPAMD_SEXP) ? exp_negated(s[p][q]) : pr[p][q] * exp_negated(SQRT5 * s[p][q]);
     if (bi == bj) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -128,19 +127,23 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     }
     if (a.full && bi != bj) {
         // mirrored tile K[j][i]: transposed through LDS so that these stores are row-contiguous too (naive transposed
-        // stores write 32-byte fragments and cost 40% of the kernel's bandwidth)
+        // stores write 32-byte fragments and cost 40% of the kernel's bandwidth).  In four passes of 16 rows through a
+        // 16 x 65 buffer that REUSES the input staging area (dead by now) -- a whole-tile buffer of its own (33 KB) held the
+        // kernel at three workgroups per CU, too few for the stores of one to hide behind the arithmetic of the others.
+        double *TT2 = lds;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int c = 0; c < 4; ++c) {
+            __syncthreads();   // (pass c - 1 read / the staged inputs consumed)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) TT[(ty + 16 * p) * 65 + tx + 16 * q] = v[p][q];
-        __syncthreads();
+            for (int q = 0; q < 4; ++q) TT2[ty * 65 + tx + 16 * q] = v[c][q];   // rows i0 + 16 c + ty of the tile, all 64 columns
+            __syncthreads();
+            // mirrored block: rows j0 + r (r = 0..63), columns i0 + 16 c + cc (cc = 0..15): a 128-byte segment per row
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int64_t gr = j0 + ty + 16 * p;   // j0 + 64 <= i0 <= n: always inside
-            double *row = Kb + gr * a.ldk + i0 + tx;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (interior || i0 + tx + 16 * q < a.n) row[16 * q] = TT[(tx + 16 * q) * 65 + ty + 16 * p];
+            for (int k = 0; k < 4; ++k) {
+                const int r = ty + 16 * k, cc = tx;
+                const int64_t gc = i0 + 16 * c + cc;
+                if (interior || gc < a.n) Kb[(j0 + r) * a.ldk + gc] = TT2[cc * 65 + r];
+            }
         }
     }
 }
@@ -173,7 +176,7 @@ int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatAr
     }
     int64_t rows = host_args[0].full ? host_args[0].n : padded_dim(host_args[0].n);
     int nbk = (int)((rows + 63) / 64);
-    size_t shm = ((size_t)2 * Dmax * 64 + (full ? 64 * 65 : 0)) * sizeof(double);
+    size_t shm = std::max((size_t)2 * Dmax * 64, full ? (size_t)16 * 65 : (size_t)0) * sizeof(double);
     hipLaunchKernelGGL(kmatrix_multi_kernel, dim3(nbk * (nbk + 1) / 2, 1, count), dim3(256), shm, ctx->stream, dev_args);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
@@ -186,7 +189,7 @@ int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a_, int batch) {
     int64_t rows = a.full ? a.n : padded_dim(a.n);
     int nbk = (int)((rows + 63) / 64);
     int ntiles = nbk * (nbk + 1) / 2;
-    size_t shm = ((size_t)2 * D * 64 + (a.full ? 64 * 65 : 0)) * sizeof(double);
+    size_t shm = std::max((size_t)2 * D * 64, a.full ? (size_t)16 * 65 : (size_t)0) * sizeof(double);
     dim3 grid(ntiles, 1, batch);
     // algorithmic bytes: the stored triangle(s) of K (8 n^2, or 4 n^2 for the lower tiles) + X once
     PROF_BEGIN(ctx, PROF_KMATRIX, (double)batch * ((a.full ? 8.0 : 4.0) * (double)rows * (double)rows + 8.0 * (double)a.n * D));

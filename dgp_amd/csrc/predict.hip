@@ -481,30 +481,6 @@ __global__ __launch_bounds__(256) void linkgp_J_kernel(LinkArgs a) {
 // test point the 64 x 64 x Dw products of a tile are a handful of v_mfma_f64_16x16x4 (accumulated on top of base_ij,
 // which sits in the accumulator layout), and the VALU work per pair drops from 3 Dw + exp to 2 adds + exp.  The row /
 // column terms and the A operand of test point t+1 are staged (double buffered in LDS) while t is evaluated.
-// exp(x) for x <= ~1 (the pair loop's arguments are -(a sum of squares)): x = k ln 2 + r, |r| <= ln 2 / 2, a degree-12 Taylor
-// polynomial in r (remainder 1.7e-16 relative) and v_ldexp -- 18 VALU instructions, no branches, no table (the library's exp
-// is 27 with its special cases; a 64-entry table version read LDS beside the MFMA operand reads and was slower).  Results
-// below 2^-1022 flush through ldexp's own underflow; NaN propagates.
-__device__ __forceinline__ double exp_nonpos(double x) {
-    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
-    double r = fma(k, -6.93147180369123816490e-01, x);
-    r = fma(k, -1.90821492927058770002e-10, r);
-    double p = 2.08767569878680989792e-09;               // 1/12!
-    p = fma(p, r, 2.50521083854417187751e-08);            // 1/11!
-    p = fma(p, r, 2.75573192239858906526e-07);            // 1/10!
-    p = fma(p, r, 2.75573192239858906526e-06);            // 1/9!
-    p = fma(p, r, 2.48015873015873015873e-05);            // 1/8!
-    p = fma(p, r, 1.98412698412698412698e-04);            // 1/7!
-    p = fma(p, r, 1.38888888888888888889e-03);            // 1/6!
-    p = fma(p, r, 8.33333333333333333333e-03);            // 1/5!
-    p = fma(p, r, 4.16666666666666666667e-02);            // 1/4!
-    p = fma(p, r, 1.66666666666666666667e-01);            // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)fmax(k, -1100.0));
-}
-
 __global__ __launch_bounds__(256, 3) void linkgp_Jsexp_kernel(LinkArgs a) {
     extern __shared__ double lds[];
     const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
@@ -517,9 +493,9 @@ __global__ __launch_bounds__(256, 3) void linkgp_Jsexp_kernel(LinkArgs a) {
     double *tz = tv + TCH * Dw;           // [TCH][Dz]
     double *red = tz + TCH * Dz;          // [TCH][4]
     double *U = red + TCH * 4;            // [2][64][LDU]  A operand of a test point: 2 c1_k (w_ik - 2 m_k)
-    double *R = U + 2 * 64 * LDU;         // [2][4][64] row terms (one partial per staging wave)
-    double *S = R + 2 * 4 * 64;           // [2][4][64] column terms
-    double *ilg = S + 2 * 4 * 64;         // [Dz] reciprocal lengthscales of the global dimensions
+    double *R = U + 2 * 64 * LDU;         // [2][64] row terms
+    double *S = R + 2 * 64;               // [2][64] column terms
+    double *ilg = S + 2 * 64;             // [Dz] reciprocal lengthscales of the global dimensions
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -579,57 +555,39 @@ __global__ __launch_bounds__(256, 3) void linkgp_Jsexp_kernel(LinkArgs a) {
         tv[idx] = 1.0 / (8.0 * tv[idx] + 2.0 * l * l);
         tm[idx] = 2.0 * tm[idx];
     }
-    // staging of test point t by ALL threads: lane = point (row point p of the row block, column point p of the column block),
-    // wave q = the dimensions k = q, q + 4, ... (local) and g = q, q + 4, ... (global).  Every wave writes its own partial
-    // row / column terms (R, S: [buf][4][64]); the readers add the four.  All LDS reads of a wave's share are issued before
-    // the arithmetic (fixed unroll of SX passes, predicated): one LDS latency per stage instead of one per dimension -- the
-    // former staging (128 threads, a loop over all dimensions per point) cost more cycles per test point than the 16
-    // exponentials of the pair phase.
-    constexpr int SX = 4;   // passes: up to 16 local and 16 global dimensions in registers; beyond that the loops below
+    // staging of test point t: 128 point tasks (64 row points: A operand + row term; 64 column points: column term)
+    // on the even threads, so that the four waves share them evenly
     auto stage = [&](int t, int buf) {
-        const int p = lane, q = wave;
+        if (tid & 1) return;
+        const int task = tid >> 1;
         const double *c1 = tv + t * Dw, *m2 = tm + t * Dw, *zt = tz + t * Dz;
-        double wi[SX], wj[SX], ck[SX], mk[SX], gi_[SX], gj_[SX], zg[SX], lg[SX];
-#pragma unroll
-        for (int x = 0; x < SX; ++x) {
-            const int k = q + 4 * x, g = q + 4 * x;
-            const bool ok = k < Dw, og = g < Dz;
-            wi[x] = ok ? WiT[k * 64 + p] : 0.0;
-            wj[x] = ok ? WjT[k * 64 + p] : 0.0;
-            ck[x] = ok ? c1[k] : 0.0;
-            mk[x] = ok ? m2[k] : 0.0;
-            gi_[x] = og ? WiT[(Dw + g) * 64 + p] : 0.0;
-            gj_[x] = og ? WjT[(Dw + g) * 64 + p] : 0.0;
-            zg[x] = og ? zt[g] : 0.0;
-            lg[x] = og ? ilg[g] : 0.0;
+        if (task < 64) {
+            double rr = 0.0;
+            double *u = U + (buf * 64 + task) * LDU;
+            for (int k = 0; k < Dw; ++k) {
+                const double wi = WiT[k * 64 + task] - m2[k], cw = c1[k] * wi;
+                u[k] = 2.0 * cw;
+                rr = fma(cw, wi, rr);
+            }
+            for (int k = Dw; k < KP; ++k) u[k] = 0.0;
+            for (int g = 0; g < Dz; ++g) {
+                const double di = (WiT[(Dw + g) * 64 + task] - zt[g]) * ilg[g];
+                rr = fma(di, di, rr);
+            }
+            R[buf * 64 + task] = rr;
+        } else {
+            const int j = task - 64;
+            double ss = 0.0;
+            for (int k = 0; k < Dw; ++k) {
+                const double wj = WjT[k * 64 + j];
+                ss = fma(c1[k] * wj, wj, ss);
+            }
+            for (int g = 0; g < Dz; ++g) {
+                const double dj = (WjT[(Dw + g) * 64 + j] - zt[g]) * ilg[g];
+                ss = fma(dj, dj, ss);
+            }
+            S[buf * 64 + j] = ss;
         }
-        double rr = 0.0, ss = 0.0;
-        double *u = U + (buf * 64 + p) * LDU;
-#pragma unroll
-        for (int x = 0; x < SX; ++x) {
-            const int k = q + 4 * x;
-            const double d = wi[x] - mk[x], cw = ck[x] * d;
-            if (k < KP) u[k] = 2.0 * cw;   // (k >= Dw: ck = 0 -> the zero padding of the MFMA k-steps)
-            rr = fma(cw, d, rr);
-            ss = fma(ck[x] * wj[x], wj[x], ss);
-            const double di = (gi_[x] - zg[x]) * lg[x], dj = (gj_[x] - zg[x]) * lg[x];
-            rr = fma(di, di, rr);
-            ss = fma(dj, dj, ss);
-        }
-        for (int k = q + 4 * SX; k < KP; k += 4) {   // (more than 16 local dimensions)
-            const double c = k < Dw ? c1[k] : 0.0, d = (k < Dw ? WiT[k * 64 + p] : 0.0) - (k < Dw ? m2[k] : 0.0), cw = c * d;
-            const double w2 = k < Dw ? WjT[k * 64 + p] : 0.0;
-            u[k] = 2.0 * cw;
-            rr = fma(cw, d, rr);
-            ss = fma(c * w2, w2, ss);
-        }
-        for (int g = q + 4 * SX; g < Dz; g += 4) {
-            const double di = (WiT[(Dw + g) * 64 + p] - zt[g]) * ilg[g], dj = (WjT[(Dw + g) * 64 + p] - zt[g]) * ilg[g];
-            rr = fma(di, di, rr);
-            ss = fma(dj, dj, ss);
-        }
-        R[(buf * 4 + q) * 64 + p] = rr;
-        S[(buf * 4 + q) * 64 + p] = ss;
     };
     __syncthreads();
     if (nt > 0) stage(0, 0);
@@ -648,16 +606,12 @@ __global__ __launch_bounds__(256, 3) void linkgp_Jsexp_kernel(LinkArgs a) {
         }
         double rr[4], acc = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double *Rq = R + buf * 256 + mrow + 4 * r;
-            rr[r] = (Rq[0] + Rq[64]) + (Rq[128] + Rq[192]);
-        }
+        for (int r = 0; r < 4; ++r) rr[r] = R[buf * 64 + mrow + 4 * r];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const double *Sq = S + buf * 256 + 16 * tt + mcol;
-            const double ss = (Sq[0] + Sq[64]) + (Sq[128] + Sq[192]);
+            const double ss = S[buf * 64 + 16 * tt + mcol];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = fma(Cr[tt][r], exp_nonpos(-(e[tt][r] + rr[r] + ss)), acc);
+            for (int r = 0; r < 4; ++r) acc = fma(Cr[tt][r], exp_negated(e[tt][r] + rr[r] + ss), acc);
         }
         acc = wave_sum_p(acc);
         if (lane == 0) red[t * 4 + wave] = acc;
@@ -705,36 +659,6 @@ __global__ __launch_bounds__(256) void sexp_records_kernel(LinkArgs a, int KPA) 
     ra[a.Dw + 1] = 1.0;
     for (int k = a.Dw + 2; k < KPA; ++k) ra[k] = 0.0;
     a.gfac[tt * a.npad + i] = ss;
-}
-
-// exp(-x) for x >= ~-1 (see exp_nonpos), with full-rate instructions only: the rounding to the nearest integer is the
-// "1.5 * 2^52" addition (the integer then sits in the low word of the sum: no v_rndne / v_cvt), the scaling by 2^k a
-// multiplication by a double whose exponent field is written with integer arithmetic (no v_ldexp).  On gfx950 v_rndne_f64,
-// v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of v_fma_f64's rate: three of them cost as much as the twelve
-// multiply-adds of the polynomial (PMC: 31 VALU instructions per pair but 78 % of the issue cycles).  k is clamped at -1022:
-// arguments beyond ~708 give ~1e-308 instead of 0, which the weights multiply into nothing.
-__device__ __forceinline__ double exp_negated(double x) {
-    const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
-    const double kf = fma(x, -1.44269504088896338700e+00, MAGIC);
-    const double k = kf - MAGIC;
-    double r = fma(k, -6.93147180369123816490e-01, -x);
-    r = fma(k, -1.90821492927058770002e-10, r);
-    double p = 2.08767569878680989792e-09;
-    p = fma(p, r, 2.50521083854417187751e-08);
-    p = fma(p, r, 2.75573192239858906526e-07);
-    p = fma(p, r, 2.75573192239858906526e-06);
-    p = fma(p, r, 2.48015873015873015873e-05);
-    p = fma(p, r, 1.98412698412698412698e-04);
-    p = fma(p, r, 1.38888888888888888889e-03);
-    p = fma(p, r, 8.33333333333333333333e-03);
-    p = fma(p, r, 4.16666666666666666667e-02);
-    p = fma(p, r, 1.66666666666666666667e-01);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    int ki = __double2loint(kf);               // k as a two's-complement integer
-    ki = ki < -1022 ? -1022 : ki;
-    return p * __hiloint2double((ki + 1023) << 20, 0);
 }
 
 #define SX_KS 4   // k-steps held in registers: Dw + 2 <= 16
@@ -1207,7 +1131,7 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
                 PROF_END(ctx, PROF_LINKGP_J);
             } else {
                 const int KP = (Dw + 3) & ~3, LDU = KP + 2;
-                const size_t shm_s = ((size_t)2 * DT * 64 + (size_t)KP * LDK + (size_t)TCH * (2 * Dw + Dz) + TCH * 4 + 2 * 64 * LDU + 16 * 64 + Dz) * sizeof(double);
+                const size_t shm_s = ((size_t)2 * DT * 64 + (size_t)KP * LDK + (size_t)TCH * (2 * Dw + Dz) + TCH * 4 + 2 * 64 * LDU + 4 * 64 + Dz) * sizeof(double);
                 if (shm_s > 48 * 1024)
                     HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsexp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_s));
                 hipLaunchKernelGGL(linkgp_Jsexp_kernel, dim3(ntiles, tb), dim3(256), shm_s, ctx->stream, a);
