@@ -270,12 +270,14 @@ def main():
                 ach = tot_w / (tot_ms * 1e-3) / 1e12
                 roof = dict(bound='mfma', kernel={'syrk': 'potrf_mega_kernel (one launch = one batched factorisation, with or without the fused inverse)'}.get(args.prof_kernel, 'tile_gemm_kernel<%s>' % args.prof_kernel), achieved=ach,
                             peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None)
-            pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_bench_potrf_kernel.json')
+            pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_bench_potrf_kernel.json')
+            if not os.path.exists(pmc):
+                pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_bench_potrf_kernel.json')
             if args.prof_kernel == 'syrk' and os.path.exists(pmc):   # HBM bytes per launch, measured offline with rocprofv3 --pmc
                 with open(pmc) as f:
                     pj = json.load(f)
                 roof['traffic'] = pj['hbm_bytes_per_launch']
-                roof['traffic_source'] = ('profiles/r02_pmc_bench_potrf_kernel.json: FETCH_SIZE x2 + WRITE_SIZE per launch of the same '
+                roof['traffic_source'] = ('profiles/' + os.path.basename(pmc) + ': FETCH_SIZE x2 + WRITE_SIZE per launch of the same '
                                           'kernel in separate rocprofv3 --pmc passes of `%s` (an earlier run, not this one)' % pj.get('command', '?'))
             roof.update(launches=tot_n, avg_launch_us=1e3 * tot_ms / tot_n, work_per_launch=tot_w / tot_n,
                         event_pair_overhead_us=ev_us, avg_launch_us_if_event_overhead_removed=1e3 * corrected_ms / tot_n,

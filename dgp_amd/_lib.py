@@ -33,7 +33,9 @@ class Node(C.Structure):
                 ('reserved', C.c_int), ('ldloc', C.c_int64), ('Xloc', C.c_void_p), ('colmap', C.c_void_p),
                 ('Xglob', C.c_void_p), ('length', C.c_void_p), ('nugget', C.c_double), ('W', C.c_void_p),
                 ('y', C.c_void_p), ('vecch_ord', C.c_void_p), ('vecch_nn', C.c_void_p), ('vecch_nd', C.c_void_p),
-                ('vecch_y', C.c_void_p), ('vecch_m', C.c_int), ('reserved2', C.c_int)]
+                ('vecch_y', C.c_void_p), ('vecch_m', C.c_int), ('reserved2', C.c_int),
+                ('lik_kind', C.c_int), ('lik_classes', C.c_int), ('lik_nobs', C.c_int64), ('lik_rep', C.c_void_p),
+                ('lik_par', C.c_double)]
 
 
 SIGNATURES = {
@@ -64,6 +66,8 @@ SIGNATURES = {
     'dgpamd_loglik_finish': (_i, [_p, _l, _p, _l, _i, _p, _d, _p]),
     'dgpamd_loglik': (_i, [_p, _i, _l, _p, _l, _l, _p, _i, _p, _i, _p, _i, _d, _p, _d, _p, _p, _l, _i, _p, _p, _p]),
     'dgpamd_trmv_lower': (_i, [_p, _l, _p, _l, _p, _p, _p, _i]),
+    'dgpamd_lik_workspace': (_z, [_i]),
+    'dgpamd_lik_loglik': (_i, [_p, _p, _l, _i, _p, _l, _i, _p, _p]),
     'dgpamd_ess_propose': (_i, [_p, _l, _i, _p, _p, _p, _i, _p]),
     'dgpamd_potri': (_i, [_p, _l, _p, _p, _i, _p]),
     'dgpamd_potri_batched': (_i, [_p, _l, _p, _p, _l, _i, _i, _p]),

@@ -1196,7 +1196,10 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTab
     // DGPAMD_MEGA_LAZY / _SLAZY / _NEAR / _LAG / _XCATCH / _STAIL override (tuning only).
     const char *lz = getenv("DGPAMD_MEGA_LAZY"), *sz = getenv("DGPAMD_MEGA_SLAZY");
     const bool deep = batch >= 6;
-    const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : (deep ? 10 : MEGA_LAZY), slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? 10 : MEGA_SLAZY);
+    // (n = 5000, ten matrices with their inverses: 25.9 ms at 8 panels per visit, 25.3 at 12, 25.4 at 16 -- 49 TFLOP/s; one matrix is
+    //  fastest at 8: the chain waits for deeper visits)
+    const int deep_lazy = nbk >= 64 ? 12 : 10;
+    const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : (deep ? deep_lazy : MEGA_LAZY), slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? deep_lazy : MEGA_SLAZY);
     const char *en = getenv("DGPAMD_MEGA_NEAR"), *el = getenv("DGPAMD_MEGA_LAG"), *ex = getenv("DGPAMD_MEGA_XCATCH");
     const char *es = getenv("DGPAMD_MEGA_STAIL");
     // (a task waits on 1 + 2 nkb version words, one per lane of ONE wave: the overrides are clamped so that the deepest visit --

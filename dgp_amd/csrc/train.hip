@@ -669,6 +669,7 @@ struct EssScratch {   // device scratch of one queue (dgpamd_ess_queue_scratch b
     double th[DGPAMD_MAXB], lo[DGPAMD_MAXB], hi[DGPAMD_MAXB], cs[DGPAMD_MAXB], sn[DGPAMD_MAXB], ll[DGPAMD_MAXB], logdet[DGPAMD_MAXB];
     int32_t info[DGPAMD_MAXB], infomax[DGPAMD_MAXB];
     int32_t nb, done, acc, halt;   // halt: the queue has stopped (status != 0): later updates launch nothing
+    double likpart[DGPAMD_MAXB * 32];   // a likelihood node's partial sums (LIK_CHUNKS per candidate)
 };
 #define ESS_TWO_PI 6.283185307179586
 
@@ -838,6 +839,176 @@ __global__ void ess_vnode_ll_kernel(const double *o, double scale, int B, int fi
     }
 }
 
+// ---- likelihood node upstairs (the reference's plugin protocol llik(): likelihood_class.py:30-90 Poisson, :245-292 NegBin,
+// :470-621 ZIP, :624-812 ZINB, Categorical) ----
+// log p(y_i | f_i) summed over the observations of every candidate block: obs i reads latent row rep[i] (replicates) or i,
+// columns cols[0..ncol).  LIK_CHUNKS fixed slices of the observations per candidate, each summed by one workgroup in a fixed
+// order (thread-strided, then a tree), the slices added in order by lik_sum / ess_liknode_ll_kernel: the same bits from the
+// queue and from dgpamd_lik_loglik.
+#define LIK_CHUNKS 32
+struct LikArgs {
+    const double *X;
+    int64_t stride_x;
+    int M, kind, ncol, classes;
+    int cols[DGPAMD_MAXD];
+    const int64_t *rep;
+    const double *y;
+    int64_t nobs;
+    double par;
+    double *part;   // [B][LIK_CHUNKS]
+    const int32_t *pred;
+};
+__device__ __forceinline__ double lik_logaddexp(double a, double b) {   // numpy.logaddexp
+    if (a == b) return a + 0.6931471805599453;   // (also -inf, -inf and +inf, +inf)
+    const double d = a - b;
+    if (d > 0.0) return a + log1p(exp(-d));
+    if (d <= 0.0) return b + log1p(exp(d));
+    return a + b;   // NaN
+}
+__device__ __forceinline__ double lik_log_ndtr(double x) {   // scipy.special.log_ndtr
+    if (x > 0.0) return log1p(-0.5 * erfc(x * 0.7071067811865476));
+    if (x > -20.0) return log(0.5 * erfc(-x * 0.7071067811865476));
+    const double r = 1.0 / (x * x);   // asymptotic series of the Mills ratio
+    const double ser = 1.0 + r * (-1.0 + r * (3.0 + r * (-15.0 + r * (105.0 + r * (-945.0)))));
+    return -0.5 * x * x - log(-x) - 0.9189385332046727 + log(ser);
+}
+// NegBin._logpmf (likelihood_class.py:245-292): gammaln(y + size) - gammaln(size) - gammaln(y + 1) + y a - (y + size) logaddexp(0, a),
+// size = exp(-f2), a = f1 + f2.  For counts up to 64 the first difference is evaluated as sum_{j<y} log(size + j) -- the same
+// number, without the cancellation of two gammaln values of order size log size that makes the expression noise (+-10^3 at
+// size = 1e16) when a slice-sampling proposal drives the dispersion latent far negative; a chain fed that noise gets trapped on
+// spuriously high values.  Where the reference's expression is well conditioned the two agree to rounding.
+__device__ __forceinline__ double lik_negbin(double y, double f1, double f2) {
+    const double size = exp(-f2), a = f1 + f2;
+    double lg;
+    if (y >= 0.0 && y <= 64.0 && y == floor(y)) {
+        lg = 0.0;
+        for (double j = 0.0; j < y; j += 1.0) lg += log(size + j);
+    } else {
+        lg = lgamma(y + size) - lgamma(size);
+    }
+    return lg - lgamma(y + 1.0) + y * a - (y + size) * lik_logaddexp(0.0, a);
+}
+__device__ __forceinline__ double lik_expit(double x) { return 1.0 / (1.0 + exp(-x)); }
+__device__ double lik_point(const LikArgs &a, const double *f, double y) {
+    const int *c = a.cols;
+    switch (a.kind) {
+    case DGPAMD_LIK_POISSON: {
+        const double v = f[c[0]];
+        return y * v - exp(v) - lgamma(y + 1.0);
+    }
+    case DGPAMD_LIK_NEGBIN:
+        return lik_negbin(y, f[c[0]], f[c[1]]);
+    case DGPAMD_LIK_ZIP: {
+        const double fl = f[c[0]], lam = exp(fl), pi = lik_expit(f[c[1]]);
+        if (y == 0.0) return lik_logaddexp(log(pi), log1p(-pi) - lam);
+        return log1p(-pi) - lam + y * fl - lgamma(y + 1.0);
+    }
+    case DGPAMD_LIK_ZINB: {
+        const double nb = lik_negbin(y, f[c[0]], f[c[1]]), pi = lik_expit(f[c[2]]);
+        if (y == 0.0) return lik_logaddexp(log(pi), log1p(-pi) + nb);
+        return log1p(-pi) + nb;
+    }
+    case DGPAMD_LIK_BIN_LOGIT: {
+        const double v = f[c[0]];
+        return y * v - lik_logaddexp(0.0, v);
+    }
+    case DGPAMD_LIK_BIN_PROBIT: {
+        const double v = f[c[0]];
+        return y * lik_log_ndtr(v) + (1.0 - y) * lik_log_ndtr(-v);
+    }
+    case DGPAMD_LIK_ROBUSTMAX: {
+        int best = 0;
+        double top = f[c[0]];
+        bool nan = top != top;   // (numpy.argmax returns the first NaN)
+        for (int k = 1; k < a.ncol && !nan; ++k) {
+            const double v = f[c[k]];
+            if (v != v) { best = k; nan = true; }
+            else if (v > top) { top = v; best = k; }
+        }
+        return best == (int)y ? log(1.0 - a.par) : log(a.par / (a.classes - 1));
+    }
+    default: {   // DGPAMD_LIK_SOFTMAX
+        double top = f[c[0]];
+        for (int k = 1; k < a.ncol; ++k) {
+            const double v = f[c[k]];
+            top = (v > top || v != v) ? v : top;
+        }
+        double s = 0.0;
+        for (int k = 0; k < a.ncol; ++k) s += exp(f[c[k]] - top);
+        return f[c[(int)y]] - (log(s) + top);
+    }
+    }
+}
+__global__ __launch_bounds__(256) void lik_partial_kernel(LikArgs a) {
+    if (a.pred && *a.pred) return;
+    __shared__ double red[256];
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int64_t per = (a.nobs + LIK_CHUNKS - 1) / LIK_CHUNKS, lo = ch * per, hi = lo + per < a.nobs ? lo + per : a.nobs;
+    const double *Xb = a.X + (int64_t)b * a.stride_x;
+    double acc = 0.0;
+    for (int64_t i = lo + tid; i < hi; i += 256) {
+        const int64_t row = a.rep ? a.rep[i] : i;
+        acc += lik_point(a, Xb + row * a.M, a.y[i]);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) a.part[b * LIK_CHUNKS + ch] = red[0];
+}
+__global__ void lik_sum_kernel(const double *part, int B, double *out) {
+    const int b = threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int c = 0; c < LIK_CHUNKS; ++c) s += part[b * LIK_CHUNKS + c];
+    out[b] = s;
+}
+__global__ void ess_liknode_ll_kernel(const double *part, int B, int first, EssScratch *sc, double *st) {
+    const int b = threadIdx.x;
+    if (sc->done) return;
+    if (b < B) {
+        double s = 0.0;
+        for (int c = 0; c < LIK_CHUNKS; ++c) s += part[b * LIK_CHUNKS + c];
+        sc->ll[b] = (first ? 0.0 : sc->ll[b]) + s;
+        if (first) sc->infomax[b] = 0;
+    }
+    if (st) {
+        __threadfence_block();
+        __syncthreads();
+        if (b == 0) ess_decide(st, sc);
+    }
+}
+static int lik_launch(dgpamd_ctx *ctx, const dgpamd_node &nd, int64_t n, int M, const double *X, int64_t stride_x, int B, double *part) {
+    if (nd.lik_kind < DGPAMD_LIK_POISSON || nd.lik_kind > DGPAMD_LIK_SOFTMAX) BAD_ARG(ctx, "unknown likelihood");
+    if (!nd.y || nd.lik_nobs <= 0 || !nd.colmap || nd.Dl <= 0 || nd.Dl > DGPAMD_MAXD) BAD_ARG(ctx, "incomplete likelihood node");
+    static const int need[] = {0, 1, 2, 2, 3, 1, 1, 0, 0};
+    if (need[nd.lik_kind] && nd.Dl != need[nd.lik_kind]) BAD_ARG(ctx, "wrong number of latent columns for this likelihood");
+    if (nd.lik_kind >= DGPAMD_LIK_ROBUSTMAX && (nd.lik_classes != nd.Dl || nd.Dl < 2)) BAD_ARG(ctx, "one latent column per class");
+    if (!nd.lik_rep && nd.lik_nobs != n) BAD_ARG(ctx, "observations and latent rows differ without a replicate map");
+    LikArgs a;
+    a.X = X; a.stride_x = stride_x; a.M = M; a.kind = nd.lik_kind; a.ncol = nd.Dl; a.classes = nd.lik_classes;
+    for (int d = 0; d < nd.Dl; ++d) {
+        a.cols[d] = ((const int32_t *)nd.colmap)[d];
+        if (a.cols[d] < 0 || a.cols[d] >= M) BAD_ARG(ctx, "latent column out of range");
+    }
+    a.rep = nd.lik_rep; a.y = nd.y; a.nobs = nd.lik_nobs; a.par = nd.lik_par; a.part = part; a.pred = ctx->pred;
+    hipLaunchKernelGGL(lik_partial_kernel, dim3(LIK_CHUNKS, B), dim3(256), 0, ctx->stream, a);
+    return DGPAMD_OK;
+}
+extern "C" int dgpamd_lik_loglik(dgpamd_ctx *ctx, const dgpamd_node *node, int64_t n, int M, const double *X, int64_t stride_x, int batch,
+                                 double *work, double *out) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (!node || !X || !work || !out || n <= 0 || M <= 0 || batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "bad arguments");
+    int rc = lik_launch(ctx, *node, n, M, X, stride_x, batch, work);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lik_sum_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)work, batch, out);
+    LAUNCH_CHECK(ctx);
+    return DGPAMD_OK;
+}
+extern "C" size_t dgpamd_lik_workspace(int batch) { return (size_t)batch * LIK_CHUNKS * sizeof(double); }
+
 extern "C" size_t dgpamd_ess_queue_scratch(void) { return (sizeof(EssScratch) + 15) / 16 * 16; }
 // gathered inputs (batch x n x D) + per-row partials (batch x n x 2) + the row sums (batch x 2)
 extern "C" size_t dgpamd_ess_queue_vwork(int64_t n, int D, int batch) {
@@ -852,6 +1023,13 @@ static int ess_queue_logliks(dgpamd_ctx *ctx, int64_t n, int M, const double *X,
     double *ws = (double *)work;
     for (int k = 0; k < nnodes; ++k) {
         const dgpamd_node &nd = nodes[k];
+        if (nd.lik_kind) {   // a likelihood node: the summed log-density of the observations
+            int rc = lik_launch(ctx, nd, n, M, X, stride_x, B, sc->likpart);
+            if (rc) return rc;
+            hipLaunchKernelGGL(ess_liknode_ll_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)sc->likpart, B,
+                               k == 0 ? 1 : 0, sc, k == nnodes - 1 ? st_decide : nullptr);
+            continue;
+        }
         if (!(scales_h[k] > 0.0)) BAD_ARG(ctx, "scale must be positive");
         if (nd.vecch_nn) {
             const int D = nd.Dl + nd.Dg;

@@ -211,10 +211,11 @@ class emulator:
                         rys.append(ry)
                     stats[(l, k)] = dict(shared=True, Rinv=Rinv, ld=Np, ry=torch.cat(rys), n=n, Wall=e.tensor(nd._X()))
                 else:
-                    def build(s, l=l, nd=nd, factor=factor, ys=ys):
+                    def build(s, l=l, nd=nd, factor=factor, ys=ys, Xg=Xg):
                         Xin = self.latents[s][l - 1][:, nd.input_dim]
                         Rinv, ry = factor(e.tensor(Xin), e.tensor(ys(s)[None, :]))
-                        return dict(Rinv=Rinv, ry=ry[0].contiguous(), W=e.tensor(Xin))
+                        cells = e.linkgp_cells(nd.name, Xin, Xg, Rinv, ry[0])   # (Matern: training points grouped by cells)
+                        return cells if cells is not None else dict(Rinv=Rinv, ry=ry[0].contiguous(), W=e.tensor(Xin))
                     stats[(l, k)] = dict(shared=False, per=_LazyPer(self, (l, k), build, Np * Np * 8), ld=Np, n=n, Wg=Xg)
         self._stats = stats
         self._per_cache = collections.OrderedDict()
@@ -260,7 +261,7 @@ class emulator:
                     for s in range(S):
                         ps = st['per'][s]
                         mk, vk = e.linkgp_predict(nd.name, pm[s][:, idx].contiguous(), pv[s][:, idx].contiguous(), z, ps['W'],
-                                                  st['Wg'], nd.length, ps['Rinv'], st['ld'], ps['ry'], nd.scale[0],
+                                                  ps.get('Wg', st['Wg']), nd.length, ps['Rinv'], st['ld'], ps['ry'], nd.scale[0],
                                                   nd.nugget[0])
                         mean[s, :, k] = mk
                         var[s, :, k] = vk
@@ -316,8 +317,8 @@ class emulator:
                     for s in range(S):
                         ps = st['per'][s]
                         ms, vs = pm[s][:, idx].contiguous(), pv[s][:, idx].contiguous()
-                        d = torch.arange(n, device=xd.device, dtype=torch.int32)
-                        mk, vk = e.linkgp_predict(nd.name, ms, vs, z, ps['W'], st['Wg'], nd.length, ps['Rinv'], st['ld'],
+                        d = ps['pos'] if 'pos' in ps else torch.arange(n, device=xd.device, dtype=torch.int32)
+                        mk, vk = e.linkgp_predict(nd.name, ms, vs, z, ps['W'], ps.get('Wg', st['Wg']), nd.length, ps['Rinv'], st['ld'],
                                                   ps['ry'], nd.scale[0], nd.nugget[0], drop=d)
                         mean[s, :, k], var[s, :, k] = mk, vk
             per_layer.append((mean, var))

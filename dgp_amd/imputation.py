@@ -20,6 +20,7 @@ Randomness: one numpy Generator for fmvn's normals and one for the uniforms (the
 reference also uses two streams: numba's for randn, numpy's global for uniform);
 both can be injected for deterministic replay.
 """
+import os
 import numpy as np
 from numpy.linalg import LinAlgError
 from .ops import raise_not_pd
@@ -230,7 +231,7 @@ class imputer:
         st['_engine'] = None
         st['_factor_cache'] = {}
         st['_ess_plans'] = {}
-        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_vecch_y', '_adopt', '_adopt_ll', '_given_inputs', '_sp_levels'):   # device state: rebuilt by the next sample()
+        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_vecch_y', '_adopt', '_adopt_ll', '_given_inputs', '_sp_levels', '_lik_cache'):   # device state: rebuilt by the next sample()
             st.pop(key, None)
         return st
 
@@ -468,11 +469,12 @@ class imputer:
         layer, upper = self.all_layer[0], self.all_layer[1]
         if not self._queue_applies(0):
             return 0, None
-        if self._ll_cache.get(0) is None:   # the first threshold's log-likelihood: handed over by the M-step if it can be ...
+        gp_top = all(nd.type == 'gp' for nd in upper)
+        if self._ll_cache.get(0) is None and gp_top:   # the first threshold's log-likelihood: handed over by the M-step if it can be ...
             v = self._adopted_ll0()
             if v is not None:
                 self._ll_cache[0] = v
-        if self._ll_cache.get(0) is None and not any(nd.vecch for nd in layer + upper):   # ... else factored together with the prior's matrices
+        if self._ll_cache.get(0) is None and gp_top and not any(nd.vecch for nd in layer + upper):   # ... else factored together with the prior's matrices
             self._want_ll0 = list(enumerate(upper))
         nu = self._prior_draws_ahead(sweeps, prefetch=False)   # (sweeps, n, M); the next call's normals are started below
         self.__dict__.pop('_want_ll0', None)
@@ -484,7 +486,7 @@ class imputer:
         plan = self._queue_plan(0)
         b0, bn, qmax = self._queue_batches(0)
         per = 2 + (b0 - 1) + (qmax - 1) * bn + 2
-        scales = [float(nd.scale[0]) for nd in upper]
+        scales = [float(nd.scale[0]) if nd.type == 'gp' else 1.0 for nd in upper]
         first = 0
         while first < sweeps:
             us = self.draws.uniform_peek((sweeps - first) * per)
@@ -516,18 +518,51 @@ class imputer:
         return sweeps, nu
 
     def _queue_applies(self, l):
-        """Can the updates of hidden layer l run through dgpamd_ess_queue?  Block updates; GP nodes only, in the layer and
-        above it, without a reference prior upstairs (its constant depends on the proposal and is evaluated on the host);
+        """Can the updates of hidden layer l run through dgpamd_ess_queue?  Block updates; GP nodes in the layer; above it GP
+        nodes without a reference prior (its constant depends on the proposal and is evaluated on the host) or likelihood
+        nodes whose log-density the library evaluates (_lik_device_kind);
         the layer's own nodes all dense or all Vecchia; the Vecchia rows not split over ranks (that needs an all-reduce per
         batch)."""
         if not self.block or not getattr(self, 'queued', True) or ddist.rows_split():
             return False
         layer, upper = self.all_layer[l], self.all_layer[l + 1]
-        if any(nd.type != 'gp' for nd in layer) or any(nd.type != 'gp' or nd.prior_name == 'ref' for nd in upper):
+        if any(nd.type != 'gp' for nd in layer):
             return False
+        for nd in upper:
+            if nd.type == 'likelihood':
+                if self._lik_device_kind(nd) is None:
+                    return False
+            elif nd.type != 'gp' or nd.prior_name == 'ref':
+                return False
         if len({bool(nd.vecch) for nd in layer}) != 1 or len(layer) > 64:
             return False
         return True
+
+    @staticmethod
+    def _lik_device_kind(nd):
+        """Name of the library's log-density for likelihood node nd (dgpamd_lik_loglik), or None: Hetero (its mean latent is
+        drawn from an exact posterior, node-wise updates) and user plugins stay with the host protocol llik()."""
+        from . import likelihood_class as lc
+        if getattr(nd, 'exact_post_idx', None) is not None or os.environ.get('DGPAMD_LIK_HOST') == '1':   # (the switch: comparison runs)
+            return None
+        if type(nd) in (lc.Poisson, lc.NegBin, lc.ZIP, lc.ZINB):
+            return nd.name
+        if type(nd) is lc.Categorical:
+            if nd.num_classes == 2:
+                return 'logit' if nd.link == 'logit' else 'probit'
+            return 'robustmax' if nd.link == 'robustmax' else 'softmax'
+        return None
+
+    def _lik_dev(self, nd):
+        """Device-side description of likelihood node nd for Engine.lik_loglik / the queue: observations, replicate map."""
+        hit = self.__dict__.setdefault('_lik_cache', {}).get(id(nd))
+        if hit is None or hit[0] is not nd.output or hit[1] is not nd.rep:
+            e = self.engine
+            d = dict(kind=self._lik_device_kind(nd), y=e.tensor(np.asarray(nd.output, dtype=float).reshape(-1)),
+                     rep=None if nd.rep is None else torch.as_tensor(np.asarray(nd.rep, dtype=np.int64), device=self.F[0].device),
+                     classes=getattr(nd, 'num_classes', 0), par=getattr(nd, 'robustmax_eps', 0.0))
+            hit = self._lik_cache[id(nd)] = (nd.output, nd.rep, d)
+        return hit[2]
 
     def _queue_batches(self, l):
         """(first batch, later batches, batches queued per update) of the device queue for hidden layer l.  Dense nodes upstairs:
@@ -549,7 +584,8 @@ class imputer:
         upper = self.all_layer[l + 1]
         n, M = self.F[l].shape
         last = l + 1 == len(self.all_layer) - 1
-        key = tuple((tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), self._node_y(l + 1, k).data_ptr() if last else None,
+        key = tuple(('lik', self._lik_dev(nd)['y'].data_ptr(), tuple(np.asarray(nd.input_dim).tolist())) if nd.type == 'likelihood' else
+                    (tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), self._node_y(l + 1, k).data_ptr() if last else None,
                      None if self._glob[(l + 1, k)] is None else self._glob[(l + 1, k)].data_ptr(),
                      (id(nd.ord), id(nd.NNarray), None if nd.rep is None else id(nd.W_diag)) if nd.vecch else None)
                     for k, nd in enumerate(upper)) + (self._queue_batches(l)[0], n, M)
@@ -557,6 +593,9 @@ class imputer:
         if hit is None or hit[0] != key:
             nodes, ybuf = [], {}
             for k, nd in enumerate(upper):
+                if nd.type == 'likelihood':
+                    nodes.append(dict(colmap=np.asarray(nd.input_dim, dtype=np.int32), lik=self._lik_dev(nd)))
+                    continue
                 y = self._node_y(l + 1, k) if last else e.empty(n)
                 d = dict(kind=nd.name, colmap=np.asarray(nd.input_dim, dtype=np.int32), Xglob=self._glob[(l + 1, k)], length=nd.length,
                          nugget=nd.nugget[0], W=None if nd.rep is None else e.tensor(nd.W_diag), y=y)
@@ -645,7 +684,7 @@ class imputer:
                     nu = self._prior_draw_queued(l, Zdev[(s_, l)], lead)
                 nus[j] = nu
                 self._queue_refresh_y(l, plan)
-                scales = [float(nd.scale[0]) for nd in self.all_layer[l + 1]]
+                scales = [float(nd.scale[0]) if nd.type == 'gp' else 1.0 for nd in self.all_layer[l + 1]]
                 plan.queue(self.F[l], nu[None], scales, us, 0, None, True, qb[l][1], qb[l][2], fresh=(j == pos))
             st = lead.fetch()
             status, done = int(st['status']), int(st['updates'])
@@ -870,6 +909,9 @@ class imputer:
                     if FPh is None:
                         FPh = FP.cpu().numpy()
                     host += self._ref_prior_terms(nd, FPh)
+            elif self._lik_device_kind(nd) is not None:
+                # likelihood node the library knows (likelihood_class.py llik()): summed on the device, in the order the queue uses
+                dev_terms.append(e.lik_loglik(self._lik_dev(nd), np.asarray(nd.input_dim, dtype=np.int32), FP))
             else:
                 # likelihood node: host plugin protocol llik() on .input (likelihood_class.py:30-90)
                 if FPh is None:
@@ -950,6 +992,8 @@ class imputer:
         else:
             log_y, theta, lo, hi, pending = resume['log_y'], resume['theta'], resume['lo'], resume['hi'], resume['pending']
         B = self.batch
+        if resume is not None and self.batch_next:   # (the queue's batches were the wide ones: carry on as the host loop would)
+            B = min(self.batch, int(self.batch_next))
         self.stats['updates'] += 1
         plan = self._ess_plan(l)
         if plan is not None:   # one dense GP node upstairs: the whole shrinking-bracket loop is one library call

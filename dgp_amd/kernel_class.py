@@ -613,10 +613,20 @@ class kernel:
                                       self._pred_nn(x, w), e.tensor(np.asarray(self.output, float).reshape(-1)),
                                       self.scale[0], self.length, self.nugget[0], e.tensor(nd))
         else:
-            st = self._stats
+            st = self._link_stats()
             mo, vo = e.linkgp_predict(self.name, e.tensor(m), e.tensor(v), zt, st['W'], st['Wg'], self.length, st['Rinv'],
                                       st['ld'], st['ry'], self.scale[0], self.nugget[0])
         return mo.cpu().numpy(), vo.cpu().numpy()
+
+    def _link_stats(self):
+        """compute_stats' arrays as the linked predictor takes them: for a Matern-2.5 node a copy with the training points
+        grouped by cells of the local inputs (Engine.linkgp_cells; built at the first linked prediction, dropped with the
+        statistics), else the statistics themselves."""
+        st = self._stats
+        if 'link' not in st:
+            cells = self.engine.linkgp_cells(self.name, self.input, st['Wg'], st['Rinv'], st['ry'])
+            st['link'] = st if cells is None else dict(cells, ld=st['ld'])
+        return st['link']
 
     def linkgp_prediction_full(self, m, v, m_z, v_z, z):
         """Linked prediction when part of the node's GLOBAL input is itself uncertain (outputs of feeding

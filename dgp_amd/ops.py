@@ -366,6 +366,38 @@ class Engine:
         self._chk(self._enter() or lib.dgpamd_fetch2(self.h, _dp(ll), 8 * B, _dp(info), 4 * B, buf.ctypes.data_as(C.c_void_p)))
         return buf[:8 * B].view(np.float64), buf[8 * B:].view(np.int32)
 
+    def linkgp_cells(self, kind, W_host, Wg, Rinv, ry):
+        """Prediction statistics of a linked Matern-2.5 node with the training points grouped by cells (cell_order): the
+        pair kernel then needs one record product instead of two for about half of its work (linkgp_Jsep_kernel's order
+        classes).  W_host: (n x Dw) numpy inputs; Wg (n x Dz device or None), Rinv (ld x ld device, valid [:n, :n]), ry (n
+        device) in the same row order.  Returns dict(W, Wg, Rinv, ry, pos) -- pos[i] = row of training point i in the new
+        order (int32, what a leave-one-out call passes as `drop`) -- or None for kernels whose pair phase has no classes.
+        The predictions are the same sums over all pairs (functions.py:421-494) in another order."""
+        if kind != 'matern2.5' or os.environ.get('DGPAMD_LINK_CELLS', '1') == '0':
+            return None
+        n = len(W_host)
+        p = cell_order(W_host)
+        pd = torch.as_tensor(p, device=Rinv.device)
+        pos = np.empty(n, dtype=np.int32)
+        pos[p] = np.arange(n, dtype=np.int32)
+        Rp = torch.zeros_like(Rinv)
+        Rp[:n, :n] = Rinv[:n, :n][pd][:, pd]
+        return dict(W=self.tensor(np.ascontiguousarray(np.asarray(W_host, dtype=float)[p])), Wg=None if Wg is None else Wg[pd].contiguous(),
+                    Rinv=Rp, ry=ry[pd].contiguous(), pos=torch.as_tensor(pos, device=Rinv.device))
+
+    def lik_loglik(self, lik, colmap, FP):
+        """A likelihood node's log-likelihood of every candidate block FP[b] (B x n x M) -> device tensor (B,)
+        (dgpamd_lik_loglik; imputation.py:71-78,91-106 -> <likelihood>.llik()).  lik: dict(kind, y, rep, classes, par) with
+        device tensors y (observations) and rep (int64 latent row per observation, or None)."""
+        B, n, M = FP.shape
+        nd = _lib.Node()
+        keep = _fill_lik_node(nd, colmap, lik, M)
+        work = self.workspace(('likW', B), int(lib.dgpamd_lik_workspace(B)))
+        out = self.empty(B)
+        self._chk(self._enter() or lib.dgpamd_lik_loglik(self.h, C.byref(nd), n, M, _dp(FP), n * M, B, _dp(work), _dp(out)))
+        del keep
+        return out
+
     def ess_queue_plan(self, n, M, nodes, batch):
         return _EssQueue(self, n, M, nodes, batch)
 
@@ -626,6 +658,50 @@ class _LlikPlan:
         return out
 
 
+def cell_order(W, leaf=16, block=64):
+    """A permutation of the rows of W (n x D training inputs of a linked node) that groups them by cells: recursive
+    splits at an order statistic of one coordinate (the coordinates in turn), every part a multiple of `block` rows while it
+    is larger than a block and of `leaf` rows below, down to `leaf` rows.  Rows 16 a .. 16 a + 15 of the permuted array are
+    then a cell, and two cells that were separated by a split in coordinate k satisfy max x_k <= min x_k one way round.  The
+    Matern pair kernel (linkgp_Jsep_kernel) needs one of its two record products for such a (sub-tile, coordinate) and both
+    for the others; any order gives the same predictions (functions.py:453-494 sums over all pairs)."""
+    W = np.asarray(W, dtype=float)
+    n, D = W.shape
+    out = []
+    stack = [(np.arange(n), 0)]
+    while stack:
+        idx, depth = stack.pop()
+        m = len(idx)
+        if m <= leaf:
+            out.append(idx)
+            continue
+        unit = block if m > block else leaf
+        left = unit * max(1, int(round(m / (2.0 * unit))))
+        if left >= m:
+            left = m - (m % unit or unit)
+        k = depth % D
+        o = idx[np.argsort(W[idx, k], kind='stable')]
+        stack.append((o[left:], depth + 1))   # (popped after the left part: the output keeps left before right)
+        stack.append((o[:left], depth + 1))
+    return np.concatenate(out)
+
+
+LIK_KIND = {'Poisson': 1, 'NegBin': 2, 'ZIP': 3, 'ZINB': 4, 'logit': 5, 'probit': 6, 'robustmax': 7, 'softmax': 8}
+
+
+def _fill_lik_node(nd, colmap, lik, M):
+    """dgpamd_node fields of a likelihood node (include/dgp_amd.h); returns what must stay alive with the struct."""
+    colmap = np.ascontiguousarray(np.asarray(colmap, dtype=np.int32))
+    nd.kind, nd.Dl, nd.Dg, nd.nlen, nd.ldloc = 0, len(colmap), 0, 0, M
+    nd.colmap = colmap.ctypes.data
+    nd.y = lik['y'].data_ptr()
+    nd.lik_kind, nd.lik_classes = LIK_KIND[lik['kind']], int(lik.get('classes') or 0)
+    nd.lik_nobs = int(lik['y'].numel())
+    nd.lik_rep = None if lik.get('rep') is None else lik['rep'].data_ptr()
+    nd.lik_par = float(lik.get('par') or 0.0)
+    return (colmap, lik['y'], lik.get('rep'))
+
+
 class _EssQueue:
     """Several elliptical-slice updates of one latent block queued without host synchronisation (dgpamd_ess_queue):
     node structs, scratch and the device state are kept alive here; fetch() is the one synchronisation.  Several queues
@@ -642,7 +718,11 @@ class _EssQueue:
         self.keep = []
         arr = (_lib.Node * len(nodes))()
         dense, Dv = False, 0
+        nodes = list(nodes)
         for i, d in enumerate(nodes):
+            if d.get('lik') is not None:   # a likelihood node: dict(kind, y, rep, classes, par) + colmap
+                self.keep.append(_fill_lik_node(arr[i], d['colmap'], d['lik'], M))
+                continue
             colmap = np.ascontiguousarray(np.asarray(d['colmap'], dtype=np.int32))
             length = np.ascontiguousarray(np.asarray(d['length'], dtype=np.float64))
             self.keep += [colmap, length, d['Xglob'], d['W'], d['y'], d.get('vecch')]

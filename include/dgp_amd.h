@@ -200,7 +200,26 @@ typedef struct {
     const double *vecch_nd;     /* device, n: nugget weights in ordered coordinates (ones without replicates) */
     const double *vecch_y;      /* device, n: the outputs in ordered coordinates */
     int vecch_m, reserved2;
+    /* Likelihood node on top of the model (read by dgpamd_ess_queue and dgpamd_lik_loglik only; lik_kind == 0: a GP node).
+     * The reference's plugin protocol llik() (likelihood_class.py:30-90 Poisson, :245-292 NegBin, :470-621 ZIP, :624-812 ZINB,
+     * the classification likelihood): y = the lik_nobs observations (device; class indices for the categorical kinds),
+     * colmap / Dl = the latent columns it reads (one per class for SOFTMAX / ROBUSTMAX), lik_rep = latent row of every
+     * observation (device, replicates) or NULL (observation i reads row i), lik_par = robustmax's epsilon. */
+    int lik_kind, lik_classes;
+    int64_t lik_nobs;
+    const int64_t *lik_rep;
+    double lik_par;
 } dgpamd_node;
+enum { DGPAMD_LIK_POISSON = 1, DGPAMD_LIK_NEGBIN = 2, DGPAMD_LIK_ZIP = 3, DGPAMD_LIK_ZINB = 4, DGPAMD_LIK_BIN_LOGIT = 5,
+       DGPAMD_LIK_BIN_PROBIT = 6, DGPAMD_LIK_ROBUSTMAX = 7, DGPAMD_LIK_SOFTMAX = 8 };
+
+/* ---- a7  a likelihood node's log-likelihood of `batch` candidate blocks ------------
+ * imputation.py:71-78,91-106 -> <likelihood>.llik(): sum_i log p(y_i | f_i) for every block X[b] (n x M, stride_x doubles
+ * apart; 0: one block), f_i = row lik_rep[i] (or i), columns colmap.  out (device, batch); work: dgpamd_lik_workspace(batch)
+ * bytes.  The sums are formed in a fixed order (the same bits as inside dgpamd_ess_queue). */
+size_t dgpamd_lik_workspace(int batch);
+int dgpamd_lik_loglik(dgpamd_ctx *ctx, const dgpamd_node *node, int64_t n, int M, const double *X, int64_t stride_x, int batch,
+                      double *work, double *out);
 
 /* ---- a7  one elliptical-slice update of a latent block, loop and all ------------
  * imputation.one_sample_block imputation.py:81-119 for the common case of ONE dense GP node upstairs: the
@@ -242,6 +261,7 @@ int dgpamd_ess_update(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double
  *     ordered inputs and evaluates vecchia_llik for all of them in one row launch; vwork (dgpamd_ess_queue_vwork(n, max
  *     Dl + Dg, batch_first) bytes, device) holds the gathered inputs and the per-row partials.  A, work may be NULL when
  *     every node upstairs is a Vecchia node; vwork may be NULL when none is.
+ *   A likelihood node upstairs (nodes[k].lik_kind != 0; scales_h[k] is ignored): the summed log-density of its observations.
  *   A queue may be continued: a later call on the same `state` that the caller has NOT zeroed carries on from its cursor,
  *     status and counters (ll is recomputed with compute_ll0 when the target changed) -- the layers of a deeper model are
  *     queued one update at a time this way, with one fetch of the state at the end. */

@@ -1185,6 +1185,58 @@ def test_queued_ess_equals_host_loop_other_shapes(eng, shape, batch):
     assert uq == uh
 
 
+@pytest.mark.parametrize('lik', ['Poisson', 'NegBin', 'ZIP', 'ZINB', 'logit', 'probit', 'softmax', 'robustmax'])
+@pytest.mark.parametrize('batch', [12, 2])
+def test_queued_ess_equals_host_loop_likelihood_tops(eng, lik, batch):
+    """The device-resident accept / shrink loop with a likelihood node on top (imputation.py:71-78,
+    91-106 -> <likelihood>.llik()): the node's summed log-density is a library kernel (dgpamd_lik_loglik) that the host
+    loop and the queue both use, so the two take the same decisions -- same latents in every layer, same proposal /
+    batch / update counts, the uniform stream left at the same position.  Count data with replicates for NegBin."""
+    from dgp_amd import dgp, kernel, combine, Poisson, NegBin, ZIP, ZINB, Categorical
+    rng = np.random.default_rng(23)
+    n, d = 180, 2
+    X = rng.uniform(size=(n, d))
+    if lik == 'NegBin':   # replicated sites
+        X = np.concatenate((X[:120], X[:60]))
+    eta = 1.2 + np.sin(4 * X[:, 0]) + X[:, 1]
+    if lik in ('Poisson', 'NegBin', 'ZIP', 'ZINB'):
+        Y = rng.poisson(np.exp(eta)).astype(float)[:, None]
+        if lik in ('ZIP', 'ZINB'):
+            Y[rng.uniform(size=n) < 0.25] = 0.0
+        top = {'Poisson': Poisson, 'NegBin': NegBin, 'ZIP': ZIP, 'ZINB': ZINB}[lik]()
+        nlat = {'Poisson': 1, 'NegBin': 2, 'ZIP': 2, 'ZINB': 3}[lik]
+    elif lik in ('logit', 'probit'):
+        Y = (eta > 2.2).astype(int)[:, None]
+        top, nlat = Categorical(num_classes=2, link=lik), 1
+    else:
+        Y = np.digitize(eta, [1.8, 2.6])[:, None]
+        top, nlat = Categorical(num_classes=3, link=lik), 3
+
+    def run(queued):
+        np.random.seed(7)   # (warm starts that draw from numpy's global stream: the same in both runs)
+        layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                         [kernel(length=np.array([0.9]), name='sexp' if k % 2 else 'matern2.5', scale_est=True, connect=np.arange(d))
+                          for k in range(nlat)], [top])
+        model = dgp(X, Y, layers, seed=3)
+        model.imp.batch = batch
+        model.imp.batch_next = min(4, batch)
+        model.imp._batch_default = False
+        model.imp.queued = queued
+        for _ in range(2):
+            model.imp.sample(burnin=4)
+        F = [np.stack([nd.output[:, 0] for nd in layer], 1) for layer in model.all_layer[:-1]]
+        return F, dict(model.imp.stats), model.imp.draws.uniform_peek(3)
+
+    Fq, sq, uq = run(True)
+    Fh, sh, uh = run(False)
+    for a, b in zip(Fq, Fh):
+        assert np.all(np.isfinite(a))
+        close(a, b, rtol=1e-9, atol=1e-11)
+    assert sq == sh, (sq, sh)
+    assert uq == uh
+    assert sq['updates'] > 0 and sq['batches'] >= sq['updates']
+
+
 def test_mice_var_ghdiag_nllik_match_reference(eng, golden):
     """functions.mice_var / ghdiag (functions.py:233-256) and emulator.nllik (emulation.py:856-914) against values recorded
     from the reference (g22, g23): the smoothed candidate-set variance behind metric('MICE'), the Gauss-Hermite predictive

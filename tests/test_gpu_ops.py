@@ -862,3 +862,55 @@ def test_one_workspace_shared_by_batch_sizes_and_modes(eng):
                 assert np.array_equal(npy(ld), ref.setdefault(B, npy(ld))), (r, mode, B)
     finally:
         eng.set_potrf_mode(1)
+
+
+@pytest.mark.parametrize('kind', ['Poisson', 'NegBin', 'ZIP', 'ZINB', 'logit', 'probit', 'softmax', 'robustmax'])
+@pytest.mark.parametrize('replicates', [False, True])
+def test_lik_loglik_vs_host_protocol(eng, kind, replicates):
+    """dgpamd_lik_loglik == the host plugin protocol's llik() (the reference's likelihood_class.py llik methods as restated in
+    dgp_amd/likelihood_class.py and pinned by g17 / g18) for every candidate block, with and without a replicate map, on
+    ordinary latents and on the wild ones a slice-sampling proposal can reach (|f| up to 30: the probit tail series, exp
+    overflow guards of logaddexp); candidate blocks the sampler must reject (NaN) come back as NaN."""
+    import torch
+    from dgp_amd import Poisson, NegBin, ZIP, ZINB, Categorical
+    rng = np.random.default_rng(31)
+    n, M, B = 700, 5, 4
+    FP = rng.normal(size=(B, n, M))
+    FP[1] *= 6.0
+    FP[2, :50] = rng.uniform(-30, 30, size=(50, M))
+    nobs = 950 if replicates else n
+    rep = np.concatenate((np.arange(n), rng.integers(0, n, nobs - n))) if replicates else None
+    if kind in ('Poisson', 'NegBin', 'ZIP', 'ZINB'):
+        y = rng.poisson(3.0, size=nobs).astype(float)
+        y[rng.uniform(size=nobs) < 0.2] = 0.0
+        node = {'Poisson': Poisson, 'NegBin': NegBin, 'ZIP': ZIP, 'ZINB': ZINB}[kind]()
+        cols = {'Poisson': [3], 'NegBin': [0, 2], 'ZIP': [4, 1], 'ZINB': [1, 2, 3]}[kind]
+        K = 0
+    elif kind in ('logit', 'probit'):
+        y = rng.integers(0, 2, nobs).astype(float)
+        node, cols, K = Categorical(num_classes=2, link=kind), [2], 2
+    else:
+        y = rng.integers(0, 4, nobs).astype(float)
+        node, cols, K = Categorical(num_classes=4, link=kind), [4, 0, 1, 3], 4
+    lik = dict(kind=kind, y=eng.tensor(y), rep=None if rep is None else torch.as_tensor(rep, device='cuda'), classes=K, par=1e-3)
+    got = eng.lik_loglik(lik, np.asarray(cols, dtype=np.int32), eng.tensor(FP)).cpu().numpy()
+    node.output = y[:, None]
+    want = np.empty(B)
+    for b in range(B):
+        node.input = (FP[b][rep] if replicates else FP[b])[:, cols]
+        want[b] = float(np.sum(node.llik()))
+    assert np.all(np.isfinite(want))
+    atol = np.full(B, 1e-9)
+    if kind in ('NegBin', 'ZINB'):
+        # gammaln(y + size) - gammaln(size) cancels when the dispersion latent is very negative (size = exp(-f) up to 1e13
+        # here): numpy's sum carries that rounding as much as the device's, so the bound is eps x the size of the terms
+        from scipy.special import gammaln
+        for b in range(B):
+            f = (FP[b][rep] if replicates else FP[b])[:, cols]
+            size = np.exp(-f[:, 1])
+            atol[b] += 8e-16 * np.sum(np.abs(gammaln(y + size)) + np.abs(gammaln(size)) + (y + size) * np.logaddexp(0.0, f[:, 0] + f[:, 1]))
+    assert np.all(np.abs(got - want) <= 2e-13 * np.abs(want) + atol), (got, want, atol)
+    bad = FP.copy()
+    bad[0, 7, cols[0]] = np.nan
+    got = eng.lik_loglik(lik, np.asarray(cols, dtype=np.int32), eng.tensor(bad)).cpu().numpy()
+    assert np.isnan(got[0]) or (kind == 'robustmax') and np.all(np.isfinite(got[1:]))

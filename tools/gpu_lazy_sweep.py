@@ -4,14 +4,14 @@ import os, subprocess, sys
 if len(sys.argv) == 1:
     for lz, sz, cap in [tuple(int(v) for v in a.split(",")) for a in os.environ.get("SWEEP", "6,6,0 6,6,12").split()]:
         env = dict(os.environ, DGPAMD_MEGA_LAZY=str(lz), DGPAMD_MEGA_SLAZY=str(sz), DGPAMD_MEGA_CAP=str(cap))   # (CAP: experimental tables, not in the tree any more)
-        r = subprocess.run([sys.executable, __file__, 'run'], env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, __file__, 'run'], env=env, capture_output=True, text=True, timeout=600)
         print('LAZY %d SLAZY %d CAP %d' % (lz, sz, cap)); print(r.stdout[-1500:], r.stderr[-300:] if r.returncode else '')
     sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dgp_amd.ops import Engine
 eng = Engine(0)
-n = 2000; Np = eng.padded_dim(n)
+n = int(os.environ.get('N', 2000)); Np = eng.padded_dim(n)   # N=5000: cfg3's size
 ev0, ev1 = eng.event(), eng.event()
 for B in [int(v) for v in os.environ.get("BLIST", "1,3,6,12").split(",")]:
     r = np.random.default_rng(B)

@@ -10,6 +10,10 @@ n, Dw, Dz, M = (int(v) for v in (sys.argv[2:6] if len(sys.argv) > 5 else (5000, 
 eng = Engine(0)
 rng = np.random.default_rng(5)
 W, Wg = rng.normal(size=(n, Dw)), (rng.uniform(size=(n, Dz)) if Dz else None)
+if os.environ.get('ORDER'):   # training points grouped by cells (dgp_amd.ops.cell_order): what the emulator hands the Matern pair kernel
+    from dgp_amd.ops import cell_order
+    p = cell_order(W)
+    W, Wg = W[p], (Wg[p] if Dz else None)
 length, scale, nugget = np.array([2.5]), 1.3, 1e-4
 # a symmetric "R^-1" and "R^-1 y" of plausible size (the kernel's time does not depend on their values)
 G = rng.normal(size=(n, 8)) / np.sqrt(n)
