@@ -197,8 +197,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1:
         dd.init_from_env(args.backend)
+    shared_device = False
     if args.backend == 'gloo':
+        shared_device = world > torch.cuda.device_count()
         local = local % max(1, torch.cuda.device_count())
+        if shared_device:
+            # several ranks on ONE GPU (the functional check of the N > 1 flow on a one-GPU box, never a deployment): the
+            # one-launch factorisation expects its workgroups co-resident and, time-sliced against another process, runs
+            # into its hand-off bound (DgpAmdError; INTEGRATION.md, operational notes) -- the per-block-step kernel does not spin
+            os.environ['DGPAMD_POTRF_MODE'] = '0'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local) if args.backend == 'nccl' else None   # (gloo reduces host tensors)
 
@@ -434,7 +441,8 @@ def main():
         ids = dd.allgather_vector(np.array([float(rank), float(local), float(torch.cuda.current_device())]), device=dev)
         dist_info = dict(world_size=td.get_world_size(), backend=td.get_backend(),
                          ranks=[dict(rank=int(r[0]), local_rank=int(r[1]), device='cuda:%d' % int(r[2])) for r in ids],
-                         device_name=torch.cuda.get_device_name(local), devices_visible=torch.cuda.device_count())
+                         device_name=torch.cuda.get_device_name(local), devices_visible=torch.cuda.device_count(),
+                         ranks_share_a_device=shared_device)
 
     if rank == 0:
         out = {
