@@ -194,6 +194,30 @@ __device__ __forceinline__ double exp_negated(double x) {
     return p * __hiloint2double((ki + 1023) << 20, 0);
 }
 
+// The same with a 64-entry table tab[j] = 2^(j/64) (in LDS): exp(-x) = 2^e tab[j] exp(r), k = round(-64 x / ln 2) = 64 e + j,
+// |r| <= ln 2 / 128, so a degree-5 polynomial (truncation 3.5e-17) replaces the degree-12 one: 10 double-precision
+// instructions instead of 17, plus five integer ones and one LDS read that do not occupy the double-precision units.  For a
+// kernel whose inner loop leaves the LDS pipe idle (linkgp_Jsexp2_kernel; in one that feeds MFMA operands from LDS the table
+// reads cost more than they saved, round 2).
+__device__ __forceinline__ double exp_negated_tab(double x, const double *tab) {
+    const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+    const double kf = fma(x, -9.23324826168936567680e+01, MAGIC);   // 64 / ln 2
+    const double k = kf - MAGIC;
+    double r = fma(k, -6.93147180369123816490e-01 / 64.0, -x);
+    r = fma(k, -1.90821492927058770002e-10 / 64.0, r);
+    double p = 8.33333333333333333333e-03;
+    p = fma(p, r, 4.16666666666666666667e-02);
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const int ki = __double2loint(kf);
+    int e = ki >> 6;
+    e = e < -1021 ? -1021 : e;
+    const double v = tab[ki & 63] * p;
+    return __hiloint2double(__double2hiint(v) + (e << 20), __double2loint(v));
+}
+
 // lower-triangle tile index t -> (bi, bj), bi >= bj, t = bi(bi+1)/2 + bj
 __device__ __forceinline__ void tri_decode(int t, int &bi, int &bj) {
     int b = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);

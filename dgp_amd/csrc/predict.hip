@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void sexp_records_kernel(LinkArgs a, int KPA) 
 // consecutive test points alternate between two register sets without copies.
 #define TCH2 128   // test points per workgroup of the second SExp form: the tile's weights and base exponents (a 32-KB tile of
                    // R^-1 read, 16 x Dw LDS reads per lane) are set up once per TCH2 test points -- at 32 that was 40 % of the run time
-template <int KS>
+template <int KS, bool TAB>
 __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
     extern __shared__ double lds[];
     constexpr int KPA = 4 * KS;
@@ -676,9 +676,11 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
     double *WiT = lds;                    // [Dw][64]
     double *WjT = WiT + Dw * 64;          // [Dw][64]
     double *red = WjT + Dw * 64;          // [TCH2][4]
+    double *etab = red + TCH2 * 4;        // [64]: 2^(j/64), exp_negated_tab's table
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
     const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
     const int64_t tbase = a.t0 + (int64_t)blockIdx.y * TCH2, tt0 = (int64_t)blockIdx.y * TCH2;
     int nt = TCH2;
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
     // exponentials of column tile g of `e`, weights Cr
     auto group = [&](const d4 (&e)[4], int g, double &acc) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = fma(Cr[g][r], exp_negated(e[g][r]), acc);
+        for (int r = 0; r < 4; ++r) acc = fma(Cr[g][r], TAB ? exp_negated_tab(e[g][r], etab) : exp_negated(e[g][r]), acc);
     };
     // test point t from `e`, while test point t + 1 (fragments f1) goes into `en`; f2 <- fragments of t + 2
     auto step = [&](int t, const d4 (&e)[4], d4 (&en)[4], const Frag &f1, Frag &f2) {
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 21, 0);   // the VALU instructions of about one exponential
+                    __builtin_amdgcn_sched_group_barrier(0x002, TAB ? 19 : 21, 0);   // the VALU instructions of about one exponential
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1142,6 +1144,7 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
     a.Rinv = Rinv; a.ldr = ldr; a.ry = ry; a.scale = scale; a.nugget = nugget; a.mean = mean; a.var = var;
     a.partial = (double *)work;
     a.drop = drop;
+    a.no_order_classes = 0;
     int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
     if (Mc > MC_MAX) Mc = MC_MAX;
     const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
@@ -1175,16 +1178,21 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
                 hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_SEXP, false>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else if (Dw + 2 <= 4 * SX_KS && !getenv("DGPAMD_SEXP_FORM1")) {
                 const int KPA = (Dw + 2 + 3) & ~3;
-                const size_t shm2 = ((size_t)2 * Dw * 64 + TCH2 * 4) * sizeof(double);
+                const size_t shm2 = ((size_t)2 * Dw * 64 + TCH2 * 4 + 64) * sizeof(double);
+                const bool poly = getenv("DGPAMD_SEXP_POLY") != nullptr;   // (comparison run: the table-free exponential)
                 const unsigned tb2 = (unsigned)((mc + TCH2 - 1) / TCH2);
                 hipLaunchKernelGGL(sexp_records_kernel, dim3((unsigned)((a.npad + 255) / 256), (unsigned)mc), dim3(256), 0, ctx->stream, a, KPA);
                 PROF_BEGIN(ctx, PROF_LINKGP_J, (double)mc * (double)n * (double)(n + 1) * 0.5);   // pair evaluations (one exponential each)
+#define JSEXP2(KS_) \
+    if (poly) hipLaunchKernelGGL((linkgp_Jsexp2_kernel<KS_, false>), dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a); \
+    else hipLaunchKernelGGL((linkgp_Jsexp2_kernel<KS_, true>), dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a)
                 switch (KPA / 4) {
-                    case 1: hipLaunchKernelGGL(linkgp_Jsexp2_kernel<1>, dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a); break;
-                    case 2: hipLaunchKernelGGL(linkgp_Jsexp2_kernel<2>, dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a); break;
-                    case 3: hipLaunchKernelGGL(linkgp_Jsexp2_kernel<3>, dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a); break;
-                    default: hipLaunchKernelGGL(linkgp_Jsexp2_kernel<4>, dim3(ntiles, tb2), dim3(256), shm2, ctx->stream, a); break;
+                    case 1: JSEXP2(1); break;
+                    case 2: JSEXP2(2); break;
+                    case 3: JSEXP2(3); break;
+                    default: JSEXP2(4); break;
                 }
+#undef JSEXP2
                 PROF_END(ctx, PROF_LINKGP_J);
             } else {
                 const int KP = (Dw + 3) & ~3, LDU = KP + 2;

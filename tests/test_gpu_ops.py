@@ -914,3 +914,58 @@ def test_lik_loglik_vs_host_protocol(eng, kind, replicates):
     bad[0, 7, cols[0]] = np.nan
     got = eng.lik_loglik(lik, np.asarray(cols, dtype=np.int32), eng.tensor(bad)).cpu().numpy()
     assert np.isnan(got[0]) or (kind == 'robustmax') and np.all(np.isfinite(got[1:]))
+
+
+@pytest.mark.parametrize('n,M,Dw,Dz', [(400, 70, 3, 2), (650, 40, 5, 0), (130, 33, 1, 1), (1000, 20, 2, 0)])
+def test_linkgp_order_classes_equal_any_order(eng, n, M, Dw, Dz):
+    """The Matern pair kernel's order classes (one record product where a wave's rows all lie on one side of the tile's
+    columns in a dimension): the training points grouped by cells (Engine.linkgp_cells -> ops.cell_order) give the
+    predictions of the caller's order -- the same sums over all pairs, functions.py:453-494 -- to rounding, the class-free run
+    (DGPAMD_JSEP_NOCLASS) and the direct formula included; inputs with zero variances, ties between coordinates (the
+    class bounds are <= / >), sizes off the tile edge; the leave-one-out call takes `pos` as its drop list."""
+    import os
+    import torch
+    from oracle import dgp_oracle as O
+    from dgp_amd.ops import cell_order
+    rng = np.random.default_rng(77)
+    X = rng.uniform(size=(n, Dw + Dz))
+    X[: n // 3, 0] = np.round(X[: n // 3, 0], 1)   # ties
+    y = rng.normal(size=n)
+    length = rng.uniform(0.4, 1.3, size=Dw + Dz)
+    nug = 1e-2
+    st = O.compute_stats(X, y, length, nug, 'matern2.5', Dw)
+    mm = rng.uniform(-0.2, 1.2, size=(M, Dw))
+    vv = 10.0 ** rng.uniform(-5, 0, size=(M, Dw))
+    vv[0] = 0.0
+    z = rng.uniform(size=(M, Dz)) if Dz else None
+    Rinv, ry = eng.tensor(st['Rinv']), eng.tensor(st['Rinv_y'])
+    W, Wg = X[:, :Dw], (eng.tensor(X[:, Dw:]) if Dz else None)
+    dm, dv, dz = eng.tensor(mm), eng.tensor(vv), (eng.tensor(z) if Dz else None)
+    m0, v0 = (npy(t) for t in eng.linkgp_predict('matern2.5', dm, dv, dz, eng.tensor(W), Wg, length, Rinv, n, ry, 1.3, nug))
+    cells = eng.linkgp_cells('matern2.5', W, Wg, Rinv, ry)
+    p = cell_order(W)
+    assert sorted(p.tolist()) == list(range(n)) and np.array_equal(npy(cells['W']), W[p])
+    assert np.array_equal(npy(cells['pos'])[p], np.arange(n))
+    m1, v1 = (npy(t) for t in eng.linkgp_predict('matern2.5', dm, dv, dz, cells['W'], cells['Wg'], length, cells['Rinv'], n,
+                                                 cells['ry'], 1.3, nug))
+    close(m1, m0, rtol=1e-9, atol=1e-11)   # (sums of terms up to 1e3 times their total, taken in another order)
+    close(v1, v0, rtol=1e-6, atol=1e-8)
+    os.environ['DGPAMD_JSEP_NOCLASS'] = '1'
+    try:
+        m2, v2 = (npy(t) for t in eng.linkgp_predict('matern2.5', dm, dv, dz, cells['W'], cells['Wg'], length, cells['Rinv'], n,
+                                                     cells['ry'], 1.3, nug))
+    finally:
+        del os.environ['DGPAMD_JSEP_NOCLASS']
+    close(m2, m1, rtol=1e-13, atol=1e-14)   # (the mean does not pass through the pair kernel)
+    close(v2, v1, rtol=1e-6, atol=1e-8)
+    lmr, lvr = O.link_gp_predict(mm, vv, z, W, X[:, Dw:] if Dz else None, st['Rinv'], st['Rinv_y'], 1.3, length, nug, 'matern2.5')
+    close(m1, lmr, rtol=1e-8, atol=1e-10)
+    close(v1, lvr, rtol=1e-5, atol=1e-7)   # (random outputs, test points outside the data: variances of 10 x scale from sums 1e4 times larger)
+    # leave-one-out: test row t drops training point t % n, in either order
+    Ml = min(M, n)
+    d0 = torch.arange(Ml, device='cuda', dtype=torch.int32)
+    a0 = eng.linkgp_predict('matern2.5', dm[:Ml], dv[:Ml], None if dz is None else dz[:Ml], eng.tensor(W), Wg, length, Rinv, n, ry, 1.3, nug, drop=d0)
+    a1 = eng.linkgp_predict('matern2.5', dm[:Ml], dv[:Ml], None if dz is None else dz[:Ml], cells['W'], cells['Wg'], length, cells['Rinv'], n,
+                            cells['ry'], 1.3, nug, drop=cells['pos'][:Ml].contiguous())
+    close(npy(a1[0]), npy(a0[0]), rtol=1e-8, atol=1e-10)
+    close(npy(a1[1]), npy(a0[1]), rtol=1e-5, atol=1e-7)

@@ -533,3 +533,35 @@ def test_llik_finish_scalar_path_is_bit_identical():
         fb, gb = ns['_llik_finish'](b, host)
         assert np.array_equal(np.ravel(fa), np.ravel(fb)) and np.array_equal(np.ravel(ga), np.ravel(gb))
         assert np.array_equal(np.ravel(a.scale), np.ravel(b.scale))
+
+
+def test_cell_order_groups_rows_into_separated_cells():
+    """ops.cell_order (the order the emulator hands a linked Matern node's training points to the pair kernel in): a
+    permutation; every part produced by a split is aligned to 64 rows while larger than a block and to 16 below; two parts
+    separated by a split in coordinate k satisfy max <= min in that coordinate (what linkgp_Jsep_kernel's class bounds test);
+    with D coordinates in turn about half of the (16-row cell, 64-row block, coordinate) triples are separated at n = 2000, D = 5."""
+    import importlib
+    ops_src = open(os.path.join(ROOT, 'dgp_amd', 'ops.py')).read()
+    ns = {'np': np}
+    start = ops_src.index('def cell_order(')
+    end = ops_src.index('\n\n\n', start)
+    exec(ops_src[start:end], ns)   # (the function alone: importing dgp_amd.ops needs the HIP library)
+    cell_order = ns['cell_order']
+    rng = np.random.default_rng(3)
+    for n, D in [(2000, 5), (1990, 5), (70, 2), (16, 3), (17, 3), (130, 1), (5000, 10)]:
+        W = rng.normal(size=(n, D))
+        W[: n // 4, 0] = np.round(W[: n // 4, 0], 1)   # ties
+        p = cell_order(W)
+        assert sorted(p.tolist()) == list(range(n))
+        Wp = W[p]
+        if n > 64:   # the first split is in coordinate 0, at a multiple of 64 rows
+            left = 64 * max(1, int(round(n / 128.0)))
+            assert Wp[:left, 0].max() <= Wp[left:, 0].min()
+        if (n, D) == (2000, 5):
+            nb, nc = (n + 63) // 64, (n + 15) // 16
+            blo = np.array([Wp[64 * b:64 * b + 64].min(0) for b in range(nb)]); bhi = np.array([Wp[64 * b:64 * b + 64].max(0) for b in range(nb)])
+            clo = np.array([Wp[16 * c:16 * c + 16].min(0) for c in range(nc)]); chi = np.array([Wp[16 * c:16 * c + 16].max(0) for c in range(nc)])
+            sep = (chi[:, None, :] <= blo[None, :, :]) | (clo[:, None, :] > bhi[None, :, :])
+            lower = (np.arange(nc)[:, None] // 4) > np.arange(nb)[None, :]   # cells of block rows strictly below the diagonal
+            frac = sep[lower].mean()
+            assert 0.42 < frac < 0.6, frac
