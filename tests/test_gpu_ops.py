@@ -969,3 +969,42 @@ def test_linkgp_order_classes_equal_any_order(eng, n, M, Dw, Dz):
                             cells['ry'], 1.3, nug, drop=cells['pos'][:Ml].contiguous())
     close(npy(a1[0]), npy(a0[0]), rtol=1e-8, atol=1e-10)
     close(npy(a1[1]), npy(a0[1]), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['sexp', 'matern2.5'])
+@pytest.mark.parametrize('D,pm', [(3, 10), (8, 50), (12, 51), (8, 25)])
+def test_vecchia_gp_register_kernel_equals_lds_kernel(eng, name, D, pm):
+    """gp_vecch (vecchia.py:635-654) through the register-resident kernel (one row of the conditioning block per lane,
+    readlane broadcasts, no LDS) and through the one-wave-per-point LDS kernel it replaces (DGPAMD_VECCHIA_LDS=1): the same
+    means and variances; conditioning sets shorter than pm (trailing -1 entries), a test-point count off the four-per-
+    workgroup grid, replicate weights on the nugget, anisotropic lengthscales; a few points against the oracle."""
+    import os
+    import torch
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(5 + D)
+    n, M = 1500, 1001
+    X = rng.uniform(size=(n, D))
+    y = np.sin(X.sum(1)) + 0.1 * rng.normal(size=n)
+    xq = rng.uniform(size=(M, D))
+    length = rng.uniform(0.5, 1.5, size=D)
+    nd = rng.uniform(0.5, 2.0, size=n)
+    dX, dq = eng.tensor(X), eng.tensor(xq)
+    NN = eng.nn_query(eng.tensor(xq / length), eng.tensor(X / length), pm).clone()
+    short = rng.integers(0, M, 40)
+    for i, t in enumerate(short):   # shorter sets: the valid entries come first
+        NN[t, max(1, pm - 1 - i % pm):] = -1
+    args = (name, dq, dX, NN, eng.tensor(y), 1.7, length, 1e-3, eng.tensor(nd))
+    m1, v1 = (npy(t) for t in eng.vecchia_gp(*args))
+    os.environ['DGPAMD_VECCHIA_LDS'] = '1'
+    try:
+        m0, v0 = (npy(t) for t in eng.vecchia_gp(*args))
+    finally:
+        del os.environ['DGPAMD_VECCHIA_LDS']
+    assert np.all(np.isfinite(m1)) and np.all(v1 > 0)
+    close(m1, m0, rtol=1e-9, atol=1e-11)
+    close(v1, v0, rtol=1e-8, atol=1e-11)
+    NNh = npy(NN).astype(int)
+    pick = np.array(list(short[:4]) + [0, 1, M - 1])
+    mo, vo = O.gp_vecch(xq[pick], X, NNh[pick], y, 1.7, length, 1e-3, nd, name)
+    close(m1[pick], mo, rtol=1e-8, atol=1e-10)
+    close(v1[pick], vo, rtol=1e-7, atol=1e-10)
