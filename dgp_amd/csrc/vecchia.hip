@@ -7,6 +7,7 @@
 // device (multi-pass selection in (distance, index) order -> deterministic).
 #include "common.hpp"
 #include "linkfun.hpp"
+#include "vecchia_pred.hpp"
 
 #include <math.h>
 #include <utility>
@@ -19,11 +20,6 @@ __device__ __forceinline__ double wsum(double v) {
     return __shfl(v, 0, 64);
 }
 
-struct VParams {
-    int kind, D, nlen;
-    double inv_len[DGPAMD_MAXD];
-    double nugget;
-};
 
 static int fill_vparams(dgpamd_ctx *ctx, VParams &p, int kind, int D, const double *length_h, int nlen, double nugget) {
     if (kind != DGPAMD_SEXP && kind != DGPAMD_MATERN25) BAD_ARG(ctx, "kind must be 0 or 1");
@@ -1789,15 +1785,6 @@ extern "C" int dgpamd_vecchia_spsolve_levels(dgpamd_ctx *ctx, int64_t n, int m, 
 // ---------------------------------------------------------------------------
 // a22  gp_vecch (vecchia.py:635-654): block = [pm neighbours ; test point], rhs row y
 // ---------------------------------------------------------------------------
-struct VGpArgs {
-    VParams vp;
-    int64_t M, n;
-    int pm;
-    const double *x, *w, *y, *nugget_diag;
-    const int64_t *NN;
-    double scale;
-    double *mean, *var;
-};
 
 template <int KIND>
 __global__ __launch_bounds__(VW) void vecchia_gp_kernel(VGpArgs a) {
@@ -1837,106 +1824,6 @@ __global__ __launch_bounds__(VW) void vecchia_gp_kernel(VGpArgs a) {
     }
 }
 
-// The same prediction with the block in REGISTERS (pm <= VG_BC, D <= 16): one wave per test point, one ROW of the
-// (b + 2) x (b + 1) block [neighbours ; test point ; y] per lane -- lane r holds row r's b neighbour columns in reg[] and the
-// test point's column in `last`.  A column of the block is built by broadcasting point c's scaled coordinates from lane c
-// (v_readlane: an SGPR operand for every lane) and evaluating the correlation in all lanes at once; pivot j's elimination
-// broadcasts row j entry by entry the same way: reg[c] -= (reg[j] / d_j) * A[j][c] for the rows below j.  No LDS, no barrier,
-// no dependent LDS round trips; four test points per workgroup.  (LDL^T without square roots: the Schur complement of the test
-// point and the eliminated y row are the same numbers as with gp_vecch's Cholesky, vecchia.py:635-654.)  The LDS kernel above
-// ran one wave per point at 3-6 workgroups per CU on chains of dependent LDS reads: 8.3 ms per 100 000 points at pm = 50, D = 8.
-#define VG_BC 51
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ double rcp_newton(double d) {
-    double x = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
-    e = fma(-d, x, 1.0);
-    return fma(x, e, x);
-}
-template <int KIND, int DM>
-__global__ __launch_bounds__(256) void vecchia_gp_reg_kernel(VGpArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= a.M) return;   // (wave-uniform)
-    const int pm = a.pm, D = a.vp.D;
-    const int64_t nnv = lane < pm ? a.NN[t * pm + lane] : -1;
-    const int b = __builtin_amdgcn_readfirstlane(__popcll(__ballot(nnv >= 0)));   // the valid neighbours come first
-    const int bb = b + 1;
-    double xr[DM];
-    {
-        const double *src = lane < b ? a.w + nnv * D : a.x + t * D;
-#pragma unroll
-        for (int d = 0; d < DM; ++d) xr[d] = (d < D && lane <= b) ? src[d] * a.vp.inv_len[d] : 0.0;
-    }
-    const double yv = lane < b ? a.y[nnv] : 0.0;
-    const double dg = 1.0 + a.vp.nugget * (lane < b ? a.nugget_diag[nnv] : 1.0);
-    auto column = [&](int c) {   // column c of the block for every row at once
-        double s = 0.0, pr = 1.0;
-#pragma unroll
-        for (int d = 0; d < DM; ++d) {
-            const double df = xr[d] - readlane_f64(xr[d], c);
-            if (KIND == DGPAMD_SEXP)
-                corr_accum_sexp(df, s);
-            else
-                corr_accum_matern(df, pr, s);
-        }
-        double v = (KIND == DGPAMD_SEXP) ? exp_negated(s) : pr * exp_negated(SQRT5 * s);
-        v = lane == c ? dg : v;
-        return lane == bb ? readlane_f64(yv, c) : v;   // (the y row; yv is 0 in the test point's lane)
-    };
-    // (static_for: every reg[] index is a compile-time constant -- left to `#pragma unroll` the compiler keeps the loops and the
-    //  array goes to scratch)
-    double reg[VG_BC];
-    static_for<0, VG_BC>([&](auto ic) {
-        constexpr int c = decltype(ic)::value;
-        reg[c] = 0.0;
-        if (c < b) reg[c] = column(c);
-    });
-    double last = column(b);
-    // elimination of the b neighbour columns (columns beyond b hold zeros and stay zero: skipped in groups of eight)
-    static_for<0, VG_BC>([&](auto ij) {
-        constexpr int j = decltype(ij)::value;
-        if (j < b) {
-            const double rd = rcp_newton(readlane_f64(reg[j], j));
-            const double mi = lane > j ? reg[j] * rd : 0.0;
-            static_for<(j + 1) / 8, (VG_BC + 7) / 8>([&](auto ig) {
-                constexpr int c0 = 8 * decltype(ig)::value;
-                if (c0 < b) {
-                    static_for<0, 8>([&](auto iq) {
-                        constexpr int c = c0 + decltype(iq)::value;
-                        if constexpr (c > j && c < VG_BC) reg[c] = fma(-mi, readlane_f64(reg[c], j), reg[c]);
-                    });
-                }
-            });
-            last = fma(-mi, readlane_f64(last, j), last);
-        }
-    });
-    const double var = readlane_f64(last, b), mean = readlane_f64(last, bb);
-    if (lane == 0) {
-        a.mean[t] = -mean;
-        a.var[t] = a.scale * var;
-    }
-}
-
-template <int KIND>
-static void launch_vgp_reg(dgpamd_ctx *ctx, const VGpArgs &a) {
-    const unsigned grid = (unsigned)((a.M + 3) / 4);
-    if (a.vp.D <= 8)
-        hipLaunchKernelGGL((vecchia_gp_reg_kernel<KIND, 8>), dim3(grid), dim3(256), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((vecchia_gp_reg_kernel<KIND, 16>), dim3(grid), dim3(256), 0, ctx->stream, a);
-}
-
 extern "C" int dgpamd_vecchia_gp(dgpamd_ctx *ctx, int kind, int64_t M, int64_t n, int D, int pm, const double *x,
                                  const double *w, const int64_t *NN, const double *y, double scale,
                                  const double *length_h, int nlen, double nugget, const double *nugget_diag,
@@ -1951,10 +1838,7 @@ extern "C" int dgpamd_vecchia_gp(dgpamd_ctx *ctx, int kind, int64_t M, int64_t n
     {
         const char *env = getenv("DGPAMD_VECCHIA_LDS");   // (1: the LDS version for every size -- the tests compare the two)
         if (pm <= VG_BC && D <= 16 && !(env && atoi(env))) {
-            if (kind == DGPAMD_SEXP)
-                launch_vgp_reg<DGPAMD_SEXP>(ctx, a);
-            else
-                launch_vgp_reg<DGPAMD_MATERN25>(ctx, a);
+            launch_vecchia_gp_reg(ctx, a);
             LAUNCH_CHECK(ctx);
             return DGPAMD_OK;
         }
@@ -1979,15 +1863,6 @@ extern "C" int dgpamd_vecchia_gp(dgpamd_ctx *ctx, int kind, int64_t M, int64_t n
 // a23  link_gp_vecch (vecchia.py:758-796) with IJ_nb (vecchia.py:838-907)
 // ---------------------------------------------------------------------------
 
-struct VLinkArgs {
-    int kind, Dw, Dz, pm;
-    int64_t M, n;
-    const double *m, *v, *z, *w1, *wg, *y, *nugget_diag;
-    const int64_t *NN;
-    double len[DGPAMD_MAXD];
-    double scale, nugget;
-    double *mean, *var;
-};
 
 template <int KIND>
 __global__ __launch_bounds__(VW) void vecchia_linkgp_kernel(VLinkArgs a) {
@@ -2145,6 +2020,14 @@ extern "C" int dgpamd_vecchia_linkgp(dgpamd_ctx *ctx, int kind, int64_t M, int64
     a.kind = kind; a.Dw = Dw; a.Dz = Dz; a.pm = pm; a.M = M; a.n = n; a.m = m; a.v = v; a.z = z; a.w1 = w1; a.wg = wg;
     a.y = y; a.nugget_diag = nugget_diag; a.NN = NN; a.scale = scale; a.nugget = nugget; a.mean = mean; a.var = var;
     for (int d = 0; d < Dw + Dz; ++d) a.len[d] = length_h[nlen == 1 ? 0 : d];
+    {
+        const char *env = getenv("DGPAMD_VECCHIA_LDS");   // (1: the LDS version for every size -- the tests compare the two)
+        if (kind == DGPAMD_SEXP && pm <= VL_BC && Dw <= 8 && Dz <= 8 && !(env && atoi(env))) {
+            launch_vecchia_linkgp_sexp_reg(ctx, a);
+            LAUNCH_CHECK(ctx);
+            return DGPAMD_OK;
+        }
+    }
     const int lda = pm + 2;
     const size_t shm = ((size_t)(pm + 1) * lda + (size_t)pm * lda + (size_t)pm * (Dw + Dz) + pm + lda) * sizeof(double) +
                        (size_t)pm * sizeof(int);
