@@ -40,6 +40,15 @@ head -12 "$O/pmc_bench_potrf_kernel.json"
   timeout 120 python3 tools/gpu_cfg4_phases.py 2>&1 | tail -14
 } > "$O/cfg4_vecchia.txt"
 cat "$O/cfg4_vecchia.txt"
+{
+  echo "## python3 tools/gpu_vecchia_pred_bench.py"
+  timeout 300 python3 tools/gpu_vecchia_pred_bench.py 2>&1 | tail -3
+  echo "## ITERS=3 MPRED=100000 rocprofv3 --kernel-trace --stats -- python3 tools/gpu_scale_probe.py cfg4train ; tools/kernel_stats_top.py (training of 3 iterations + prediction)"
+  ITERS=3 MPRED=100000 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cfg4pred -- python3 tools/gpu_scale_probe.py cfg4train > /tmp/cfg4pred.log 2>&1
+  grep predict /tmp/cfg4pred.log
+  python3 tools/kernel_stats_top.py /tmp/cfg4pred 12
+} > "$O/cfg4_predict_kernels.txt" 2>&1
+cat "$O/cfg4_predict_kernels.txt"
 TRAIN_ONLY=1 ITERS=40 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cfg4prof -- python3 tools/gpu_scale_probe.py cfg4train > "$O/cfg4_prof.log" 2>&1
 {
   echo "## TRAIN_ONLY=1 ITERS=40 rocprofv3 --kernel-trace --stats -- python3 tools/gpu_scale_probe.py cfg4train ; tools/kernel_stats_top.py, tools/analyze_gaps.py (second half of the trace)"
