@@ -268,3 +268,41 @@ def test_cfg5_chain_at_full_size_vs_oracle_walk(eng):
     assert mu[0].shape == (M, 1) and np.all(np.isfinite(mu[0])) and np.all(var[0] > -1e-10)
     close(mu[0][:K, 0], m3, rtol=1e-6, atol=1e-8)
     close(var[0][:K, 0], v3, rtol=1e-5, atol=1e-7)
+
+
+def test_cfg4_vecchia_prediction_at_full_size_vs_oracle(eng):
+    """cfg4's prediction kernels at their own size (n = 50 000 training points, 50 neighbours, 20 000 test points): gp_vecch
+    (vecchia.py:635-654, D = 8) and link_gp_vecch (:758-796, Dw = Dz = 8, squared exponential) through the register-resident
+    kernels, twelve test points spread over the launch against the oracle's per-point Cholesky, the neighbour rows of those
+    points against brute force; every output finite and the variances positive."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(404)
+    n, M, pm = 50000, 20000, 50
+    X = rng.uniform(size=(n, 8))
+    W = np.sin(3 * X) + 0.1 * rng.normal(size=(n, 8))
+    y = np.sin(X.sum(1)) + 0.05 * rng.normal(size=n)
+    xq = rng.uniform(size=(M, 8))
+    mm = np.sin(3 * xq) + 0.02 * rng.normal(size=(M, 8))
+    vv = rng.uniform(0.001, 0.05, size=(M, 8))
+    ones = np.ones(n)
+    l1, l2 = np.array([0.6]), np.array([1.5])
+    NN1 = eng.nn_query(eng.tensor(xq / l1), eng.tensor(X / l1), pm)
+    A2, Q2 = np.concatenate((W, X), 1), np.concatenate((mm, xq), 1)
+    NN2 = eng.nn_query(eng.tensor(Q2 / l2), eng.tensor(A2 / l2), pm)
+    gm, gv = (npy(t) for t in eng.vecchia_gp('sexp', eng.tensor(xq), eng.tensor(X), NN1, eng.tensor(y), 1.2, l1, 1e-4, eng.tensor(ones)))
+    lm, lv = (npy(t) for t in eng.vecchia_linkgp('sexp', eng.tensor(mm), eng.tensor(vv), eng.tensor(xq), eng.tensor(W), eng.tensor(X), NN2,
+                                                 eng.tensor(y), 1.2, l2, 1e-4, eng.tensor(ones)))
+    assert np.all(np.isfinite(gm)) and np.all(gv > 0) and np.all(np.isfinite(lm)) and np.all(lv >= 0)
+    pick = np.array([0, 1, 2, 3, 777, 5000, 9999, 10001, 15000, 19997, 19998, 19999])
+    N1, N2 = npy(NN1).astype(int)[pick], npy(NN2).astype(int)[pick]
+    for i, t in enumerate(pick):   # the neighbour rows: brute force, nearest first
+        d = ((X - xq[t]) ** 2).sum(1)
+        assert set(N1[i].tolist()) == set(np.argsort(d, kind='stable')[:pm].tolist())
+        d = ((A2 - Q2[t]) ** 2).sum(1)
+        assert set(N2[i].tolist()) == set(np.argsort(d, kind='stable')[:pm].tolist())
+    mo, vo = O.gp_vecch(xq[pick], X, N1, y, 1.2, l1, 1e-4, ones, 'sexp')
+    close(gm[pick], mo, rtol=1e-8, atol=1e-10)
+    close(gv[pick], vo, rtol=1e-6, atol=1e-10)
+    mo, vo = O.link_gp_vecch(mm[pick], vv[pick], xq[pick], W, X, N2, y, 1.2, l2, 1e-4, ones, 'sexp')
+    close(lm[pick], mo, rtol=1e-8, atol=1e-10)
+    close(lv[pick], vo, rtol=1e-6, atol=1e-9)
