@@ -648,6 +648,11 @@ class kernel:
                                       self.nugget[0], e.tensor(nd))
         else:
             st = self._stats
-            mo, vo = e.linkgp_predict(self.name, e.tensor(mm), e.tensor(vv), zt, e.tensor(W), Wgt, self.length, st['Rinv'],
-                                      st['ld'], st['ry'], self.scale[0], self.nugget[0])
+            hit = st.get('link_full')   # (Matern: the training points grouped by cells of the widened local input, built once)
+            if hit is None or hit[0] != nz:
+                cells = e.linkgp_cells(self.name, W, Wgt, st['Rinv'], st['ry'])
+                hit = st['link_full'] = (nz, cells if cells is not None else dict(W=e.tensor(W), Wg=Wgt, Rinv=st['Rinv'], ry=st['ry']))
+            c = hit[1]
+            mo, vo = e.linkgp_predict(self.name, e.tensor(mm), e.tensor(vv), zt, c['W'], c['Wg'], self.length, c['Rinv'],
+                                      st['ld'], c['ry'], self.scale[0], self.nugget[0])
         return mo.cpu().numpy(), vo.cpu().numpy()
