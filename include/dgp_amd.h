@@ -419,7 +419,11 @@ int dgpamd_vecchia_het_rows(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, 
                             const double *gamma, const double *y, double *Lrows, int64_t *NNl, double *t, int32_t *info);
 
 /* ---- a22/a23  Vecchia prediction -------------------------------------------------
- * gp_vecch vecchia.py:635-654 ; link_gp_vecch :758-796 (IJ_nb :838-907).          */
+ * gp_vecch vecchia.py:635-654 ; link_gp_vecch :758-796 (IJ_nb :838-907).
+ * NN: (M x pm) conditioning sets, the valid entries first, -1 padded.  Up to 51 (gp; D <= 16) resp. 50 (link_gp, squared
+ * exponential, Dw <= 8, Dz <= 8) neighbours run in the register-resident kernels (csrc/vecchia_pred.hip: one wave per test
+ * point, no LDS); larger sets, wider inputs and the Matern link_gp in the one-wave-per-point LDS kernels (conditioning
+ * sets up to what fits 160 KiB of LDS).  DGPAMD_VECCHIA_LDS=1 selects the LDS kernels throughout (the tests compare the two). */
 int dgpamd_vecchia_gp(dgpamd_ctx *ctx, int kind, int64_t M, int64_t n, int D, int pm, const double *x,
                       const double *w, const int64_t *NN, const double *y, double scale,
                       const double *length_h, int nlen, double nugget, const double *nugget_diag,
