@@ -63,8 +63,10 @@ head -8 "$O/cfg4_train_kernel_stats.txt"
   timeout 200 python3 tools/gpu_linkgp_bench.py sexp 5000 10 10 2048 2>&1 | tail -2
   echo "## DGPAMD_SEXP_FORM1=1 ...   (round 2's kernel with the full-rate exp)"
   DGPAMD_SEXP_FORM1=1 timeout 200 python3 tools/gpu_linkgp_bench.py sexp 5000 10 10 2048 2>&1 | tail -2
-  echo "## python3 tools/gpu_linkgp_bench.py matern2.5 2000 5 5 4096"
+  echo "## python3 tools/gpu_linkgp_bench.py matern2.5 2000 5 5 4096   (training points in the caller's order: every step mixed)"
   CHECK=0 timeout 200 python3 tools/gpu_linkgp_bench.py matern2.5 2000 5 5 4096 2>&1 | tail -1
+  echo "## ORDER=1 ...   (training points grouped by cells, as the emulator hands them over: order classes)"
+  ORDER=1 CHECK=0 timeout 200 python3 tools/gpu_linkgp_bench.py matern2.5 2000 5 5 4096 2>&1 | tail -1
   echo "## python3 tools/gpu_kmatrix_bench.py"
   timeout 200 python3 tools/gpu_kmatrix_bench.py 2>&1 | tail -17
 } > "$O/pair_kernels.txt"
