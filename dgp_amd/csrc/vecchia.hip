@@ -391,7 +391,8 @@ __device__ __forceinline__ void topk_insert(double (&ld)[K], int (&li)[K], doubl
     }
 }
 
-#define NN_PEND 8   // accepted candidates a lane may hold back before the wave merges them into the sorted lists
+#define NN_PEND 16   // accepted candidates a lane may hold back before the wave merges them into the sorted lists (8: 15 % slower in the query form -- the
+                     // passes of a flush are as many as the fullest lane holds, mostly empty for the others; 32: the ordered search loses occupancy to the 24 KB of notes)
 
 template <int DMAX, int K>
 __global__ __launch_bounds__(64) void nn_scan_kernel(int64_t nq, int64_t nx, int D, const double *__restrict__ q,
@@ -426,10 +427,13 @@ __global__ __launch_bounds__(64) void nn_scan_kernel(int64_t nq, int64_t nx, int
     double tau = INFINITY;
     int cnt = 0;
     auto flush = [&]() {
-#pragma unroll
+        // (a LOOP over the passes: unrolled, the NN_PEND copies of the K-step insertion are 40 KB of code per call site, more
+        //  than the instruction cache holds, and the waves -- each at another point of it -- ran at the speed of its misses)
+#pragma unroll 1
         for (int p = 0; p < NN_PEND; ++p) {
             const bool have = p < cnt;
-            if (__any(have)) topk_insert<K>(ld, li, have ? pend_d[p * 64 + lane] : INFINITY, have ? pend_i[p * 64 + lane] : INT_MAX);
+            if (!__any(have)) break;
+            topk_insert<K>(ld, li, have ? pend_d[p * 64 + lane] : INFINITY, have ? pend_i[p * 64 + lane] : INT_MAX);
         }
         cnt = 0;
         tau = ld[K - 1];
