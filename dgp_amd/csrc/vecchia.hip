@@ -490,6 +490,7 @@ __global__ __launch_bounds__(64) void nn_merge_kernel(int64_t nq, int64_t nx, in
     }
     for (int c = 1; c < nch; ++c) {
         const int64_t item = qb * nchunk + c;
+#pragma unroll 1   // (unrolled this was K copies of the K-step insertion: 137 KB of code at K = 51)
         for (int t = 0; t < K; ++t) {
             const double cd = sd[(item * K + t) * 64 + lane];
             const int ci = si[(item * K + t) * 64 + lane];
