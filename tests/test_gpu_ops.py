@@ -996,10 +996,11 @@ def test_vecchia_gp_register_kernel_equals_lds_kernel(eng, name, D, pm):
     args = (name, dq, dX, NN, eng.tensor(y), 1.7, length, 1e-3, eng.tensor(nd))
     m1, v1 = (npy(t) for t in eng.vecchia_gp(*args))
     os.environ['DGPAMD_VECCHIA_LDS'] = '1'
+    os.environ['DGPAMD_POISON_LDS'] = '1'   # (every CU's LDS filled with NaNs before the LDS kernel's launch)
     try:
         m0, v0 = (npy(t) for t in eng.vecchia_gp(*args))
     finally:
-        del os.environ['DGPAMD_VECCHIA_LDS']
+        del os.environ['DGPAMD_VECCHIA_LDS'], os.environ['DGPAMD_POISON_LDS']
     assert np.all(np.isfinite(m1)) and np.all(v1 > 0)
     close(m1, m0, rtol=1e-9, atol=1e-11)
     close(v1, v0, rtol=1e-8, atol=1e-11)
@@ -1040,10 +1041,11 @@ def test_vecchia_linkgp_register_kernel_equals_lds_kernel(eng, Dw, Dz, pm):
             eng.tensor(y), 1.4, length, 1e-3, eng.tensor(nd))
     m1, v1 = (npy(t) for t in eng.vecchia_linkgp(*args))
     os.environ['DGPAMD_VECCHIA_LDS'] = '1'
+    os.environ['DGPAMD_POISON_LDS'] = '1'   # (every CU's LDS filled with NaNs before the LDS kernel's launch)
     try:
         m0, v0 = (npy(t) for t in eng.vecchia_linkgp(*args))
     finally:
-        del os.environ['DGPAMD_VECCHIA_LDS']
+        del os.environ['DGPAMD_VECCHIA_LDS'], os.environ['DGPAMD_POISON_LDS']
     assert np.all(np.isfinite(m1)) and np.all(np.isfinite(v1))
     close(m1, m0, rtol=1e-9, atol=1e-11)
     close(v1, v0, rtol=1e-7, atol=1e-10)
