@@ -571,8 +571,12 @@ class imputer:
         n = 50 000) and a queued batch costs no host round trip, so narrow batches waste fewer candidates: 6, then 3, five
         queued (cfg4 I-step 50 -> 40 ms; profiles/r03_cfg4_vecchia.txt).  Explicit settings of the caller are kept."""
         upper = self.all_layer[l + 1]
-        if all(nd.type == 'gp' and nd.vecch for nd in upper) and self._batch_default and self.batch == 12 and self.batch_next == 4 \
-                and self.queue_max_batches == 2:
+        default = self._batch_default and self.batch == 12 and self.batch_next == 4 and self.queue_max_batches == 2
+        if default and all(nd.type == 'gp' and nd.vecch for nd in upper):
+            return 6, 3, 5
+        # dense nodes of cfg3's size: a candidate's factorisation (n^3 / 3 at the engine's ~45 TFLOP/s: 0.9 ms at n = 5000) costs as
+        # much as the whole pivot chain (n / 64 steps of 15 us), so wasted candidates are no longer free: 1.29 -> 1.41 SI it/s
+        if default and all(nd.type == 'gp' for nd in upper) and self.F[l].shape[0] >= 4000:
             return 6, 3, 5
         return self.batch, int(self.batch_next) if self.batch_next else self.batch, self.queue_max_batches
 

@@ -24,8 +24,15 @@ if which == 'cfg3':
     t = time.perf_counter()
     model = dgp(X, Y, seed=1)          # default structure: d SExp nodes (shared lengthscale) -> q SExp nodes with global connection
     sync(); print('cfg3 n=%d: construct (11 sweeps) %.2f s' % (n, time.perf_counter() - t))
-    t = time.perf_counter(); model.train(N=2, ess_burn=10, disable=True); sync()
-    print('cfg3: 2 SI iterations %.2f s -> %.2f it/s' % (time.perf_counter() - t, 2 / (time.perf_counter() - t)))
+    if os.environ.get('BATCH'):   # (speculative batch sizes of the I-step: first, later, batches queued per update)
+        model.imp.batch, model.imp.batch_next = int(os.environ['BATCH']), int(os.environ.get('BATCH_NEXT', os.environ['BATCH']))
+        model.imp.queue_max_batches = int(os.environ.get('QMAX', '2'))
+        model.imp._batch_default = False
+    its = int(os.environ.get('ITERS', '2'))
+    t = time.perf_counter(); model.train(N=its, ess_burn=10, disable=True); sync()
+    print('cfg3: %d SI iterations %.2f s -> %.2f it/s; stats %s' % (its, time.perf_counter() - t, its / (time.perf_counter() - t), model.imp.stats))
+    if os.environ.get('TRAIN_ONLY'):
+        sys.exit(0)
     S, M = int(os.environ.get('S', '6')), int(os.environ.get('M', '4096'))
     t = time.perf_counter(); emu = emulator(model.estimate(burnin=0), N=S, seed=3); sync()
     print('cfg3: emulator(N=%d) %.2f s' % (S, time.perf_counter() - t))
