@@ -1237,6 +1237,35 @@ def test_queued_ess_equals_host_loop_likelihood_tops(eng, lik, batch):
     assert sq['updates'] > 0 and sq['batches'] >= sq['updates']
 
 
+def test_queued_ess_equals_host_loop_vecchia_under_a_likelihood(eng):
+    """Vecchia GP layers with a count likelihood on top: the queue's three ingredients at once -- sparse prior draws by the
+    level schedule, a Vecchia node upstairs of the first layer, the library's log-density upstairs of the second -- against
+    the host loop: same latents, same counts, same position in the uniform stream."""
+    from dgp_amd import dgp, kernel, combine, Poisson
+    rng = np.random.default_rng(29)
+    n, d = 240, 2
+    X = rng.uniform(size=(n, d))
+    Y = rng.poisson(np.exp(1.0 + np.sin(4 * X[:, 0]) + X[:, 1])).astype(float)[:, None]
+
+    def run(queued):
+        np.random.seed(7)
+        layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                         [kernel(length=np.array([0.9]), name='sexp', scale_est=True, connect=np.arange(d))], [Poisson()])
+        model = dgp(X, Y, layers, seed=3, vecchia=True, m=10)
+        model.imp.batch, model.imp.batch_next, model.imp._batch_default, model.imp.queued = 6, 3, False, queued
+        for _ in range(2):
+            model.imp.sample(burnin=3)
+        F = [np.stack([nd.output[:, 0] for nd in layer], 1) for layer in model.all_layer[:-1]]
+        return F, dict(model.imp.stats), model.imp.draws.uniform_peek(3)
+
+    Fq, sq, uq = run(True)
+    Fh, sh, uh = run(False)
+    for a, b in zip(Fq, Fh):
+        assert np.all(np.isfinite(a))
+        close(a, b, rtol=1e-9, atol=1e-11)
+    assert sq == sh and uq == uh, (sq, sh)
+
+
 def test_mice_var_ghdiag_nllik_match_reference(eng, golden):
     """functions.mice_var / ghdiag (functions.py:233-256) and emulator.nllik (emulation.py:856-914) against values recorded
     from the reference (g22, g23): the smoothed candidate-set variance behind metric('MICE'), the Gauss-Hermite predictive
