@@ -27,10 +27,11 @@ def timed(f):
 
 
 res = {}
+kind = os.environ.get('KIND', 'sexp')
 for lds in ('0', '1'):
     os.environ['DGPAMD_VECCHIA_LDS'] = lds
-    tg, og = timed(lambda: eng.vecchia_gp('sexp', dq, dX, NN1, dy, 1.3, np.ones(1), 1e-4, ones))
-    tl, ol = timed(lambda: eng.vecchia_linkgp('sexp', dm, dv, dq, dW, dX, NN2, dy, 1.3, np.array([2.0]), 1e-4, ones))
+    tg, og = timed(lambda: eng.vecchia_gp(kind, dq, dX, NN1, dy, 1.3, np.ones(1), 1e-4, ones))
+    tl, ol = timed(lambda: eng.vecchia_linkgp(kind, dm, dv, dq, dW, dX, NN2, dy, 1.3, np.array([2.0]), 1e-4, ones))
     res[lds] = (tg, tl, [t.cpu().numpy() for t in og + ol])
     print('%s kernels: gp_vecch %.2f ms, link_gp_vecch %.2f ms per %d points (pm = %d)' % ('LDS     ' if lds == '1' else 'register', tg, tl, M, pm))
 d = [float(np.max(np.abs(a - b) / (np.abs(b) + 1e-300))) for a, b in zip(res['0'][2], res['1'][2])]
