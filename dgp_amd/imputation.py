@@ -454,6 +454,7 @@ class imputer:
                         self.one_sample(l, k)
         self._detach()
 
+    queued_calls = 0        # sample() calls that ran through the device queue (the tests read it)
     queue_max_batches = 2   # speculative batches queued per update (batch, then batch_next): 12 + 4 proposals; an update that
                             # needs more (a few per cent) is finished by the host loop and the rest of the I-step queued anew
 
@@ -494,6 +495,8 @@ class imputer:
             plan.queue(F, nu[first:], scales, us, 0, cur, cur is None, bn, qmax)
             if first == 0:   # the next call's normals: generated by a background thread while this one waits in fetch()
                 self.draws.prefetch(sweeps * M * n, engine=e)   # (started only now: it would fight the launches above for the interpreter)
+            if first == 0:
+                self.queued_calls += 1
             st = plan.fetch()   # the one synchronisation of the queue (of the whole I-step unless an update was left open)
             status, done = int(st['status']), int(st['updates'])
             self.draws.uniform_take(int(st['cursor']))
@@ -712,6 +715,7 @@ class imputer:
             pos += 1
         if nu0 is not None:
             self.draws.prefetch(sweeps * self.F[0].shape[1] * n, engine=e)
+        self.queued_calls += 1
         return True
 
     def _layer_factors(self, l, dense):

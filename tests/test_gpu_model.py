@@ -51,15 +51,17 @@ def build_structure(d, pre, eng):
 @pytest.mark.parametrize('batch', [1, 3, 8])
 def test_ess_trajectory_matches_reference(eng, golden, tag, batch):
     """imputer.sample with the reference's own draws: same accepted latents, and the speculative batches consume
-    exactly the uniforms the sequential sampler consumed.  The two-layer recordings run through the device-resident
-    accept / shrink loop (dgpamd_ess_queue); 'matern200' is n = 200 (four 64-wide tiles per matrix, global input
-    connected: panel / bulk tasks and the flag hand-offs of the factorisation are all on the path)."""
+    exactly the uniforms the sequential sampler consumed.  Every recording runs through the device-resident accept /
+    shrink loop (dgpamd_ess_queue) -- the two-layer ones as one queue per I-step, 'deep' (three layers) layer by layer
+    on one shared device state; 'matern200' is n = 200 (four 64-wide tiles per matrix, global input connected: panel /
+    bulk tasks and the flag hand-offs of the factorisation are all on the path)."""
     from dgp_amd.imputation import imputer, DrawStream
     d = golden('g5_ess_' + tag)
     layers = build_structure(d, 'pre_', eng)
     draws = DrawStream(z=list(d['z']), u=list(d['u']))
     imp = imputer(layers, block=True, draws=draws, engine=eng, batch=batch)
     imp.sample(burnin=1 if tag == 'matern200' else 2)
+    assert imp.queued_calls == 1, 'the replay must have run through the device queue'
     assert draws.exhausted(), 'all logged draws must be consumed, no more and no fewer'
     post = build_structure(d, 'post_', eng)
     for la, lb in zip(layers, post):
