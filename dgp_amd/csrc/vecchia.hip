@@ -662,9 +662,9 @@ __global__ __launch_bounds__(VW) void vecchia_row_kernel(VRowArgs a) {
         xs[e] = a.X[(int64_t)idx[r] * D + d] * a.vp.inv_len[d];
     }
     __syncthreads();
-    for (int e = lane; e < b * b; e += VW) {
-        int r = e / b, c = e - r * b;
-        if (c > r) continue;
+    for (int e = lane; e < b * (b + 1) / 2; e += VW) {   // (the lower triangle only: no idle lanes)
+        int r, c;
+        tri_decode(e, r, c);
         double v;
         if (r == c)
             v = 1.0 + a.vp.nugget * (MODE == V_LMAT ? 1.0 : a.nugget_diag[idx[r]]);
@@ -707,9 +707,10 @@ __global__ __launch_bounds__(VW) void vecchia_row_kernel(VRowArgs a) {
     const double *u = V, *al = V + lda;
     for (int k = 0; k < npl; ++k) {
         double tl = 0.0, s = 0.0;
-        for (int e = lane; e < b * b; e += VW) {
-            int r = e / b, c = e - r * b;
-            if (c >= r) continue;
+        for (int e = lane; e < b * (b - 1) / 2; e += VW) {   // (strictly lower triangle: row r + 1, column c of the decoded pair)
+            int r, c;
+            tri_decode(e, r, c);
+            ++r;
             double kv = corr_pts<KIND>(xs + r * D, xs + c * D, D), cf = 0.0;
             if (a.vp.nlen == 1)
                 for (int d = 0; d < D; ++d) cf += dcoef_v<KIND>(xs[r * D + d] - xs[c * D + d]);
@@ -1365,9 +1366,9 @@ __global__ __launch_bounds__(VW) void vecchia_het_rows_kernel(VHetArgs a) {
         xs[e] = a.X[p * D + d] * a.vp.inv_len[d];
     }
     __syncthreads();
-    for (int e = lane; e < b * b; e += VW) {
-        const int r = e / b, c = e - r * b;
-        if (c > r) continue;
+    for (int e = lane; e < b * (b + 1) / 2; e += VW) {
+        int r, c;
+        tri_decode(e, r, c);
         double v;
         if (r == c)
             v = a.scale + (idx[r] >= n ? 0.0 : a.gamma[idx[r]]) + 1e-10;
@@ -1810,9 +1811,9 @@ __global__ __launch_bounds__(VW) void vecchia_gp_kernel(VGpArgs a) {
     }
     __syncthreads();
     const int bb = b + 1;
-    for (int e = lane; e < bb * bb; e += VW) {
-        int r = e / bb, c = e - r * bb;
-        if (c > r) continue;
+    for (int e = lane; e < bb * (bb + 1) / 2; e += VW) {
+        int r, c;
+        tri_decode(e, r, c);
         double v;
         if (r == c)
             v = 1.0 + a.vp.nugget * (r < b ? a.nugget_diag[idx[r]] : 1.0);
