@@ -222,6 +222,19 @@ def main():
         return orig_finish(self, host)
     kernel_class.kernel._llik_finish = counted
 
+    # ... and the lock-step optimiser rounds of every M-step: the reference's L-BFGS-B runs take between 6 and 45 rounds per
+    # iteration along a training path (the slowest node's evaluations; maxfun = 45), so the work inside K timed steps varies
+    # by +-10 % at K = 20 between builds whose objectives differ in the last bit -- the line reports it beside the rate
+    from dgp_amd import mstep as mstep_mod
+    rounds = {'n': 0}
+    orig_lock = mstep_mod.minimize_lockstep
+
+    def counted_lock(*a, **k):
+        r = orig_lock(*a, **k)
+        rounds['n'] += r
+        return r
+    mstep_mod.minimize_lockstep = counted_lock
+
     def step():
         model.imp.sample(burnin=args.ess_burn)
         model._m_step()
@@ -230,6 +243,7 @@ def main():
     for _ in range(args.warmup):
         step()
     calls['l1'] = calls['l2'] = 0
+    rounds['n'] = 0
     st0 = dict(model.imp.stats)
     dd.barrier()
     torch.cuda.synchronize()
@@ -249,7 +263,8 @@ def main():
     upd = max(1, st1['updates'] - st0['updates'])
     counts = dict(proposals_per_iter=(st1['proposals'] - st0['proposals']) / args.steps,
                   batches_per_update=(st1['batches'] - st0['batches']) / upd,
-                  llik_l1_per_iter=calls['l1'] / args.steps, llik_l2_per_iter=calls['l2'] / args.steps)
+                  llik_l1_per_iter=calls['l1'] / args.steps, llik_l2_per_iter=calls['l2'] / args.steps,
+                  mstep_rounds_per_iter=rounds['n'] / args.steps)
 
     # ---- roofline of the dominant kernel: HIP events around each of its launches, same steps ----
     roof = None
