@@ -77,7 +77,10 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            v[p][q] = (KIND == DGPAMD_SEXP) ? exp_negated(s[p][q]) : pr[p][q] * exp_negated(SQRT5 * s[p][q]);
+            // (the library exp, as the gradient reductions that recompute these entries: csrc/train.hip -- the objective's K and the
+            //  gradient's dK then hold the same bits, and training paths are reproducible against the earlier rounds' runs; the
+            //  full-rate exp_negated of the pair kernels bought nothing here, the kernel's time is its stores)
+            v[p][q] = (KIND == DGPAMD_SEXP) ? exp(-s[p][q]) : pr[p][q] * exp(-SQRT5 * s[p][q]);
     if (bi == bj) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
