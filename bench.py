@@ -272,7 +272,7 @@ def main():
         engines = [eng]
         for e in engines:
             e.prof_enable(args.prof_kernel)
-        for _ in range(max(1, min(4, args.steps))):
+        for _ in range(max(1, min(12, args.steps))):   # (twelve extra steps: an iteration holds 6 to 45 optimiser rounds, four were a noisy sample)
             step()
         tot_n, tot_ms, tot_w = 0, 0.0, 0.0
         for e in engines:
