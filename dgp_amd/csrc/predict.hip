@@ -947,7 +947,7 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
             clo = x < clo ? x : clo;
             chi = x > chi ? x : chi;
         }
-        smode[idx] = (a.no_order_classes & 1) ? 0 : ((a.no_order_classes & 8) ? 1 : (rhi <= clo ? 1 : (rlo > chi ? 2 : 0)));
+        smode[idx] = a.no_order_classes ? 0 : (rhi <= clo ? 1 : (rlo > chi ? 2 : 0));
     }
     __syncthreads();
     // The records of step (t, k) are double buffered in LDS: ONE barrier per step.
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
             __syncthreads();   // records of this step landed (the barrier's wait covers the LDS-DMA); every wave is done with the other buffer
             {   // the next step's records into the other buffer.  Past the end the last step is staged again (harmless).
                 const int s1 = step + 1 < nstep ? step + 1 : nstep - 1;
-                if (!(a.no_order_classes & 2)) stage(s1 / Dw, s1 % Dw, (step & 1) ? PT : PT1);
+                stage(s1 / Dw, s1 % Dw, (step & 1) ? PT : PT1);
             }
             // volatile: keeps these fragment reads as ds_read_b64 (2 LDS cycles, 64 banks: conflict-free with PST = 30); merged
             // into ds_read2_b64 by the compiler they take 8 cycles and bank modulo 32 (2-way conflicts here)
@@ -1210,7 +1210,7 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
                 hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_MATERN25, false>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else {
                 const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)TCH * Dz + TCH * 4 + 2 * 128 * PST) * sizeof(double) + (size_t)Dw * 4 * sizeof(int);
-                a.no_order_classes = getenv("DGPAMD_JSEP_NOCLASS") ? atoi(getenv("DGPAMD_JSEP_NOCLASS")) : 0;
+                a.no_order_classes = getenv("DGPAMD_JSEP_NOCLASS") ? 1 : 0;
                 if (shm_sep > 48 * 1024)
                     HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_sep));
                 hipLaunchKernelGGL(matern_records_kernel, dim3((unsigned)((a.npad + 127) / 128), Dw, (unsigned)mc), dim3(256), 0, ctx->stream, a);
