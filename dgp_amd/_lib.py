@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdgp_amd.so')
+# (DGPAMD_LIB: another build of the same library, for same-box A/B timing of kernel variants by the tools)
+LIB_PATH = os.environ.get('DGPAMD_LIB') or os.path.join(_HERE, 'libdgp_amd.so')
 
 OK, NOT_PD, BAD_ARG, HIP_ERROR = 0, 1, 2, 3
 SEXP, MATERN25 = 0, 1

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(GemmArgs g) {
 // Deadlock freedom: only SOLVE / TDIAG workgroups and the placeholders wait, and only for the chain workgroup of the SAME launch, which
 // has a lower block index (dispatched first) and never waits itself.  The spin is bounded (info = -1).
 // ----------------------------------------------------------------------------
-enum { T_STORE = 0, T_SOLVE = 1, T_CHAIN = 2, T_TDIAG = 3 };
+enum { T_STORE = 0, T_SOLVE = 1, T_CHAIN = 2, T_TDIAG = 3, T_LOOK = 4, T_LOOKD = 5 };
 enum { BUF_A = 0, BUF_T = 1, BUF_S = 2 };
 
 struct StepArgs {
@@ -333,14 +333,19 @@ __device__ __forceinline__ void diag_update_cb(d4 (&acc)[4], const double *C, co
         }
     }
 }
-// out += sign * in * Bg^T   (in: accumulator-layout 64x64 tile, Bg: 64x64 row-major tile in global memory).  Both
-// halves of Bg are requested up front: one exposed load latency instead of two on the panel's critical path.
+// out += in * Bg^T   (in: accumulator-layout 64x64 tile, Bg: 64x64 row-major LOWER-TRIANGULAR tile in global memory: the
+// inverse W_k of a diagonal block's factor).  Both halves of Bg are requested up front: one exposed load latency instead
+// of two on the panel's critical path.  Column tile t of the product takes the 16-blocks kb <= t of the sum only (40
+// instead of 64 MFMAs per wave: the blocks above W_k's diagonal are exact zeros, and the f64 MFMA runs at the vector
+// rate on gfx950, so the skipped zeros are time).
 template <bool SC1 = false>
-__device__ __forceinline__ void mul_acc_bt(d4 (&out)[4], const d4 (&in)[4], const double *Bg, int64_t ldb, double sign,
+__device__ __forceinline__ void mul_acc_bt(d4 (&out)[4], const d4 (&in)[4], const double *Bg, int64_t ldb,
                                            double *As, double *Bs, int tid, int wave, int lane) {
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
     const HalfTile b0 = SC1 ? fetch_mk_sc1(Bg, ldb, tid, 0) : fetch_mk(Bg, ldb, tid, 0);
     const HalfTile b1 = SC1 ? fetch_mk_sc1(Bg, ldb, tid, 1) : fetch_mk(Bg, ldb, tid, 1);
+    const vlds_double *Ap = (const vlds_double *)As, *Bp = (const vlds_double *)Bs;
+    const int m = lane & 15, kk = lane >> 4;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
@@ -350,7 +355,14 @@ __device__ __forceinline__ void mul_acc_bt(d4 (&out)[4], const d4 (&in)[4], cons
             for (int r = 0; r < 4; ++r) As[(crow + 4 * r) * LDM + 16 * t + ccol] = in[2 * h + t][r];
         commit_mk(h == 0 ? b0 : b1, Bs, tid);
         __syncthreads();
-        mfma_tile<OP_MK, OP_MK>(As, Bs, out, wave, lane, sign);
+#pragma unroll
+        for (int k0 = 0; k0 < KC; k0 += 4) {
+            const int kb = 2 * h + (k0 >> 4);
+            const double av = Ap[(16 * wave + m) * LDM + k0 + kk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t >= kb) out[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bp[(16 * t + m) * LDM + k0 + kk], out[t], 0, 0, 0);
+        }
     }
 }
 __device__ __forceinline__ void wg_release_store(int32_t *flag, int value, int tid) {
@@ -501,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
     d4 out[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) out[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    mul_acc_bt(out, acc.v, Wk, 64, 1.0, As, Bs, tid, wave, lane);
+    mul_acc_bt(out, acc.v, Wk, 64, As, Bs, tid, wave, lane);
     store_acc(out, C, ld, crow, ccol);
     if (stamp) STAMP(10);
     if (wtr) wtr[1] = wall_clock64();
@@ -527,6 +539,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
 // Workers that share a CU with a chain leave at once (the chain is issue- and LDS-bound; see the CU guard above).
 // ----------------------------------------------------------------------------
 #define VER_FINAL 0x40000000
+#define VER_PLANES 4   // version words per matrix: buffers A, T, S + one plane of auxiliary words
 #define MEGA_SPIN_LIMIT (1 << 20)   // polls of ~1 us: a lost hand-off gives up after about a second
 
 struct MegaSync {   // zeroed by a memset node ahead of every launch; the version words follow it
@@ -553,11 +566,13 @@ struct MegaArgs {
     int ntask;               // per matrix
     const int2 *chain_need;  // per block k: worker visits of A[k+1][k] and of A[k+1][k+1] the chain waits for
     MegaSync *sync;
-    int32_t *ver;            // [batch][3][nbk * nbk]
+    int32_t *ver;            // [batch][VER_PLANES][nbk * nbk]: versions of the tiles of A, T, S; auxiliary words (see T_LOOKD)
     double *logdet;
     int32_t *info;
     long long *trace;
     const int32_t *pred;     // null, or a device word: the launch does nothing when it is non-zero
+    double *piv;             // [batch][ld]: the pivots (second chain form: their logarithms are summed at the end)
+    int nowait;              // debug (DGPAMD_MEGA_NOWAIT=1, timing only, results invalid): the chain does not wait for the workers
     int ngroups;             // The matrices are dealt into this many groups (matrix b: group b % ngroups), the XCDs as well
                              // (XCD x: group x % ngroups; 1, 2, 4 or 8), and a worker takes the tasks of its own group's
                              // matrices first: every XCD has its own L2, so with one queue for all a panel tile was fetched
@@ -645,7 +660,7 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
     const int crow = 16 * wave + lu, ccol = lm;
     const int64_t ld = g.ld;
     double *A = g.buf[BUF_A] + (int64_t)b * g.stride_a;
-    int32_t *ver = g.ver + (int64_t)b * 3 * g.nbk * g.nbk;   // buffer A's versions first
+    int32_t *ver = g.ver + (int64_t)b * VER_PLANES * g.nbk * g.nbk;   // buffer A's versions first
     int32_t *wflag = g.sync->wflag + b;
     long long *tr = (g.trace && b == 0 && tid == 0) ? g.trace : nullptr;
     __builtin_amdgcn_s_setprio(3);
@@ -665,11 +680,13 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
         // (whether the workers' tiles for the next block have arrived is asked during the factorisation: DiagPoll)
         const int2 need = g.chain_need[k < g.nbk - 1 ? k : 0];
         DiagPoll poll;
-        poll.f0 = ver + (k + 1) * g.nbk + k; poll.f1 = ver + (k + 1) * g.nbk + k + 1;
-        poll.need0 = need.x; poll.need1 = need.y;
+        // A[k+1][k] (lane 0), A[k+1][k+1] (lane 1); no poll in the last block (a null word: the struct itself is always handed
+        // over -- a select between its address and null kept it in scratch memory)
+        poll.f = k + 1 < g.nbk ? ver + (k + 1) * g.nbk + k + (lane == 0 ? 0 : 1) : nullptr;
+        poll.need = lane == 0 ? need.x : need.y;
         const int bad = diag_factor(D, winv, sh, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr,
-                                    k + 1 < g.nbk ? &poll : nullptr);
-        const int ready = sh.ready;   // (read before Bs, which holds the factor's LDS, is reused)
+                                    &poll);
+        const int ready = sh.ready == 3;   // (read before Bs, which holds the factor's LDS, is reused)
         if (tr) tr[16 * k + 1] = wall_clock64();
         diag_store_inverse<true>(winv, Wk);
         wg_publish(wflag, k + 1, tid);   // the panel tasks of this block can run
@@ -755,17 +772,373 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
     }
 }
 
+// ---- the chain, second form (round 4) -------------------------------------------------------------------------------
+// The same arithmetic as mega_chain in the same order (bit-identical results), re-arranged around what bounded the block
+// step (profiles/r03_potrf_phase_trace.txt: 7.0 factor + 0.8 publish + 2.0 wait + 1.7 solve + 3.5 update):
+//   * the solve produces P^T in the accumulator layout, P^T = W_k Q^T (operands swapped: the same products in the same order).
+//     An accumulator tile is, register for register, an MFMA operand of the next product (the layout duality diagfac.hpp
+//     uses), so the update D -= P P^T takes its B operand straight from the wave's own registers and its A operand from the
+//     other waves' registers, exchanged through LDS AS THEY STAND: one barrier, no transposition, no staging by halves;
+//   * Q and W_k are staged whole (LDQ = 66), so the 40 MFMAs of the solve run without a barrier in between;
+//   * only the tiles t <= w of the next diagonal block are updated (the factor reads no others), and NO barrier separates
+//     the update from the next factorisation: wave 0 (16 MFMAs) starts eliminating while wave 3 (64) is still updating --
+//     it is not needed before the first 16-block's barrier;
+//   * W_k is published behind the wait for the panel tile's loads (vmcnt counts in order: the older W stores have drained
+//     when the younger loads have landed), not behind a drain of its own;
+//   * the panel tile's version word, the log-determinant of block k and the drain of the panel stores ride in the shadow
+//     of the next factorisation's first elimination (DiagShadow).
+#define LDQ 66   // LDS leading dimension of a whole 64x64 f64 tile: bank(4 row + 2 k), conflict-free ds_read_b64 fragments
+// The lower factor L = U^T of a block factored by diag_factor, stored ROW-contiguously: wave w writes rows 16w .. 16w + 15
+// of the tile (the 16x16 tiles (w, t), t <= w, transposed inside the wave through `scratch` -- 16 x 16 doubles of LDS per
+// wave -- and zeros right of the diagonal): four full 128-byte lines per store instruction where the transposed 8-byte
+// stores of diag_store_factor touch sixteen.  Blocks with carried rows (the last one) take diag_store_factor.
+template <int wave>
+__device__ __forceinline__ void diag_store_factor_rows(const Tile64 &tile, double *Ab, int64_t ld, int lane, double *scratch) {
+    const int lm = lane & 15, lu = lane >> 4;
+    vlds_double *S = (vlds_double *)scratch + wave * 256;   // element (i, j) at i * 16 + (j ^ i): both passes conflict-free
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t <= wave) {   // L[16w + lu + 4r][16t + lm] = U[16t + lm][16w + lu + 4r]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(lu + 4 * r) * 16 + (lm ^ (lu + 4 * r))] = tile.v[t][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double trv = S[lm * 16 + ((lu + 4 * r) ^ lm)];   // U[16t + lm][16w + lu + 4r]
+                Ab[(int64_t)(16 * wave + lu + 4 * r) * ld + 16 * t + lm] = (t == wave && lm > lu + 4 * r) ? 0.0 : trv;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ab[(int64_t)(16 * wave + lu + 4 * r) * ld + 16 * t + lm] = 0.0;
+        }
+    }
+}
+
+// P (64x64, row-major in global memory) from P^T in the accumulator layout -- lane l of wave w holds
+// P[16w + lm][16t + lu + 4r] in register (t, r) -- as write-through 16-byte stores: the lanes of DPP rows lu and lu ^ 1 hold
+// neighbouring columns, so each pair of registers (r0, r1) is exchanged across the two rows (v_permlane16_swap: odd rows of
+// the first operand with even rows of the second): the even row ends up with columns (lu, lu + 1) of r0, the odd row with
+// columns (lu - 1, lu) of r1.
+__device__ __forceinline__ void store_pt_sc1(const d4 (&P)[4], double *Pg, int64_t ld, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)Pg, 0, 0x7fffffff, 0x00020000);
+    const int lm = lane & 15, lu = lane >> 4, odd = lu & 1;
+    const int base = (int)(((int64_t)(16 * wave + lm) * ld + (lu & ~1) + 4 * odd) * 8);   // row 16w + lm, column (lu & ~1) + 4 odd
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            const double x = P[t][2 * rp], y = P[t][2 * rp + 1];
+            const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+            u32x4 v;
+            v.x = lo[0]; v.y = hi[0]; v.z = lo[1]; v.w = hi[1];
+            // (one per-lane base offset; the tile / register-pair part is a constant that folds into the instruction)
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, base, (16 * t + 8 * rp) * 8, 16);
+        }
+}
+
+// ---- the per-wave parts of the chain's block step as static programs (W = wave: every role decision is a compile-time
+// constant; left as run-time conditions on the wave index they became a basic block per instruction, each with its own
+// full wait) ----
+// W_k -> LDS, row-major (the blocks on and below the diagonal: the solve reads no others)
+template <int W>
+__device__ __forceinline__ void chain_stage_w(const Tile64 &winv, double *Ws, int lm, int lu) {
+#pragma unroll
+    for (int I = W; I < 4; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ws[(16 * I + lu + 4 * r) * LDQ + 16 * W + lm] = winv.v[I][r];
+}
+// The next diagonal tile's request (lower 16x16 tiles of row block W, row-contiguous loads).  Its update is dealt so that
+// waves 1-3 carry three tiles each and wave 0, which starts the next elimination, one: tile (0, 3) of wave 3's column
+// block is computed by wave 1 -- in wave 3's layout, loaded transposed straight from the lower triangle (H) -- and handed
+// over through LDS behind the next factorisation's first barrier.
+template <int W>
+__device__ __forceinline__ void chain_request_next(d4 (&nat)[4], d4 &H, const double *Cn, int64_t ld, int lm, int lu) {
+#pragma unroll
+    for (int t = (W == 3 ? 1 : 0); t <= W; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            nat[t][r] = __hip_atomic_load(Cn + (int64_t)(16 * W + lu + 4 * r) * ld + 16 * t + lm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (W == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            H[r] = __hip_atomic_load(Cn + (int64_t)(48 + lm) * ld + lu + 4 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void store_pt_sc1(const d4 (&P)[4], double *Pg, int64_t ld, int wave, int lane);
+// D = A[k+1][k+1] - P P^T in the column-block layout: wave W's tiles (see chain_request_next), the operands of the other
+// waves from the exchange buffer Xc two k-steps ahead of their MFMAs (one wave per SIMD: a read waited for in front of
+// its MFMA exposes the LDS latency, ~90 cycles per 64-cycle MFMA).
+template <int W>
+__device__ __forceinline__ void chain_update(Tile64 &Dn, const d4 (&P)[4], const d4 (&nat)[4], d4 &H, vlds_double *Xc, double *scratch,
+                                             vlds_double *hand, double *Pg, int64_t ld, int lane, int *pcount, int ptarget, int32_t *pflag) {
+    const int lm = lane & 15, lu = lane >> 4;
+    constexpr int T0 = (W == 3 ? 1 : 0);   // wave 3's tile 0 comes from wave 1
+    // The panel tile, final, as write-through stores.  Wave 0 goes straight on to the next elimination and stores nothing:
+    // its rows are wave 1's (from the exchange buffer: the same registers, lane for lane).
+    if (W != 0) store_pt_sc1(P, Pg, ld, W, lane);
+    if (W == 1) {
+        d4 P0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P0[t][r] = Xc[((0 * 4 + t) * 4 + r) * 64 + lane];
+        store_pt_sc1(P0, Pg, ld, 0, lane);
+    }
+    vlds_double *S = (vlds_double *)scratch + W * 256;   // element (i, j) at i * 16 + (j ^ i): both passes conflict-free
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t >= T0 && t <= W) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(lu + 4 * r) * 16 + (lm ^ (lu + 4 * r))] = nat[t][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double trv = S[lm * 16 + ((lu + 4 * r) ^ lm)];
+                Dn.v[t][r] = (t == W && lu + 4 * r >= lm) ? nat[t][r] : trv;
+            }
+        } else {
+            Dn.v[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+    }
+    if (W != 0) {
+        // The tile's version word as soon as the stores have drained: waves 1-3 count themselves in LDS when theirs have (the
+        // wait costs them ~0.5 us they have -- wave 0 eliminates for 1.2 us after its single tile), the last one publishes.
+        // (Round 4's first form published from the next factorisation's first barrier, 1 us later: the look-ahead task waits
+        // for this word before it can update the tile the chain needs next.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && atomicAdd(pcount, 1) == ptarget)
+            __hip_atomic_store(pflag, VER_FINAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    double xa[3][4], xh[3];   // a ring of three k-steps (sched_barrier: the scheduler must not gather all the reads up front)
+    auto rd = [&](int s_) {
+        const int o = s_ % 3;
+#pragma unroll
+        for (int t = T0; t < W; ++t) xa[o][t] = Xc[(t * 16 + s_) * 64 + lane];
+        if (W == 1) xh[o] = Xc[(3 * 16 + s_) * 64 + lane];
+    };
+    rd(0);
+    rd(1);
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {   // k-step (c, r) = (s_ / 4, s_ % 4): columns 16 c + 4 r .. + 3 of the panel tile
+        if (s_ + 2 < 16) rd(s_ + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const double pv = P[s_ >> 2][s_ & 3], bv = -pv;
+#pragma unroll
+        for (int t = T0; t <= W; ++t)
+            Dn.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(t == W ? pv : xa[s_ % 3][t], bv, Dn.v[t], 0, 0, 0);
+        if (W == 1)   // tile (0, 3): rows of block 0 against the rows of block 3, both from the exchange buffer
+            H = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s_ % 3][0], -xh[s_ % 3], H, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (W == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hand[r * 64 + lane] = H[r];
+    }
+}
+
+__device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, double *Qs, double *Ws, DiagShared &sh) {
+    // (wave in a scalar register: the per-wave roles below are then scalar branches, not sixteen exec-masked blocks)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
+    const int64_t ld = g.ld;
+    double *A = g.buf[BUF_A] + (int64_t)b * g.stride_a;
+    int32_t *ver = g.ver + (int64_t)b * VER_PLANES * g.nbk * g.nbk;   // buffer A's versions first
+    int32_t *wflag = g.sync->wflag + b;
+    long long *tr = (g.trace && b == 0 && tid == 0) ? g.trace : nullptr;
+    double *scratch = &sh.u[0][0][0];   // (wave-private 16 x 16 transposition areas; the factor writes sh.u only behind its first barrier)
+    __builtin_amdgcn_s_setprio(3);
+    if (tid == 0) __hip_atomic_store(&g.sync->cukey[b], cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tr) __hip_atomic_store(&g.trace[5999], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Tile64 D;
+    load_cb_lower(D.v, A, ld, wave, lane0, scratch);
+    DiagShadow shw;
+    shw.hand = nullptr;
+    if (tid == 0) sh.pcount = 0;   // (visible to the other waves behind the first factorisation's barriers)
+    double *pivots = g.piv + (int64_t)b * g.ld;   // every block's pivots: their logarithms are summed when the chain has ended
+    int info = 0;
+    vlds_double *hand = (vlds_double *)Ws;   // (Ws is idle between the solve and the next block's W_k)
+    const vlds_double *Qp = (const vlds_double *)Qs, *Wp = (const vlds_double *)Ws;
+    vlds_double *Xc = (vlds_double *)Qs;   // exchange of the P^T registers: Xc[((w * 4 + t) * 4 + r) * 64 + lane] (32 KB, over Qs)
+    for (int k = 0; k < g.nbk; ++k) {
+        // (opaque to the optimiser: the dozens of per-lane offsets below are loop invariants that would otherwise be hoisted
+        //  out of the block loop and held in registers across the factorisation, where the pressure peaks -- spills)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int lm = lane & 15, lu = lane >> 4;
+        if (tr) tr[16 * k + 0] = wall_clock64();
+        const int64_t rem = g.n - (int64_t)k * 64;
+        const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+        double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096;
+        Tile64 winv;
+        // (whether the workers' tiles for the next block have arrived is asked during the factorisation: DiagPoll)
+        const int2 need = g.chain_need[k < g.nbk - 1 ? k : 0];
+        DiagPoll poll;
+        // A[k+1][k] (lane 0), A[k+1][k+1] (lane 1); no poll in the last block (a null word: the struct itself is always handed
+        // over -- a select between its address and null kept it in scratch memory)
+        poll.f = k + 1 < g.nbk ? ver + (k + 1) * g.nbk + k + (lane == 0 ? 0 : 1) : nullptr;
+        poll.need = lane == 0 ? need.x : need.y;
+        const int bad = diag_factor(D, winv, sh, ncol, (g.trace && b == 0) ? g.trace + 1024 + 16 * k : nullptr,
+                                    &poll, &shw);
+        const int ready = g.nowait ? 3 : sh.ready;
+        if (tr) tr[16 * k + 1] = wall_clock64();
+        if (bad && !info) info = k * 64 + bad;
+        if (wave == 3) __hip_atomic_store(pivots + 64 * k + lane, sh.piv[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        shw.hand = nullptr;
+        diag_store_inverse<true>(winv, Wk);
+        if (k + 1 == g.nbk) {
+            diag_store_factor(D, A + ((int64_t)k * 64) * ld + (int64_t)k * 64, ld, ncol);
+            wg_publish(wflag, k + 1, tid);   // (the last block's inverse: T tasks of the fused inverse)
+            break;
+        }
+        // ---- the next block's inputs from the workers: A[k+1][k] and A[k+1][k+1] with the panels <= k-1 applied ----
+        // (bit 0: the panel tile A[k+1][k] had arrived when the factorisation polled, bit 1: the diagonal tile A[k+1][k+1] --
+        //  the second is needed one solve later and is waited for separately)
+        bool published = false;
+        if (!(ready & 1)) {
+            wg_publish(wflag, k + 1, tid);   // (the panel tasks of this block must not wait for the chain's own inputs)
+            published = true;
+            wg_wait_flags<true>(tid == 0 ? ver + (k + 1) * g.nbk + k : nullptr, need.x, 100 + k, &g.sync->status, tid);
+            if (__hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // (a lost hand-off ends the launch)
+        }
+        double *Pg = A + ((int64_t)(k + 1) * 64) * ld + (int64_t)k * 64;
+        const double *Cn = A + ((int64_t)(k + 1) * 64) * ld + (int64_t)(k + 1) * 64;
+        const HalfTile a0 = fetch_mk_sc1(Pg, ld, tid, 0), a1 = fetch_mk_sc1(Pg, ld, tid, 1);
+        // while the panel tile is on its way: W_k into LDS, and the factor's own tile (nobody's input) to memory
+        {
+            double *Akk = A + ((int64_t)k * 64) * ld + (int64_t)k * 64;
+            switch (wave) {
+                case 0: chain_stage_w<0>(winv, Ws, lm, lu); diag_store_factor_rows<0>(D, Akk, ld, lane, scratch); break;
+                case 1: chain_stage_w<1>(winv, Ws, lm, lu); diag_store_factor_rows<1>(D, Akk, ld, lane, scratch); break;
+                case 2: chain_stage_w<2>(winv, Ws, lm, lu); diag_store_factor_rows<2>(D, Akk, ld, lane, scratch); break;
+                default: chain_stage_w<3>(winv, Ws, lm, lu); diag_store_factor_rows<3>(D, Akk, ld, lane, scratch); break;
+            }
+        }
+        // the panel tile has landed -- and with it, vmcnt counting in order, this wave's older W_k stores have drained
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const int c2 = (tid & 15) * 2;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = (tid >> 4) + 16 * it;
+                Qs[r * LDQ + c2] = a0.v[it].x; Qs[r * LDQ + c2 + 1] = a0.v[it].y;
+                Qs[r * LDQ + 32 + c2] = a1.v[it].x; Qs[r * LDQ + 32 + c2 + 1] = a1.v[it].y;
+            }
+        }
+        lds_barrier();
+        if (tid == 0 && !published) __hip_atomic_store(wflag, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the panel tasks of this block can run
+        if (tr) tr[16 * k + 2] = tr[16 * k + 3] = wall_clock64();
+        if (!(ready & 2)) {
+            wg_wait_flags<true>(tid == 0 ? ver + (k + 1) * g.nbk + k + 1 : nullptr, need.y, 200 + k, &g.sync->status, tid);
+            if (__hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+        // the next diagonal tile: requested now, in flight during the solve
+        d4 nat[4];
+        d4 H = (d4){0.0, 0.0, 0.0, 0.0};
+        switch (wave) {
+            case 0: chain_request_next<0>(nat, H, Cn, ld, lm, lu); break;
+            case 1: chain_request_next<1>(nat, H, Cn, ld, lm, lu); break;
+            case 2: chain_request_next<2>(nat, H, Cn, ld, lm, lu); break;
+            default: chain_request_next<3>(nat, H, Cn, ld, lm, lu); break;
+        }
+        if (tr) tr[16 * k + 6] = wall_clock64();
+        // ---- P^T = W_k Q^T: tile t of wave w is P[16w.., 16t..]^T; W_k is LOWER triangular, so tile t sums the 16-blocks kb <= t ----
+        d4 P[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) P[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        // (one wave per SIMD: an operand read waited for in front of its MFMA exposes the LDS latency, ~90 cycles per 64-cycle
+        //  MFMA -- the fragments of k-step s + 2 are requested before the MFMAs of step s are issued)
+        {
+            double qv[3], wv[3][4];   // a ring of three k-steps (sched_barrier: the scheduler must not gather all the reads up front)
+            auto rd = [&](int s) {
+                const int k0 = 4 * s, kb = s >> 2, o = s % 3;
+                qv[o] = Qp[(16 * wave + lm) * LDQ + k0 + lu];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t >= kb) wv[o][t] = Wp[(16 * t + lm) * LDQ + k0 + lu];
+            };
+            rd(0);
+            rd(1);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (s + 2 < 16) rd(s + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t >= (s >> 2)) P[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[s % 3][t], qv[s % 3], P[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (tr) tr[16 * k + 4] = wall_clock64();
+        lds_barrier();   // (Qs / Ws are no longer read: the exchange buffer lies over Qs)
+        if (tr) tr[16 * k + 7] = wall_clock64();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xc[((wave * 4 + t) * 4 + r) * 64 + lane] = P[t][r];
+        shw.hand = (const double *)Ws;
+        lds_barrier();
+        if (tr) tr[16 * k + 8] = wall_clock64();
+        // ---- D = A[k+1][k+1] - P P^T in the column-block layout ----
+        Tile64 Dn;
+        switch (wave) {
+            case 0: chain_update<0>(Dn, P, nat, H, Xc, scratch, hand, Pg, ld, lane, &sh.pcount, 3 * k + 2, ver + (k + 1) * g.nbk + k); break;
+            case 1: chain_update<1>(Dn, P, nat, H, Xc, scratch, hand, Pg, ld, lane, &sh.pcount, 3 * k + 2, ver + (k + 1) * g.nbk + k); break;
+            case 2: chain_update<2>(Dn, P, nat, H, Xc, scratch, hand, Pg, ld, lane, &sh.pcount, 3 * k + 2, ver + (k + 1) * g.nbk + k); break;
+            default: chain_update<3>(Dn, P, nat, H, Xc, scratch, hand, Pg, ld, lane, &sh.pcount, 3 * k + 2, ver + (k + 1) * g.nbk + k); break;
+        }
+        D = Dn;
+        if (tr) tr[16 * k + 5] = wall_clock64();
+    }
+    // The log-determinant: per 64-block the logarithms of its pivots summed over the lanes (the same tree, then the same
+    // running sum over the blocks as diag_logdet: the same bits).  Kept out of the block steps -- the double-precision
+    // logarithm costs the wave that evaluates it ~0.5 us and twenty registers of polynomial constants that the compiler
+    // holds across the whole loop -- and done here for all blocks at once, the four waves taking every fourth block.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    vlds_double *vs = (vlds_double *)Qs;
+    for (int kk = wave; kk < g.nbk; kk += 4) {
+        const int64_t rem = g.n - (int64_t)kk * 64;
+        const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+        const double pv = __hip_atomic_load(pivots + 64 * kk + lane0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double v = (lane0 < ncol && pv > 0.0) ? log(pv) : 0.0;   // (a failed pivot is reported through info)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane0 == 0) vs[kk] = v;
+    }
+    lds_barrier();
+    if (tid == 0) {
+        double logdet = 0.0;
+        for (int kk = 0; kk < g.nbk; ++kk) logdet += vs[kk];
+        __hip_atomic_store(g.logdet + b, logdet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g.info + b, info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();   // (Qs becomes a worker's staging tile next)
+}
+
+#ifndef MEGA_V2
+#define MEGA_V2 1   // 0: the chain of rounds 2-3 (mega_chain), kept for same-box comparisons
+#endif
 __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
-    __shared__ double tiles[2 * 64 * LDM];   // As | Bs
+    __shared__ double tiles[2 * 64 * LDM];   // As | Bs (workers); the chain's whole panel tile Q, then its register exchange
     __shared__ int32_t bc[4];
     double *As = tiles, *Bs = tiles + 64 * LDM;
+#if MEGA_V2
+    // the chain keeps W_k and the factor's LDS beside the panel tile (79.8 KB per workgroup: two workgroups per CU still fit 160 KB)
+    __shared__ double wtile[64 * LDQ];
+    __shared__ DiagShared dsh;
+    static_assert(64 * LDQ <= 2 * 64 * LDM, "the chain's panel tile must fit the workers' staging tiles");
+    static_assert(2 * (sizeof(double) * (2 * 64 * LDM + 64 * LDQ) + sizeof(DiagShared) + 16) <= 160 * 1024, "two workgroups per CU");
+#else
     DiagShared &sh = *reinterpret_cast<DiagShared *>(Bs);   // (idle while a chain workgroup factors)
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int crow = 16 * wave + (lane >> 4), ccol = lane & 15;
     const int batch = g.batch;
     if (g.pred && *g.pred) return;   // (a speculative batch that an earlier one has made unnecessary: dgpamd_ess_queue)
     if ((int)blockIdx.x < batch) {
+#if MEGA_V2
+        mega_chain2(g, blockIdx.x, tiles, wtile, dsh);
+#else
         mega_chain(g, blockIdx.x, As, Bs, sh, &sh.u[0][0][0]);
+#endif
     } else {
         // a worker beside a chain leaves (bounded wait for the chains' keys: they are dispatched first)
         if (tid < 64) {
@@ -826,7 +1199,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         const int need_c = mt.b.x, fin = mt.b.y, wk = mt.b.z;
         const int64_t mo = (int64_t)b * g.stride_a;
         const int nb2 = g.nbk * g.nbk;
-        int32_t *ver = g.ver + (int64_t)b * 3 * nb2;
+        int32_t *ver = g.ver + (int64_t)b * VER_PLANES * nb2;
         int32_t *vC = ver + bufC * nb2 + ci * g.nbk + cj;
         double *C = g.buf[bufC] + mo + ((int64_t)ci * 64) * ld + (int64_t)cj * 64;
         double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)wk * 4096;
@@ -836,8 +1209,8 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         auto pull_next = [&]() {
             if (tid == 0) qn = __hip_atomic_fetch_add(&g.sync->ghead[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        auto finish = [&]() {   // drain (the tile's stores and the pull), publish, hand the next task to the loop's head
-            wg_publish(vC, newver, tid);
+        auto finish = [&](int32_t *vflag, int vvalue) {   // drain (the tile's stores and the pull), publish, hand the next task to the loop's head
+            wg_publish(vflag, vvalue, tid);
             if (tid == 0) bc[1] = qn;
             if (st) st[4] = wall_clock64();
             if (agg) {
@@ -868,7 +1241,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
                 const int r = idx >> 6, c = idx & 63;
                 __hip_atomic_store(C + (int64_t)r * ld + c, r < nrow ? tiles[c * 65 + r] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            finish();
+            finish(vC, newver);
             continue;
         }
         // ---- inputs: the output tile's earlier visits, the operand tiles final ----
@@ -892,19 +1265,100 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
             pull_next();
             store_acc_sc1(acc.v, C, ld, crow, ccol);
             if (st) st[3] = wall_clock64();
-            finish();
+            finish(vC, newver);
             continue;
         }
-        // T_SOLVE: wait for W_k, then tile <- tile * W_k^T
+        // T_SOLVE / T_LOOK / T_LOOKD: wait for W_k, then tile <- tile * W_k^T
+        // debug: the look-ahead tasks of every block of matrix 0 stamp their phases into trace[7000 + 8 k ..]
+        long long *lk = ((post == T_LOOK || post == T_LOOKD) && g.trace && b == 0 && tid == 0 && wk < 120) ? g.trace + 7000 + 8 * wk : nullptr;
+        if (lk && post == T_LOOK) { lk[0] = a0; lk[1] = wall_clock64(); }
+        int32_t *vX = ver + 3 * nb2 + ci * g.nbk + cj;   // auxiliary word of the tile: T_LOOK has read it (T_LOOKD may overwrite it)
+        if (post == T_LOOK) {   // (acc holds everything this task reads of the tile)
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(vX, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         wg_wait_flags<true>(tid == 0 ? wflag : nullptr, wk + 1, 3000 + wk, &g.sync->status, tid);
+        if (lk && post == T_LOOK) lk[2] = wall_clock64();
         d4 out[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) out[t] = (d4){0.0, 0.0, 0.0, 0.0};
-        mul_acc_bt<true>(out, acc.v, Wk, 64, 1.0, As, Bs, tid, wave, lane);
-        pull_next();
-        store_acc_sc1(out, C, ld, crow, ccol);
-        if (st) st[3] = wall_clock64();
-        finish();
+        mul_acc_bt<true>(out, acc.v, Wk, 64, As, Bs, tid, wave, lane);
+        if (post == T_SOLVE) {
+            pull_next();
+            store_acc_sc1(out, C, ld, crow, ccol);
+            if (st) st[3] = wall_clock64();
+            finish(vC, newver);
+            continue;
+        }
+        // ---- T_LOOK / T_LOOKD: the chain's look-ahead.  S = A[k+2][k] is final now and stays in registers; panel k is applied
+        // with it to one of the two tiles the chain picks up after its next factorisation: T_LOOK  Q = A[k+2][k+1] -= S P^T
+        // (P = A[k+1][k], the chain's own panel tile; this task also stores S), T_LOOKD  D = A[k+2][k+2] -= S S^T.  As three
+        // tasks (solve, two updates) the chain's inputs were two worker hand-offs behind W_k (store, drain, publish, poll,
+        // acquire, reload of S: ~15 us against a 15-us block step); the same products in the same order, so the same bits.
+        {
+            int32_t *vA = ver + BUF_A * nb2;
+            double *Ab = g.buf[BUF_A] + mo;
+            const int need2 = mt.b.w;   // earlier visits of the tile this task updates
+            if (post == T_LOOK) {
+                int32_t *vQ = vA + ci * g.nbk + cj + 1;
+                // lanes 0 / 1: the chain's panel tile A[k+1][k] final; the earlier visits of Q (the catch-up tasks of the block
+                // before: two hand-offs behind W_k-1, so NOT waited for ahead of the solve)
+                const int32_t *addr = tid == 0 ? vA + (ci - 1) * g.nbk + cj : (tid == 1 ? vQ : nullptr);
+                const int nd = tid == 0 ? VER_FINAL : need2;
+                if (lk) lk[3] = wall_clock64();
+                wg_wait_flags<true>(addr, nd, 4000 + wk, &g.sync->status, tid);
+                if (lk) lk[4] = wall_clock64();
+                const double *Pg = Ab + ((int64_t)(ci - 1) * 64) * ld + (int64_t)cj * 64;
+                double *Qg = Ab + ((int64_t)ci * 64) * ld + (int64_t)(cj + 1) * 64;
+                const HalfTile p0 = fetch_mk_sc1(Pg, ld, tid, 0), p1 = fetch_mk_sc1(Pg, ld, tid, 1);
+                Tile64 qt;
+                load_acc_sc1(qt.v, Qg, ld, crow, ccol);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    __syncthreads();
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) As[(crow + 4 * r) * LDM + 16 * t + ccol] = out[2 * h + t][r];
+                    commit_mk(h == 0 ? p0 : p1, Bs, tid);
+                    __syncthreads();
+                    mfma_tile_ahead<OP_MK, OP_MK>(As, Bs, qt.v, wave, lane, -1.0);
+                }
+                pull_next();
+                store_acc_sc1(qt.v, Qg, ld, crow, ccol);
+                if (st) st[3] = wall_clock64();
+                finish(vQ, need2 + 1);
+                if (lk) lk[5] = wall_clock64();
+            } else {
+                int32_t *vD = vA + ci * g.nbk + ci;
+                // lane 0: the earlier visits of D; lane 1: T_LOOK has read the tile that S replaces
+                wg_wait_flags<true>(tid == 0 ? vD : (tid == 1 ? vX : nullptr), tid == 0 ? need2 : 1, 5000 + wk, &g.sync->status, tid);
+                store_acc_sc1(out, C, ld, crow, ccol);   // the solved tile, final
+                double *Dg = Ab + ((int64_t)ci * 64) * ld + (int64_t)ci * 64;
+                Tile64 d;
+                load_acc_sc1(d.v, Dg, ld, crow, ccol);
+                // ... published as soon as it has drained (the wait covers D's loads as well): the next block's catch-up tasks need it
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(vC, newver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lk) lk[7] = wall_clock64();
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    __syncthreads();
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) As[(crow + 4 * r) * LDM + 16 * t + ccol] = out[2 * h + t][r];
+                    __syncthreads();
+                    mfma_tile_ahead<OP_MK, OP_MK>(As, As, d.v, wave, lane, -1.0);
+                }
+                pull_next();
+                store_acc_sc1(d.v, Dg, ld, crow, ccol);
+                if (st) st[3] = wall_clock64();
+                finish(vD, need2 + 1);
+                if (lk) lk[6] = wall_clock64();
+            }
+        }
     }
 }
 
@@ -978,8 +1432,12 @@ static size_t mega_sync_offset(int64_t n, int batch) {
     const size_t b = potrf_ws_doubles(n, batch) * sizeof(double) + 3 * DGPAMD_MAXB * sizeof(int32_t);   // + info, step flags, chain CU keys
     return (b + 15) / 16 * 16;
 }
-extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
+// offset of the one-launch kernel's pivot array (batch x Np doubles) behind the synchronisation block
+static size_t mega_piv_offset(int64_t n, int batch) {
     return mega_sync_offset(n, batch) + mega_sync_bytes(padded_dim(n) / 64, batch);
+}
+extern "C" size_t dgpamd_potrf_workspace(int64_t n, int batch) {
+    return mega_piv_offset(n, batch) + (size_t)batch * padded_dim(n) * sizeof(double);
 }
 
 // Task tables (see potrf_step_kernel): one vector of tasks per launch, cached on the device per (nbk, inverse).
@@ -1091,7 +1549,7 @@ struct MegaTable {
 };
 
 static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::vector<int2> &need, int lazy, int slazy,
-                             int near = 0, int lag = 0, int xcatch = 0, int stail = 0) {
+                             int near = 0, int lag = 0, int xcatch = 0, int stail = 0, int look = 1) {
     const int nb2 = nbk * nbk;
     std::vector<int> appliedA(nb2, 0), visitsA(nb2, 0), appliedT(nb2, 0), visitsT(nb2, 0), visitsS(nb2, 0), appliedS(nbk, 0);
     for (int q = 0; q < nbk; ++q) appliedS[q] = q;   // row q of K^-1 sums the panels kb >= q
@@ -1124,6 +1582,31 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
         emit(make_task(T_SOLVE, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap), visitsA[i * nbk + k]++, 1, k);
         appliedA[i * nbk + k] = k;
     };
+    // The look-ahead of block k as TWO tasks that run side by side, each with the solve of A[k+2][k] in it: T_LOOK applies
+    // panel k to A[k+2][k+1], T_LOOKD stores the solved tile and applies panel k to A[k+2][k+2] (each tile lacks exactly that
+    // panel: the catch-up tasks of block k-1 have brought them up to the panels < k).  One task for both left the diagonal
+    // tile 4 us behind the panel tile, which the chain then waited for; and the solved tile is published by the task that has
+    // time for it (the next block's catch-up tasks wait for it: published behind the panel-tile update it was 7 us late).
+    auto lookA = [&](int k) -> bool {
+        const int i = k + 2;
+        if (!look || appliedA[i * nbk + k + 1] != k || appliedA[i * nbk + i] != k) return false;
+        const int ap = appliedA[i * nbk + k];
+        // T_LOOK first (it waits for nothing of T_LOOKD's; T_LOOKD waits for T_LOOK's "input read" word before it stores the
+        // solved tile over the input): the table stays a topological order
+        MTask t;
+        t.a = make_task(T_LOOK, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap);
+        t.b = make_int4(visitsA[i * nbk + k], 0, k, visitsA[i * nbk + k + 1]);
+        out.push_back(t);
+        MTask d;
+        d.a = make_task(T_LOOKD, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap);
+        d.b = make_int4(visitsA[i * nbk + k]++, 1, k, visitsA[i * nbk + i]);
+        out.push_back(d);
+        ++visitsA[i * nbk + k + 1];
+        ++visitsA[i * nbk + i];
+        appliedA[i * nbk + k] = k;
+        appliedA[i * nbk + k + 1] = appliedA[i * nbk + i] = k + 1;
+        return true;
+    };
     const int nl = nbk + (inv ? 1 + lag : 0);   // (one more pass flushes what is left of K^-1)
     for (int k = 0; k < nl; ++k) {
         if (k < nbk) {
@@ -1132,9 +1615,11 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
             // ahead of their bulk, so the chain's serial part (solve, update, factor: ~15 us) runs beside that bulk
             // instead of after it.
             if (k + 2 < nbk) {
-                solveA(k + 2, k);
-                updA(k + 2, k + 2, k + 1);
-                updA(k + 2, k + 1, k + 1);
+                if (!lookA(k)) {
+                    solveA(k + 2, k);
+                    updA(k + 2, k + 2, k + 1);
+                    updA(k + 2, k + 1, k + 1);
+                }
                 need[k + 1] = make_int2(visitsA[(k + 2) * nbk + k + 1], visitsA[(k + 2) * nbk + k + 2]);
             }
             if (inv) emit(make_task(T_TDIAG, 1, 0, 0, BUF_T, k, k, BUF_A, 0, BUF_A, 0, 0, 0), visitsT[k * nbk + k]++, 1, k);
@@ -1206,12 +1691,14 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTab
     //  lazy + 1 + near + lag panels -- stays within 64 flags, and build_mega_tasks' output is checked below)
     const int near_raw = en ? atoi(en) : MEGA_NEAR, lag_raw = el ? atoi(el) : 0;
     const int near = near_raw < 0 ? 0 : (near_raw > 3 ? 3 : near_raw), lag = lag_raw < 0 ? 0 : (lag_raw > 2 ? 2 : lag_raw), xcatch = (ex ? atoi(ex) : 0) + 2 * (es ? atoi(es) : (inv && batch <= 3 ? 1 : 0));
-    static std::map<std::pair<dgpamd_ctx *, std::array<int, 7>>, MegaTable> cache;
-    MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy, near, lag, xcatch}}];
+    const char *elk = getenv("DGPAMD_MEGA_LOOK");   // 0: the look-ahead as three tasks (rounds 2-3)
+    const int look = elk ? (atoi(elk) != 0) : 1;
+    static std::map<std::pair<dgpamd_ctx *, std::array<int, 8>>, MegaTable> cache;
+    MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy, near, lag, xcatch, look}}];
     if (!mt.dev) {
         std::vector<MTask> tasks;
         std::vector<int2> need;
-        build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy, near, lag, xcatch & 1, xcatch >> 1);
+        build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy, near, lag, xcatch & 1, xcatch >> 1, look);
         for (const MTask &t : tasks)   // wg_wait_flags polls with the 64 lanes of one wave
             if (1 + 2 * (t.a.w >> 16) > 64) BAD_ARG(ctx, "task table: a visit applies more panels than one wave can wait for");
         mt.ntask = (int)tasks.size();
@@ -1236,13 +1723,13 @@ static int mega_wgs_per_cu() {
 
 // bytes of the one-launch kernel's synchronisation block (MegaSync + tile versions), a multiple of 16
 static size_t mega_sync_bytes(int64_t nbk, int batch) {
-    size_t b = sizeof(MegaSync) + (size_t)batch * 3 * nbk * nbk * sizeof(int32_t);
+    size_t b = sizeof(MegaSync) + (size_t)batch * VER_PLANES * nbk * nbk * sizeof(int32_t);
     return (b + 15) / 16 * 16;
 }
 
 static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, double *S, int64_t stride_a, int batch,
-                             double *logdet, int32_t *info, double *ws, void *syncmem, const MegaTable *mt, bool no_post = false,
-                             bool sync_cleared = false) {
+                             double *logdet, int32_t *info, double *ws, void *syncmem, double *piv, const MegaTable *mt,
+                             bool no_post = false, bool sync_cleared = false) {
     const int64_t Np = padded_dim(n);
     const int nbk = (int)(Np / 64);
     if (!sync_cleared) HIP_TRY(ctx, hipMemsetAsync(syncmem, 0, mega_sync_bytes(nbk, batch), ctx->stream));
@@ -1253,7 +1740,11 @@ static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, d
     g.tasks = mt->dev; g.ntask = mt->ntask; g.chain_need = mt->need_dev;
     g.sync = reinterpret_cast<MegaSync *>(syncmem);
     g.ver = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(syncmem) + sizeof(MegaSync));
-    g.logdet = logdet; g.info = info; g.trace = ctx->trace; g.pred = ctx->pred;
+    g.logdet = logdet; g.info = info; g.trace = ctx->trace; g.pred = ctx->pred; g.piv = piv;
+    {
+        static const int nowait = getenv("DGPAMD_MEGA_NOWAIT") ? atoi(getenv("DGPAMD_MEGA_NOWAIT")) : 0;
+        g.nowait = nowait;
+    }
     {
         const char *eg = getenv("DGPAMD_MEGA_GROUPS");
         // (measured at n = 2000, tools/gpu_lazy_sweep.py: uneven groups are fine -- an XCD whose own queue has run out takes
@@ -1371,7 +1862,8 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
         if (rc) return rc;
         (void)mega_wgs_per_cu();
         void *syncmem = reinterpret_cast<char *>(ws) + mega_sync_offset(n, batch);
-        rc = potrf_mega_launch(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, syncmem, mt, post != nullptr, sync_cleared);
+        double *piv = reinterpret_cast<double *>(reinterpret_cast<char *>(ws) + mega_piv_offset(n, batch));
+        rc = potrf_mega_launch(ctx, n, A, T, S, stride_a, batch, ld_ws, info_ws, ws, syncmem, piv, mt, post != nullptr, sync_cleared);
         if (rc) return rc;
         if (post) {
             post->pending = 1;

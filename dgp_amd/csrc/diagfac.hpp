@@ -51,15 +51,22 @@ struct DiagShared {
     double u[4][4][64];     // u[w][r][lane] = U[J][w] in accumulator layout (wave w's tile of the current block row)
     double piv[64];         // pivots (1 for carried rows): the log-determinant's input
     int bad[4];             // per 16-block: 1 + index of its first non-positive pivot, or 0
-    int ready;              // DiagPoll: the flags polled beside the last 16-block's elimination had reached their values
+    int ready;              // DiagPoll: bit i = the word lane i polled beside the last 16-block's elimination had reached its value
+    int pcount;             // one-launch chain: waves whose stores of the panel tile have drained (a running count)
 };
 
 // Two version words (and the values they must reach) that wave 0 polls ONCE while wave 3 eliminates the last 16-block --
 // the wave has nothing else to do then, so the ~1 us round trip of the poll costs the factorisation nothing.  The
 // one-launch kernel's chain asks this way whether its next inputs have arrived.
 struct DiagPoll {
-    const int *f0, *f1;
-    int need0, need1;
+    const int *f;   // per lane: lanes 0 and 1 poll one word each (the caller fills both fields per lane: a select between two
+    int need;       // struct members on the lane index kept the struct in scratch memory, a scratch load beside the poll)
+};
+
+// What the one-launch kernel's chain hands to the factorisation that follows its block step.
+struct DiagShadow {
+    const double *hand; // LDS, or null: wave 3's tile X[0] as another wave computed it (hand[r * 64 + lane]); read behind the
+                        // first barrier, ahead of the tile's first use
 };
 
 struct Tile64 {
@@ -145,7 +152,7 @@ __device__ __forceinline__ void lds_barrier() {
 // column block W of the inverse.
 template <int W>
 __device__ __forceinline__ void diag_wave(d4 (&X)[4], d4 (&Y)[4], DiagShared &sh, const int ncol, const int l,
-                                          long long *stamp, const DiagPoll *poll) {
+                                          long long *stamp, const DiagPoll *poll, DiagShadow *shadow) {
     const int lm = l & 15, lu = l >> 4;
     vlds_f64 *f = (vlds_f64 *)sh.f, *ss = (vlds_f64 *)sh.s, *cs = (vlds_f64 *)sh.cs, *piv = (vlds_f64 *)sh.piv;
 #pragma unroll
@@ -210,18 +217,21 @@ __device__ __forceinline__ void diag_wave(d4 (&X)[4], d4 (&Y)[4], DiagShared &sh
                 Y[J][r] = (row == lm) ? sr : (row > lm ? fv * csl : 0.0);
             }
         }
-        if (W == 0 && J == 3 && poll) {
-            const int *fp = l == 0 ? poll->f0 : poll->f1;
-            const int nd = l == 0 ? poll->need0 : poll->need1;
-            const bool ok = l >= 2 || __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nd;
-            const bool all = __all(ok);
-            if (l == 0) sh.ready = all ? 1 : 0;
+        if (W == 0 && J == 3 && poll && poll->f) {
+            const bool ok = l >= 2 || __hip_atomic_load(poll->f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= poll->need;
+            const unsigned long long arrived = __ballot(ok);
+            if (l == 0) sh.ready = (int)(arrived & 3ull);   // bit 0: lane 0's word had reached its value, bit 1: lane 1's
             // the acquire for those inputs is taken here too (it completes beside the elimination); if the poll failed
             // the caller waits and acquires again
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         lds_barrier();   // B1: V_J (s, cs, f) visible
+        if (J == 0 && W == 3 && shadow && shadow->hand) {
+            const vlds_f64 *hd = (const vlds_f64 *)shadow->hand;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[0][r] = hd[r * 64 + l];
+        }
         if (W == 0 && stamp && l == 0) stamp[2 * J + 1] = wall_clock64();
         if (W != J) {
             // ---- solve: tile <- V_J * tile   (column block W of A for W > J, of the inverse for W < J) ----
@@ -275,7 +285,7 @@ __device__ __forceinline__ void diag_wave(d4 (&X)[4], d4 (&Y)[4], DiagShared &sh
 // non-positive pivot, or 0.  `stamp`: optional 9 slots of wall_clock64 stamps (wave 0, lane 0): start of 16-block J, its
 // first barrier, end.
 __device__ __forceinline__ int diag_factor(Tile64 &tile, Tile64 &Winv, DiagShared &sh, int ncol_, long long *stamp = nullptr,
-                                           const DiagPoll *poll = nullptr) {
+                                           const DiagPoll *poll = nullptr, DiagShadow *shadow = nullptr) {
     d4 (&X)[4] = tile.v;
     d4 (&Y)[4] = Winv.v;
     int tid = threadIdx.x;
@@ -287,10 +297,10 @@ __device__ __forceinline__ int diag_factor(Tile64 &tile, Tile64 &Winv, DiagShare
 #pragma unroll
     for (int t = 0; t < 4; ++t) Y[t] = (d4){0.0, 0.0, 0.0, 0.0};
     switch (w) {
-        case 0: diag_wave<0>(X, Y, sh, ncol, l, stamp, poll); break;
-        case 1: diag_wave<1>(X, Y, sh, ncol, l, stamp, poll); break;
-        case 2: diag_wave<2>(X, Y, sh, ncol, l, stamp, poll); break;
-        default: diag_wave<3>(X, Y, sh, ncol, l, stamp, poll); break;
+        case 0: diag_wave<0>(X, Y, sh, ncol, l, stamp, poll, shadow); break;
+        case 1: diag_wave<1>(X, Y, sh, ncol, l, stamp, poll, shadow); break;
+        case 2: diag_wave<2>(X, Y, sh, ncol, l, stamp, poll, shadow); break;
+        default: diag_wave<3>(X, Y, sh, ncol, l, stamp, poll, shadow); break;
     }
     if (stamp && tid == 0) stamp[8] = wall_clock64();
     lds_barrier();

@@ -119,6 +119,33 @@ __device__ __forceinline__ void mfma_tile(const double *As_, const double *Bs_, 
     }
 }
 
+// The same product with the operand fragments requested two k-steps ahead of their MFMAs (a ring of three steps, held in
+// place by scheduling barriers): for code that runs alone on its SIMD, where a fragment read waited for in front of its
+// MFMA exposes the LDS latency.  Same operations in the same order as mfma_tile: the same bits.
+template <int OPA, int OPB>
+__device__ __forceinline__ void mfma_tile_ahead(const double *As_, const double *Bs_, d4 acc[4], int wave, int lane,
+                                                double sign) {
+    const vlds_double *As = (const vlds_double *)As_, *Bs = (const vlds_double *)Bs_;
+    const int m = lane & 15, kk = lane >> 4;
+    double av[3], bv[3][4];
+    auto rd = [&](int s) {
+        const int k0 = 4 * s, o = s % 3;
+        av[o] = (OPA == OP_MK) ? As[(16 * wave + m) * LDM + k0 + kk] : As[(k0 + kk) * LDK + 16 * wave + m];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[o][t] = (OPB == OP_MK) ? Bs[(16 * t + m) * LDM + k0 + kk] : Bs[(k0 + kk) * LDK + 16 * t + m];
+    };
+    rd(0);
+    rd(1);
+#pragma unroll
+    for (int s = 0; s < KC / 4; ++s) {
+        if (s + 2 < KC / 4) rd(s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const double a = av[s % 3] * sign;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s % 3][t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // MK half-tile with row/column masking (rows >= row_limit or columns >= col_limit read as zero)
 __device__ __forceinline__ void load_mk_masked(const double *__restrict__ g, int64_t ldg, double *__restrict__ s,

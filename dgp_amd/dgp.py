@@ -17,7 +17,7 @@ from tqdm import trange, tqdm
 from .kernel_class import kernel as ker, combine
 from . import dist as ddist
 from .imputation import imputer, DrawStream
-from .ops import Engine, default_engine
+from .ops import Engine, default_engine, HandoffError
 from . import utils
 
 
@@ -435,7 +435,11 @@ class dgp:
                     nd.r2()
             try:
                 self._fit_nodes(nodes, mstep, eng)
-            except (np.linalg.LinAlgError, SystemError, RuntimeError) as exc:   # (RuntimeError: DgpAmdError, a lost hand-off)
+            except KeyboardInterrupt:
+                raise
+            except BaseException as exc:   # noqa: BLE001  (LinAlgError: restart together; anything else -- DgpAmdError, an
+                # optimiser's ValueError, MemoryError -- give up together: a rank that skipped the collective would leave
+                # the others blocked in the all-gather)
                 if not split:
                     raise
                 failure = exc   # rank-local: the other ranks are on their way into the collective -- join it, then fail together
@@ -484,6 +488,8 @@ class dgp:
         got = ddist.allgather_vector(mine, device=getattr(self.engine, 'device', None)).reshape(w, per_rank, width)
         bad = [q for q in range(w) if got[q, :, 0].any()]
         if bad:
+            # (the fits this rank did make stay applied; every rank raises, and train()'s restart -- reinit_all_layer with
+            #  reset_lengthscale -- puts scale, nugget and lengthscales of ALL nodes back to para_path[row] on every rank)
             msg = 'M-step failed on rank(s) %s of the node split%s' % (bad, '' if failure is None else ': %s' % failure)
             if got[:, :, 0].max() >= 2.0:
                 raise RuntimeError(msg) from failure
@@ -505,15 +511,17 @@ class dgp:
             try:
                 pgb = trange(1, N + 1, disable=disable)
                 for i in pgb:
-                    if i == 1:
-                        with self._init_scale():
-                            self.imp.sample(burnin=ess_burn)
-                    else:
-                        self.imp.sample(burnin=ess_burn)
-                    it = self.N + i
-                    if self.vecch and (it & (it - 1)) == 0 and it > 1:   # NN refresh at iterations 2,4,8,.. (dgp.py:1388)
-                        self.imp.update_ord_nn()
-                    self._m_step()
+                    for attempt in (0, 1):
+                        try:
+                            self._si_iteration(i, ess_burn)
+                            break
+                        except HandoffError as exc:
+                            # the one-launch factorisation lost a hand-off (its workgroups were not co-resident): once, the
+                            # iteration is run again through the per-block-step kernel, which has no in-kernel waits; the
+                            # elliptical-slice transition is valid from wherever the interrupted I-step left the latents
+                            if attempt or ddist.is_active():   # (ranks must not diverge: with a training split every rank raises)
+                                raise
+                            self._handoff_fallback(exc)
                     pgb.set_description('Iteration %i: Layer %i' % (i, self.n_layer))
                 self.N += N
                 return
@@ -527,6 +535,29 @@ class dgp:
                     tqdm.write(f"Restart {restarts}/{max_restarts}:")
                 self.N = N0
                 self.reinit_all_layer(reset_lengthscale=True, row=self.N)
+
+    def _si_iteration(self, i, ess_burn):
+        """One iteration of stochastic EM: I-step, neighbour refresh, M-step (dgp.py:1377-1398)."""
+        if i == 1:
+            with self._init_scale():
+                self.imp.sample(burnin=ess_burn)
+        else:
+            self.imp.sample(burnin=ess_burn)
+        it = self.N + i
+        if self.vecch and (it & (it - 1)) == 0 and it > 1:   # NN refresh at iterations 2,4,8,.. (dgp.py:1388)
+            self.imp.update_ord_nn()
+        self._m_step()
+
+    def _handoff_fallback(self, exc):
+        import warnings
+        warnings.warn('dgp_amd: %s -- this engine now factors with one launch per block step (set_potrf_mode(0)); the '
+                      'iteration is repeated' % exc, RuntimeWarning)
+        self.engine.sync()
+        self.engine.set_potrf_mode(0)
+        imp = getattr(self, 'imp', None)
+        if imp is not None:   # nothing computed by the interrupted launches may be reused
+            imp._ll_cache, imp._factor_cache = {}, {}
+            imp.__dict__.pop('_want_ll0', None)
 
     def ptrain(self, N=500, ess_burn=10, disable=False, core_num=None):
         """dgp.py:1414-1472 optimised the nodes of a layer in a process pool; here they already run concurrently on the

@@ -365,14 +365,19 @@ class emulator:
                         mo[:, k], vo[:, k] = nd.prediction(m=m_in[:, nd.input_dim], v=v_in[:, nd.input_dim])
                         continue
                     z = None if nd.connect is None else x[:, nd.connect]
-                    if l == 0:
-                        xq = x[:, nd.input_dim]
-                        hand_over(nd, l, s, xq if z is None else np.concatenate((xq, z), 1))
-                        mo[:, k], vo[:, k] = nd.gp_prediction(xq, z)
-                    else:
-                        mq = m_in[:, nd.input_dim]
-                        hand_over(nd, l, s, mq if z is None else np.concatenate((mq, z), 1))
-                        mo[:, k], vo[:, k] = nd.linkgp_prediction(mq, v_in[:, nd.input_dim], z)
+                    try:
+                        if l == 0:
+                            xq = x[:, nd.input_dim]
+                            hand_over(nd, l, s, xq if z is None else np.concatenate((xq, z), 1))
+                            mo[:, k], vo[:, k] = nd.gp_prediction(xq, z)
+                        else:
+                            mq = m_in[:, nd.input_dim]
+                            hand_over(nd, l, s, mq if z is None else np.concatenate((mq, z), 1))
+                            mo[:, k], vo[:, k] = nd.linkgp_prediction(mq, v_in[:, nd.input_dim], z)
+                    finally:
+                        # a set this call did not consume (a branch without a neighbour search, an exception on the way)
+                        # must not meet a later prediction with the same number of rows
+                        nd.__dict__.pop('_nn_given', None)
                 m_in, v_in = mo, vo
                 layers[l].append((mo, vo))
         return [(np.stack([a for a, _ in L]), np.stack([b for _, b in L])) for L in layers]

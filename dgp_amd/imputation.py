@@ -679,6 +679,11 @@ class imputer:
             us = self.draws.uniform_peek((len(ops) - pos) * per)
             lead = plans[ops[pos][1]]
             nus = {}
+            # The window's device state is reset BEFORE its first operation: that operation's prior factorisation (a deeper
+            # layer's, or layer 0's under an injected stream) notes its info word in the state, and a reset behind it would
+            # drop a non-positive-definite prior silently (the queue would carry on with nu from a failed factor instead of
+            # raising LinAlgError like the host loop and the reference, imputation.py:54-63).
+            lead.reset_state(0, None)
             for j in range(pos, len(ops)):
                 s_, l = ops[j]
                 plan = plans[l]
@@ -692,7 +697,7 @@ class imputer:
                 nus[j] = nu
                 self._queue_refresh_y(l, plan)
                 scales = [float(nd.scale[0]) if nd.type == 'gp' else 1.0 for nd in self.all_layer[l + 1]]
-                plan.queue(self.F[l], nu[None], scales, us, 0, None, True, qb[l][1], qb[l][2], fresh=(j == pos))
+                plan.queue(self.F[l], nu[None], scales, us, 0, None, True, qb[l][1], qb[l][2], fresh=False)
             st = lead.fetch()
             status, done = int(st['status']), int(st['updates'])
             self.draws.uniform_take(int(st['cursor']))

@@ -573,7 +573,7 @@ class kernel:
         e = self.engine
         n = len(w)
         given = self.__dict__.pop('_nn_given', None)   # (handed over by the emulator: a sibling's search, see _layer_moments_vecchia)
-        if given is not None and given.shape[0] == len(x):
+        if given is not None and given.shape[0] == len(x) and given.shape[1] == min(self.pred_m, n) - (1 if self.loo_state else 0):
             return given
         if self.pred_m >= n:
             import torch

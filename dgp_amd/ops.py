@@ -22,6 +22,12 @@ class DgpAmdError(RuntimeError):
     pass
 
 
+class HandoffError(DgpAmdError):
+    """The one-launch factorisation gave up waiting for another workgroup (its workgroups were not co-resident: a device
+    shared with another process, a debugger, a time-sliced partition).  Not a numerical failure; the per-block-step
+    factorisation (Engine.set_potrf_mode(0)) has no such waits -- dgp.train retries the iteration once through it."""
+
+
 def raise_not_pd(info):
     """A non-zero factorisation status as the exception it stands for.  info > 0: LAPACK's index of the first
     non-positive pivot -> numpy.linalg.LinAlgError, the reference's signal (dgp.train restarts on it, compute_stats
@@ -29,7 +35,7 @@ def raise_not_pd(info):
     never a numerical one, so it must not be swallowed by those recovery paths: DgpAmdError."""
     info = int(info)
     if info < 0:
-        raise DgpAmdError('factorisation: an in-kernel hand-off timed out (info = %d); this is not a numerical failure' % info)
+        raise HandoffError('factorisation: an in-kernel hand-off timed out (info = %d); this is not a numerical failure' % info)
     raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite' % info)
 
 
@@ -763,6 +769,14 @@ class _EssQueue:
                 both = np.concatenate((us, np.log(us)))
             self.udev = (uniforms, e.tensor(both), len(us))
 
+    def reset_state(self, cursor=0, ll=None):
+        """A fresh device state (status, counters, info zero; the uniform cursor and the cached log-likelihood as given).  What
+        queue(fresh=True) does first; callers that queue other work between the reset and the first update -- a deeper layer's
+        prior factorisation, whose info word note_info() folds into this state -- reset here and queue with fresh=False."""
+        st0 = np.zeros(self.STATE)
+        st0[4], st0[7] = cursor, 0.0 if ll is None else ll
+        self.state.copy_(self.e.tensor(st0))
+
     def queue(self, F, NU, scales, uniforms, cursor, ll, compute_ll0, batch_next, max_batches, fresh=True):
         """Queue NU.shape[0] updates (NU: (nupd, n, M) device tensor).  uniforms: the sampler's upcoming uniforms (host);
         cursor: how many of them earlier queues of this I-step have consumed.  fresh=False: the device state is the one an
@@ -771,9 +785,7 @@ class _EssQueue:
         self.upload_uniforms(uniforms)
         ud, nuni = self.udev[1], self.udev[2]
         if fresh:
-            st0 = np.zeros(self.STATE)
-            st0[4], st0[7] = cursor, 0.0 if ll is None else ll
-            self.state.copy_(e.tensor(st0))
+            self.reset_state(cursor, ll)
         sc = np.ascontiguousarray(np.asarray(scales, dtype=np.float64))
         e._chk(e._enter() or lib.dgpamd_ess_queue(e.h, self.n, self.M, _dp(F), _dp(NU), int(NU.shape[0]), C.cast(self.nodes, C.c_void_p),
                                     sc.ctypes.data_as(C.c_void_p), self.nnodes, _dp(self.state), _dp(ud), _dp(ud[nuni:]), nuni,

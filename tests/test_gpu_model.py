@@ -1187,6 +1187,37 @@ def test_queued_ess_equals_host_loop_other_shapes(eng, shape, batch):
     assert uq == uh
 
 
+@pytest.mark.parametrize('bad_layer', [0, 1])
+def test_queued_deep_reports_a_failed_prior_factor(eng, bad_layer):
+    """A prior covariance that is not positive definite must stop the device queue exactly as it stops the host loop and
+    the reference (imputation.py:54-63 -> numpy's cholesky raises; dgp.train restarts on it): LinAlgError, whichever
+    operation of a fetch window the factorisation belongs to.  ADVICE r03: the FIRST operation of a window noted its info
+    word in the shared device state and the queue's fresh reset then wiped it -- the sampler carried on with nu from a
+    failed factor.  Three layers under an injected normal stream, so that layer 0's prior is factored inside the window
+    too (bad_layer = 0: the window's first operation; 1: a later one)."""
+    from dgp_amd import dgp, kernel, combine
+    from dgp_amd.imputation import DrawStream
+    rng = np.random.default_rng(11)
+    n, d = 200, 3
+    X = rng.uniform(size=(n, d))
+    Y = (np.sin(3 * X[:, :1]) + X[:, 1:2] ** 2)
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    for queued in (True, False):
+        ls = [[kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+              [kernel(length=np.array([1.2]), name='sexp' if k else 'matern2.5', connect=np.arange(d)) for k in range(2)],
+              [kernel(length=np.array([0.8]), name='matern2.5', scale_est=True, connect=np.arange(d))]]
+        model = dgp(X, Y, combine(*ls), seed=3)
+        model.imp.queued = queued
+        model.imp.sample(burnin=1)   # (a healthy call first: plans and buffers exist)
+        assert model.imp.queued_calls == (1 if queued else 0)   # (the shape does run through the device queue)
+        zr = np.random.default_rng(5)
+        model.imp.draws = DrawStream(seed=9, z=[zr.normal(size=n) for _ in range(64)])
+        model.all_layer[bad_layer][0].nugget = np.array([-2.0])   # K + nugget I with a negative diagonal
+        model.imp._factor_cache = {}
+        with pytest.raises(np.linalg.LinAlgError):
+            model.imp.sample(burnin=2)
+
+
 @pytest.mark.parametrize('lik', ['Poisson', 'NegBin', 'ZIP', 'ZINB', 'logit', 'probit', 'softmax', 'robustmax'])
 @pytest.mark.parametrize('batch', [12, 2])
 def test_queued_ess_equals_host_loop_likelihood_tops(eng, lik, batch):

@@ -40,10 +40,22 @@ for k in range(nbk - 1):
     r = t[k]
     print('%2d | %5.1f  %5.1f  %5.1f  %5.1f  %5.1f | %5.1f' % (k, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], t[k + 1][0] - r[0]))
 print('total chain %.1f us' % (t[nbk - 1][1] - t[0][0]))
+if t[5][6] > 0:   # the second chain form's finer stamps (round 4)
+    print('block 5 after its factorisation (us): W drained + panel tile landed + staged %.2f | next diagonal tile requested, factor tile stored %.2f | solve MFMAs %.2f | barrier %.2f | exchange, panel stores, barrier %.2f | tile landed + transposed + update MFMAs (wave 0) %.2f' % (
+        t[5][2] - t[5][1], t[5][6] - t[5][2], t[5][4] - t[5][6], t[5][7] - t[5][4], t[5][8] - t[5][7], t[5][5] - t[5][8]))
 d = raw[1024:1024 + 16 * nbk].reshape(-1, 16)
 r = d[5]
 print('block 5, diagonal factor (us from its start): ' + ' | '.join(
     '16-block %d: start %.2f, factored %.2f' % (J, r[2 * J] - r[0], r[2 * J + 1] - r[0]) for J in range(4)) + ' | end %.2f' % (r[8] - r[0]))
+# the fused look-ahead task of block k (T_LOOK, round 4), relative to the END of the chain's factorisation of block k
+lk = raw[7000:7000 + 8 * nbk].reshape(-1, 8)
+if lk[:, 0].any():
+    print('look-ahead tasks of block k, us after the chain factored block k: pulled | own inputs | W_k seen | S solved | P, Q flags seen | Q published | D published | S published || chain: W_k published, next factor done')
+    for k in range(2, min(nbk - 2, 12)):
+        if lk[k][0] == 0:
+            continue
+        t0 = t[k][1]
+        print('%2d | %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f || %5.1f %5.1f' % ((k,) + tuple(lk[k][i] - t0 for i in range(8)) + (t[k][2] - t0, t[k + 1][1] - t0)))
 w = raw[2048:2048 + 640].reshape(-1, 8)
 iw = tr.cpu().numpy()[2048:2048 + 640].reshape(-1, 8)
 print('one worker, per task (us): kind panels | wait inputs  compute  store  publish | total   gap to next pull')
