@@ -56,7 +56,16 @@ def cpu_baseline(model, counts, ess_burn):
     rng = np.random.default_rng(1)
     l1, l2 = model.all_layer[0][0], model.all_layer[1][0]
     n = len(l1.output)
-    reps_f, reps_l, reps_g = 3, 3, 2     # after one untimed call of each: ~5 s in all (the baseline must not outlast the GPU legs)
+    reps_f, reps_l, reps_g = 3, 3, 3     # after one untimed call of each: a few seconds in all (the baseline must not outlast the GPU legs)
+    # BLAS threads = physical cores.  The OpenBLAS inside numpy / scipy wheels is built with a fixed maximum (64 in
+    # the wheels of this image): asking for more is clamped by the library, and the count it reports afterwards goes into the line.
+    phys = psutil.cpu_count(logical=False) or 1
+    limiter, blas_note = None, None
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=phys, user_api='blas')
+    except Exception as exc:   # noqa: BLE001
+        blas_note = 'threadpoolctl: %s' % exc
 
     def timed(f, reps):
         f()   # untimed: first-touch, BLAS thread pool start-up
@@ -88,15 +97,88 @@ def cpu_baseline(model, counts, ess_burn):
         threads = [dict(api=i.get('user_api'), lib=i.get('internal_api'), threads=i.get('num_threads')) for i in threadpool_info()]
     except Exception:   # noqa: BLE001
         pass
-    blas_threads = max([t['threads'] for t in (threads or []) if t.get('api') == 'blas'] or [psutil.cpu_count(logical=False)])
-    return dict(value=1.0 / per_iter, unit='SI it/s', cores=int(blas_threads), physical_cores=psutil.cpu_count(logical=False), kind='port',
-                threadpools=threads,
+    blas_threads = max([t['threads'] for t in (threads or []) if t.get('api') == 'blas'] or [phys])
+    if blas_threads < phys and blas_note is None:
+        blas_note = ('asked the BLAS for %d threads (= physical cores), it runs %d: the OpenBLAS built into the numpy / scipy wheels has a '
+                     'compile-time maximum' % (phys, blas_threads))
+    if limiter is not None:
+        limiter.restore_original_limits()
+    return dict(value=1.0 / per_iter, unit='SI it/s', cores=int(blas_threads), physical_cores=phys, kind='port',
+                threadpools=threads, blas_threads_note=blas_note,
                 sample=('one untimed call, then the median of %d fmvn, %d log_likelihood_func and 2x%d llik calls at n=%d (%.1f s of timed '
                         'CPU work), scaled by the per-iteration call counts of the GPU run: %d sweeps x %d fmvn, %.1f+%d log-liks, '
                         '%.1f/%.1f llik calls (layer 1/2)'
                         % (reps_f, reps_l, reps_g, n, sum(all_f) + sum(all_l) + sum(all_g), sweeps, n_l1,
                            counts['proposals_per_iter'], sweeps, counts['llik_l1_per_iter'], counts['llik_l2_per_iter'])),
                 seconds_per_call=dict(fmvn=t_fmvn, log_likelihood_func=t_ll, llik_layer1=t_llik[0], llik_layer2=t_llik[1]))
+
+
+def potrf_table(eng, torch, n=2000):
+    """The factorisation alone at the bench size, by batch (HIP events on the engine's stream, minimum of 5): ms and algorithmic
+    TFLOP/s (n^3/3 per matrix, n^3 with the fused inverse) -- the headline roofline fraction averages over whatever batch sizes
+    the sampled iterations held (half of all M-step rounds carry one matrix), this table does not."""
+    Np = eng.padded_dim(n)
+    rng = np.random.default_rng(1)
+    out = {}
+    ev0, ev1 = eng.event(), eng.event()
+    for B in (1, 6, 12):
+        X = eng.tensor(rng.uniform(size=(B, n, 5)))
+        y = eng.tensor(rng.normal(size=n))
+        A, T, S = eng.empty(B, Np, Np), eng.empty(B, Np, Np), eng.empty(B, Np, Np)
+        work = eng.potrf_workspace(n, B)
+        tf, tv = [], []
+        for rep in range(6):
+            eng.kmatrix('matern2.5', X, None, None, [1.0], 1e-6, out=A, full=False, Y=y, batch=B)
+            eng.record(ev0); eng.potrf(n, A, batch=B, work=work); eng.record(ev1)
+            torch.cuda.synchronize()
+            tf.append(eng.elapsed_ms(ev0, ev1))
+            eng.kmatrix('matern2.5', X, None, None, [1.0], 1e-6, out=A, full=False, Y=y, batch=B)
+            eng.record(ev0); eng.potrf_inv(n, A, T, S, batch=B, work=work); eng.record(ev1)
+            torch.cuda.synchronize()
+            tv.append(eng.elapsed_ms(ev0, ev1))
+        f, v = min(tf[1:]), min(tv[1:])
+        out['B=%d' % B] = dict(potrf_ms=f, potrf_tflops=B * n ** 3 / 3 / f / 1e9, potrf_frac=B * n ** 3 / 3 / f / 1e9 / F64_PEAK_TFLOPS,
+                               potrf_inv_ms=v, potrf_inv_tflops=B * n ** 3 / v / 1e9, potrf_inv_frac=B * n ** 3 / v / 1e9 / F64_PEAK_TFLOPS)
+        del A, T, S
+    out['note'] = 'n=%d; one call = one potrf_mega_kernel launch (+ its memset / copy-out); one matrix is bound by the 31-step pivot chain' % n
+    return out
+
+
+def vecchia_leg(eng, torch, n=50000, d=8, m=25, B=6):
+    """SURVEY 8(d), Vecchia rows at BASELINE configs[3]'s shape (vecchia.py:20-109,164-242): ordered m-NN search, log-likelihood
+    rows (alone and as a speculative batch), objective + gradient rows, sparse-factor rows; HIP-event timed, ~2 s in all."""
+    rng = np.random.default_rng(7)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X[:, 0]) + X[:, 1] ** 2 + 0.1 * rng.normal(size=n)
+    length = np.array([0.8])
+    dX, dy, ones = eng.tensor(X), eng.tensor(y), eng.tensor(np.ones(n))
+    XB = dX.unsqueeze(0).repeat(B, 1, 1).contiguous()
+    xs = eng.tensor(X / length)
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        with eng.stream():
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                fn()
+            e1.record(st)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps   # ms
+    t_nn = timed(lambda: eng.nn_ordered(xs, m), 3)
+    NN = eng.nn_ordered(xs, m)
+    t1 = timed(lambda: eng.vecchia_llik('matern2.5', dX, dy, NN, length, 1e-4, ones), 20)
+    tb = timed(lambda: eng.vecchia_llik_batch('matern2.5', XB, dy, NN, length, 1e-4, ones), 20)
+    t2 = timed(lambda: eng.vecchia_nllik('matern2.5', dX, dy, NN, length, 1e-4, ones, True), 20)
+    t3 = timed(lambda: eng.vecchia_lmatrix('matern2.5', dX, NN, length, 1e-4), 20)
+    gather = n * (m + 1) * (d + 1) * 8.0   # bytes a likelihood evaluation gathers through the neighbour array (coordinates + output per neighbour)
+    return dict(shape='n=%d, d=%d, m=%d, Matern-2.5' % (n, d, m), ordered_nn_ms=t_nn,
+                llik_ms=t1, llik_rows_per_s=n / t1 * 1e3, llik_gather_GBs=gather / t1 / 1e6,
+                llik_batch=dict(candidates=B, ms=tb, rows_per_s=B * n / tb * 1e3, gather_GBs=B * gather / tb / 1e6),
+                nllik_ms=t2, nllik_rows_per_s=n / t2 * 1e3, lmatrix_ms=t3, lmatrix_rows_per_s=n / t3 * 1e3,
+                bound='f64 VALU issue (0.59 of peak, profiles/r02_cfg4_pmc_row_kernel.txt): the gather is %.1f MB per evaluation, '
+                      'a few per cent of the HBM roofline' % (gather / 1e6))
 
 
 def strong_leg_cfg3(dd, torch, local, dev, world, n=5000, d=10, q=3, S=16, M=2048):
@@ -158,9 +240,9 @@ def main():
     ap.add_argument('--ess-burn', type=int, default=10)
     ap.add_argument('--predict-points', type=int, default=16384)
     ap.add_argument('--predict-seconds', type=float, default=3.0, help='the prediction leg repeats its predict() call until it has run this long')
-    ap.add_argument('--min-gpu-seconds', type=float, default=6.0,
-                    help='after the timed region: keep stepping (untimed) until the GPU legs have lasted this long in all, so that a '
-                         'sampler of device activity sees the device busy whatever --steps was')
+    ap.add_argument('--min-gpu-seconds', type=float, default=0.0,
+                    help='telemetry padding, off by default: after everything that is measured, keep stepping (untimed, unreported) until the '
+                         'GPU legs have lasted this long in all, for an external sampler of device activity that needs a longer run')
     ap.add_argument('--no-strong-legs', action='store_true', help='N > 1: skip the strong-scaling legs (cfg3 prediction with the imputations sharded, cfg4 training with the Vecchia rows split)')
     ap.add_argument('--imputations', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -351,6 +433,17 @@ def main():
                                       'this kernel issues ~45 f64 VALU instructions per entry beside its stores')
         del outs
 
+    ptab = vleg = None
+    if rank == 0 and args.prof_kernel != 'none':
+        try:
+            ptab = potrf_table(eng, torch, args.n)
+        except Exception as exc:   # noqa: BLE001  (informational: must not cost the run its result line)
+            ptab = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
+        try:
+            vleg = vecchia_leg(eng, torch)
+        except Exception as exc:   # noqa: BLE001
+            vleg = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
+
     # ---- prediction leg: emulator with the imputations sharded over the ranks --------------------
     pred = None
     if not args.no_predict:
@@ -391,6 +484,19 @@ def main():
                                                 achieved=ach, peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None,
                                                 launches=p_n, avg_launch_us=1e3 * p_ms / p_n,
                                                 note='algorithmic flops = M n^2/2 x D x 30 x 2 per launch (DESIGN section 3)')
+            # the first layer's predictor (functions.py:379-394: r^T R^-1 r on MFMA), a shorter pass of the same call
+            xg = xt[:min(len(xt), 4096)]
+            if rank == 0:
+                eng.prof_enable('gp_quad')
+            emu.predict(xg)
+            g_n, g_ms, g_w = eng.prof_collect() if rank == 0 else (0, 0.0, 0.0)
+            if g_n:
+                ach = g_w / (g_ms * 1e-3) / 1e12
+                pred['roofline_gp'] = dict(bound='mfma', kernel='gp_quad_kernel (r^T R^-1 r over the lower tiles of R^-1, f64 MFMA)', achieved=ach,
+                                           peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None, launches=g_n,
+                                           avg_launch_us=1e3 * g_ms / g_n, points=len(xg),
+                                           note='algorithmic flops = 2 n^2 M per launch (R^-1 r, then the dot product, as the reference forms it); '
+                                                'the kernel uses the symmetry of R^-1 and executes half of them')
 
     # ---- N > 1: ONE model trained by all ranks with the M-step's nodes split over them (dist.split_training; every rank
     #      runs the same I-step from the same seed, node i is fitted by rank i mod N, one all-gather per M-step) -- the
@@ -469,7 +575,8 @@ def main():
                                    'train(ess_burn=%d): one step = one SI iteration' % (args.d, args.n, args.d, args.ess_burn),
                        'parallelism': 'replicas x%d (SI chain does not shard); predict: imputations sharded, 1 all-reduce' % world},
             'predict': pred, 'counts': counts, 'roofline': roof, 'roofline_kmatrix': roof_k, 'roofline_kmatrix_standalone': roof_ks,
-            'roofline_predict': (pred or {}).get('roofline_predict'), 'cpu_baseline': cpu, 'mstep_nodes_split': split,
+            'roofline_predict': (pred or {}).get('roofline_predict'), 'roofline_gp': (pred or {}).get('roofline_gp'),
+            'potrf_table': ptab, 'vecchia': vleg, 'cpu_baseline': cpu, 'mstep_nodes_split': split,
             'speedup_vs_cpu_baseline': (value / world / cpu['value']) if cpu else None,
             'strong_scaling': strong, 'distributed': dist_info,
             'gpu_legs': dict(seconds=gpu_leg_seconds, untimed_extra_steps=extra_steps),

@@ -222,7 +222,7 @@ __device__ __forceinline__ void store_acc(const d4 (&acc)[4], double *C, int64_t
 // the next half tile are in flight (registers) while the MFMAs of the current one run.  In the 64-block number
 // mask_kb (relative to the first) the columns >= klim of both operands read as zero.
 // SC1: every global load bypasses L1 (operands handed over inside a launch: the one-launch kernel).
-template <bool SC1 = false>
+template <bool SC1 = false, bool AHEAD = false>
 __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const double *Lp, const double *Rp, int64_t ld,
                                             int nkb, double sign, int mask_kb, int klim, double *As, double *Bs, int tid,
                                             int wave, int lane) {
@@ -274,7 +274,10 @@ __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const
         }
         if (hh + 1 < nh) fetch(hh + 1);
         __syncthreads();
-        mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, sign);
+        // (AHEAD: the one-launch kernel's workers, two waves per SIMD -- the operand fragments requested two k-steps ahead gave
+        //  the fused inverse 1-2.5 % at 6-12 matrices; the per-step kernel's four waves per SIMD hide the LDS latency themselves)
+        if (AHEAD) mfma_tile_ahead<OP_MK, OP_MK>(As, Bs, acc, wave, lane, sign);
+        else mfma_tile<OP_MK, OP_MK>(As, Bs, acc, wave, lane, sign);
     }
 }
 // The pivot chain's diagonal tile in the COLUMN-BLOCK layout of diagfac.hpp (wave w: acc[t][r] = S[16t + lu + 4r][16w + lm]),
@@ -950,7 +953,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
     Tile64 D;
     load_cb_lower(D.v, A, ld, wave, lane0, scratch);
     DiagShadow shw;
-    shw.hand = nullptr;
+    shw.hand = nullptr; shw.wout = nullptr;
     if (tid == 0) sh.pcount = 0;   // (visible to the other waves behind the first factorisation's barriers)
     double *pivots = g.piv + (int64_t)b * g.ld;   // every block's pivots: their logarithms are summed when the chain has ended
     int info = 0;
@@ -982,6 +985,8 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
         if (bad && !info) info = k * 64 + bad;
         if (wave == 3) __hip_atomic_store(pivots + 64 * k + lane, sh.piv[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         shw.hand = nullptr;
+        // (W_k row block by row block from inside the factorisation -- DiagShadow::wout -- published it 0.4 us earlier and cost
+        //  the factorisation 0.8 us: measured, not used)
         diag_store_inverse<true>(winv, Wk);
         if (k + 1 == g.nbk) {
             diag_store_factor(D, A + ((int64_t)k * 64) * ld + (int64_t)k * 64, ld, ncol);
@@ -1256,7 +1261,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         if (st) st[1] = wall_clock64();
         if (agg) a1 = wall_clock64();
         Tile64 acc;
-        tile_update<true>(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
+        tile_update<true, true>(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
                           g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
                           mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
         if (st) st[2] = wall_clock64();
@@ -1832,10 +1837,12 @@ __global__ void potrf_copy_out_kernel(const double *ld_ws, const int32_t *info_w
 }
 
 static bool potrf_uses_mega(const dgpamd_ctx *ctx, int batch, bool inv) {
-    // mode 2: whichever is faster for the call (measured at n = 2000, profiles/r02_potrf_modes.txt): the one persistent
-    // launch while the pivot chains bound the time (few matrices), the per-step launches (four workgroups per CU) when
-    // the bulk does.
-    return ctx->potrf_mode == 1 || (ctx->potrf_mode == 2 && batch <= (inv ? 4 : 8)) || (ctx->pred && ctx->potrf_mode != 0);
+    // mode 1 (default): the one persistent launch; mode 0: one launch per block step (no in-kernel waits between workgroups: the
+    // fallback when the device is shared -- HandoffError -- and the same-run reference of the tools).  The device queue's
+    // predicated launches exist for the one-launch kernel only.  (Round 2's mode 2, chosen per call by batch size, had no advantage
+    // at any batch size and is gone.)
+    (void)batch; (void)inv;
+    return ctx->potrf_mode == 1;
 }
 
 void potrf_sync_area(dgpamd_ctx *ctx, int64_t n, int batch, bool inv, double *ws, int32_t **ptr, int *words) {
@@ -1894,7 +1901,7 @@ int run_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch
 
 extern "C" int dgpamd_set_potrf_mode(dgpamd_ctx *ctx, int mode) {
     if (!ctx) return DGPAMD_BAD_ARG;
-    if (mode < 0 || mode > 2) BAD_ARG(ctx, "mode must be 0 (one launch per block step), 1 (one persistent launch) or 2 (chosen per call)");
+    if (mode < 0 || mode > 1) BAD_ARG(ctx, "mode must be 0 (one launch per block step) or 1 (one persistent launch)");
     ctx->potrf_mode = mode;
     return DGPAMD_OK;
 }

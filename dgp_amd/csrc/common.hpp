@@ -244,6 +244,7 @@ struct KmatArgs {
     const int32_t *pred;   // null, or a device word: the launch does nothing when it is non-zero
     int32_t *zero_ptr;     // null, or words to clear on the way (the factorisation's synchronisation block: saves its memset launch)
     int zero_words;
+    int nbk;               // 64-blocks per dimension of the launch's tile grid (set by the launchers)
 };
 int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a, int batch);
 int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatArgs *host_args, int count);   // same n / mode

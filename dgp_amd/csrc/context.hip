@@ -25,7 +25,7 @@ extern "C" int dgpamd_create(int device, void *stream, dgpamd_ctx **out) {
     ctx->linkgp_direct = 0;
     ctx->potrf_mode = 1;
     ctx->pred = nullptr;
-    if (const char *pm = getenv("DGPAMD_POTRF_MODE")) ctx->potrf_mode = (pm[0] >= '0' && pm[0] <= '2') ? pm[0] - '0' : 1;   // (experiments)
+    if (const char *pm = getenv("DGPAMD_POTRF_MODE")) ctx->potrf_mode = (pm[0] == '0') ? 0 : 1;   // (0: per-block-step launches, e.g. on a shared device)
     ctx->trace = nullptr;
     {
         int ncu = 0;

@@ -65,6 +65,9 @@ struct DiagPoll {
 
 // What the one-launch kernel's chain hands to the factorisation that follows its block step.
 struct DiagShadow {
+    double *wout;       // global, or null: W = L^-1 (row-major 64x64) is stored from inside the factorisation, row block J as soon as
+                        // it is final (write-through stores; drained before the factorisation's last barrier): the caller can
+                        // publish it at once instead of storing and draining 32 KB behind the factorisation
     const double *hand; // LDS, or null: wave 3's tile X[0] as another wave computed it (hand[r * 64 + lane]); read behind the
                         // first barrier, ahead of the tile's first use
 };
@@ -253,6 +256,12 @@ __device__ __forceinline__ void diag_wave(d4 (&X)[4], d4 (&Y)[4], DiagShared &sh
                 for (int r = 0; r < 4; ++r) sh.u[W][r][l] = acc[r];
             }
         }
+        if (shadow && shadow->wout) {   // row block J of the inverse is final: wave W holds its columns 16W .. 16W + 15 (zero right of the diagonal)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __hip_atomic_store(shadow->wout + (16 * J + lu + 4 * r) * 64 + 16 * W + lm, (J >= W) ? Y[J][r] : 0.0, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (J == 3) break;
         lds_barrier();   // B2: U[J][w'] of the other waves visible
         // ---- update with block row J (carried rows of the block are no pivots: masked out of the A operand) ----
@@ -303,6 +312,7 @@ __device__ __forceinline__ int diag_factor(Tile64 &tile, Tile64 &Winv, DiagShare
         default: diag_wave<3>(X, Y, sh, ncol, l, stamp, poll, shadow); break;
     }
     if (stamp && tid == 0) stamp[8] = wall_clock64();
+    if (shadow && shadow->wout) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's stores of the inverse have drained)
     lds_barrier();
     int bad = 0;
 #pragma unroll

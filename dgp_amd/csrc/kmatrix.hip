@@ -4,9 +4,13 @@
 //
 // One 256-thread workgroup per 64x64 LOWER tile (bi >= bj); the two 64-row slabs
 // of X are gathered ([Xloc[:,colmap] | Xglob]), scaled by 1/lengthscale and
-// staged transposed in LDS; each thread owns a 4x4 strided micro-tile
-// (rows ty+16a, cols tx+16b) so that every store instruction of a wave writes
-// four full 128-byte lines.  The kernel is f64-VALU + HBM-write bound.
+// staged transposed in LDS; each thread owns a 4x4 micro-tile -- rows ty+16a,
+// column PAIRS 2tx, 2tx+1 and 32+2tx, 33+2tx -- so that every store is a 16-byte
+// global_store_dwordx4 and a wave's store instruction writes four 256-byte row
+// segments (round 3: 8-byte stores, four 128-byte lines per instruction).
+// Tiles below the diagonal come first in the grid, the diagonal tiles (which
+// write no mirrored tile in symmetric mode) last: the tail of the launch is its
+// cheapest work.  The kernel is f64-VALU + HBM-write bound.
 #include "common.hpp"
 #include <algorithm>
 
@@ -18,7 +22,15 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     double *XiT = lds;            // [D][64]
     double *XjT = lds + D * 64;   // [D][64]
     int bi, bj;
-    tri_decode(blockIdx.x, bi, bj);
+    {   // strictly-lower tiles first (row-major in the triangle), then the diagonal
+        const int nb = a.nbk, nlow = nb * (nb - 1) / 2, t = blockIdx.x;
+        if (t < nlow) {
+            tri_decode(t, bi, bj);   // t = b(b+1)/2 + j with j <= b: the strictly-lower tile (b + 1, j)
+            ++bi;
+        } else {
+            bi = bj = t - nlow;
+        }
+    }
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64;
@@ -43,6 +55,7 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     }
     __syncthreads();
 
+    // micro-tile: rows ty + 16 p, columns col(q) = 32 (q >> 1) + 2 tx + (q & 1)
     double s[4][4], pr[4][4];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -54,9 +67,11 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     for (int d = 0; d < D; ++d) {
         double xi[4], xj[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            xi[p] = XiT[d * 64 + ty + 16 * p];
-            xj[p] = XjT[d * 64 + tx + 16 * p];
+        for (int p = 0; p < 4; ++p) xi[p] = XiT[d * 64 + ty + 16 * p];
+        {
+            const double2 lo = *reinterpret_cast<const double2 *>(XjT + d * 64 + 2 * tx);
+            const double2 hi = *reinterpret_cast<const double2 *>(XjT + d * 64 + 32 + 2 * tx);
+            xj[0] = lo.x; xj[1] = lo.y; xj[2] = hi.x; xj[3] = hi.y;
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -86,18 +101,19 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (ty + 16 * p == tx + 16 * q) {
+                if (ty + 16 * p == 32 * (q >> 1) + 2 * tx + (q & 1)) {
                     const int64_t gi = i0 + ty + 16 * p;
                     v[p][q] = 1.0 + a.kp.nugget * (a.W ? a.W[gi < a.n ? gi : 0] : 1.0);
                 }
     }
     const bool interior = i0 + 64 <= a.n;   // j0 <= i0: the whole tile lies inside the n x n correlation block
-    if (interior) {
+    const bool even_ld = (a.ldk & 1) == 0;  // (16-byte stores need 16-byte addresses: base pointers are, rows are when ldk is even)
+    if (interior && even_ld) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            double *row = Kb + (i0 + ty + 16 * p) * a.ldk + j0 + tx;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) row[16 * q] = v[p][q];
+            double *row = Kb + (i0 + ty + 16 * p) * a.ldk + j0 + 2 * tx;
+            *reinterpret_cast<double2 *>(row) = make_double2(v[p][0], v[p][1]);
+            *reinterpret_cast<double2 *>(row + 32) = make_double2(v[p][2], v[p][3]);
         }
     } else if (a.full) {
 #pragma unroll
@@ -105,18 +121,19 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
             const int64_t gi = i0 + ty + 16 * p;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int64_t gj = j0 + tx + 16 * q;
+                const int64_t gj = j0 + 32 * (q >> 1) + 2 * tx + (q & 1);
                 if (gi < a.n && gj < a.n) Kb[gi * a.ldk + gj] = v[p][q];
             }
         }
     } else {
-        // augmented factorisation buffer: rows >= n carry right-hand sides, corner zero
+        // augmented factorisation buffer: rows >= n carry right-hand sides, corner zero (ldk = padded dimension: even)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int64_t gi = i0 + ty + 16 * p;
+            double w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int64_t gj = j0 + tx + 16 * q;
+                const int64_t gj = j0 + 32 * (q >> 1) + 2 * tx + (q & 1);
                 double val = v[p][q];
                 if (gi >= a.n) {
                     int64_t qy = gi - a.n;
@@ -124,8 +141,11 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
                 } else if (gj >= a.n) {
                     val = 0.0;
                 }
-                Kb[gi * a.ldk + gj] = val;
+                w[q] = val;
             }
+            double *row = Kb + gi * a.ldk + j0 + 2 * tx;
+            *reinterpret_cast<double2 *>(row) = make_double2(w[0], w[1]);
+            *reinterpret_cast<double2 *>(row + 32) = make_double2(w[2], w[3]);
         }
     }
     if (a.full && bi != bj) {
@@ -133,19 +153,28 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
         // stores write 32-byte fragments and cost 40% of the kernel's bandwidth).  In four passes of 16 rows through a
         // 16 x 65 buffer that REUSES the input staging area (dead by now) -- a whole-tile buffer of its own (33 KB) held the
         // kernel at three workgroups per CU, too few for the stores of one to hide behind the arithmetic of the others.
+        // Per pass the mirrored block is 64 rows x 16 columns: eight lanes cover a row's 128-byte line with 16-byte stores.
         double *TT2 = lds;
+        const int pc = 2 * (tx & 7), pr0 = 2 * ty + (tx >> 3);   // column pair / row of this lane inside the block (rows pr0, pr0 + 32)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             __syncthreads();   // (pass c - 1 read / the staged inputs consumed)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) TT2[ty * 65 + tx + 16 * q] = v[c][q];   // rows i0 + 16 c + ty of the tile, all 64 columns
+            for (int q = 0; q < 4; ++q) TT2[ty * 65 + 32 * (q >> 1) + 2 * tx + (q & 1)] = v[c][q];   // rows i0 + 16 c + ty of the tile, all 64 columns
             __syncthreads();
-            // mirrored block: rows j0 + r (r = 0..63), columns i0 + 16 c + cc (cc = 0..15): a 128-byte segment per row
+            // mirrored block: rows j0 + r (r = 0..63), columns i0 + 16 c + cc (cc = 0..15)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = ty + 16 * k, cc = tx;
-                const int64_t gc = i0 + 16 * c + cc;
-                if (interior || gc < a.n) Kb[(j0 + r) * a.ldk + gc] = TT2[cc * 65 + r];
+            for (int k = 0; k < 2; ++k) {
+                const int r = pr0 + 32 * k;
+                const int64_t gc = i0 + 16 * c + pc;
+                const double m0 = TT2[pc * 65 + r], m1 = TT2[(pc + 1) * 65 + r];
+                double *dst = Kb + (j0 + r) * a.ldk + gc;
+                if (interior && even_ld) {
+                    *reinterpret_cast<double2 *>(dst) = make_double2(m0, m1);
+                } else {
+                    if (interior || gc < a.n) dst[0] = m0;
+                    if (interior || gc + 1 < a.n) dst[1] = m1;
+                }
             }
         }
     }
@@ -193,6 +222,7 @@ int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a_, int batch) {
     int nbk = (int)((rows + 63) / 64);
     int ntiles = nbk * (nbk + 1) / 2;
     size_t shm = std::max((size_t)2 * D * 64, a.full ? (size_t)16 * 65 : (size_t)0) * sizeof(double);
+    a.nbk = nbk;
     dim3 grid(ntiles, 1, batch);
     // algorithmic bytes: the stored triangle(s) of K (8 n^2, or 4 n^2 for the lower tiles) + X once
     PROF_BEGIN(ctx, PROF_KMATRIX, (double)batch * ((a.full ? 8.0 : 4.0) * (double)rows * (double)rows + 8.0 * (double)a.n * D));
@@ -239,6 +269,7 @@ int build_kmat_args(dgpamd_ctx *ctx, KmatArgs &a, int kind, int64_t n, const dou
     a.ldy = ldy;
     a.stride_y = stride_y;
     a.r = r;
+    a.nbk = (int)(((full ? n : padded_dim(n)) + 63) / 64);
     return DGPAMD_OK;
 }
 

@@ -191,7 +191,11 @@ extern "C" int dgpamd_gp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M
             hipLaunchKernelGGL(cross_corr_kernel<DGPAMD_SEXP>, dim3(nb, tb), dim3(256), shm, ctx->stream, c);
         else
             hipLaunchKernelGGL(cross_corr_kernel<DGPAMD_MATERN25>, dim3(nb, tb), dim3(256), shm, ctx->stream, c);
+        // algorithmic flops of r^T R^-1 r for mc test points as the reference forms it (functions.py:379-394: R^-1 r, then the dot
+        // product): 2 n^2 mc; the kernel reads the lower tiles of R^-1 only and executes half of that
+        PROF_BEGIN(ctx, PROF_GP_QUAD, 2.0 * (double)n * (double)n * (double)mc);
         hipLaunchKernelGGL(gp_quad_kernel, dim3(nb, tb), dim3(256), 0, ctx->stream, q);
+        PROF_END(ctx, PROF_GP_QUAD);
         hipLaunchKernelGGL(gp_finalize_kernel, dim3((unsigned)((mc + 63) / 64), (unsigned)(nry < 64 ? nry : 64)),
                            dim3(256), 0, ctx->stream, (const double *)R, (const double *)partial, ry, nry, n, nb, Mc,
                            t0, M, scale, nugget, mean, var);

@@ -15,8 +15,21 @@ import torch
 import torch.distributed as td
 
 
+def _forced():
+    """DGPAMD_DIST_FORCE=1: treat an initialised process group of ONE rank as active, so that every collective of the library
+    really goes through the backend (RCCL on a one-GPU box: the first-contact test of the `nccl` path)."""
+    return os.environ.get('DGPAMD_DIST_FORCE') == '1'
+
+
 def is_active():
-    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    return td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or _forced())
+
+
+def _dev(device=None):
+    """Where a collective's tensor lives: the device under nccl / RCCL (it reduces device memory only), the host under gloo."""
+    if td.get_backend() == 'nccl':
+        return device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
 
 
 def rank():
@@ -34,8 +47,14 @@ def share(total, r, w):
 
 def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
-    if td.is_initialized() or int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+    if td.is_initialized() or (int(os.environ.get('WORLD_SIZE', '1')) <= 1 and not _forced()):
         return
+    if _forced():   # a group of one needs no launcher: fill in what torch.distributed.run would have set
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('LOCAL_RANK', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if backend == 'nccl':
@@ -45,11 +64,18 @@ def init_from_env(backend=None):
 
 
 def allreduce_sum(*tensors):
-    """In-place sum over ranks of each tensor (device tensors under nccl/RCCL, CPU tensors under gloo)."""
+    """In-place sum over ranks of each tensor.  nccl / RCCL reduces device tensors, gloo host tensors: a tensor on the other
+    side makes the round trip through a copy (under gloo with several ranks on one GPU: the functional checks)."""
     if not is_active():
         return
+    want = _dev().type
     for t in tensors:
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+        if t.device.type == want:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+        else:
+            h = t.to(_dev())
+            td.all_reduce(h, op=td.ReduceOp.SUM)
+            t.copy_(h)
 
 
 def row_range(total, r, w):
@@ -70,7 +96,7 @@ def allgather_rows(local, total, device=None):
     chunk = -(-total // w)
     pad = np.zeros((chunk,) + local.shape[1:])
     pad[:len(local)] = local
-    t = torch.from_numpy(pad).to(device if device is not None else 'cpu')
+    t = torch.from_numpy(pad).to(_dev(device))
     parts = [torch.empty_like(t) for _ in range(w)]
     td.all_gather(parts, t)
     return np.concatenate([p.cpu().numpy() for p in parts], 0)[:total]
@@ -80,9 +106,21 @@ def allreduce_max_scalar(value, device=None):
     """max over ranks of a python float (bench.py: the slowest rank's time)."""
     if not is_active():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else 'cpu')
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_dev(device))
     td.all_reduce(t, op=td.ReduceOp.MAX)
     return float(t.item())
+
+
+def broadcast_int(value, src=0, device=None):
+    """A python int (up to 128 bits: a SeedSequence entropy) from rank `src` to every rank, as four int64 words -- no pickling,
+    a device tensor under nccl / RCCL."""
+    if not is_active():
+        return int(value)
+    v = int(value)
+    words = [(v >> (32 * i)) & 0xffffffff for i in range(4)]
+    t = torch.tensor(words, dtype=torch.int64, device=_dev(device))
+    td.broadcast(t, src=src)
+    return sum(int(w) << (32 * i) for i, w in enumerate(t.tolist()))
 
 
 def barrier():
@@ -160,7 +198,7 @@ def allgather_vector(vec, device=None):
     on_dev = td.get_backend() == 'nccl'
     t = torch.from_numpy(vec)
     if on_dev:
-        t = t.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
+        t = t.to(_dev(device))
     out = torch.empty((world(), len(vec)), dtype=torch.float64, device=t.device)
     td.all_gather_into_tensor(out, t) if on_dev else td.all_gather(list(out.unbind(0)), t)
     return out.cpu().numpy()

@@ -83,9 +83,7 @@ class emulator:
                     nd.engine = self.engine
         self.N = ddist.share(self.N_total, rank, world)
         if self.shard_points and seed is None:      # all ranks must draw the same imputations: rank 0's entropy for everyone
-            box = [np.random.SeedSequence().entropy]
-            ddist.td.broadcast_object_list(box, src=0)
-            seed = box[0]
+            seed = ddist.broadcast_int(np.random.SeedSequence().entropy, src=0, device=self.engine.device)   # (no pickling: RCCL moves device words)
         ss = np.random.SeedSequence(seed)
         self.imp = imputer(all_layer, block, draws=DrawStream(ss.spawn(world)[rank]), engine=self.engine)
         self._sample_rng = np.random.default_rng(ss.spawn(world)[rank])   # predict(method='sampling')

@@ -118,7 +118,7 @@ class Engine:
         self._chk(self._enter() or lib.dgpamd_set_graphs(self.h, 1 if enable else 0))
 
     def set_potrf_mode(self, mode):
-        """1 (default): the factorisation is one persistent dataflow launch; 0: one launch per 64-column block step; 2: chosen per call."""
+        """1 (default): the factorisation is one persistent dataflow launch; 0: one launch per 64-column block step."""
         self._chk(self._enter() or lib.dgpamd_set_potrf_mode(self.h, int(mode)))
 
     def stream(self):

@@ -119,9 +119,10 @@ int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int ba
 /* How dgpamd_potrf / dgpamd_potrf_inv (and everything built on them) run the blocked factorisation:
  * mode 1 (default): ONE persistent launch -- a pivot-chain workgroup per matrix plus workers that pull tile tasks
  * from a queue, ordered by per-tile version words (csrc/chol.hip, potrf_mega_kernel); mode 0: one launch per 64-column
- * block step, replayed as a hipGraph; mode 2: mode 1 for small batches (chain-bound), mode 0 for large ones
- * (bulk-bound).  The results are bit-identical (every tile applies its panels in the same order).
- * info[b] = -1 reports a lost in-kernel hand-off (a bounded spin gave up), never a numerical failure. */
+ * block step, replayed as a hipGraph (no waits between workgroups inside a launch: the mode for a device shared with other
+ * processes).  The results are bit-identical (every tile applies its panels in the same order).
+ * info[b] = -1 reports a lost in-kernel hand-off (a bounded spin gave up), never a numerical failure: the caller
+ * rebuilds the matrices and runs the call again in mode 0 (dgp_amd.dgp.train does, once per iteration). */
 int dgpamd_set_potrf_mode(dgpamd_ctx *ctx, int mode);
 
 /* Read the quadratic forms out of factored buffers: quad[b*r*r + q*r + q'] =

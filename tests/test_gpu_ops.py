@@ -834,7 +834,7 @@ def test_one_workspace_shared_by_batch_sizes_and_modes(eng):
     """The scenario of the hazard round 2 parked (per-step graphs of two batch sizes replayed on one workspace
     after a one-launch call gave a wrong `info` once): ONE workspace shared by factorisations of different batch sizes --
     whose layouts alias: the info / log-determinant words of a 4-matrix call lie where a 12-matrix call keeps diagonal-
-    block inverses -- under all three modes (per-step graphs, one launch, chosen per call), queued back to back with NO
+    block inverses -- under both modes (per-step graphs, one launch; round 2's third mode, chosen per call, is gone), queued back to back with NO
     synchronisation; afterwards every call must report info = 0 and, per batch size, bit-identical log-determinants.
     (Not reproduced in round 3 in 30 runs of the original sequence, tools/gpu_iter_split.py, nor by this stress;
     the words are now written and read with device-scope accesses, so that no stale per-XCD L2 line of an earlier layout
@@ -847,7 +847,7 @@ def test_one_workspace_shared_by_batch_sizes_and_modes(eng):
     y = eng.tensor(rng.normal(size=n))
     A = eng.empty(Bmax, Np, Np)
     work = eng.potrf_workspace(n, Bmax)
-    seq = [(1, 12), (0, 4), (0, 12), (1, 3), (0, 6), (2, 12), (2, 4), (0, 4), (1, 12), (0, 12), (2, 9), (0, 3)]
+    seq = [(1, 12), (0, 4), (0, 12), (1, 3), (0, 6), (1, 12), (1, 4), (0, 4), (1, 12), (0, 12), (1, 9), (0, 3)]
     ref = {}
     try:
         for r in range(12):
