@@ -996,8 +996,22 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
         // ---- the next block's inputs from the workers: A[k+1][k] and A[k+1][k+1] with the panels <= k-1 applied ----
         // (bit 0: the panel tile A[k+1][k] had arrived when the factorisation polled, bit 1: the diagonal tile A[k+1][k+1] --
         //  the second is needed one solve later and is waited for separately)
+        // A tile that had not arrived at the factorisation's poll usually has by now (the look-ahead tasks publish the panel tile
+        // ~10 us after W_k-1, the poll is 1.7 us before this point): ONE more look -- a write-through load of the word by one
+        // lane, handed to the others through LDS -- and the step goes on as if the poll had seen it.  No acquire here: every
+        // load of these tiles below bypasses L1 (sc1), every store of them was write-through and drained ahead of the word,
+        // and this CU holds the chain alone (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire, first row).
+        int ready2 = ready;
+        if (ready != 3) {
+            if (tid < 2 && !((ready >> tid) & 1)) {
+                const int got = __hip_atomic_load(ver + (k + 1) * g.nbk + k + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got >= (tid == 0 ? need.x : need.y)) atomicOr(&sh.ready, 1 << tid);
+            }
+            lds_barrier();
+            ready2 = g.nowait ? 3 : sh.ready;
+        }
         bool published = false;
-        if (!(ready & 1)) {
+        if (!(ready2 & 1)) {
             wg_publish(wflag, k + 1, tid);   // (the panel tasks of this block must not wait for the chain's own inputs)
             published = true;
             wg_wait_flags<true>(tid == 0 ? ver + (k + 1) * g.nbk + k : nullptr, need.x, 100 + k, &g.sync->status, tid);
@@ -1030,7 +1044,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
         lds_barrier();
         if (tid == 0 && !published) __hip_atomic_store(wflag, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the panel tasks of this block can run
         if (tr) tr[16 * k + 2] = tr[16 * k + 3] = wall_clock64();
-        if (!(ready & 2)) {
+        if (!(ready2 & 2)) {
             wg_wait_flags<true>(tid == 0 ? ver + (k + 1) * g.nbk + k + 1 : nullptr, need.y, 200 + k, &g.sync->status, tid);
             if (__hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         }
@@ -1636,6 +1650,11 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
                     updA(k + 3, k + 3, k + 1);
                     updA(k + 3, k + 2, k + 1);
                     if (xcatch) updA(k + 3, k + 1, k + 1);   // (the next look-ahead solve then has no panel left to apply)
+                    // The next block's look-ahead tile A[k+3][k+1] up to the panels < k: all final by now.  The look-ahead tasks
+                    // then apply ONE panel (k, whose operand the solve of A[k+3][k] publishes ~5 us before W_k+1) where they
+                    // applied the three the lazy cadence leaves -- 5 us of arithmetic between the arrival of the last operand
+                    // (the previous block's solved tile) and the solve, on the path to the tile the chain waits for.
+                    else if (look) updA(k + 3, k + 1, k);
                 }
             }
             if (inv)

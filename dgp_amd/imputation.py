@@ -207,15 +207,18 @@ class imputer:
     """Args as dgpsi.imputer (imputation.py:13) plus `draws` (a DrawStream), `engine`, and
     `batch` (speculative proposals per launch)."""
 
-    def __init__(self, all_layer, block=True, draws=None, engine=None, batch=12):
+    def __init__(self, all_layer, block=True, draws=None, engine=None, batch=10):
         self.all_layer = all_layer
         self.block = block
         self.draws = draws if draws is not None else DrawStream()
         self._engine = engine
         self.batch = int(batch)
-        self._batch_default = int(batch) == 12   # (the queue picks its own sizes for Vecchia nodes upstairs unless the caller chose)
-        self.batch_next = 4      # size of the 2nd, 3rd, ... speculative batch of an update: after a rejected batch the
-                                 # bracket is narrow and acceptance is near (measured: I-step -7% against 12 throughout)
+        self._batch_default = int(batch) == 10   # (the queue picks its own sizes for Vecchia nodes upstairs unless the caller chose)
+        self.batch_next = 6      # size of the 2nd, 3rd, ... speculative batch of an update: after a rejected batch the
+                                 # bracket is narrow and acceptance is near.  10 then 6 (round 4, with the one-launch kernel's
+                                 # new timings -- a batch of 10 costs 0.79 ms, of 12 0.91: tools/gpu_ess_batch_choice.py, an update
+                                 # needs 7.9 proposals on average and more than 16 in 2 % of the cases): bench 34.1 against 34.7 ms
+                                 # per iteration with 12 then 4 (rounds 1-3) on the same training path
         self._factor_cache = {}
         self._ess_plans = {}
         self.stats = dict(proposals=0, updates=0, batches=0)
@@ -574,7 +577,11 @@ class imputer:
         n = 50 000) and a queued batch costs no host round trip, so narrow batches waste fewer candidates: 6, then 3, five
         queued (cfg4 I-step 50 -> 40 ms; profiles/r03_cfg4_vecchia.txt).  Explicit settings of the caller are kept."""
         upper = self.all_layer[l + 1]
-        default = self._batch_default and self.batch == 12 and self.batch_next == 4 and self.queue_max_batches == 2
+        default = self._batch_default and self.batch == 10 and self.batch_next == 6 and self.queue_max_batches == 2
+        env = os.environ.get('DGPAMD_ESS_BATCH')   # "first,next,queued": tuning runs (tools/gpu_ess_batch_choice.py)
+        if default and env:
+            b0, bn, qm = (int(v) for v in env.split(','))
+            return b0, bn, qm
         if default and all(nd.type == 'gp' and nd.vecch for nd in upper):
             return 6, 3, 5
         # dense nodes of cfg3's size: a candidate's factorisation (n^3 / 3 at the engine's ~45 TFLOP/s: 0.9 ms at n = 5000) costs as

@@ -25,8 +25,27 @@ cum = 0
 for k in sorted(h):
     cum += h[k]
     print('%3d: %4d  cum %.3f' % (k, h[k], cum / len(need)))
-# factorisation time (ms) of a batch of B matrices, n = 2000 (profiles/r02_potrf_modes.txt, one-launch kernel, 6-panel visits)
-tB = {1: 0.517, 2: 0.54, 3: 0.58, 4: 0.63, 5: 0.67, 6: 0.705, 7: 0.78, 8: 0.85, 9: 0.90, 10: 0.95, 11: 1.0, 12: 1.06, 14: 1.2, 16: 1.35}
+# factorisation time (ms) of a batch of B matrices, n = 2000, measured here (one-launch kernel; HIP events, minimum of 5)
+eng = model.engine
+n = 2000
+Np = eng.padded_dim(n)
+rng = np.random.default_rng(0)
+ev0, ev1 = eng.event(), eng.event()
+tB = {}
+import torch
+for B in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16):
+    Xb = eng.tensor(rng.uniform(size=(B, n, 5)))
+    yb = eng.tensor(rng.normal(size=n))
+    A = eng.empty(B, Np, Np)
+    work = eng.potrf_workspace(n, B)
+    ts = []
+    for rep in range(6):
+        eng.kmatrix('matern2.5', Xb, None, None, [1.0], 1e-6, out=A, full=False, Y=yb, batch=B)
+        eng.record(ev0); eng.potrf(n, A, batch=B, work=work); eng.record(ev1)
+        torch.cuda.synchronize()
+        ts.append(eng.elapsed_ms(ev0, ev1))
+    tB[B] = min(ts[1:])
+print('potrf ms by batch:', ' '.join('%d:%.3f' % kv for kv in tB.items()))
 def t(B):
     return tB[B] + 0.06 + 0.004 * B   # + K assembly and the small kernels
 best = []
