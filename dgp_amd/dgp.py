@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from tqdm import trange, tqdm
 
-from .kernel_class import kernel as ker, combine
+from .kernel_class import kernel as ker, combine, bind_private, peek
 from . import dist as ddist
 from .imputation import imputer, DrawStream
 from .ops import Engine, default_engine, HandoffError
@@ -347,20 +347,20 @@ class dgp:
                         raise Exception(('You need one and only one GP node', 'You need two and only two GP nodes',
                                          'You need three and only three GP nodes')[need - 1]
                                         + ' to feed the ' + nd.name + ' likelihood node.')
-                    nd.input = In[nd.rep, :][:, nd.input_dim] if nd.rep is not None else In[:, nd.input_dim]
+                    bind_private(nd, 'input', In[nd.rep, :][:, nd.input_dim] if nd.rep is not None else In[:, nd.input_dim])
                     nd.output = self.Y[:, [k]]
                     continue
-                nd.input = In[:, nd.input_dim]
+                bind_private(nd, 'input', In[:, nd.input_dim])
                 if nd.type == 'gp':
                     if nd.connect is not None:
                         if l == 0 and len(np.intersect1d(nd.connect, nd.input_dim)) != 0:
                             raise Exception('The local input and global input should not have any overlap. Change '
                                             'input_dim or connect so they do not have any common indices.')
-                        nd.global_input = global_in[:, nd.connect]
+                        bind_private(nd, 'global_input', global_in[:, nd.connect])
                     nd.vecch, nd.m, nd.nn_method = self.vecch, self.m, self.nn_method
                     if self.ord_fun is not None:
                         nd.ord_fun = self.ord_fun
-                    nd.D = nd.input.shape[1] + (0 if nd.connect is None else len(nd.connect))
+                    nd.D = peek(nd, 'input').shape[1] + (0 if nd.connect is None else len(nd.connect))
                     nd.engine = self.engine
                 if last:
                     if nd.type == 'gp' and nd.rep is not None:
@@ -588,13 +588,13 @@ class dgp:
                 if last:
                     nd.rep = self.indices
                 if nd.type == 'likelihood':
-                    nd.input = In[nd.rep, :][:, nd.input_dim] if nd.rep is not None else In[:, nd.input_dim]
+                    bind_private(nd, 'input', In[nd.rep, :][:, nd.input_dim] if nd.rep is not None else In[:, nd.input_dim])
                     nd.output = self.Y[:, [k]].copy()
                     continue
-                nd.input = In[:, nd.input_dim]
+                bind_private(nd, 'input', In[:, nd.input_dim])
                 if nd.type == 'gp':
                     if nd.connect is not None:
-                        nd.global_input = global_in[:, nd.connect]
+                        bind_private(nd, 'global_input', global_in[:, nd.connect])
                     nd.m = self.m
                     if reset_lengthscale:
                         est = nd.para_path[row]
@@ -630,7 +630,7 @@ class dgp:
                     continue
                 nd.engine = self.engine
                 nd.para_path = np.atleast_2d(np.concatenate((nd.scale, nd.length, nd.nugget)))
-                nd.D = nd.input.shape[1] + (0 if nd.connect is None else len(nd.connect))
+                nd.D = peek(nd, 'input').shape[1] + (0 if nd.connect is None else len(nd.connect))
                 if nd.prior_name == 'ref':
                     p = nd.D
                     nd.prior_coef[1] = 1 / len(nd.output) ** (1 / p) * (nd.prior_coef[0] + p)
@@ -705,19 +705,19 @@ class dgp:
                     mu = nd.gp_prediction(In[~mask, :][:, nd.input_dim], zz)[0]
                     Out[sub_idx, k] = nd.output.flatten()
                     Out[~mask, k] = np.asarray(mu).flatten()
-                    nd.input = In[:, nd.input_dim].copy()
+                    bind_private(nd, 'input', In[:, nd.input_dim].copy())
                     nd.output = Out[:, [k]].copy()
                     if nd.connect is not None:
-                        nd.global_input = global_in[:, nd.connect].copy()
+                        bind_private(nd, 'global_input', global_in[:, nd.connect].copy())
                     nd._stats = None
                 else:
                     nd.rep = self.indices
                     if nd.type == 'likelihood' and nd.rep is not None:
-                        nd.input = In[nd.rep, :][:, nd.input_dim].copy()
+                        bind_private(nd, 'input', In[nd.rep, :][:, nd.input_dim].copy())
                     else:
-                        nd.input = In[:, nd.input_dim].copy()
+                        bind_private(nd, 'input', In[:, nd.input_dim].copy())
                     if nd.type == 'gp' and nd.connect is not None:
-                        nd.global_input = global_in[:, nd.connect].copy()
+                        bind_private(nd, 'global_input', global_in[:, nd.connect].copy())
                     self._set_final_output(nd, k)
                 if nd.type == 'gp' and nd.prior_name == 'ref':
                     nd.compute_cl()
@@ -733,17 +733,17 @@ class dgp:
             for k, nd in enumerate(layer):
                 if last and nd.type == 'likelihood':
                     if nd.rep is not None:    # back to one row per distinct site first
-                        nd.input = np.concatenate([np.unique(nd.input[nd.rep == i, :], axis=0) for i in range(np.max(nd.rep) + 1)], axis=0)
-                    nd.input = nd.input[sub_idx, :]
+                        bind_private(nd, 'input', np.concatenate([np.unique(peek(nd, 'input')[nd.rep == i, :], axis=0) for i in range(np.max(nd.rep) + 1)], axis=0))
+                    bind_private(nd, 'input', peek(nd, 'input')[sub_idx, :])
                     if self.indices is not None:
-                        nd.input = nd.input[self.indices, :]
+                        bind_private(nd, 'input', peek(nd, 'input')[self.indices, :])
                 else:
-                    nd.input = nd.input[sub_idx, :]
+                    bind_private(nd, 'input', peek(nd, 'input')[sub_idx, :])
                 if last:
                     nd.rep = self.indices
                 if nd.type == 'gp':
                     if nd.connect is not None:
-                        nd.global_input = self.X[:, nd.connect].copy()
+                        bind_private(nd, 'global_input', self.X[:, nd.connect].copy())
                     nd.m = self.m
                     nd._stats = None
                 if last:

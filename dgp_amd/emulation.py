@@ -24,6 +24,7 @@ import collections
 import os
 
 import numpy as np
+from .kernel_class import bind_private, peek
 import torch
 
 from .imputation import imputer, DrawStream
@@ -162,7 +163,7 @@ class emulator:
                 if l < self.n_layer - 1:
                     nd.output = lat[l][:, [k]].copy()
                 if l > 0:
-                    nd.input = lat[l - 1][:, nd.input_dim].copy()
+                    bind_private(nd, 'input', lat[l - 1][:, nd.input_dim].copy())
         return al
 
     # ------------------------------------------------------------------ statistics
@@ -179,7 +180,7 @@ class emulator:
                 n = len(nd.output)
                 Np = e.padded_dim(n)
                 cap = Np - n
-                Xg = None if nd.global_input is None else e.tensor(nd.global_input)
+                Xg = None if peek(nd, 'global_input') is None else e.tensor(peek(nd, 'global_input'))
                 W = None if nd.rep is None else e.tensor(nd.W_diag)
 
                 def ys(s, l=l, k=k):   # (defaults: the closures below are called after this loop has moved on)
@@ -201,7 +202,7 @@ class emulator:
                     return Ainv, (-Ainv[n:n + r, :n]).contiguous()
 
                 if l == 0:
-                    Xl = e.tensor(nd.input)
+                    Xl = e.tensor(peek(nd, 'input'))
                     rys, Rinv = [], None
                     for c0 in range(0, S, cap):   # all imputations' y as right-hand sides of ONE factorisation
                         Y = e.tensor(np.stack([ys(s) for s in range(c0, min(S, c0 + cap))]))

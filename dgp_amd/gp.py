@@ -2,6 +2,7 @@
 import copy
 
 import numpy as np
+from .kernel_class import bind_private, peek
 
 from .ops import default_engine
 
@@ -49,18 +50,18 @@ class gp:
         k = self.kernel
         if k.input_dim is None:
             k.input_dim = np.arange(self.X.shape[1])
-            k.input = self.X.copy()
+            bind_private(k, 'input', self.X.copy())
         else:
-            k.input = self.X[:, k.input_dim]
+            bind_private(k, 'input', self.X[:, k.input_dim])
         if self.indices is not None:
             k.rep, k.W_diag, k.sum_residual = self.indices, self.W_diag, self.sum_residual
         if k.connect is not None:
             if len(np.intersect1d(k.connect, k.input_dim)) != 0:
                 raise Exception('The local input and global input should not have any overlap. Change input_dim or '
                                 'connect so they do not have any common indices.')
-            k.global_input = self.X[:, k.connect]
+            bind_private(k, 'global_input', self.X[:, k.connect])
         k.output = self.Y.copy()
-        k.D = k.input.shape[1] + (0 if k.connect is None else len(k.connect))
+        k.D = peek(k, 'input').shape[1] + (0 if k.connect is None else len(k.connect))
         k.para_path = np.atleast_2d(np.concatenate((k.scale, k.length, k.nugget)))
         k.vecch, k.m = self.vecch, self.m
         if self.ord_fun is not None:
@@ -104,12 +105,12 @@ class gp:
             k.rep, k.W_diag, k.sum_residual = self.indices, self.W_diag, self.sum_residual
         else:
             k.rep = k.W_diag = k.sum_residual = None
-        k.input = self.X[:, k.input_dim]
+        bind_private(k, 'input', self.X[:, k.input_dim])
         if k.connect is not None:
             if len(np.intersect1d(k.connect, k.input_dim)) != 0:
                 raise Exception('The local input and global input should not have any overlap. Change input_dim or '
                                 'connect so they do not have any common indices.')
-            k.global_input = self.X[:, k.connect]
+            bind_private(k, 'global_input', self.X[:, k.connect])
         k.output = self.Y.copy()
         k.m = self.m
         k._stats = None

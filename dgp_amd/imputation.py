@@ -28,6 +28,7 @@ from . import dist as ddist
 import torch
 
 from .ops import default_engine
+from .kernel_class import TrackedInputs, bind_private, peek
 
 TWO_PI = 2.0 * np.pi
 _NO_UPLOAD_AHEAD = bool(__import__('os').environ.get('DGPAMD_NO_UPLOAD_AHEAD'))   # (A/B switch of DrawStream.prefetch's early upload)
@@ -239,40 +240,31 @@ class imputer:
         return st
 
     # ------------------------------------------------------------------ device state
-    def _dev_const(self, key, arr):
+    def _dev_const(self, key, arr, private=False):
         """Device copy of a host array that rarely changes (inputs, observed outputs): uploaded again only when the host
-        values differ from the ones uploaded last (the numpy attributes stay the source of truth, as in the reference)."""
+        values differ from the ones uploaded last (the numpy attributes stay the source of truth, as in the reference).
+        private: the array object is one nobody outside the library holds (TrackedInputs._private) -- as long as the node
+        still binds THAT object its values cannot have changed, and the comparison by value (0.3 ms per 3-MB array, a dozen
+        per iteration at n = 50 000) is skipped; every other array is compared on every call and stays writable."""
         cache = self.__dict__.setdefault('_const', {})
         hit = cache.get(key)
-        if self._const_same(key, arr):
+        if self._const_same(key, arr, private):
             return hit[1]
+        if hit is not None:
+            self._inputs_changed = True   # (values that were uploaded before have changed: nothing computed from them may be reused)
         src = arr
         arr = np.ascontiguousarray(arr, dtype=float)
         t = self.engine.tensor(arr)
-        # The node's own array object is remembered and made read-only when it owns its data: as long as the attribute still
-        # IS that object its values cannot have changed, and the next calls skip the comparison (0.3 ms per 3 MB array, a
-        # dozen of them per iteration at n = 50 000).  Views and foreign dtypes keep the comparison by value.
-        owner = None
-        if key[0] in ('x', 'g') and isinstance(src, np.ndarray) and src.dtype == np.float64:   # (node inputs: copies the model made)
-            # (the array owns its data, or -- numpy's X[:, columns] -- is the full transposed view of an anonymous owner)
-            base = src.base
-            if base is None or (isinstance(base, np.ndarray) and base.base is None and base.size == src.size):
-                try:
-                    if base is not None:
-                        base.flags.writeable = False
-                    src.flags.writeable = False
-                    owner = src
-                except ValueError:
-                    owner = None
-        cache[key] = (arr if owner is not None else arr.copy(), t, owner)
+        owner = src if (private and isinstance(src, np.ndarray)) else None
+        cache[key] = (arr if (arr is not src and not np.shares_memory(arr, src)) else arr.copy(), t, owner)
         return t
 
-    def _const_same(self, key, arr):
+    def _const_same(self, key, arr, private=False):
         """Does the host array `arr` hold the values last uploaded under `key`?"""
         hit = self.__dict__.get('_const', {}).get(key)
         if hit is None:
             return False
-        if len(hit) > 2 and hit[2] is not None and arr is hit[2] and not arr.flags.writeable:
+        if private and len(hit) > 2 and hit[2] is not None and arr is hit[2]:
             return True
         a = np.asarray(arr, dtype=float)
         return hit[0].shape == a.shape and np.array_equal(hit[0], a)
@@ -300,12 +292,16 @@ class imputer:
             for k, nd in enumerate(self.all_layer[l]):
                 if nd.type != 'gp':
                     continue
-                self._glob[(l, k)] = None if nd.global_input is None else self._dev_const(('g', l, k), nd.global_input)
+                self._glob[(l, k)] = None if nd._global_input is None else self._dev_const(('g', l, k), nd._global_input, nd._private('global_input'))
                 if l == 0:
-                    self._x0[k] = self._dev_const(('x', k), nd.input)
+                    self._x0[k] = self._dev_const(('x', k), nd._input, nd._private('input'))
                 if l == L - 1:
                     self._yy[k] = self._dev_const(('y', k), np.asarray(nd.output, dtype=float).reshape(-1))
         self._ll_cache = {}
+        if self.__dict__.pop('_inputs_changed', False):   # an input was edited (in place or re-bound) since the last call
+            self._factor_cache = {}
+            self.__dict__.pop('_adopt_ll', None)
+            self.__dict__.pop('_adopt', None)
 
     def _detach(self):
         """Refresh the numpy attributes the reference's sampler mutates (imputation.py:94,109)."""
@@ -319,11 +315,14 @@ class imputer:
             given = self.__dict__.setdefault('_given_inputs', {})
             for nd in self.all_layer[l + 1]:
                 if nd.rep is not None and nd.type == 'likelihood':
-                    nd.input = Fh[nd.rep, :][:, nd.input_dim]
+                    new_in = Fh[nd.rep, :][:, nd.input_dim]
                 else:
-                    nd.input = Fh[:, nd.input_dim]
-                    nd.input.flags.writeable = False   # (stage_for_mstep recognises it by identity instead of comparing 3 MB)
-                    given[id(nd)] = nd.input
+                    new_in = Fh[:, nd.input_dim]
+                if isinstance(nd, TrackedInputs):
+                    nd._input = new_in           # a private copy: stage_for_mstep recognises it by identity until it is handed out
+                    given[id(nd)] = new_in
+                else:
+                    nd.input = new_in            # (a user plugin node: a plain attribute)
 
     def adopt_from_mstep(self, nd, Aslot, host):
         """Called by the lock-step M-step when a node's optimiser has ended, with the factored buffer and the host results of
@@ -355,7 +354,7 @@ class imputer:
                         st['buf'] = buf
                         self._factor_cache.pop(0, None)   # (its buffer is being rewritten)
                     buf[k].copy_(Aslot)
-                    st[k] = (k, nd.name, tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), id(nd.input))
+                    st[k] = (k, nd.name, tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), id(nd._input))
                     if all(j in st for j in range(M)):
                         self._factor_cache[0] = (tuple(st[j] for j in range(M)), buf)
                 elif l == L - 1 and L == 2 and nd.prior_name != 'ref':
@@ -400,14 +399,14 @@ class imputer:
                 const = self.__dict__.get('_const', {})
                 y_ok = np.array_equal(np.asarray(nd.output, dtype=float).reshape(-1),
                                       Fh[l][:, k] if l < L - 1 else const.get(('y', k), (None,))[0])
-                g_ok = nd.global_input is None or self._const_same(('g', l, k), nd.global_input)
+                g_ok = nd._global_input is None or self._const_same(('g', l, k), nd._global_input, nd._private('global_input'))
                 if l == 0:
-                    x_ok = self._const_same(('x', k), nd.input)
+                    x_ok = self._const_same(('x', k), nd._input, nd._private('input'))
                     Xl = self._x0[k]
                 else:
                     idx = np.asarray(nd.input_dim)
                     mine = self.__dict__.get('_given_inputs', {}).get(id(nd))
-                    x_ok = (mine is nd.input and not nd.input.flags.writeable) or np.array_equal(nd.input, Fh[l - 1][:, idx])
+                    x_ok = (mine is nd._input and nd._private('input')) or np.array_equal(nd._input, Fh[l - 1][:, idx])
                     src = self.F[l - 1]
                     Xl = src if (len(idx) == src.shape[1] and np.array_equal(idx, np.arange(src.shape[1]))) \
                         else src[:, torch.as_tensor(idx, device=src.device)].contiguous()
@@ -742,7 +741,7 @@ class imputer:
         n = self.F[l].shape[0]
         Np = e.padded_dim(n)
         sigs = tuple((k, layer[k].name, tuple(np.asarray(layer[k].length, float)), float(layer[k].nugget[0]),
-                      id(layer[k].input) if l == 0 else None) for k in dense)
+                      id(layer[k]._input) if l == 0 else None) for k in dense)   # (an input edited in place empties this cache: _attach)
         hit = self._factor_cache.get(l)
         if l != 0 or hit is None or hit[0] != sigs:
             extra = self.__dict__.pop('_want_ll0', None) if l == 0 else None
@@ -960,13 +959,14 @@ class imputer:
     def _ref_prior_terms(nd, FPh):
         """Reference-prior term of the ESS target for every candidate block (kernel_class.py:489-491,507-509): the prior's
         scaling constant depends on the node's inputs, i.e. on the proposal."""
-        keep, keep_cl = nd.input, getattr(nd, 'cl', None)
+        keep, keep_cl = peek(nd, 'input'), getattr(nd, 'cl', None)
         out = np.empty(FPh.shape[0])
         for b in range(FPh.shape[0]):
-            nd.input = FPh[b][:, nd.input_dim]
+            bind_private(nd, 'input', FPh[b][:, nd.input_dim])
             nd.compute_cl()
             out[b] = float(np.sum(nd.log_prior()))
-        nd.input, nd.cl = keep, keep_cl
+        bind_private(nd, 'input', keep)
+        nd.cl = keep_cl
         return out
 
     def _ess_plan(self, l):

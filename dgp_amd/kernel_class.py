@@ -27,7 +27,70 @@ def combine(*layers):
     return [layer for layer in layers]
 
 
-class kernel:
+class TrackedInputs:
+    """`input` / `global_input` of a node as the reference has them -- plain, writable numpy arrays (its sampler writes
+    node.input[:, idx] in place, imputation.py:160-202) -- with one addition: the node remembers which array it has HANDED
+    OUT.  The sampler keeps device copies of the node inputs and recognises an unchanged array by identity instead of
+    comparing megabytes on every call (0.3 ms per 3-MB array, a dozen per iteration at n = 50 000); an array somebody else
+    holds a reference to can change behind that test, so from the moment it is read -- or assigned -- through the public
+    attribute it is compared by value.  The library's own code reads `_input` / `_global_input` and binds its private
+    copies there (a new object: not handed out).  Rounds 2-3 froze the arrays instead (flags.writeable = False) and in-place
+    writes raised ValueError."""
+    _input = None
+    _global_input = None
+    _input_esc = 0            # id() of the array last handed out / assigned from outside
+    _global_input_esc = 0
+
+    @property
+    def input(self):
+        a = self._input
+        if a is not None:
+            self._input_esc = id(a)
+        return a
+
+    @input.setter
+    def input(self, v):
+        self._input = v
+        self._input_esc = id(v)
+
+    @property
+    def global_input(self):
+        a = self._global_input
+        if a is not None:
+            self._global_input_esc = id(a)
+        return a
+
+    @global_input.setter
+    def global_input(self, v):
+        self._global_input = v
+        self._global_input_esc = id(v)
+
+    def _private(self, name):
+        """Is the array bound to `name` ('input' / 'global_input') one nobody outside the library has seen?"""
+        a = getattr(self, '_' + name)
+        return a is not None and getattr(self, '_' + name + '_esc') != id(a)
+
+    def __setstate__(self, st):   # (objects pickled by rounds 1-3 kept the arrays under the public names)
+        for k in ('input', 'global_input'):
+            if k in st:
+                st['_' + k] = st.pop(k)
+        self.__dict__.update(st)
+
+
+def bind_private(nd, name, arr):
+    """Bind a private array (one the library has just made: nobody else holds it) as node.input / node.global_input."""
+    if isinstance(nd, TrackedInputs):
+        setattr(nd, '_' + name, arr)
+    else:
+        setattr(nd, name, arr)   # (a user plugin node: plain attributes)
+
+
+def peek(nd, name):
+    """node.input / node.global_input for the library's own reads: does not count as handing the array out."""
+    return getattr(nd, '_' + name) if isinstance(nd, TrackedInputs) else getattr(nd, name)
+
+
+class kernel(TrackedInputs):
     """A GP node.  Arguments as dgpsi.kernel (kernel_class.py:86); `engine` selects the
     device context (default: the process-wide engine of LOCAL_RANK)."""
 
@@ -52,7 +115,7 @@ class kernel:
         self.nugget_est, self.scale_est = nugget_est, scale_est
         self.input_dim, self.connect, self.bds = input_dim, connect, bds
         self.para_path = None
-        self.global_input = self.input = self.output = None
+        self._global_input = self._input = self.output = None
         self.rep = self.rep_hetero = self.W_diag = self.sum_residual = None
         self.vecch = None
         self.D = None
@@ -115,7 +178,7 @@ class kernel:
         return self._dev_of('rev_ord')
 
     def _X(self):
-        return self.input if self.global_input is None else np.concatenate((self.input, self.global_input), 1)
+        return self._input if self._global_input is None else np.concatenate((self._input, self._global_input), 1)
 
     def _stage(self):
         """Upload the node's current numpy state (inputs, output, replicate weights)."""
@@ -124,7 +187,7 @@ class kernel:
             self._staged = pre
             return pre
         e = self.engine
-        s = dict(Xl=e.tensor(self.input), Xg=None if self.global_input is None else e.tensor(self.global_input),
+        s = dict(Xl=e.tensor(self._input), Xg=None if self._global_input is None else e.tensor(self._global_input),
                  y=e.tensor(np.asarray(self.output, dtype=float).reshape(-1)),
                  W=None if self.rep is None else e.tensor(self.W_diag))
         self._staged = s
@@ -168,9 +231,9 @@ class kernel:
         constant of the node, so its rank test and an orthonormal basis of its column space are kept between calls
         (the reference redoes two SVD ranks and an SVD least-squares fit per M-step); the residual sums are
         |y - Q Q'y|^2, which is what lstsq returns for a full-column-rank design."""
-        if self.global_input is None:
+        if self._global_input is None:
             return
-        G = self.global_input
+        G = self._global_input
         sig = (id(G), G.shape, float(G[0, 0]), float(G[-1, -1]), float(G.sum()))
         hit = self.__dict__.get('_r2_cache')
         if hit is None or hit[0] != sig:
@@ -182,14 +245,15 @@ class kernel:
                 Q = np.linalg.qr(Xd)[0]
             hit = self._r2_cache = (sig, Xd, Q)
         _, Xd, Q = hit
+        Xin = self._input
         if Xd.shape[0] == Xd.shape[1]:
-            resid = np.zeros(self.input.shape[1])
+            resid = np.zeros(Xin.shape[1])
         elif Q is not None:
-            r = self.input - Q @ (Q.T @ self.input)
+            r = Xin - Q @ (Q.T @ Xin)
             resid = np.einsum('ij,ij->j', r, r)
         else:
-            resid = np.linalg.lstsq(Xd, self.input, rcond=None)[1]
-        rsq = 1 - resid / (len(self.input) * np.var(self.input, axis=0))
+            resid = np.linalg.lstsq(Xd, Xin, rcond=None)[1]
+        rsq = 1 - resid / (len(Xin) * np.var(Xin, axis=0))
         self.R2 = np.atleast_2d(rsq) if overwritten else np.vstack((self.R2, rsq))
 
     def gfod(self, x):
@@ -348,7 +412,7 @@ class kernel:
         """Ordering and ordered nearest neighbours (kernel_class.py:245-277); NN search on device."""
         if ord is None:
             if self.ord_fun is None:
-                self.ord = np.random.permutation(self.input.shape[0])
+                self.ord = np.random.permutation(self._input.shape[0])
             else:
                 self.ord = self.ord_fun(self._X() / self.length)
         else:
@@ -394,8 +458,8 @@ class kernel:
                 ones = self._dev_cache['ones'] = e.tensor(np.ones(len(self.output)))
             return dict(X=pre['X'][od].contiguous(), y=pre['y'][od].contiguous(), NN=self.nn_dev(), nd=ones)
         nd = np.ones(len(self.output)) if self.rep is None else self.W_diag
-        sig = (id(self.input), id(self.global_input), id(self.ord), id(self.NNarray), id(nd) if self.rep is not None else None,
-               float(np.sum(self.input)), float(np.sum(self.output)), float(np.sum(self.ord[:16])), len(self.output), id(e))
+        sig = (id(self._input), id(self._global_input), id(self.ord), id(self.NNarray), id(nd) if self.rep is not None else None,
+               float(np.sum(self._input)), float(np.sum(self.output)), float(np.sum(self.ord[:16])), len(self.output), id(e))
         hit = self.__dict__.get('_vecch_cache')
         pre = self.__dict__.pop('_vecch_prestaged', None)   # (device views of input and output handed over by the imputer)
         if hit is not None and hit[0] == sig:
@@ -534,8 +598,8 @@ class kernel:
             ry = e.gemv(Ainv[:n, :n], s['y'])
         else:
             ry = (-Ainv[n, :n]).contiguous()
-        self._stats = dict(Rinv=Ainv, ld=Np, ry=ry, W=e.tensor(self.input),
-                           Wg=None if self.global_input is None else e.tensor(self.global_input),
+        self._stats = dict(Rinv=Ainv, ld=Np, ry=ry, W=e.tensor(self._input),
+                           Wg=None if self._global_input is None else e.tensor(self._global_input),
                            Wall=e.tensor(self._X()), n=n)
 
     @property
@@ -549,20 +613,20 @@ class kernel:
     @property
     def R2sexp(self):
         """exp(-sqdist/2) on the scaled local inputs (kernel_class.py:752-763); built on demand, never used internally."""
-        if self.name != 'sexp' or self.input is None:
+        if self.name != 'sexp' or self._input is None:
             return None
         e = self.engine
-        ll = self.length if len(self.length) == 1 else self.length[:self.input.shape[1]]
-        K = e.kmatrix('sexp', e.tensor(self.input), None, None, ll * np.sqrt(2.0), 0.0).cpu().numpy()
+        ll = self.length if len(self.length) == 1 else self.length[:self._input.shape[1]]
+        K = e.kmatrix('sexp', e.tensor(self._input), None, None, ll * np.sqrt(2.0), 0.0).cpu().numpy()
         np.fill_diagonal(K, 1.0)
         return K
 
     @property
     def Psexp(self):
-        if self.name != 'sexp' or self.input is None:
+        if self.name != 'sexp' or self._input is None:
             return None
-        ll = self.length if len(self.length) == 1 else self.length[:self.input.shape[1]]
-        Xl = self.input / ll
+        ll = self.length if len(self.length) == 1 else self.length[:self._input.shape[1]]
+        Xl = self._input / ll
         return np.stack([Xl[:, d][:, None] + Xl[:, d][None, :] for d in range(Xl.shape[1])])
 
     def _pred_nn(self, x, w):
@@ -608,8 +672,8 @@ class kernel:
             x = m if z is None else np.concatenate((m, z), 1)
             w = self._X()
             nd = np.ones(len(self.output)) if self.rep is None else self.W_diag
-            mo, vo = e.vecchia_linkgp(self.name, e.tensor(m), e.tensor(v), zt, e.tensor(self.input),
-                                      None if self.global_input is None else e.tensor(self.global_input),
+            mo, vo = e.vecchia_linkgp(self.name, e.tensor(m), e.tensor(v), zt, e.tensor(self._input),
+                                      None if self._global_input is None else e.tensor(self._global_input),
                                       self._pred_nn(x, w), e.tensor(np.asarray(self.output, float).reshape(-1)),
                                       self.scale[0], self.length, self.nugget[0], e.tensor(nd))
         else:
@@ -624,7 +688,7 @@ class kernel:
         statistics), else the statistics themselves."""
         st = self._stats
         if 'link' not in st:
-            cells = self.engine.linkgp_cells(self.name, self.input, st['Wg'], st['Rinv'], st['ry'])
+            cells = self.engine.linkgp_cells(self.name, self._input, st['Wg'], st['Rinv'], st['ry'])
             st['link'] = st if cells is None else dict(cells, ld=st['ld'])
         return st['link']
 
@@ -635,8 +699,8 @@ class kernel:
         e = self.engine
         nz = m_z.shape[1]
         mm, vv = np.concatenate((m, m_z), axis=1), np.concatenate((v, v_z), axis=1)
-        W = np.concatenate((self.input, self.global_input[:, :nz]), axis=1)
-        Wg = self.global_input[:, nz:]
+        W = np.concatenate((self._input, self._global_input[:, :nz]), axis=1)
+        Wg = self._global_input[:, nz:]
         zt = None if z is None else e.tensor(z)
         Wgt = None if z is None else e.tensor(Wg)
         if self.vecch:

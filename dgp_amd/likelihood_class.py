@@ -8,6 +8,8 @@ import itertools
 
 import numpy as np
 
+from .kernel_class import TrackedInputs   # (node.input as a tracked attribute: see there)
+
 
 def ghdiag(fct, mu, var, y):
     """E[exp(fct(y, f))] under f ~ N(mu, diag(var)) by the tensor-product 10-point Gauss-Hermite rule
@@ -20,7 +22,7 @@ def ghdiag(fct, mu, var, y):
     return np.sum(np.exp(np.log(weights[None, :]) + fct(y[:, None], fn)), axis=1)
 
 
-class _CountLikelihood:
+class _CountLikelihood(TrackedInputs):
     """Shared state of the count likelihoods (attributes of the plugin protocol, likelihood_class.py:30-37)."""
     name = None
 
@@ -176,7 +178,7 @@ class ZINB(_CountLikelihood):
         return np.where(u < expit(f_sample[:, 2]), 0, np.random.negative_binomial(size, p)).flatten()
 
 
-class Categorical:
+class Categorical(TrackedInputs):
     """Categorical likelihood (likelihood_class.py:294-467).  Two classes: one latent, link 'logit' (default) or 'probit';
     K > 2 classes: K latents, link 'softmax' (default) or 'robustmax' (the arg-max class has probability 1 - eps, the
     others eps/(K-1)).  Outputs are class indices 0..K-1 (dgp encodes the labels).  prediction() returns class
@@ -280,7 +282,7 @@ class Categorical:
         return ex / np.sum(ex, axis=1, keepdims=True)
 
 
-class Hetero:
+class Hetero(TrackedInputs):
     """Heteroskedastic Gaussian likelihood (likelihood_class.py:94-243): y_i ~ N(f_i0, exp(f_i1)) with the two latents
     coming from the two GP nodes `input_dim` of the feeding layer.  Final layer only."""
 

@@ -4,6 +4,7 @@ reference.  Assembly, factorisation and the triangular product run on the device
 import copy
 
 import numpy as np
+from .kernel_class import bind_private, peek
 
 from .ops import default_engine
 
@@ -17,7 +18,7 @@ class path:
         for layer in self.all_layer:
             for nd in layer:
                 if nd.connect is not None:
-                    nd.global_input = self.X[:, nd.connect].copy()
+                    bind_private(nd, 'global_input', self.X[:, nd.connect].copy())
 
     @staticmethod
     def k_matrix(X, length, name):
@@ -44,7 +45,7 @@ class path:
                 for k, nd in enumerate(layer):
                     In = x if nd.input_dim is None else x[:, nd.input_dim]
                     if nd.connect is not None:
-                        In = np.concatenate((In, nd.global_input), 1)
+                        In = np.concatenate((In, peek(nd, 'global_input')), 1)
                     e.kmatrix(nd.name, e.tensor(In), None, None, nd.length, nd.nugget[0], out=A, full=False)
                     _, info = e.potrf(n, A, work=work)
                     if int(e.fetch(info)[0]):

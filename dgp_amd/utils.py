@@ -1,5 +1,6 @@
 """Small host utilities that keep dgpsi's names (utils.py:51-66, 203-269)."""
 import numpy as np
+from .kernel_class import bind_private, peek
 
 _threads = [8]
 
@@ -117,7 +118,8 @@ def load_structure(npz_file, engine=None):
                         nd.class_encoder.classes_ = d[p + 'cat_classes'].copy()
                 else:
                     nd = getattr(likelihood_class, str(d[p + 'likelihood']))(input_dim=g('input_dim'))
-                nd.input, nd.output, nd.rep = g('input'), g('output'), g('rep')
+                nd.output, nd.rep = g('output'), g('rep')
+                bind_private(nd, 'input', g('input'))
                 layer.append(nd)
                 continue
             flags = d[p + 'flags']
@@ -128,11 +130,13 @@ def load_structure(npz_file, engine=None):
             nd.prior_name, nd.prior_coef = prior, g('prior_coef')   # stored coefficients are the adjusted ones
             if prior == 'ref':
                 nd.cl = None
-            nd.input, nd.output, nd.global_input = g('input'), g('output'), g('global_input')
+            nd.output = g('output')
+            bind_private(nd, 'input', g('input'))
+            bind_private(nd, 'global_input', g('global_input'))
             nd.para_path, nd.rep = g('para_path'), g('rep')
             nd.vecch = bool(flags[2])
             nd.m = None if int(d[p + 'm']) < 0 else int(d[p + 'm'])
-            nd.D = nd.input.shape[1] + (0 if nd.global_input is None else nd.global_input.shape[1])
+            nd.D = peek(nd, 'input').shape[1] + (0 if peek(nd, 'global_input') is None else peek(nd, 'global_input').shape[1])
             if nd.rep is not None:
                 cnt = np.bincount(nd.rep, minlength=nd.rep.max() + 1)
                 nd.W_diag = 1.0 / cnt

@@ -270,6 +270,81 @@ def test_cfg5_chain_at_full_size_vs_oracle_walk(eng):
     close(var[0][:K, 0], v3, rtol=1e-5, atol=1e-7)
 
 
+def test_cfg5_chain_default_nugget_backward_error_form(eng):
+    """BASELINE configs[4] at its own size AND at the reference's default nugget 1e-6 (kernel_class.py:34: cond(R) ~ 1e8 with
+    1000 points on a line).  A forward comparison of predictions says nothing there -- LAPACK and the device each lose eight
+    digits of R^-1 y in their own way (the test above raises the nuggets for that reason) -- so the chain GP -> DGP -> GP is
+    checked in backward-error form: (1) every node's device statistics solve their systems to working accuracy,
+    |R (R^-1 y) - y| and |R R^-1 - I| small relative to |R| |R^-1| (what a backward-stable solver guarantees, whatever the
+    conditioning); (2) node by node -- gp for the first GP, link_gp for the DGP's two layers and the last GP
+    (linkgp.py:285-501 walks exactly these) -- the device's predictor against the oracle's fed with THE DEVICE'S R^-1 and
+    R^-1 y and the same inputs, within bounds stated in the magnitudes of the sums involved; lgp.predict of the whole chain
+    runs and stays finite."""
+    from oracle import dgp_oracle as O
+    from dgp_amd.linkgp import container, lgp
+    n, M = 1000, 64
+    rng = np.random.default_rng(19)
+    X1 = rng.uniform(size=(n, 3))
+    Y1 = np.sin(3 * X1[:, 0]) + X1[:, 1] ** 2 - X1[:, 2]
+    Y1 = (Y1 - Y1.mean()) / Y1.std()
+    Y2 = np.tanh(2 * Y1) + 0.3 * Y1 ** 2
+    Y2 = (Y2 - Y2.mean()) / Y2.std()
+    Y3 = np.cos(2 * Y2)
+    Y3 = (Y3 - Y3.mean()) / Y3.std()
+    lat = np.tanh(1.5 * Y1) + 0.05 * rng.standard_normal(n)
+    g1 = _node(eng, 'matern2.5', [0.8, 1.2, 1.0], X1, Y1, scale=1.1)          # nugget 1e-6: the default
+    h = _node(eng, 'matern2.5', [1.1], Y1[:, None], lat, scale=1.0)
+    t = _node(eng, 'matern2.5', [0.9], lat[:, None], Y2, scale=1.2)
+    g3 = _node(eng, 'matern2.5', [1.0], Y2[:, None], Y3, scale=0.9)
+    one = []
+    for l, st in enumerate(([[g1]], [[h], [t]], [[g3]])):
+        c = container.__new__(container)
+        c.vecch, c.local_input_idx = False, (np.array([0, 1, 2]) if l == 0 else np.array([0]))
+        if len(st) == 1:
+            c.type, c.structure = 'gp', st[0][0]
+        else:
+            c.type, c.structure = 'dgp', st
+        one.append([c])
+    sysm = lgp.__new__(lgp)
+    sysm.L, sysm.all_layer, sysm.num_model, sysm.all_layer_set = 3, one, [1, 1], [one]
+    xt = rng.uniform(size=(M, 3))
+    mu, var = sysm.predict([xt, [None], [None]])
+    assert mu[0].shape == (M, 1) and np.all(np.isfinite(mu[0])) and np.all(np.isfinite(var[0]))
+    dev = {}
+    for nd in (g1, h, t, g3):
+        if nd._stats is None:
+            nd.compute_stats()
+        R = O.k_matrix(nd.input, nd.length, nd.nugget[0], nd.name)
+        Ri, ry = nd.Rinv, nd.Rinv_y
+        y = nd.output[:, 0]
+        nR, nRi = np.abs(R).sum(1).max(), np.abs(Ri).sum(1).max()
+        assert nR * nRi > 1e6          # (the conditioning this test is about)
+        assert np.abs(R @ ry - y).max() <= 1e-11 * (nR * np.abs(ry).max() + np.abs(y).max())
+        assert np.abs(R @ Ri - np.eye(n)).max() <= 1e-11 * nR * nRi
+        assert np.abs(Ri - Ri.T).max() <= 1e-12 * nRi
+        dev[id(nd)] = (Ri, ry)
+    # (2) node by node, the same inputs and the same R^-1 / R^-1 y on both sides.  What is left is the order of sums whose terms
+    # are as large as |R^-1 y|_1 (mean) and |R^-1 y|_1^2 + |R^-1|_1 (variance: y'R^-1 J R^-1 y - tr(R^-1 J) with |J| <= 1), so
+    # the bounds are stated in those magnitudes -- at this conditioning they are 1e5 .. 1e12, which is also why the three-node
+    # chain as a whole cannot be compared forward (each implementation's 1e-13 relative differences in I and J come out of
+    # these sums as 1e-3 of a variance and grow from node to node; the reference's own LAPACK run has the same property).
+    K = 12   # (the oracle's Matern link_gp takes ~0.4 s per point and node)
+    Ri, ry = dev[id(g1)]
+    mo, vo = O.gp_predict(xt[:K], X1, Ri, ry, g1.scale, g1.length, g1.nugget, g1.name)
+    md, vd = g1.gp_prediction(xt[:K], None)
+    close(np.ravel(md), np.ravel(mo), rtol=1e-9, atol=1e-12 * np.abs(ry).sum())
+    close(np.ravel(vd), np.ravel(vo), rtol=1e-9, atol=1e-12 * float(g1.scale[0]) * np.abs(Ri).sum())
+    for nd, lo, hi in ((h, Y1.min(), Y1.max()), (t, lat.min(), lat.max()), (g3, Y2.min(), Y2.max())):
+        Ri, ry = dev[id(nd)]
+        m_in = rng.uniform(lo, hi, size=(K, 1))
+        v_in = rng.uniform(1e-4, 5e-2, size=(K, 1))
+        mo, vo = O.link_gp_predict(m_in, v_in, None, nd.input, None, Ri, ry, nd.scale, nd.length, nd.nugget, nd.name)
+        md, vd = nd.linkgp_prediction(m_in, v_in, None)
+        s1 = np.abs(ry).sum()
+        close(np.ravel(md), np.ravel(mo), rtol=1e-9, atol=1e-12 * s1)
+        close(np.ravel(vd), np.ravel(vo), rtol=1e-9, atol=1e-12 * float(nd.scale[0]) * (s1 * s1 + np.abs(Ri).sum()))
+
+
 def test_cfg4_vecchia_prediction_at_full_size_vs_oracle(eng):
     """cfg4's prediction kernels at their own size (n = 50 000 training points, 50 neighbours, 20 000 test points): gp_vecch
     (vecchia.py:635-654, D = 8) and link_gp_vecch (:758-796, Dw = Dz = 8, squared exponential) through the register-resident
