@@ -53,6 +53,8 @@ SIGNATURES = {
     'dgpamd_gemv': (_i, [_p, _l, _l, _p, _l, _p, _p]),
     'dgpamd_fetch': (_i, [_p, _p, _p, _z]),
     'dgpamd_fetch2': (_i, [_p, _p, _z, _p, _z, _p]),
+    'dgpamd_post': (_i, [_p, _p, _z, _i]),
+    'dgpamd_collect': (_i, [_p, _i, _p, _z]),
     'dgpamd_set_graphs': (_i, [_p, _i]),
     'dgpamd_set_linkgp_direct': (_i, [_p, _i]),
     'dgpamd_set_potrf_mode': (_i, [_p, _i]),

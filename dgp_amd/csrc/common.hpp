@@ -41,6 +41,16 @@ struct dgpamd_ctx {
     size_t devargs_bytes;
     size_t pinned_bytes;
     std::map<std::array<uint64_t, 10>, hipGraphExec_t> graphs;
+    struct Mailbox {                                  // dgpamd_post / dgpamd_collect: a result on its way to the host
+        char *host = nullptr;                         // pinned, host-coherent; the last 8 bytes are the sequence word
+        size_t cap = 0, bytes = 0;
+        hipEvent_t ev = nullptr;
+        const void *src = nullptr;
+        unsigned long long seq = 0;
+        int pending = 0, by_kernel = 0;
+    } mail[DGPAMD_MAILBOXES + 1];                     // (the last one is dgpamd_fetch's own)
+    double *vscratch = nullptr;                        // per-row partial results of the Vecchia row kernels (grown on demand: the
+    size_t vscratch_bytes = 0;                         // stream orders its users; a stream-ordered allocation per call cost ~0.2 ms of host time)
 };
 
 #define HIP_TRY(ctx, expr)                                                                         \

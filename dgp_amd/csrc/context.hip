@@ -50,7 +50,12 @@ extern "C" int dgpamd_destroy(dgpamd_ctx *ctx) {
     for (auto &kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto &mb : ctx->mail) {
+        if (mb.host) (void)hipHostFree(mb.host);
+        if (mb.ev) (void)hipEventDestroy(mb.ev);
+    }
     if (ctx->devargs) (void)hipFree(ctx->devargs);
+    if (ctx->vscratch) (void)hipFree(ctx->vscratch);
     if (ctx->hostargs) (void)hipHostFree(ctx->hostargs);
     delete ctx;
     return DGPAMD_OK;
@@ -79,6 +84,7 @@ int ensure_devargs(dgpamd_ctx *ctx, size_t bytes) {
     if (ctx->devargs_bytes >= bytes) return DGPAMD_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing may still read the old arrays
     if (ctx->devargs) (void)hipFree(ctx->devargs);
+    if (ctx->vscratch) (void)hipFree(ctx->vscratch);
     if (ctx->hostargs) (void)hipHostFree(ctx->hostargs);
     ctx->devargs = ctx->hostargs = nullptr;
     ctx->devargs_bytes = 0;
@@ -89,10 +95,104 @@ int ensure_devargs(dgpamd_ctx *ctx, size_t bytes) {
     return DGPAMD_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Mailboxes: results to the host without a stream synchronisation.  A small result is written into host-coherent pinned
+// memory by a one-block kernel, followed by a sequence word the host spins on (a wake-up from hipStreamSynchronize costs
+// tens of microseconds, per round of an optimiser that is the turn-around time); a large one goes through the copy engine
+// path of hipMemcpyAsync and the host polls the event recorded behind it.  Either way the wait is for THIS result: later
+// launches on the stream do not delay it.
+// ---------------------------------------------------------------------------
+#define MAIL_KERNEL_MAX 16384   // bytes; above this the blit path is faster than one workgroup writing across the bus
+
+__global__ void mail_publish_kernel(const uint32_t *src, uint32_t *host, int words, unsigned long long *flag, unsigned long long seq) {
+    for (int i = threadIdx.x; i < words; i += blockDim.x) host[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int mail_post(dgpamd_ctx *ctx, dgpamd_ctx::Mailbox &mb, const void *src, size_t bytes) {
+    if (mb.pending) BAD_ARG(ctx, "the mailbox still holds a result nobody collected");
+    if (mb.cap < bytes + 8) {
+        if (mb.host) (void)hipHostFree(mb.host);
+        mb.host = nullptr; mb.cap = 0;
+        size_t want = bytes + 8 < 65536 ? 65536 : ((bytes + 8 + 4095) & ~(size_t)4095);
+        if (hipHostMalloc((void **)&mb.host, want, hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(ctx, hipHostMalloc((void **)&mb.host, want, hipHostMallocDefault));
+        }
+        mb.cap = want;
+    }
+    if (!mb.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&mb.ev, hipEventDisableTiming));
+    unsigned long long *flag = reinterpret_cast<unsigned long long *>(mb.host + mb.cap - 8);
+    mb.by_kernel = bytes <= MAIL_KERNEL_MAX && bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+    mb.seq = ++ctx->host_seq;
+    mb.src = src; mb.bytes = bytes;
+    if (mb.by_kernel) {
+        __atomic_store_n(flag, 0ull, __ATOMIC_RELEASE);
+        hipLaunchKernelGGL(mail_publish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *)src, (uint32_t *)mb.host,
+                           (int)(bytes / 4), flag, mb.seq);
+        LAUNCH_CHECK(ctx);
+    } else
+        HIP_TRY(ctx, hipMemcpyAsync(mb.host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(mb.ev, ctx->stream));
+    mb.pending = 1;
+    return DGPAMD_OK;
+}
+
+static int mail_collect(dgpamd_ctx *ctx, dgpamd_ctx::Mailbox &mb, void *host_dst, size_t bytes) {
+    if (!mb.pending) BAD_ARG(ctx, "nothing was posted to this mailbox");
+    if (host_dst && bytes != mb.bytes) BAD_ARG(ctx, "size differs from the posted one");
+    mb.pending = 0;
+    const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(mb.host + mb.cap - 8);
+    for (unsigned long long it = 1;; ++it) {
+        if (mb.by_kernel) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == mb.seq) break;
+            __builtin_ia32_pause();
+            if ((it & 0xffff) != 0) continue;   // now and then: is the stream still alive? (a fault would leave the word unwritten)
+        }
+        const hipError_t q = hipEventQuery(mb.ev);
+        if (q == hipSuccess) {
+            if (mb.by_kernel && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != mb.seq)   // (this memory is not coherent: the slow way)
+                HIP_TRY(ctx, hipMemcpy(mb.host, mb.src, mb.bytes, hipMemcpyDeviceToHost));
+            break;
+        }
+        if (q != hipErrorNotReady) HIP_TRY(ctx, q);
+        if (!mb.by_kernel) {
+            __builtin_ia32_pause();
+            if (it > 200000) {   // (~0.1 s of polling: sleep instead)
+                HIP_TRY(ctx, hipEventSynchronize(mb.ev));
+                break;
+            }
+        }
+    }
+    if (host_dst) memcpy(host_dst, mb.host, mb.bytes);
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_post(dgpamd_ctx *ctx, const void *device_src, size_t bytes, int slot) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (!device_src || bytes == 0) BAD_ARG(ctx, "null pointer or nothing to copy");
+    if (slot < 0 || slot >= DGPAMD_MAILBOXES) BAD_ARG(ctx, "no such mailbox");
+    return mail_post(ctx, ctx->mail[slot], device_src, bytes);
+}
+
+extern "C" int dgpamd_collect(dgpamd_ctx *ctx, int slot, void *host_dst, size_t bytes) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (slot < 0 || slot >= DGPAMD_MAILBOXES) BAD_ARG(ctx, "no such mailbox");
+    return mail_collect(ctx, ctx->mail[slot], host_dst, bytes);
+}
+
 extern "C" int dgpamd_fetch(dgpamd_ctx *ctx, const void *device_src, void *host_dst, size_t bytes) {
     if (!ctx) return DGPAMD_BAD_ARG;
     if (!device_src || !host_dst) BAD_ARG(ctx, "null pointer");
     if (bytes == 0) return DGPAMD_OK;
+    static const bool spin = !(getenv("DGPAMD_FETCH_SPIN") && getenv("DGPAMD_FETCH_SPIN")[0] == '0');
+    if (spin && bytes <= MAIL_KERNEL_MAX) {   // the few words a sampler / optimiser step returns: no sleep, no wake-up
+        int rc = mail_post(ctx, ctx->mail[DGPAMD_MAILBOXES], device_src, bytes);
+        if (rc) return rc;
+        return mail_collect(ctx, ctx->mail[DGPAMD_MAILBOXES], host_dst, bytes);
+    }
     int rc = ensure_pinned(ctx, bytes);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -1244,7 +1244,21 @@ static int launch_vrow(dgpamd_ctx *ctx, VRowArgs &a, int batch = 1) {
 // scratch for the per-row partials lives behind the public outputs: the caller passes device buffers sized
 // for the reduced result only, so the library keeps one growable scratch per context-less call via hipMallocAsync.
 static int with_partials(dgpamd_ctx *ctx, size_t bytes, double **p) {
-    HIP_TRY(ctx, hipMallocAsync((void **)p, bytes, ctx->stream));
+    // One scratch buffer per context, grown on demand.  Its users follow each other on the context's stream (row kernel writes,
+    // column sums read), so the next call may overwrite it; round 3's hipMallocAsync / hipFreeAsync pair per call cost ~0.2 ms of
+    // host time -- the first launch of every lock-step M-step round at n = 50 000 waited for it.
+    if (ctx->vscratch_bytes < bytes) {
+        if (ctx->vscratch) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->vscratch);
+            ctx->vscratch = nullptr;
+            ctx->vscratch_bytes = 0;
+        }
+        const size_t want = bytes + bytes / 4;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->vscratch, want));
+        ctx->vscratch_bytes = want;
+    }
+    *p = ctx->vscratch;
     return DGPAMD_OK;
 }
 
@@ -1279,7 +1293,6 @@ extern "C" int dgpamd_vecchia_llik_batch(dgpamd_ctx *ctx, int kind, int64_t n, i
     rc = launch_vrow<V_LLIK>(ctx, a, batch);
     if (rc) return rc;
     hipLaunchKernelGGL(colsum_kernel, dim3(2, (unsigned)batch), dim3(1024), 0, ctx->stream, (const double *)a.partial, n, 2, out_llik);
-    HIP_TRY(ctx, hipFreeAsync(a.partial, ctx->stream));
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }
@@ -1307,7 +1320,6 @@ extern "C" int dgpamd_vecchia_nllik(dgpamd_ctx *ctx, int kind, int64_t n, int D,
     rc = launch_vrow<V_NLLIK>(ctx, a);
     if (rc) return rc;
     hipLaunchKernelGGL(colsum_kernel, dim3(w), dim3(1024), 0, ctx->stream, (const double *)a.partial, n, w, out_nllik);
-    HIP_TRY(ctx, hipFreeAsync(a.partial, ctx->stream));
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
 }

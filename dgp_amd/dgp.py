@@ -10,11 +10,12 @@ latents every node's objective involves only its own hyper-parameters
 (dgp.py:1391-1398).
 """
 import copy
+import os
 import numpy as np
 import torch
 from tqdm import trange, tqdm
 
-from .kernel_class import kernel as ker, combine, bind_private, peek
+from .kernel_class import kernel as ker, combine, bind_private, peek, TrackedInputs
 from . import dist as ddist
 from .imputation import imputer, DrawStream
 from .ops import Engine, default_engine, HandoffError
@@ -414,8 +415,9 @@ class dgp:
                     nd.r2(overwritten=True)
 
     # ------------------------------------------------------------------ training
-    def _m_step(self):
-        """One L-BFGS-B fit per GP node (dgp.py:1391-1398).  The dense nodes' optimisers advance in lock-step from this
+    def _m_step(self, early=False):
+        """One L-BFGS-B fit per GP node (dgp.py:1391-1398).  early (see _mstep_can_start_early): the imputer's detach and the
+        R2 diagnostics run after the lock-step driver has queued its first round of evaluations.  The dense nodes' optimisers advance in lock-step from this
         thread, their objective evaluations batched on the device (dgp_amd.mstep); Vecchia nodes (and every node if
         scipy's L-BFGS-B core is not the expected one) run kernel.maximise() one after another like the reference."""
         from . import mstep
@@ -427,14 +429,25 @@ class dgp:
             nodes = [nodes[i] for i in range(ddist.rank(), len(nodes), ddist.world())]
         failure = None
         with eng.stream():
-            for l, nd in every:   # (diagnostics on EVERY rank, also for the nodes another rank fits: identical R2 histories)
-                nd.engine = eng
-                if nd.prior_name == 'ref':
-                    nd.compute_cl()
-                if l != 0:
-                    nd.r2()
+            def diagnostics():
+                for l, nd in every:   # (on EVERY rank, also for the nodes another rank fits: identical R2 histories)
+                    nd.engine = eng
+                    if nd.prior_name == 'ref':
+                        nd.compute_cl()
+                    if l != 0:
+                        nd.r2()
+            if early:
+                for _, nd in every:
+                    nd.engine = eng
+
+                def hook():
+                    self.imp.finish_detach()
+                    diagnostics()
+            else:
+                hook = None
+                diagnostics()
             try:
-                self._fit_nodes(nodes, mstep, eng)
+                self._fit_nodes(nodes, mstep, eng, hook)
             except KeyboardInterrupt:
                 raise
             except BaseException as exc:   # noqa: BLE001  (LinAlgError: restart together; anything else -- DgpAmdError, an
@@ -446,9 +459,16 @@ class dgp:
             if split:
                 self._exchange_fits(every, failure)
 
-    def _fit_nodes(self, nodes, mstep, eng):
+    def _fit_nodes(self, nodes, mstep, eng, hook=None):
         dense = [nd for _, nd in nodes if not nd.vecch] if mstep._HAVE_CORE else []
-        pre = self.imp.stage_for_mstep() if getattr(self, 'imp', None) is not None and mstep._HAVE_CORE else {}
+        if hook is not None:
+            pre = self.imp.stage_for_mstep(trusted=True)
+            if any(id(nd) not in pre for _, nd in nodes):   # (cannot happen for the shapes _mstep_can_start_early admits)
+                hook()
+                hook = None
+                pre = self.imp.stage_for_mstep()
+        else:
+            pre = self.imp.stage_for_mstep() if getattr(self, 'imp', None) is not None and mstep._HAVE_CORE else {}
         for _, nd in nodes:
             if id(nd) in pre:
                 if nd.vecch:
@@ -463,9 +483,11 @@ class dgp:
         # node and evaluation)
         vlock = [nd for _, nd in nodes if nd.vecch and mstep._HAVE_CORE and not (nd.target == 'gp' and len(nd.length) != 1)]
         if len(vlock) > 1:
-            mstep.maximise_lockstep_vecch(eng, vlock)
+            mstep.maximise_lockstep_vecch(eng, vlock, after_first_launch=hook)
         else:
             vlock = []
+            if hook is not None:
+                hook()
         for _, nd in nodes:
             if not any(nd is d for d in dense) and not any(nd is d for d in vlock):
                 nd.maximise()
@@ -538,15 +560,39 @@ class dgp:
 
     def _si_iteration(self, i, ess_burn):
         """One iteration of stochastic EM: I-step, neighbour refresh, M-step (dgp.py:1377-1398)."""
-        if i == 1:
-            with self._init_scale():
-                self.imp.sample(burnin=ess_burn)
-        else:
-            self.imp.sample(burnin=ess_burn)
         it = self.N + i
-        if self.vecch and (it & (it - 1)) == 0 and it > 1:   # NN refresh at iterations 2,4,8,.. (dgp.py:1388)
-            self.imp.update_ord_nn()
-        self._m_step()
+        refresh = self.vecch and (it & (it - 1)) == 0 and it > 1   # NN refresh at iterations 2,4,8,.. (dgp.py:1388)
+        early = not refresh and self._mstep_can_start_early()
+        try:
+            if i == 1:
+                with self._init_scale():
+                    self.imp.sample(burnin=ess_burn, detach=not early)
+            else:
+                self.imp.sample(burnin=ess_burn, detach=not early)
+            if refresh:
+                self.imp.update_ord_nn()
+            self._m_step(early)
+        finally:
+            self.imp.finish_detach()   # (whatever happened: the nodes' numpy attributes are the state the sampler left)
+
+    def _mstep_can_start_early(self):
+        """True when the M-step's first objective evaluations can be queued on the device BEFORE the host has refreshed the
+        nodes' numpy attributes from the I-step's device state (imputer.sample(detach=False)): every GP node is a Vecchia
+        node fitted by the lock-step driver, from the imputer's own device views -- no reference prior (compute_cl reads the
+        numpy input), no replicates, one rank."""
+        from . import mstep
+        if not (self.vecch and mstep._HAVE_CORE) or ddist.is_active() or os.environ.get('DGPAMD_MSTEP_EARLY', '1') == '0':
+            return False
+        gps = [nd for layer in self.all_layer for nd in layer if nd.type == 'gp']
+        if len(gps) < 2:
+            return False
+        for layer in self.all_layer:
+            for nd in layer:
+                if nd.rep is not None or not isinstance(nd, TrackedInputs):
+                    return False
+                if nd.type == 'gp' and (not nd.vecch or nd.prior_name == 'ref' or (nd.target == 'gp' and len(nd.length) != 1)):
+                    return False
+        return True
 
     def _handoff_fallback(self, exc):
         import warnings

@@ -231,6 +231,7 @@ class imputer:
         return self._engine
 
     def __getstate__(self):
+        self.finish_detach()
         st = dict(self.__dict__)
         st['_engine'] = None
         st['_factor_cache'] = {}
@@ -303,12 +304,26 @@ class imputer:
             self.__dict__.pop('_adopt_ll', None)
             self.__dict__.pop('_adopt', None)
 
-    def _detach(self):
+    def finish_detach(self):
+        """The deferred half of sample(detach=False): bring the nodes' numpy attributes up to date."""
+        if self.__dict__.pop('_detach_pending', False):
+            self._detach()
+
+    def _detach(self, defer=False):
         """Refresh the numpy attributes the reference's sampler mutates (imputation.py:94,109)."""
         L = len(self.all_layer)
+        if defer:
+            self._detach_pending = True
+            # the latents start their way to the host NOW, ahead of whatever the caller queues next (the M-step's first
+            # evaluations): finish_detach() waits for these copies only
+            self._F_posted = {l: self.engine.post(self.F[l], 2 + l) for l in range(L - 1)} if L - 1 <= self.engine.MAILBOXES - 2 else {}
+            return
+        self.__dict__.pop('_detach_pending', None)
+        posted = self.__dict__.pop('_F_posted', {})
         self._Fh = {}
         for l in range(L - 1):
-            Fh = self.engine.fetch(self.F[l])   # (pinned staging: ~10x cheaper than torch's pageable .cpu() for 80 KB)
+            # (pinned staging: ~10x cheaper than torch's pageable .cpu() for 80 KB)
+            Fh = self.engine.collect(posted[l]) if l in posted else self.engine.fetch(self.F[l])
             self._Fh[l] = Fh
             for k, nd in enumerate(self.all_layer[l]):
                 nd.output[:, 0] = Fh[:, k]
@@ -379,17 +394,40 @@ class imputer:
             tot += ll
         return tot
 
-    def stage_for_mstep(self):
+    def stage_for_mstep(self, trusted=False):
         """Device views of every dense GP node's (input, global input, output) in the state the last sample() left --
         what kernel._stage() would upload from the numpy attributes _detach has just written, without the round trip
         through the host (24 small uploads per M-step at the bench shape).  {id(node): dict}; nodes with replicates,
-        Vecchia nodes and likelihood nodes are left to their own staging."""
+        Vecchia nodes and likelihood nodes are left to their own staging.
+        trusted: called by dgp.train's loop straight after sample(detach=False) -- the device state IS the truth (the numpy
+        attributes have not even been refreshed yet), nothing is compared."""
         out = {}
         self.__dict__.pop('_adopt', None)
         self.__dict__.pop('_adopt_ll', None)
+        L = len(self.all_layer)
+        if trusted:
+            if self.__dict__.get('F') is None:
+                return out
+            for l in range(L):
+                for k, nd in enumerate(self.all_layer[l]):
+                    if nd.type != 'gp' or nd.rep is not None:
+                        continue
+                    if l == 0:
+                        Xl = self._x0[k]
+                    else:
+                        idx = np.asarray(nd.input_dim)
+                        src = self.F[l - 1]
+                        Xl = src if (len(idx) == src.shape[1] and np.array_equal(idx, np.arange(src.shape[1]))) \
+                            else src[:, torch.as_tensor(idx, device=src.device)].contiguous()
+                    if nd.vecch:
+                        Xg = self._glob[(l, k)]
+                        out[id(nd)] = dict(X=Xl if Xg is None else torch.cat((Xl, Xg), 1), y=self._node_y(l, k))
+                    else:
+                        out[id(nd)] = dict(Xl=Xl, Xg=self._glob[(l, k)], y=self._node_y(l, k), W=None)
+            return out
+        self.finish_detach()
         if not self.__dict__.get('_Fh') or self.__dict__.get('F') is None:   # (no sample() yet, or state dropped by pickling)
             return out
-        L = len(self.all_layer)
         Fh = self._Fh
         for l in range(L):
             for k, nd in enumerate(self.all_layer[l]):
@@ -430,16 +468,20 @@ class imputer:
         return self._yy[k] if l == L - 1 else self.F[l][:, k].contiguous()
 
     # ------------------------------------------------------------------ sampling
-    def sample(self, burnin=0):
-        """ESS-within-Gibbs over the layers (imputation.py:22-42)."""
+    def sample(self, burnin=0, detach=True):
+        """ESS-within-Gibbs over the layers (imputation.py:22-42).  detach=False (dgp.train's own loop): the numpy attributes of
+        the nodes are refreshed later, by finish_detach() -- the M-step's first lock-step round is launched from the device
+        state in between, so that the device works while the host copies 3 MB of latents back and rewrites the attributes
+        (a 4-ms hole per iteration at n = 50 000).  Everything that reads the attributes calls finish_detach() first."""
+        self.finish_detach()
         self._attach()
         n_layer = len(self.all_layer)
         if n_layer > 2 and self._sample_queued_deep(burnin + 1):   # every sweep of every hidden layer queued on the device
-            self._detach()
+            self._detach(defer=not detach)
             return
         first, ahead = self._sample_queued(burnin + 1) if n_layer == 2 else (0, None)   # sweeps done without host round trips
         if first > burnin:
-            self._detach()
+            self._detach(defer=not detach)
             return
         if ahead is None:
             ahead = self._prior_draws_ahead(burnin + 1) if n_layer > 1 else None
@@ -454,7 +496,7 @@ class imputer:
                 else:
                     for k in range(len(self.all_layer[l])):
                         self.one_sample(l, k)
-        self._detach()
+        self._detach(defer=not detach)
 
     queued_calls = 0        # sample() calls that ran through the device queue (the tests read it)
     queue_max_batches = 2   # speculative batches queued per update (batch, then batch_next): 12 + 4 proposals; an update that
@@ -1164,6 +1206,7 @@ class imputer:
     def update_ord_nn(self):
         """Refresh ordering and neighbours, sharing them between sibling nodes that see identical
         scaled inputs (imputation.py:233-262)."""
+        self.finish_detach()
         for layer in self.all_layer:
             for k, nd in enumerate(layer):
                 if nd.type != 'gp':

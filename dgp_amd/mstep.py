@@ -10,6 +10,7 @@ driven for all nodes at once, and every round the pending objective evaluations 
 device-to-host copy).  Every node sees exactly the iterates scipy.optimize.minimize would give it.
 """
 
+import os
 import numpy as np
 
 from . import dist as ddist
@@ -75,31 +76,82 @@ class _Problem:
                 return False
 
 
-def minimize_lockstep(problems, evaluate, on_finish=None):
+def minimize_lockstep(problems, evaluate, on_finish=None, after_first_launch=None, groups=1):
     """Run several independent L-BFGS-B minimisations in lock-step from ONE thread: every round, all runs that want an
     objective value get it from one call evaluate([(index, x), ...]) -> [(f, g), ...].  Each run sees exactly the
-    sequence of points scipy.optimize.minimize(method='L-BFGS-B') would give it (same core, same options)."""
+    sequence of points scipy.optimize.minimize(method='L-BFGS-B') would give it (same core, same options).
+    An `evaluate` with .launch(req, slot) -> token and .collect(req, token) halves lets `after_first_launch()` (host work
+    of the caller that does not touch what the evaluations read) run between the two halves of the FIRST round, and --
+    groups > 1 -- keeps that many groups of runs in flight: while the host waits for one group's results and advances its
+    optimisers, the other groups' evaluations keep the device busy (no idle turn-around between rounds).  The runs are
+    independent, so the grouping changes the order of the launches, not what any run sees.  Returns the number of rounds
+    of the longest-running group."""
     if not _HAVE_CORE:
         raise RuntimeError('scipy L-BFGS-B core not available')
-    rounds = 0
     told = set()
-    while True:
-        want = [i for i, p in enumerate(problems) if not p.finished and p.advance()]
+
+    def advance(members):
+        want = [i for i in members if not problems[i].finished and problems[i].advance()]
         if on_finish is not None:   # (before the next round's launches reuse the buffers of the runs that have just ended)
-            for i, p in enumerate(problems):
-                if p.finished and i not in told:
+            for i in members:
+                if problems[i].finished and i not in told:
                     told.add(i)
                     on_finish(i)
-        if not want:
-            return rounds
-        out = evaluate([(i, problems[i].x.copy()) for i in want])
-        for i, (f, g) in zip(want, out):
+        return [(i, problems[i].x.copy()) for i in want]
+
+    def absorb(req, out):
+        for (i, _), (f, g) in zip(req, out):
             p = problems[i]
             p.f = np.array(float(np.asarray(f).reshape(-1)[0]))
             p.g = np.asarray(g, dtype=np.float64).copy()
             p.nfev += 1
-        rounds += 1
 
+    split = hasattr(evaluate, 'launch')
+    groups = max(1, min(int(groups), len(problems))) if split else 1
+    if groups == 1:
+        rounds = 0
+        everyone = range(len(problems))
+        while True:
+            req = advance(everyone)
+            if not req:
+                return rounds
+            if rounds == 0 and after_first_launch is not None and split:
+                token = evaluate.launch(req, 0)
+                after_first_launch()
+                out = evaluate.collect(req, token)
+            else:
+                if rounds == 0 and after_first_launch is not None:
+                    after_first_launch()
+                out = evaluate(req)
+            absorb(req, out)
+            rounds += 1
+    members = [list(range(g, len(problems), groups)) for g in range(groups)]   # (interleaved: neighbours differ in cost)
+    flying = {}
+    rounds = [0] * groups
+    try:
+        for g in range(groups):
+            req = advance(members[g])
+            if req:
+                flying[g] = (req, evaluate.launch(req, g))
+        if after_first_launch is not None:
+            after_first_launch()
+        g = 0
+        while flying:
+            if g in flying:
+                req, token = flying.pop(g)
+                absorb(req, evaluate.collect(req, token))
+                rounds[g] += 1
+                req = advance(members[g])
+                if req:
+                    flying[g] = (req, evaluate.launch(req, g))
+            g = (g + 1) % groups
+    finally:
+        for req, token in flying.values():   # (an exception: leave no mailbox occupied)
+            try:
+                evaluate.abandon(token)
+            except Exception:   # noqa: BLE001
+                pass
+    return max(rounds)
 
 
 def maximise_lockstep(engine, nodes, cache):
@@ -164,7 +216,7 @@ def maximise_lockstep(engine, nodes, cache):
     return rounds, evals[0]
 
 
-def maximise_lockstep_vecch(engine, nodes):
+def maximise_lockstep_vecch(engine, nodes, after_first_launch=None):
     """kernel.maximise() for several Vecchia GP nodes at once: the same lock-step driver, every round's objective evaluations
     (vecchia_nllik, one launch per node) queued back to back and fetched with ONE synchronisation -- the reference (and
     kernel.maximise) pays a host round trip per node and evaluation, which at n = 50 000 is two thirds of a 1-ms kernel.
@@ -179,7 +231,7 @@ def maximise_lockstep_vecch(engine, nodes):
         nd._vecch_fixed = nd._vecch_stage(trust_pre=True)   # inputs, outputs, neighbours: fixed during the run
         nd._in_maximise = True
 
-    def evaluate(req):
+    def launch(req, slot=0):   # one row launch per node, queued back to back; the sums start their way to the host at once
         outs = []
         for i, x in req:
             nd = nodes[i]
@@ -188,7 +240,11 @@ def maximise_lockstep_vecch(engine, nodes):
         buf = torch.cat([o for o, _ in outs])
         if ddist.rows_split():   # every rank evaluated its rows of every node: ONE all-reduce per round
             buf = ddist.allreduce_sum_vector(buf)
-        host = engine.fetch(buf)
+        return outs, engine.post(buf, slot)
+
+    def collect(req, token):   # ONE wait for the round -- for these sums, not for what has been queued behind them
+        outs, posted = token
+        host = engine.collect(posted)
         res, at = [], 0
         for (i, _), (o, P) in zip(req, outs):
             k = o.numel()
@@ -197,9 +253,15 @@ def maximise_lockstep_vecch(engine, nodes):
         evals[0] += len(req)
         return res
 
+    def evaluate(req):
+        return collect(req, launch(req))
+    evaluate.launch, evaluate.collect = launch, collect   # (the groups hold different nodes: a node's state is its own run's)
+    evaluate.abandon = lambda token: engine.discard(token[1])
+    groups = int(os.environ.get('DGPAMD_MSTEP_GROUPS', '2')) if len(nodes) >= 4 else 1
+
     try:
         with engine.stream():
-            rounds = minimize_lockstep(problems, evaluate)
+            rounds = minimize_lockstep(problems, evaluate, after_first_launch=after_first_launch, groups=groups)
     finally:
         for nd in nodes:
             nd._in_maximise = False

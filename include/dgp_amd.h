@@ -62,6 +62,15 @@ int dgpamd_sync(dgpamd_ctx *ctx);
 /* Results to the host: copy `bytes` from device memory through the context's pinned staging buffer, ordered after
  * everything queued on the context's stream, and return when they have landed (one stream synchronisation). */
 int dgpamd_fetch(dgpamd_ctx *ctx, const void *device_src, void *host_dst, size_t bytes);
+/* The two halves of dgpamd_fetch for results the host does not need yet.  dgpamd_post queues the copy of `bytes` from device
+ * memory into mailbox `slot` (0 .. DGPAMD_MAILBOXES-1) behind everything queued so far and returns at once; work queued
+ * afterwards does not delay it.  dgpamd_collect waits for that one copy (not for the stream) and hands the bytes over
+ * (host_dst NULL: wait and discard).  A mailbox holds one result at a time.  The lock-step M-step keeps two groups of
+ * optimisers in flight this way (one group's objective evaluations run while the host advances the other group's
+ * optimisers); the I-step's latents travel to the host while the M-step's first evaluations run. */
+#define DGPAMD_MAILBOXES 8
+int dgpamd_post(dgpamd_ctx *ctx, const void *device_src, size_t bytes, int slot);
+int dgpamd_collect(dgpamd_ctx *ctx, int slot, void *host_dst, size_t bytes);
 /* Two device regions (e.g. log-likelihoods and their info words) into one host buffer, back to back, one sync. */
 int dgpamd_fetch2(dgpamd_ctx *ctx, const void *src_a, size_t bytes_a, const void *src_b, size_t bytes_b, void *host_dst);
 const char *dgpamd_version(void);

@@ -21,3 +21,13 @@ for s, e, name in ev[1:]:
 print('span %.1f ms, kernel busy (sum) %.1f ms, idle %.1f ms' % (span / 1e6, busy / 1e6, sum(g[0] for g in gaps.values()) / 1e6))
 for (a, b), (t, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:18]:
     print('%8.2f ms  %6d x %7.1f us   %s -> %s' % (t / 1e6, n, t / n / 1e3, a, b))
+if len(sys.argv) > 3:   # context of the gaps longer than argv[3] microseconds: the kernels either side, times relative to the gap's start
+    thr = float(sys.argv[3]) * 1e3
+    shown = 0
+    for i in range(1, len(ev)):
+        if ev[i][0] - max(e for _, e, _ in ev[max(0, i - 8):i]) > thr and shown < int(sys.argv[4]) if len(sys.argv) > 4 else 6:
+            t0 = max(e for _, e, _ in ev[max(0, i - 8):i])
+            print('--- gap of %.0f us' % ((ev[i][0] - t0) / 1e3))
+            for s, e, nm in ev[max(0, i - 4):i + 10]:
+                print('   %9.1f .. %9.1f us  %s' % ((s - t0) / 1e3, (e - t0) / 1e3, nm))
+            shown += 1
