@@ -49,8 +49,8 @@ struct dgpamd_ctx {
         unsigned long long seq = 0;
         int pending = 0, by_kernel = 0;
     } mail[DGPAMD_MAILBOXES + 1];                     // (the last one is dgpamd_fetch's own)
-    double *vscratch = nullptr;                        // per-row partial results of the Vecchia row kernels (grown on demand: the
-    size_t vscratch_bytes = 0;                         // stream orders its users; a stream-ordered allocation per call cost ~0.2 ms of host time)
+    void *scratch[2] = {nullptr, nullptr};            // device scratch grown on demand (ctx_scratch): [0] per-row partial results of the
+    size_t scratch_bytes[2] = {0, 0};                 // Vecchia row kernels, [1] per-chunk candidate lists of the neighbour searches
 };
 
 #define HIP_TRY(ctx, expr)                                                                         \
@@ -286,4 +286,7 @@ int vecchia_llik_batch_into(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, 
                             const double *nugget_diag, double *partial, double *out);
 int ensure_pinned(dgpamd_ctx *ctx, size_t bytes);   // grow the context's pinned staging buffer
 int ensure_devargs(dgpamd_ctx *ctx, size_t bytes);  // grow the device / pinned argument arrays
+// One scratch buffer per purpose and context: its users follow each other on the context's stream, so the next call may overwrite
+// it (a stream-ordered hipMallocAsync / hipFreeAsync pair per call cost ~0.2 ms of host time, milliseconds for 60 MB).
+int ctx_scratch(dgpamd_ctx *ctx, int which, size_t bytes, void **p);
 

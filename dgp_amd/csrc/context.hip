@@ -55,7 +55,8 @@ extern "C" int dgpamd_destroy(dgpamd_ctx *ctx) {
         if (mb.ev) (void)hipEventDestroy(mb.ev);
     }
     if (ctx->devargs) (void)hipFree(ctx->devargs);
-    if (ctx->vscratch) (void)hipFree(ctx->vscratch);
+    for (void *q : ctx->scratch)
+        if (q) (void)hipFree(q);
     if (ctx->hostargs) (void)hipHostFree(ctx->hostargs);
     delete ctx;
     return DGPAMD_OK;
@@ -80,11 +81,26 @@ int ensure_pinned(dgpamd_ctx *ctx, size_t bytes) {
     return DGPAMD_OK;
 }
 
+int ctx_scratch(dgpamd_ctx *ctx, int which, size_t bytes, void **p) {
+    if (ctx->scratch_bytes[which] < bytes) {
+        if (ctx->scratch[which]) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing may still use the old buffer
+            (void)hipFree(ctx->scratch[which]);
+            ctx->scratch[which] = nullptr;
+            ctx->scratch_bytes[which] = 0;
+        }
+        const size_t want = bytes + bytes / 4;
+        HIP_TRY(ctx, hipMalloc(&ctx->scratch[which], want));
+        ctx->scratch_bytes[which] = want;
+    }
+    *p = ctx->scratch[which];
+    return DGPAMD_OK;
+}
+
 int ensure_devargs(dgpamd_ctx *ctx, size_t bytes) {
     if (ctx->devargs_bytes >= bytes) return DGPAMD_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing may still read the old arrays
     if (ctx->devargs) (void)hipFree(ctx->devargs);
-    if (ctx->vscratch) (void)hipFree(ctx->vscratch);
     if (ctx->hostargs) (void)hipHostFree(ctx->hostargs);
     ctx->devargs = ctx->hostargs = nullptr;
     ctx->devargs_bytes = 0;

@@ -536,16 +536,15 @@ static int launch_nn_stream(dgpamd_ctx *ctx, int64_t nq, int64_t nx, int D, cons
     if (const char *ce = getenv("DGPAMD_NN_CHUNK")) chunk = atoll(ce) > 0 ? (atoll(ce) + 63) / 64 * 64 : chunk;   // (tuning aid)
     const int nchunk = (int)((nx + chunk - 1) / chunk);
     const size_t items = (size_t)nblk * nchunk;
-    double *sd = nullptr;
-    int *si = nullptr;
-    HIP_TRY(ctx, hipMallocAsync((void **)&sd, items * K * 64 * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipMallocAsync((void **)&si, items * K * 64 * sizeof(int), ctx->stream));
+    void *both = nullptr;
+    int rc = ctx_scratch(ctx, 1, items * K * 64 * (sizeof(double) + sizeof(int)), &both);
+    if (rc) return rc;
+    double *sd = reinterpret_cast<double *>(both);
+    int *si = reinterpret_cast<int *>(sd + items * K * 64);
     hipLaunchKernelGGL((nn_scan_kernel<DMAX, K>), dim3((unsigned)nblk, (unsigned)nchunk), dim3(64), 0, ctx->stream, nq, nx, D, q, x,
                        ordered, chunk, nchunk, sd, si);
     hipLaunchKernelGGL((nn_merge_kernel<K>), dim3((unsigned)nblk), dim3(64), 0, ctx->stream, nq, nx, m_out, ordered, chunk, nchunk,
                        (const double *)sd, (const int *)si, out);
-    HIP_TRY(ctx, hipFreeAsync(sd, ctx->stream));
-    HIP_TRY(ctx, hipFreeAsync(si, ctx->stream));
     return DGPAMD_OK;
 }
 
@@ -1241,25 +1240,10 @@ static int launch_vrow(dgpamd_ctx *ctx, VRowArgs &a, int batch = 1) {
     return DGPAMD_OK;
 }
 
-// scratch for the per-row partials lives behind the public outputs: the caller passes device buffers sized
-// for the reduced result only, so the library keeps one growable scratch per context-less call via hipMallocAsync.
+// scratch for the per-row partials lives behind the public outputs: the caller passes device buffers sized for the reduced
+// result only; the context keeps one growable buffer for them (ctx_scratch).
 static int with_partials(dgpamd_ctx *ctx, size_t bytes, double **p) {
-    // One scratch buffer per context, grown on demand.  Its users follow each other on the context's stream (row kernel writes,
-    // column sums read), so the next call may overwrite it; round 3's hipMallocAsync / hipFreeAsync pair per call cost ~0.2 ms of
-    // host time -- the first launch of every lock-step M-step round at n = 50 000 waited for it.
-    if (ctx->vscratch_bytes < bytes) {
-        if (ctx->vscratch) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->vscratch);
-            ctx->vscratch = nullptr;
-            ctx->vscratch_bytes = 0;
-        }
-        const size_t want = bytes + bytes / 4;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->vscratch, want));
-        ctx->vscratch_bytes = want;
-    }
-    *p = ctx->vscratch;
-    return DGPAMD_OK;
+    return ctx_scratch(ctx, 0, bytes, reinterpret_cast<void **>(p));   // (row kernel writes, column sums read: stream order)
 }
 
 int vecchia_llik_batch_into(dgpamd_ctx *ctx, int kind, int64_t n, int D, int m, const double *X, int64_t x_stride, int batch,

@@ -571,7 +571,10 @@ class dgp:
                 self.imp.sample(burnin=ess_burn, detach=not early)
             if refresh:
                 self.imp.update_ord_nn()
-            self._m_step(early)
+            if early:
+                self._m_step(early=True)
+            else:
+                self._m_step()
         finally:
             self.imp.finish_detach()   # (whatever happened: the nodes' numpy attributes are the state the sampler left)
 

@@ -918,7 +918,7 @@ class imputer:
         e = self.engine
         B = FP.shape[0]
         upper = self.all_layer[l + 1]
-        dev_terms, infos = [], []
+        dev_terms, infos, vec_terms = [], [], []
         host = np.zeros(B)
         FPh = None
         for k, nd in enumerate(upper):
@@ -965,7 +965,7 @@ class imputer:
                 o = e.vecchia_llik_batch(nd.name, Xall, y, NN[lo:hi], nd.length, nd.nugget[0], nd_diag)
                 if ddist.rows_split():   # one all-reduce of the batch's 2 B sums: every rank takes the same accept decisions
                     o = ddist.allreduce_sum_vector(o.reshape(-1)).reshape(B, 2)
-                dev_terms.append(-0.5 * (o[:, 1] + o[:, 0] / float(nd.scale[0])))
+                vec_terms.append((o, float(nd.scale[0])))   # (-0.5 (logdet + quad / scale): closed on the host below)
                 if nd.prior_name == 'ref':
                     if FPh is None:
                         FPh = FP.cpu().numpy()
@@ -980,6 +980,12 @@ class imputer:
                 for b in range(B):
                     nd.input = FPh[b][nd.rep, :][:, nd.input_dim] if nd.rep is not None else FPh[b][:, nd.input_dim]
                     host[b] += float(np.sum(nd.llik()))
+        if vec_terms:
+            # the Vecchia nodes' (quad, logdet) sums: ONE fetch, combined here -- a torch expression on the device would be
+            # three more launches per batch (and 0.15 s of lazy code loading the first time a process runs it)
+            sums = e.fetch(vec_terms[0][0] if len(vec_terms) == 1 else torch.cat([o.reshape(-1) for o, _ in vec_terms])).reshape(-1, B, 2)
+            for (_, sc_), o in zip(vec_terms, sums):
+                host = host + -0.5 * (o[:, 1] + o[:, 0] / sc_)
         if dev_terms:
             # results come back through the library's pinned buffer (one sync); a single GP node upstairs -- the usual
             # case -- needs no device-side packing at all
@@ -1207,6 +1213,9 @@ class imputer:
         """Refresh ordering and neighbours, sharing them between sibling nodes that see identical
         scaled inputs (imputation.py:233-262)."""
         self.finish_detach()
+        # the searches first, one behind the other on the device (their orderings drawn in node order, as the sequential loop
+        # draws them), then the nodes that borrow a sibling's result
+        waiting, borrowers = [], []
         for layer in self.all_layer:
             for k, nd in enumerate(layer):
                 if nd.type != 'gp':
@@ -1217,12 +1226,30 @@ class imputer:
                     if o.type != 'gp' or not np.array_equal(nd.input_dim, o.input_dim) or not np.array_equal(nd.connect, o.connect):
                         continue
                     if len(nd.length) == 1 and len(o.length) == 1:
-                        donor = (o.ord, o.NNarray)
+                        donor = (o, False)
                         break
                     if len(nd.length) != 1 and np.array_equal(nd.length, o.length):
-                        donor = (o.ord.copy(), o.NNarray.copy())
+                        donor = (o, True)
                         break
                 if donor is None:
-                    nd.ord_nn()
+                    if len(waiting) == self.engine.MAILBOXES:   # (every mailbox holds a search: take the oldest one in)
+                        waiting.pop(0)[1]()
+                    slot = next(i for i in range(self.engine.MAILBOXES) if all(i != s_ for s_, _ in waiting))
+                    fin = nd.ord_nn(slot=slot)
+                    if fin is not None:
+                        waiting.append((slot, fin))
                 else:
-                    nd.ord_nn(ord=donor[0], NNarray=donor[1])
+                    borrowers.append((nd,) + donor)
+        failed = None
+        for _, fin in waiting:
+            try:
+                fin()
+            except Exception as exc:   # noqa: BLE001  (take the other results in all the same: no mailbox stays occupied)
+                failed = failed or exc
+        if failed is not None:
+            raise failed
+        for nd, o, copy in borrowers:   # (a donor is an earlier node of the same layer: it has its arrays by now)
+            if copy:
+                nd.ord_nn(ord=o.ord.copy(), NNarray=o.NNarray.copy(), rev_ord=o.rev_ord.copy())
+            else:
+                nd.ord_nn(ord=o.ord, NNarray=o.NNarray, rev_ord=o.rev_ord)

@@ -408,8 +408,11 @@ class kernel(TrackedInputs):
         return nll, g
 
     # ---------------------------------------------------------------- Vecchia twins
-    def ord_nn(self, ord=None, NNarray=None, pointer=False):
-        """Ordering and ordered nearest neighbours (kernel_class.py:245-277); NN search on device."""
+    def ord_nn(self, ord=None, NNarray=None, pointer=False, slot=None, rev_ord=None):
+        """Ordering and ordered nearest neighbours (kernel_class.py:245-277); NN search on device.
+        slot (a mailbox number, imputer.update_ord_nn): the search is launched and its result posted to the host; the call
+        returns a function that waits for it and binds NNarray -- several nodes' searches then run back to back on the
+        device while the host prepares the next one."""
         if ord is None:
             if self.ord_fun is None:
                 self.ord = np.random.permutation(self._input.shape[0])
@@ -417,15 +420,26 @@ class kernel(TrackedInputs):
                 self.ord = self.ord_fun(self._X() / self.length)
         else:
             self.ord = ord
-        self.rev_ord = np.argsort(self.ord)
+        if rev_ord is not None:
+            self.rev_ord = rev_ord
+        else:   # (the inverse permutation: what np.argsort(self.ord) returns, without the sort)
+            self.rev_ord = np.empty(len(self.ord), dtype=np.intp)
+            self.rev_ord[self.ord] = np.arange(len(self.ord), dtype=np.intp)
+        finish = None
         if NNarray is None:
             e = self.engine
             Xs = (self._X() / self.length)[self.ord]
             dev = e.nn_ordered(e.tensor(Xs), self.m)
-            self.NNarray = dev.cpu().numpy()
-            self.__dict__.setdefault('_dev_cache', {}).pop('NNarray', None)
-            step = max(1, self.NNarray.shape[0] // 61)   # (seed the device cache: no upload of what was just computed there)
-            self._dev_cache['NNarray'] = ((id(self.NNarray), self.NNarray.shape, int(self.NNarray[::step].sum()), id(e)), dev, self.NNarray)
+            token = e.post(dev, 0 if slot is None else slot)   # (page-locked staging: a pageable copy of 10 MB takes 3.5 ms)
+
+            def finish():
+                self.NNarray = e.collect(token)
+                self.__dict__.setdefault('_dev_cache', {}).pop('NNarray', None)
+                step = max(1, self.NNarray.shape[0] // 61)   # (seed the device cache: no upload of what was just computed there)
+                self._dev_cache['NNarray'] = ((id(self.NNarray), self.NNarray.shape, int(self.NNarray[::step].sum()), id(e)), dev, self.NNarray)
+            if slot is None or pointer:
+                finish()
+                finish = None
         else:
             self.NNarray = NNarray
         if pointer:
@@ -441,6 +455,7 @@ class kernel(TrackedInputs):
             self.imp_NNarray = np.hstack((np.arange(n).reshape(-1, 1) + n, np.arange(n).reshape(-1, 1), NNs)).astype(np.int64)
         else:
             self.imp_NNarray = None
+        return finish
 
     def _vecch_stage(self, trust_pre=False):
         """Ordered inputs / outputs, neighbour array and nugget weights on the device.  Kept between calls while nothing

@@ -1407,6 +1407,44 @@ def test_lockstep_vecchia_mstep_equals_per_node_maximise(eng):
             assert np.array_equal(na.length, nb.length) and np.array_equal(na.scale, nb.scale) and np.array_equal(na.nugget, nb.nugget)
 
 
+def test_vecchia_training_does_not_depend_on_the_host_overlaps(eng, monkeypatch):
+    """dgp.train on a Vecchia model queues the M-step's first evaluations from the imputer's device state while the latents
+    are still travelling to the host (imputer.sample(detach=False), dgp._mstep_can_start_early) and keeps two groups of
+    optimisers in flight (mstep.minimize_lockstep(groups=2)).  Both are schedules, not algorithms: hyper-parameters, paths,
+    latents, node inputs and neighbour arrays after five iterations (refreshes at 2 and 4) equal the plain order's, bit for bit."""
+    from dgp_amd import dgp, kernel, combine
+    rng = np.random.default_rng(33)
+    n, d = 600, 4
+    X = rng.uniform(size=(n, d))
+    f = np.sin(4 * X[:, 0]) * np.cos(3 * X[:, 1]) + 0.5 * X[:, 2] - X[:, 3] ** 2
+    Y = ((f - f.mean()) / f.std())[:, None]
+
+    def run(early, groups):
+        monkeypatch.setenv('DGPAMD_MSTEP_EARLY', early)
+        monkeypatch.setenv('DGPAMD_MSTEP_GROUPS', groups)
+        np.random.seed(3)
+        layers = combine([kernel(length=np.array([1.0]), name='sexp') for _ in range(d)],
+                         [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(d))])
+        m = dgp(X, Y, layers, vecchia=True, m=10, seed=8)
+        used = []
+        inner = m._mstep_can_start_early
+        m._mstep_can_start_early = lambda: used.append(inner()) or used[-1]
+        m.train(N=5, ess_burn=3, disable=True)
+        return m, used
+
+    a, ua = run('1', '2')
+    b, ub = run('0', '1')
+    assert ua == [True, True, True] and ub == [False, False, False]   # (iterations 1, 3, 5; the refresh iterations do not ask)
+    for la, lb in zip(a.all_layer, b.all_layer):
+        for na, nb in zip(la, lb):
+            assert np.array_equal(na.para_path, nb.para_path)
+            assert np.array_equal(na.length, nb.length) and np.array_equal(na.scale, nb.scale) and np.array_equal(na.nugget, nb.nugget)
+            assert np.array_equal(na.output, nb.output) and np.array_equal(na.input, nb.input)
+            assert np.array_equal(na.ord, nb.ord) and np.array_equal(na.NNarray, nb.NNarray) and np.array_equal(na.rev_ord, np.argsort(na.ord))
+            if getattr(na, 'R2', None) is not None:
+                assert np.array_equal(np.asarray(na.R2), np.asarray(nb.R2))
+
+
 def test_one_si_iteration_at_bench_size_vs_oracle(eng):
     """ONE stochastic-imputation iteration of BASELINE's configs[1] (n = 2000, d = 5, 5 + 1 Matern-2.5 nodes) against
     the oracle with injected draws: the I-step's block update (prior draws through five n x n factors, the speculative

@@ -1086,3 +1086,40 @@ def test_vecchia_linkgp_matern_separable_records_vs_oracle(eng, Dw, Dz, pm):
     mo, vo = O.link_gp_vecch(mm, vv, z, W, Wg, npy(NN).astype(int), y, 1.4, length, 1e-3, nd, 'matern2.5')
     close(lm, mo, rtol=1e-8, atol=1e-10)
     close(lv, vo, rtol=1e-6, atol=1e-9)
+
+
+def test_mailboxes_deliver_results_without_draining_the_stream(eng):
+    """dgpamd_post / dgpamd_collect (include/dgp_amd.h): a result posted to a mailbox arrives as fetch() would deliver it --
+    small ones through the one-block publishing kernel, large ones through the copy path -- while work queued afterwards is
+    still running; a mailbox holds one result at a time; discard() frees it."""
+    import torch
+    from dgp_amd.ops import DgpAmdError
+    rng = np.random.default_rng(5)
+    small = rng.normal(size=37)
+    ints = rng.integers(-5, 5, size=(3, 7)).astype(np.int32)
+    large = rng.normal(size=(3000, 9))                     # 216 KB: above the kernel path's limit
+    ds, di, dl = eng.tensor(small), torch.as_tensor(ints, device=eng.device), eng.tensor(large)
+    with eng.stream():
+        t0 = eng.post(ds, 0)
+        t1 = eng.post(di, 1)
+        t2 = eng.post(dl * 2.0, 2)
+        big = torch.empty(4096, 4096, dtype=torch.float64, device=eng.device)
+        for _ in range(4):                                 # (work behind the posts: they must not wait for it)
+            big.normal_()
+        with pytest.raises(DgpAmdError):
+            eng.post(ds, 0)                                # the mailbox is occupied
+        assert np.array_equal(eng.collect(t2), large * 2.0)
+        assert np.array_equal(eng.collect(t0), small)
+        assert np.array_equal(eng.collect(t1), ints)
+        with pytest.raises(DgpAmdError):
+            eng.collect(t0)                                # nothing posted any more
+        for rep in range(50):                              # reuse: sequence words never repeat
+            tok = eng.post(ds + rep, rep % eng.MAILBOXES)
+            assert np.array_equal(eng.collect(tok), small + rep)
+        tok = eng.post(ds, 3)
+        eng.discard(tok)
+        tok = eng.post(dl, 3)
+        assert np.array_equal(eng.collect(tok), large)
+    with pytest.raises(DgpAmdError):
+        eng.post(ds, eng.MAILBOXES)
+    assert np.array_equal(eng.fetch(ds), small) and np.array_equal(eng.fetch(dl), large)   # (fetch: the same two paths)

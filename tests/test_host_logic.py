@@ -306,6 +306,35 @@ def test_lockstep_lbfgsb_matches_scipy_minimize():
         for a, b in zip(got[i], ref_pts[i]):
             assert np.array_equal(a, b)
         assert np.array_equal(probs[i].x, ref_last[i])
+    # several groups in flight (launch / collect halves, the Vecchia M-step's driver): another launch order, the same iterates;
+    # a group's results are collected only after the OTHER groups' launches have been queued behind it
+    for groups in (2, 3):
+        got2 = [[] for _ in cases]
+        log, hooks = [], []
+
+        def launch(req, slot):
+            log.append(('launch', slot, tuple(i for i, _ in req)))
+            for i, x in req:
+                got2[i].append(x.copy())
+            return [cases[i][0](x) for i, x in req]
+
+        def collect(req, token):
+            log.append(('collect', tuple(i for i, _ in req)))
+            return token
+
+        def evaluate2(req):
+            return collect(req, launch(req, 0))
+        evaluate2.launch, evaluate2.collect, evaluate2.abandon = launch, collect, lambda token: None
+        probs2 = [mstep._Problem(x0, lb, ub, o['maxiter'], o['maxfun']) for _, x0, lb, ub, o in cases]
+        rounds2 = mstep.minimize_lockstep(probs2, evaluate2, after_first_launch=lambda: hooks.append(len(log)), groups=groups)
+        assert hooks == [groups] and all(e[0] == 'launch' for e in log[:groups])   # the hook runs once, behind every group's first launch
+        assert rounds2 == max(len(p) for p in ref_pts)
+        for i in range(len(cases)):
+            assert len(got2[i]) == len(ref_pts[i])
+            assert all(np.array_equal(a, b) for a, b in zip(got2[i], ref_pts[i]))
+            assert np.array_equal(probs2[i].x, ref_last[i])
+        slots = {e[1] for e in log if e[0] == 'launch'}
+        assert slots == set(range(groups))
 
 
 def test_drawstream_prefetch_keeps_the_sequence():

@@ -93,7 +93,19 @@ elif which == 'cfg4train':
         sync(); spent[0] += time.perf_counter() - t0
         return r
     model._m_step = timed_m_step
+    if os.environ.get('ITER_TIMES'):   # wall time of every iteration (the neighbour refreshes at 2, 4, 8, .. stand out)
+        it_t, inner_it = [], model._si_iteration
+
+        def timed_it(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return inner_it(*a, **k)
+            finally:
+                it_t.append(time.perf_counter() - t0)
+        model._si_iteration = timed_it
     t = time.perf_counter(); model.train(N=its, ess_burn=10, disable=True); sync(); dt = time.perf_counter() - t
+    if os.environ.get('ITER_TIMES'):
+        print('cfg4train: ms per iteration ' + ' '.join('%.0f' % (1e3 * v) for v in it_t), flush=True)
     print('cfg4train: %d SI iterations %.1f s -> %.3f it/s (M-steps %.0f ms each, the rest %.0f ms); stats %s'
           % (its, dt, its / dt, 1e3 * spent[0] / its, 1e3 * (dt - spent[0]) / its, model.imp.stats), flush=True)
     if os.environ.get('TRAIN_ONLY'):
