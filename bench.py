@@ -277,7 +277,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
+    forced = world == 1 and os.environ.get('DGPAMD_DIST_FORCE') == '1'   # a process group of ONE rank: RCCL first contact on a one-GPU box
+    if world > 1 or forced:
         dd.init_from_env(args.backend)
     shared_device = False
     if args.backend == 'gloo':
@@ -374,7 +375,7 @@ def main():
                 ach = tot_w / (tot_ms * 1e-3) / 1e12
                 roof = dict(bound='mfma', kernel={'syrk': 'potrf_mega_kernel (one launch = one batched factorisation, with or without the fused inverse)'}.get(args.prof_kernel, 'tile_gemm_kernel<%s>' % args.prof_kernel), achieved=ach,
                             peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None)
-            pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_bench_potrf_kernel.json')
+            pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_bench_potrf_kernel.json')
             if not os.path.exists(pmc):
                 pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_bench_potrf_kernel.json')
             if args.prof_kernel == 'syrk' and os.path.exists(pmc):   # HBM bytes per launch, measured offline with rocprofv3 --pmc
@@ -557,9 +558,9 @@ def main():
         cpu = cpu_baseline(model, counts, args.ess_burn)
 
     dist_info = None
-    if world > 1:   # RCCL's view of the job, in the record
+    if world > 1 or forced:   # RCCL's view of the job, in the record
         import torch.distributed as td
-        ids = dd.allgather_vector(np.array([float(rank), float(local), float(torch.cuda.current_device())]), device=dev)
+        ids = dd.allgather_vector(np.array([float(rank), float(local), float(torch.cuda.current_device())]), device=dev).reshape(-1, 3)
         dist_info = dict(world_size=td.get_world_size(), backend=td.get_backend(),
                          ranks=[dict(rank=int(r[0]), local_rank=int(r[1]), device='cuda:%d' % int(r[2])) for r in ids],
                          device_name=torch.cuda.get_device_name(local), devices_visible=torch.cuda.device_count(),
@@ -582,7 +583,7 @@ def main():
             'gpu_legs': dict(seconds=gpu_leg_seconds, untimed_extra_steps=extra_steps),
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or forced:
         import torch.distributed as td
         td.destroy_process_group()
 

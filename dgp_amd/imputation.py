@@ -605,6 +605,10 @@ class imputer:
         hit = self.__dict__.setdefault('_lik_cache', {}).get(id(nd))
         if hit is None or hit[0] is not nd.output or hit[1] is not nd.rep:
             e = self.engine
+            if getattr(nd, 'num_classes', 0):   # (the device log-density indexes the latent columns by the label)
+                lab = np.asarray(nd.output, dtype=float).reshape(-1)
+                if not (np.all(lab == np.floor(lab)) and lab.min(initial=0) >= 0 and lab.max(initial=0) < nd.num_classes):
+                    raise ValueError('Categorical likelihood: class labels must be whole numbers in [0, %d)' % nd.num_classes)
             d = dict(kind=self._lik_device_kind(nd), y=e.tensor(np.asarray(nd.output, dtype=float).reshape(-1)),
                      rep=None if nd.rep is None else torch.as_tensor(np.asarray(nd.rep, dtype=np.int64), device=self.F[0].device),
                      classes=getattr(nd, 'num_classes', 0), par=getattr(nd, 'robustmax_eps', 0.0))

@@ -66,11 +66,28 @@ class NegBin(_CountLikelihood):
     name = 'NegBin'
 
     @staticmethod
+    def _lgamma_rise(y, size):
+        """log Gamma(y + size) - log Gamma(size).  For whole counts up to 64 as sum_{j<y} log(size + j), the form the device
+        log-density uses (csrc/train.hip lik_negbin): the difference of two gammaln values loses every digit once size is
+        huge (size = exp(-f2) with a wild proposal), and the host path (DGPAMD_LIK_HOST=1, plugins, pllik) must take the same
+        accept decisions as the device path."""
+        from scipy.special import gammaln
+        y, size = np.broadcast_arrays(np.asarray(y, dtype=float), np.asarray(size, dtype=float))
+        out = gammaln(y + size) - gammaln(size)
+        small = (y >= 0.0) & (y <= 64.0) & (y == np.floor(y))
+        if small.any():
+            acc = np.zeros(y.shape)
+            for j in range(int(y[small].max())):
+                acc = acc + np.where(j < y, np.log(size + j), 0.0)
+            out = np.where(small, acc, out)
+        return out
+
+    @staticmethod
     def _logpmf(y, f1, f2):
         from scipy.special import gammaln
-        with np.errstate(over='ignore', invalid='ignore'):   # (wild slice-sampling proposals may overflow: they evaluate to nan / -inf and are rejected)
+        with np.errstate(over='ignore', invalid='ignore', divide='ignore'):   # (wild slice-sampling proposals may overflow: they evaluate to nan / -inf and are rejected)
             size, a = np.exp(-f2), f1 + f2            # a = log(mean * dispersion); success odds exp(a)
-            return gammaln(y + size) - gammaln(size) - gammaln(y + 1.0) + y * a - (y + size) * np.logaddexp(0.0, a)
+            return NegBin._lgamma_rise(y, size) - gammaln(y + 1.0) + y * a - (y + size) * np.logaddexp(0.0, a)
 
     def llik(self):
         return np.sum(self._logpmf(np.asarray(self.output).flatten(), self.input[:, 0], self.input[:, 1]))

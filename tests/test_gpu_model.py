@@ -861,6 +861,14 @@ def test_categorical_dgp_end_to_end(eng, K):
         assert np.allclose(p.sum(1), 1.0, atol=1e-9)
     smp = emu.predict(xt[:7], method='sampling', sample_size=20)
     assert len(smp) == (1 if K == 2 else K) and smp[0].shape == (7, 60)
+    # a label outside [0, num_classes) never reaches the device log-density (it indexes the latent columns by the label)
+    keep = lik.output
+    lik.output = keep.astype(float).copy()
+    lik.output[3, 0] = K
+    with pytest.raises(ValueError, match='class labels'):
+        model.imp.sample(burnin=1)
+    lik.output = keep
+    model.imp.sample(burnin=1)
     avg, per = emu.nllik(xt, truth.reshape(-1, 1).astype(float if K == 2 else int))
     assert np.isfinite(avg) and per.shape == (60,) and np.all(per >= 0)     # (few iterations: confident latents, so a few
     import os, tempfile                                                    #  misclassified points dominate the average)
