@@ -35,6 +35,7 @@ class Node(C.Structure):
                 ('Xglob', C.c_void_p), ('length', C.c_void_p), ('nugget', C.c_double), ('W', C.c_void_p),
                 ('y', C.c_void_p), ('vecch_ord', C.c_void_p), ('vecch_nn', C.c_void_p), ('vecch_nd', C.c_void_p),
                 ('vecch_y', C.c_void_p), ('vecch_m', C.c_int), ('reserved2', C.c_int),
+                ('vecch_row0', C.c_int64), ('vecch_rows', C.c_int64),
                 ('lik_kind', C.c_int), ('lik_classes', C.c_int), ('lik_nobs', C.c_int64), ('lik_rep', C.c_void_p),
                 ('lik_par', C.c_double)]
 
@@ -53,6 +54,7 @@ SIGNATURES = {
     'dgpamd_gemv': (_i, [_p, _l, _l, _p, _l, _p, _p]),
     'dgpamd_fetch': (_i, [_p, _p, _p, _z]),
     'dgpamd_fetch2': (_i, [_p, _p, _z, _p, _z, _p]),
+    'dgpamd_set_reduce_hook': (_i, [_p, _p, _p]),
     'dgpamd_post': (_i, [_p, _p, _z, _i]),
     'dgpamd_collect': (_i, [_p, _i, _p, _z]),
     'dgpamd_set_graphs': (_i, [_p, _i]),

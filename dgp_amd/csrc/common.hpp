@@ -49,6 +49,8 @@ struct dgpamd_ctx {
         unsigned long long seq = 0;
         int pending = 0, by_kernel = 0;
     } mail[DGPAMD_MAILBOXES + 1];                     // (the last one is dgpamd_fetch's own)
+    dgpamd_reduce_hook reduce_hook = nullptr;         // sum over ranks of a device vector, queued on the stream (dgpamd_set_reduce_hook)
+    void *reduce_user = nullptr;
     void *scratch[2] = {nullptr, nullptr};            // device scratch grown on demand (ctx_scratch): [0] per-row partial results of the
     size_t scratch_bytes[2] = {0, 0};                 // Vecchia row kernels, [1] per-chunk candidate lists of the neighbour searches
 };

@@ -186,6 +186,13 @@ static int mail_collect(dgpamd_ctx *ctx, dgpamd_ctx::Mailbox &mb, void *host_dst
     return DGPAMD_OK;
 }
 
+extern "C" int dgpamd_set_reduce_hook(dgpamd_ctx *ctx, dgpamd_reduce_hook hook, void *user) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    ctx->reduce_hook = hook;
+    ctx->reduce_user = user;
+    return DGPAMD_OK;
+}
+
 extern "C" int dgpamd_post(dgpamd_ctx *ctx, const void *device_src, size_t bytes, int slot) {
     if (!ctx) return DGPAMD_BAD_ARG;
     if (!device_src || bytes == 0) BAD_ARG(ctx, "null pointer or nothing to copy");

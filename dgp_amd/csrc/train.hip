@@ -1043,9 +1043,20 @@ static int ess_queue_logliks(dgpamd_ctx *ctx, int64_t n, int M, const double *X,
             int64_t gb = (n * D + 255) / 256;
             if (gb > 2048) gb = 2048;
             hipLaunchKernelGGL(ess_vgather_kernel, dim3((unsigned)gb, B), dim3(256), 0, ctx->stream, ga);
-            int rc = vecchia_llik_batch_into(ctx, nd.kind, n, D, nd.vecch_m, Xall, n * (int64_t)D, B, nd.vecch_y, nd.vecch_nn, nd.length,
-                                             nd.nlen, nd.nugget, nd.vecch_nd, partial, osum);
+            // (the rows of this rank -- all of them unless the likelihood's rows are split over processes; a row reads X and y through
+            //  its neighbour list, so a block of rows needs nothing else)
+            const bool part = nd.vecch_rows > 0;
+            if (part && (nd.vecch_row0 < 0 || nd.vecch_row0 + nd.vecch_rows > n)) BAD_ARG(ctx, "row block outside the neighbour array");
+            if (part && !ctx->reduce_hook) BAD_ARG(ctx, "a row block needs a reduce hook (dgpamd_set_reduce_hook)");
+            const int64_t rows = part ? nd.vecch_rows : n;
+            int rc = vecchia_llik_batch_into(ctx, nd.kind, rows, D, nd.vecch_m, Xall, n * (int64_t)D, B, nd.vecch_y,
+                                             nd.vecch_nn + (part ? nd.vecch_row0 * (nd.vecch_m + 1) : 0), nd.length, nd.nlen, nd.nugget,
+                                             nd.vecch_nd, partial, osum);
             if (rc) return rc;
+            if (part) {   // every rank's sums together, on the stream, before the decision below reads them
+                const hipStream_t was = ctx->stream;
+                if (ctx->reduce_hook(ctx->reduce_user, osum, 2 * B) != 0 || ctx->stream != was) BAD_ARG(ctx, "the reduce hook failed");
+            }
             hipLaunchKernelGGL(ess_vnode_ll_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)osum, scales_h[k], B,
                                k == 0 ? 1 : 0, sc, k == nnodes - 1 ? st_decide : nullptr);
             continue;

@@ -568,9 +568,10 @@ class imputer:
         """Can the updates of hidden layer l run through dgpamd_ess_queue?  Block updates; GP nodes in the layer; above it GP
         nodes without a reference prior (its constant depends on the proposal and is evaluated on the host) or likelihood
         nodes whose log-density the library evaluates (_lik_device_kind);
-        the layer's own nodes all dense or all Vecchia; the Vecchia rows not split over ranks (that needs an all-reduce per
-        batch)."""
-        if not self.block or not getattr(self, 'queued', True) or ddist.rows_split():
+        the layer's own nodes all dense or all Vecchia.  With the Vecchia rows split over ranks (dist.split_training(rows=True))
+        every rank queues the same launches on its own rows and the engine's reduce hook sums each batch's partial sums
+        over the ranks on the stream (Engine.use_dist_reduce): the decisions are taken on identical numbers everywhere."""
+        if not self.block or not getattr(self, 'queued', True):
             return False
         layer, upper = self.all_layer[l], self.all_layer[l + 1]
         if any(nd.type != 'gp' for nd in layer):
@@ -647,7 +648,7 @@ class imputer:
                     (tuple(np.asarray(nd.length, float)), float(nd.nugget[0]), self._node_y(l + 1, k).data_ptr() if last else None,
                      None if self._glob[(l + 1, k)] is None else self._glob[(l + 1, k)].data_ptr(),
                      (id(nd.ord), id(nd.NNarray), None if nd.rep is None else id(nd.W_diag)) if nd.vecch else None)
-                    for k, nd in enumerate(upper)) + (self._queue_batches(l)[0], n, M)
+                    for k, nd in enumerate(upper)) + (self._queue_batches(l)[0], n, M, ddist.vecchia_rows(n) if ddist.rows_split() else None)
         hit = self._ess_plans.get(('queue', l))
         if hit is None or hit[0] != key:
             nodes, ybuf = [], {}
@@ -661,7 +662,8 @@ class imputer:
                 if nd.vecch:
                     od = nd.ord_dev()
                     d['vecch'] = dict(ord=od, nn=nd.nn_dev(), nd=e.tensor(np.ones(n) if nd.rep is None else nd.W_diag),
-                                      y=y[od].contiguous() if last else e.empty(n))
+                                      y=y[od].contiguous() if last else e.empty(n),
+                                      rows=ddist.vecchia_rows(n) if ddist.rows_split() else None)
                 if not last:
                     ybuf[k] = (y, d['vecch']['y'] if nd.vecch else None, d['vecch']['ord'] if nd.vecch else None)
                 nodes.append(d)

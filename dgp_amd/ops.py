@@ -106,6 +106,9 @@ class Engine:
             self._foreign = None
             f.wait_stream(self._torch_stream)
         if rc != 0:
+            exc = self.__dict__.pop('_reduce_exc', None)
+            if exc is not None:   # (an exception inside the reduce hook: the library call it interrupted has failed with it)
+                raise exc
             raise DgpAmdError('libdgp_amd rc=%d: %s' % (rc, lib.dgpamd_last_error(self.h).decode()))
 
     def sync(self):
@@ -375,6 +378,36 @@ class Engine:
         return out
 
     MAILBOXES = 8
+
+    def use_dist_reduce(self):
+        """Install dgp_amd.dist's all-reduce as the context's reduce hook (dgpamd_set_reduce_hook): the queued I-step of a model
+        whose Vecchia likelihood rows are split over ranks sums every batch's partial sums over the ranks on the stream,
+        between the row launch and the accept / shrink decision.  Idempotent."""
+        if getattr(self, '_reduce_cb', None) is not None:
+            return
+        from . import dist as ddist
+        HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+        def hook(user, ptr, count):
+            try:
+                t = self._view_of(int(ptr), int(count))
+                with torch.cuda.stream(self._torch_stream):
+                    ddist.allreduce_sum(t)
+                return 0
+            except BaseException as exc:   # noqa: BLE001  (never unwind through the C frames: the call fails, _chk re-raises)
+                self._reduce_exc = exc
+                return 1
+        self._reduce_cb = HOOK(hook)   # (kept alive with the engine)
+        self._chk(self._enter() or lib.dgpamd_set_reduce_hook(self.h, C.cast(self._reduce_cb, C.c_void_p), None))
+
+    def _view_of(self, ptr, count):
+        """float64 view of `count` doubles at device address `ptr` inside one of the engine's workspaces."""
+        for t in self._ws.values():
+            base = t.data_ptr()
+            if base <= ptr and ptr + 8 * count <= base + t.numel() * t.element_size():
+                off = ptr - base
+                return t.view(torch.uint8)[off:off + 8 * count].view(torch.float64)
+        raise DgpAmdError('reduce hook: the buffer is not inside a workspace of this engine')
 
     def post(self, t, slot):
         """First half of fetch(): queue the copy of device tensor t into mailbox `slot` (0..7) behind everything queued so
@@ -774,6 +807,9 @@ class _EssQueue:
                 nd.vecch_ord, nd.vecch_nn = v['ord'].data_ptr(), v['nn'].data_ptr()
                 nd.vecch_nd, nd.vecch_y = v['nd'].data_ptr(), v['y'].data_ptr()
                 nd.vecch_m = int(v['nn'].shape[1]) - 1
+                if v.get('rows') is not None:   # this rank's block of rows (dist.split_training(rows=True)): the sums are all-reduced
+                    nd.vecch_row0, nd.vecch_rows = int(v['rows'][0]), int(v['rows'][1] - v['rows'][0])
+                    eng.use_dist_reduce()
                 Dv = max(Dv, nd.Dl + nd.Dg)
             else:
                 dense = True

@@ -71,6 +71,15 @@ int dgpamd_fetch(dgpamd_ctx *ctx, const void *device_src, void *host_dst, size_t
 #define DGPAMD_MAILBOXES 8
 int dgpamd_post(dgpamd_ctx *ctx, const void *device_src, size_t bytes, int slot);
 int dgpamd_collect(dgpamd_ctx *ctx, int slot, void *host_dst, size_t bytes);
+/* A sum over ranks in the middle of a queued sequence.  With the rows of a Vecchia likelihood split over several processes
+ * (one per GPU), dgpamd_ess_queue leaves every batch's B x 2 sums of THIS rank's rows in a device buffer and calls
+ * hook(user, device_buf, count) -- on the calling thread, while it is queueing, between the launch that produced the sums and
+ * the one that reads them.  The hook queues an in-place all-reduce of the count doubles on the context's stream (RCCL:
+ * ncclAllReduce on that stream; the Python host passes torch.distributed.all_reduce) and returns 0, or non-zero to abort the
+ * call (DGPAMD_BAD_ARG).  Every rank makes the same calls in the same order whatever the accept decisions are (launches of
+ * an update that is already closed are predicated away, the hook is not).  NULL: no hook (one process). */
+typedef int (*dgpamd_reduce_hook)(void *user, double *device_buf, int count);
+int dgpamd_set_reduce_hook(dgpamd_ctx *ctx, dgpamd_reduce_hook hook, void *user);
 /* Two device regions (e.g. log-likelihoods and their info words) into one host buffer, back to back, one sync. */
 int dgpamd_fetch2(dgpamd_ctx *ctx, const void *src_a, size_t bytes_a, const void *src_b, size_t bytes_b, void *host_dst);
 const char *dgpamd_version(void);
@@ -210,6 +219,10 @@ typedef struct {
     const double *vecch_nd;     /* device, n: nugget weights in ordered coordinates (ones without replicates) */
     const double *vecch_y;      /* device, n: the outputs in ordered coordinates */
     int vecch_m, reserved2;
+    /* This rank's rows of the Vecchia likelihood (dist.split_training(rows=True)): rows vecch_row0 .. vecch_row0 + vecch_rows - 1
+     * of vecch_nn; vecch_rows == 0: all n.  The partial sums of a batch are completed by the context's reduce hook
+     * (dgpamd_set_reduce_hook) before the accept / shrink decision reads them. */
+    int64_t vecch_row0, vecch_rows;
     /* Likelihood node on top of the model (read by dgpamd_ess_queue and dgpamd_lik_loglik only; lik_kind == 0: a GP node).
      * The reference's plugin protocol llik() (likelihood_class.py:30-90 Poisson, :245-292 NegBin, :470-621 ZIP, :624-812 ZINB,
      * the classification likelihood): y = the lik_nobs observations (device; class indices for the categorical kinds),
