@@ -281,6 +281,12 @@ def main():
     if world > 1 or forced:
         dd.init_from_env(args.backend)
     shared_device = False
+    c_stdio = None
+    try:   # RCCL prints its version banner through C stdio, which a pipe buffers until exit: flushed before the result line is written,
+        import ctypes   # so that the JSON line stays the LAST line of stdout
+        c_stdio = ctypes.CDLL(None)
+    except OSError:
+        pass
     if args.backend == 'gloo':
         shared_device = world > torch.cuda.device_count()
         local = local % max(1, torch.cuda.device_count())
@@ -582,7 +588,9 @@ def main():
             'strong_scaling': strong, 'distributed': dist_info,
             'gpu_legs': dict(seconds=gpu_leg_seconds, untimed_extra_steps=extra_steps),
         }
-        print(json.dumps(out))
+        if c_stdio is not None:
+            c_stdio.fflush(None)
+        print(json.dumps(out), flush=True)
     if world > 1 or forced:
         import torch.distributed as td
         td.destroy_process_group()
