@@ -588,6 +588,7 @@ def main():
             'strong_scaling': strong, 'distributed': dist_info,
             'gpu_legs': dict(seconds=gpu_leg_seconds, untimed_extra_steps=extra_steps),
         }
+    if rank == 0:
         if c_stdio is not None:
             c_stdio.fflush(None)
         print(json.dumps(out), flush=True)
