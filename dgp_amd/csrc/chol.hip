@@ -1707,13 +1707,18 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTab
     const bool deep = batch >= 6;
     // (n = 5000, ten matrices with their inverses: 25.9 ms at 8 panels per visit, 25.3 at 12, 25.4 at 16 -- 49 TFLOP/s; one matrix is
     //  fastest at 8: the chain waits for deeper visits)
-    const int deep_lazy = nbk >= 64 ? 12 : 10;
-    const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : (deep ? deep_lazy : MEGA_LAZY), slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? deep_lazy : MEGA_SLAZY);
+    // Round 4, with the 12.5-us chain (profiles/r04_mega_table_sweeps.txt, n = 2000): with the inverse, 10 panels per visit also
+    // below six matrices (potrf_inv 0.610 -> 0.587 ms at two, 0.738 -> 0.714 at three, 0.813 -> 0.797 at four); from six on 12 panels
+    // and the cadence starting one column further right (near = 3: 1.142 -> 1.124 ms at six, 1.977 -> 1.847 at ten).  Without
+    // the inverse nothing moved (near = 3 costs one matrix 0.06 ms).
+    const int deep_lazy = (nbk >= 64 || inv) ? 12 : 10;
+    const int shallow = inv ? 10 : MEGA_LAZY, sshallow = inv ? 10 : MEGA_SLAZY;
+    const int lazy = lz && atoi(lz) > 0 ? atoi(lz) : (deep ? deep_lazy : shallow), slazy = sz && atoi(sz) > 0 ? atoi(sz) : (deep ? deep_lazy : sshallow);
     const char *en = getenv("DGPAMD_MEGA_NEAR"), *el = getenv("DGPAMD_MEGA_LAG"), *ex = getenv("DGPAMD_MEGA_XCATCH");
     const char *es = getenv("DGPAMD_MEGA_STAIL");
     // (a task waits on 1 + 2 nkb version words, one per lane of ONE wave: the overrides are clamped so that the deepest visit --
     //  lazy + 1 + near + lag panels -- stays within 64 flags, and build_mega_tasks' output is checked below)
-    const int near_raw = en ? atoi(en) : MEGA_NEAR, lag_raw = el ? atoi(el) : 0;
+    const int near_raw = en ? atoi(en) : ((inv && deep) ? 3 : MEGA_NEAR), lag_raw = el ? atoi(el) : 0;
     const int near = near_raw < 0 ? 0 : (near_raw > 3 ? 3 : near_raw), lag = lag_raw < 0 ? 0 : (lag_raw > 2 ? 2 : lag_raw), xcatch = (ex ? atoi(ex) : 0) + 2 * (es ? atoi(es) : (inv && batch <= 3 ? 1 : 0));
     const char *elk = getenv("DGPAMD_MEGA_LOOK");   // 0: the look-ahead as three tasks (rounds 2-3)
     const int look = elk ? (atoi(elk) != 0) : 1;

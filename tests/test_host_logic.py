@@ -524,7 +524,7 @@ def test_lost_handoff_is_not_a_numerical_failure():
 
 def test_llik_finish_scalar_path_is_bit_identical():
     """kernel._llik_finish has a python-float path for the common case (no replicates, gamma / inverse-gamma or no prior, one
-    or two parameters) that must reproduce the general numpy path bit for bit -- both feed L-BFGS-B, whose iterates the
+    or two parameters) and a lean numpy path for several lengthscales; both must reproduce the general numpy path bit for bit -- both feed L-BFGS-B, whose iterates the
     lock-step M-step promises to leave unchanged."""
     import inspect
     import textwrap
@@ -533,6 +533,9 @@ def test_llik_finish_scalar_path_is_bit_identical():
     src = textwrap.dedent(inspect.getsource(kc.kernel._llik_finish))
     general = src.replace("if self.rep is None and self.prior_name in (None, 'ga', 'inv_ga') and P <= 2:", "if False:")
     assert general != src
+    lean = "if self.rep is None and self.prior_name in (None, 'ga', 'inv_ga'):"   # the several-lengthscale path without numpy's wrappers
+    assert lean in general
+    general = general.replace(lean, "if False:")
     ns = {}
     exec("import numpy as np, math\n" + general, ns)
     rng = np.random.default_rng(3)
@@ -548,7 +551,7 @@ def test_llik_finish_scalar_path_is_bit_identical():
         a.scale_est = bool(trial % 2)
         a.scale = np.array([rng.uniform(0.1, 5)])
         a.nugget_est = bool((trial // 2) % 2)
-        a.length = np.array([rng.uniform(0.1, 5)])
+        a.length = rng.uniform(0.1, 5, size=1 if trial % 5 < 2 else int(rng.integers(2, 12)))   # (one shared or one per input dimension)
         a.nugget = np.array([rng.uniform(1e-8, 1e-2)])
         a._raise_if_not_pd = lambda v: None
         b = Node()
@@ -556,7 +559,7 @@ def test_llik_finish_scalar_path_is_bit_identical():
         for o in (a, b):
             for nm in ('log_prior', 'log_prior_fod', 'gfod'):
                 setattr(o, nm, types.MethodType(getattr(kc.kernel, nm), o))
-        P = 1 + int(a.nugget_est)
+        P = len(a.length) + int(a.nugget_est)
         host = np.concatenate(([rng.normal() * 100, rng.uniform(1, 5000)], rng.normal(size=2 * P) * 50, [0.0]))
         fa, ga = kc.kernel._llik_finish(a, host)
         fb, gb = ns['_llik_finish'](b, host)
