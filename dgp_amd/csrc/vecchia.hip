@@ -2065,8 +2065,11 @@ extern "C" int dgpamd_vecchia_linkgp(dgpamd_ctx *ctx, int kind, int64_t M, int64
     for (int d = 0; d < Dw + Dz; ++d) a.len[d] = length_h[nlen == 1 ? 0 : d];
     {
         const char *env = getenv("DGPAMD_VECCHIA_LDS");   // (1: the LDS version for every size -- the tests compare the two)
-        if (kind == DGPAMD_SEXP && pm <= VL_BC && Dw <= 8 && Dz <= 8 && !(env && atoi(env))) {
-            launch_vecchia_linkgp_sexp_reg(ctx, a);
+        if (pm <= VL_BC && Dw <= 8 && Dz <= 8 && !(env && atoi(env))) {
+            if (kind == DGPAMD_SEXP)
+                launch_vecchia_linkgp_sexp_reg(ctx, a);
+            else
+                launch_vecchia_linkgp_matern_reg(ctx, a);
             LAUNCH_CHECK(ctx);
             return DGPAMD_OK;
         }

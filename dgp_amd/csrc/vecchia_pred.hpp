@@ -31,6 +31,7 @@ struct VLinkArgs {
 };
 
 #define VG_BC 51   // neighbours the register-resident gp kernel holds (pm <= VG_BC, D <= 16)
-#define VL_BC 50   // neighbours the register-resident link_gp kernel holds (pm <= VL_BC, Dw <= 8, Dz <= 8, squared exponential)
+#define VL_BC 50   // neighbours the register-resident link_gp kernel holds (pm <= VL_BC, Dw <= 8, Dz <= 8; both kernels)
 void launch_vecchia_gp_reg(dgpamd_ctx *ctx, const VGpArgs &a);
 void launch_vecchia_linkgp_sexp_reg(dgpamd_ctx *ctx, const VLinkArgs &a);
+void launch_vecchia_linkgp_matern_reg(dgpamd_ctx *ctx, const VLinkArgs &a);

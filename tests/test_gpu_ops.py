@@ -1011,23 +1011,26 @@ def test_vecchia_gp_register_kernel_equals_lds_kernel(eng, name, D, pm):
     close(v1[pick], vo, rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize('kind', ['sexp', 'matern2.5'])
 @pytest.mark.parametrize('Dw,Dz,pm', [(8, 8, 50), (3, 0, 20), (5, 2, 50), (8, 0, 37)])
-def test_vecchia_linkgp_register_kernel_equals_lds_kernel(eng, Dw, Dz, pm):
-    """link_gp_vecch (vecchia.py:758-796, IJ_nb :838-907; squared-exponential kernel) through the register-resident kernel
-    (in-place Gauss-Jordan on one row per lane: K | N, J, y and I take the same row operations; no LDS) and through the LDS
-    kernel it replaces: the same means and variances, with and without deterministic global inputs, conditioning sets
-    shorter than pm, zero input variances, a test-point count off the four-per-workgroup grid; a few points against the
-    oracle."""
+def test_vecchia_linkgp_register_kernel_equals_lds_kernel(eng, Dw, Dz, pm, kind):
+    """link_gp_vecch (vecchia.py:758-796, IJ_nb :838-907; both kernels) through the register-resident kernels
+    (in-place Gauss-Jordan on one row per lane: K | N, J, y and I take the same row operations; the Matern J factors from
+    per-lane separable records broadcast with v_readlane; no LDS) and through the LDS kernel they replace: the same means and
+    variances, with and without deterministic global inputs, conditioning sets shorter than pm, zero input variances, ties
+    between coordinates, a test-point count off the four-per-workgroup grid; a few points against the oracle."""
     import os
     from oracle import dgp_oracle as O
     rng = np.random.default_rng(11 + Dw + Dz)
     n, M = 1200, 403
     W = rng.normal(size=(n, Dw))
+    W[:300, 0] = np.round(W[:300, 0], 1)          # ties between coordinates (the Matern records' orientation select)
     Wg = rng.uniform(size=(n, Dz)) if Dz else None
     y = np.sin(W.sum(1)) + 0.1 * rng.normal(size=n)
     mm = rng.normal(size=(M, Dw))
     vv = 10.0 ** rng.uniform(-4, -0.5, size=(M, Dw))
     vv[0] = 0.0
+    vv[1, Dw - 1] = 0.0
     z = rng.uniform(size=(M, Dz)) if Dz else None
     length = rng.uniform(0.8, 2.0, size=Dw + Dz)
     nd = rng.uniform(0.5, 2.0, size=n)
@@ -1037,7 +1040,7 @@ def test_vecchia_linkgp_register_kernel_equals_lds_kernel(eng, Dw, Dz, pm):
     short = rng.integers(0, M, 30)
     for i, t in enumerate(short):
         NN[t, max(2, pm - 1 - i % pm):] = -1
-    args = ('sexp', eng.tensor(mm), eng.tensor(vv), eng.tensor(z) if Dz else None, eng.tensor(W), eng.tensor(Wg) if Dz else None, NN,
+    args = (kind, eng.tensor(mm), eng.tensor(vv), eng.tensor(z) if Dz else None, eng.tensor(W), eng.tensor(Wg) if Dz else None, NN,
             eng.tensor(y), 1.4, length, 1e-3, eng.tensor(nd))
     m1, v1 = (npy(t) for t in eng.vecchia_linkgp(*args))
     os.environ['DGPAMD_VECCHIA_LDS'] = '1'
@@ -1051,12 +1054,12 @@ def test_vecchia_linkgp_register_kernel_equals_lds_kernel(eng, Dw, Dz, pm):
     close(v1, v0, rtol=1e-7, atol=1e-10)
     NNh = npy(NN).astype(int)
     pick = np.array(list(short[:3]) + [0, 1, M - 1])
-    mo, vo = O.link_gp_vecch(mm[pick], vv[pick], None if z is None else z[pick], W, Wg, NNh[pick], y, 1.4, length, 1e-3, nd, 'sexp')
+    mo, vo = O.link_gp_vecch(mm[pick], vv[pick], None if z is None else z[pick], W, Wg, NNh[pick], y, 1.4, length, 1e-3, nd, kind)
     close(m1[pick], mo, rtol=1e-8, atol=1e-10)
     close(v1[pick], vo, rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize('Dw,Dz,pm', [(3, 2, 40), (8, 0, 50), (1, 1, 12)])
+@pytest.mark.parametrize('Dw,Dz,pm', [(3, 2, 40), (8, 0, 50), (1, 1, 12), (3, 2, 60), (9, 0, 30)])   # (the last two: beyond the register kernel, LDS)
 def test_vecchia_linkgp_matern_separable_records_vs_oracle(eng, Dw, Dz, pm):
     """link_gp_vecch with the Matern-2.5 kernel (vecchia.py:758-796, IJ_nb :838-907 -> Jd / Jd0 :915-988): the kernel
     evaluates every neighbour's separable record once per dimension and a pair as 30 multiply-adds and a select
