@@ -528,6 +528,7 @@ class dgp:
     def train(self, N=500, ess_burn=10, disable=False):
         """N iterations of stochastic EM (dgp.py:1364-1412) with the same restart policy on LinAlgError."""
         N0, restarts, max_restarts = self.N, 0, 3
+        self.__dict__.pop('_imp_trusted', None)   # (between two train() calls the caller may have edited the nodes' arrays)
         while True:
             pgb = None
             try:
@@ -562,13 +563,17 @@ class dgp:
         """One iteration of stochastic EM: I-step, neighbour refresh, M-step (dgp.py:1377-1398)."""
         it = self.N + i
         refresh = self.vecch and (it & (it - 1)) == 0 and it > 1   # NN refresh at iterations 2,4,8,.. (dgp.py:1388)
-        early = not refresh and self._mstep_can_start_early()
+        early = self._mstep_can_start_early()
+        # the previous iteration of THIS train() call ended normally: the nodes' arrays are what the imputer itself wrote
+        # (nothing of the library touches them in between), so its device state is taken over without comparing them
+        trusted = self.__dict__.pop('_imp_trusted', None) is self.imp
         try:
+            later = early and not refresh    # (a refresh reads the numpy inputs: no deferred detach then)
             if i == 1:
                 with self._init_scale():
-                    self.imp.sample(burnin=ess_burn, detach=not early)
+                    self.imp.sample(burnin=ess_burn, detach=not later, trusted=trusted)
             else:
-                self.imp.sample(burnin=ess_burn, detach=not early)
+                self.imp.sample(burnin=ess_burn, detach=not later, trusted=trusted)
             if refresh:
                 self.imp.update_ord_nn()
             if early:
@@ -577,6 +582,7 @@ class dgp:
                 self._m_step()
         finally:
             self.imp.finish_detach()   # (whatever happened: the nodes' numpy attributes are the state the sampler left)
+        self._imp_trusted = self.imp
 
     def _mstep_can_start_early(self):
         """True when the M-step's first objective evaluations can be queued on the device BEFORE the host has refreshed the

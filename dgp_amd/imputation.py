@@ -236,7 +236,7 @@ class imputer:
         st['_engine'] = None
         st['_factor_cache'] = {}
         st['_ess_plans'] = {}
-        for key in ('F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_vecch_y', '_adopt', '_adopt_ll', '_given_inputs', '_sp_levels', '_lik_cache'):   # device state: rebuilt by the next sample()
+        for key in ('_attached', 'F', '_glob', '_yy', '_x0', '_ll_cache', '_const', '_Fh', '_vecch_dev', '_vecch_y', '_adopt', '_adopt_ll', '_given_inputs', '_sp_levels', '_lik_cache'):   # device state: rebuilt by the next sample()
             st.pop(key, None)
         return st
 
@@ -270,7 +270,15 @@ class imputer:
         a = np.asarray(arr, dtype=float)
         return hit[0].shape == a.shape and np.array_equal(hit[0], a)
 
-    def _attach(self):
+    def _attach(self, trusted=False):
+        """Device state for a sample() call.  trusted (dgp.train, from its second iteration on): the nodes' arrays are the ones
+        this imputer wrote at the end of the previous call and nobody has touched them since -- the device copies are kept as
+        they are, nothing is compared (0.4 ms per call at n = 50 000, with the device idle)."""
+        if trusted and self.__dict__.get('F') is not None and self.__dict__.get('_attached') and not self.__dict__.get('_inputs_changed'):
+            self._Fh = {}
+            self._ll_cache = {}
+            return
+        self._attached = False
         L = len(self.all_layer)
         # latents: what _detach wrote to the nodes is still on the device unless somebody changed the numpy side since
         Fh = self.__dict__.get('_Fh', {})
@@ -303,6 +311,7 @@ class imputer:
             self._factor_cache = {}
             self.__dict__.pop('_adopt_ll', None)
             self.__dict__.pop('_adopt', None)
+        self._attached = True
 
     def finish_detach(self):
         """The deferred half of sample(detach=False): bring the nodes' numpy attributes up to date."""
@@ -468,13 +477,13 @@ class imputer:
         return self._yy[k] if l == L - 1 else self.F[l][:, k].contiguous()
 
     # ------------------------------------------------------------------ sampling
-    def sample(self, burnin=0, detach=True):
+    def sample(self, burnin=0, detach=True, trusted=False):
         """ESS-within-Gibbs over the layers (imputation.py:22-42).  detach=False (dgp.train's own loop): the numpy attributes of
         the nodes are refreshed later, by finish_detach() -- the M-step's first lock-step round is launched from the device
         state in between, so that the device works while the host copies 3 MB of latents back and rewrites the attributes
         (a 4-ms hole per iteration at n = 50 000).  Everything that reads the attributes calls finish_detach() first."""
         self.finish_detach()
-        self._attach()
+        self._attach(trusted)
         n_layer = len(self.all_layer)
         if n_layer > 2 and self._sample_queued_deep(burnin + 1):   # every sweep of every hidden layer queued on the device
             self._detach(defer=not detach)
