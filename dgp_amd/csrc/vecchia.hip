@@ -835,9 +835,14 @@ __device__ __forceinline__ void fmac_bcast(double &acc, const double &src, const
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "i"(C));
 }
 
+// Row stride of the scaled inputs in LDS: the dimensions padded with zeros to a multiple of eight (the pair loop reads whole chunks of
+// eight: no index clamps, no selects -- two of the four VALU instructions per pair and dimension), + 2: rows stay 16-byte aligned
+// (ds_read_b128) and the sixteen rows a group reads at once fall on disjoint bank quadruples (stride 10: banks 0, 20, 40, 60, 16, ...;
+// stride 18: 0, 36, 8, 44, ...).
+#define VR4_DP(D) ((((D) + 7) & ~7) + 2)
 static size_t vrow4_lds(int BS, int D, bool grad, bool solves) {
     const size_t asz = (size_t)(BS + 1) * (BS + 2) / 2 + (grad ? (size_t)BS * (BS - 1) / 2 : 0);
-    return 4 * (asz + (size_t)BS * (D | 1) + (solves ? 2 * 32 : 0)) * sizeof(double);   // (llik: 19.6 KB at m = 25, d = 8: 8 waves per CU)
+    return 4 * (asz + (size_t)BS * VR4_DP(D) + (solves ? 2 * 32 : 0)) * sizeof(double);   // (llik: 19.9 KB at m = 25, d = 8: 8 waves per CU)
 }
 
 // four rows (row block rb) of input set `by`: the body of vecchia_row4_kernel
@@ -848,7 +853,7 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
     constexpr int asz = rows * (rows + 1) / 2 + (MODE == V_NLLIK ? T2 : 0);
     constexpr int NBB = BS > 16 ? BS : 16;            // columns kept for the second row of a lane
 #define AT(r, c) ((r) * ((r) + 1) / 2 + (c))
-    const int mp1 = a.m + 1, D = a.vp.D, DP = D | 1;   // (odd row stride: the rows of a group on distinct LDS banks)
+    const int mp1 = a.m + 1, D = a.vp.D, DP = VR4_DP(D);
     const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
     double *A = lds + (size_t)g * asz;                                   // packed lower triangle (+ K itself for the gradient)
     double *Kp = A + rows * (rows + 1) / 2;
@@ -890,7 +895,7 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
             for (int q = 0; q < 8; ++q) x8[q] = (my[h] >= 0 && d0 + q < D) ? xrow[d0 + q] : 0.0;
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (R < BS && d0 + q < D) xs[R * DP + d0 + q] = x8[q] * a.vp.inv_len[d0 + q];
+                if (R < BS) xs[R * DP + d0 + q] = d0 + q < D ? x8[q] * a.vp.inv_len[d0 + q] : 0.0;   // (zeros past D: see VR4_DP)
         }
         if (R < BS) {
             A[AT(R, R)] = my[h] >= 0 ? 1.0 + a.vp.nugget * ndv : 1.0;
@@ -909,19 +914,18 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
         double cf0 = 0.0, cf1 = 0.0;   // (gradient, one shared lengthscale: sum over the dimensions of dK/dlog(l) / K)
         const bool iso = MODE == V_NLLIK && a.vp.nlen == 1;
         for (int d0 = 0; d0 < D; d0 += 8) {
-            double u0[8], v0[8], u1[8], v1[8];
+            double2 u0[4], v0[4], u1[4], v1[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int d = d0 + q < D ? d0 + q : D - 1;   // (past the end: the last coordinate against itself below)
-                u0[q] = pa0[d];
-                v0[q] = pb0[d];
-                u1[q] = pa1[d];
-                v1[q] = pb1[d];
+            for (int q = 0; q < 4; ++q) {   // (16-byte reads; the columns past D hold zeros)
+                u0[q] = reinterpret_cast<const double2 *>(pa0 + d0)[q];
+                v0[q] = reinterpret_cast<const double2 *>(pb0 + d0)[q];
+                u1[q] = reinterpret_cast<const double2 *>(pa1 + d0)[q];
+                v1[q] = reinterpret_cast<const double2 *>(pb1 + d0)[q];
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const bool in = d0 + q < D;
-                const double f0 = in ? u0[q] - v0[q] : 0.0, f1 = in ? u1[q] - v1[q] : 0.0;   // (0: neutral for both kernels)
+                const double f0 = (q & 1) ? u0[q >> 1].y - v0[q >> 1].y : u0[q >> 1].x - v0[q >> 1].x;   // (0 - 0 past D: neutral for both kernels)
+                const double f1 = (q & 1) ? u1[q >> 1].y - v1[q >> 1].y : u1[q >> 1].x - v1[q >> 1].x;
                 if (KIND == DGPAMD_SEXP) {
                     corr_accum_sexp(f0, s0);
                     corr_accum_sexp(f1, s1);
