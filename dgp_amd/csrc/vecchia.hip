@@ -633,7 +633,12 @@ struct VRowArgs {
     double *Lmat;     // [n][m+1]
     int64_t x_stride; // doubles between the input sets of a batch (blockIdx.y); LLIK only
     const int32_t *pred;   // null, or a device word: the launch does nothing when it is non-zero (dgpamd_ess_queue)
+    long long *trace = nullptr;   // diagnostics (dgpamd_debug_trace): shader-clock stamps of the first 64 row blocks' phases, 16 words each
 };
+#define VR4_STAMP(slot)                                                                                               \
+    do {                                                                                                              \
+        if (a.trace && rowblk < 64 && by == 0 && threadIdx.x == 0) a.trace[rowblk * 16 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
 
 // gather the row's conditioning block (ascending index, self last) into LDS; returns its size
 __device__ int gather_block(const int64_t *NNrow, int mp1, int *idx, int lane) {
@@ -756,21 +761,6 @@ __global__ __launch_bounds__(VW) void vecchia_row_kernel(VRowArgs a) {
 // ---------------------------------------------------------------------------
 #define VR_MAXB 31
 
-// (r, c) of the strictly-lower entry e = (r-1) r / 2 + c, r > c, packed r | c << 8: the same for every block size, read
-// per lane from the constant cache's neighbour L1 instead of being decoded with a square root and two fix-up loops
-struct TriTable {
-    unsigned short rc[VR_MAXB * (VR_MAXB - 1) / 2 + 32];
-};
-static constexpr TriTable make_tri_table() {
-    TriTable t{};
-    int e = 0;
-    for (int r = 1; r < VR_MAXB; ++r)
-        for (int c = 0; c < r; ++c) t.rc[e++] = (unsigned short)(r | (c << 8));
-    for (; e < VR_MAXB * (VR_MAXB - 1) / 2 + 32; ++e) t.rc[e] = (unsigned short)(1 | (0 << 8));
-    return t;
-}
-__device__ const TriTable g_tri = make_tri_table();
-
 __device__ __forceinline__ void tri_decode_small(int t, int &r, int &c) {   // t < 2^16: float is plenty
     int b = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
     while ((b + 1) * (b + 2) / 2 <= t) ++b;
@@ -868,6 +858,7 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
     // conditioning set: the valid entries of the row come first; slot R <- entry b-1-(R-pad)  (ascending, self last).
     // One load of the row, the reversal by shuffle; then every slot fetches its own point (inputs, output, nugget
     // weight) with all loads in flight together: two memory latencies in all before the arithmetic starts.
+    VR4_STAMP(0);
     const int nn0 = (live && t < mp1) ? (int)a.NN[i * mp1 + t] : -1;
     const int nn1 = (live && 16 + t < mp1) ? (int)a.NN[i * mp1 + 16 + t] : -1;
     const unsigned m0 = (unsigned)(__ballot(nn0 >= 0) >> (16 * g)) & 0xffffu, m1 = (unsigned)(__ballot(nn1 >= 0) >> (16 * g)) & 0xffffu;
@@ -902,61 +893,77 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
             if (MODE != V_LMAT) A[AT(BS, R)] = yv;
         }
     }
+    VR4_STAMP(1);
     __syncthreads();
-    // strictly lower entries (r, c), r > c, two per lane and pass: their 4 x 8 coordinates are read from LDS together
-    // (the dimension loop of corr_pts waits for LDS once per coordinate: with two waves per SIMD nothing hides that)
-    for (int e0 = t; e0 < T2; e0 += 32) {
-        const int e1 = e0 + 16 < T2 ? e0 + 16 : e0;
-        const int q0 = g_tri.rc[e0], q1 = g_tri.rc[e1];
-        const int r0 = q0 & 255, c0 = q0 >> 8, r1 = q1 & 255, c1 = q1 >> 8;
-        const double *pa0 = xs + r0 * DP, *pb0 = xs + c0 * DP, *pa1 = xs + r1 * DP, *pb1 = xs + c1 * DP;
-        double s0 = 0.0, p0 = 1.0, s1 = 0.0, p1 = 1.0;
-        double cf0 = 0.0, cf1 = 0.0;   // (gradient, one shared lengthscale: sum over the dimensions of dK/dlog(l) / K)
+    VR4_STAMP(2);
+    // Strictly lower entries in 2 x 2 tiles: rows (2i, 2i + 1) against columns (2j, 2j + 1), j <= i, one tile per lane and pass -- FOUR
+    // points read from LDS for four entries.  (Two entries per lane and pass took four points as well: with the selects gone the
+    // pair loop ran at the LDS's bandwidth, 2 KB per wave, pass and dimension.)  The diagonal tiles hold one entry below the
+    // diagonal; their other three results, and those of the phantom row / column of an odd block size, are not stored.
+    {
+        constexpr int NP = (BS + 1) / 2, NT = NP * (NP + 1) / 2;
         const bool iso = MODE == V_NLLIK && a.vp.nlen == 1;
-        for (int d0 = 0; d0 < D; d0 += 8) {
-            double2 u0[4], v0[4], u1[4], v1[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {   // (16-byte reads; the columns past D hold zeros)
-                u0[q] = reinterpret_cast<const double2 *>(pa0 + d0)[q];
-                v0[q] = reinterpret_cast<const double2 *>(pb0 + d0)[q];
-                u1[q] = reinterpret_cast<const double2 *>(pa1 + d0)[q];
-                v1[q] = reinterpret_cast<const double2 *>(pb1 + d0)[q];
+        // tile e = the strictly-lower pair (i + 1, j) of an (NP + 1) x (NP + 1) matrix, j <= i: decoded once, then advanced by sixteen
+        // entries per pass with integer arithmetic (a table in memory cost a dependent load per pass: ~1000 cycles of a 12 000-cycle loop)
+        int trow, tcol;
+        tri_decode_small(t, trow, tcol);
+        ++trow;
+        for (int e = t; e < NT; e += 16) {
+            const int ti = trow - 1, tj = tcol;
+            tcol += 16;
+            while (tcol >= trow) {
+                tcol -= trow;
+                ++trow;
             }
+            const int r0 = 2 * ti, r1 = 2 * ti + 1, c0 = 2 * tj, c1 = 2 * tj + 1;
+            const double *pr0 = xs + r0 * DP, *pr1 = xs + (r1 < BS ? r1 : BS - 1) * DP;
+            const double *pc0 = xs + c0 * DP, *pc1 = xs + (c1 < BS ? c1 : BS - 1) * DP;
+            double sa[4] = {0.0, 0.0, 0.0, 0.0}, pa[4] = {1.0, 1.0, 1.0, 1.0}, cfa[4] = {0.0, 0.0, 0.0, 0.0};   // (r0,c0) (r0,c1) (r1,c0) (r1,c1)
+            for (int d0 = 0; d0 < D; d0 += 8) {
+                double2 x0[4], x1[4], y0[4], y1[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double f0 = (q & 1) ? u0[q >> 1].y - v0[q >> 1].y : u0[q >> 1].x - v0[q >> 1].x;   // (0 - 0 past D: neutral for both kernels)
-                const double f1 = (q & 1) ? u1[q >> 1].y - v1[q >> 1].y : u1[q >> 1].x - v1[q >> 1].x;
-                if (KIND == DGPAMD_SEXP) {
-                    corr_accum_sexp(f0, s0);
-                    corr_accum_sexp(f1, s1);
-                } else {
-                    corr_accum_matern(f0, p0, s0);
-                    corr_accum_matern(f1, p1, s1);
-                    if (iso) {
-                        cf0 += dcoef_v<KIND>(f0);
-                        cf1 += dcoef_v<KIND>(f1);
+                for (int h = 0; h < 4; ++h) {   // (16-byte reads; the columns past D hold zeros: 0 - 0, neutral for both kernels)
+                    x0[h] = reinterpret_cast<const double2 *>(pr0 + d0)[h];
+                    x1[h] = reinterpret_cast<const double2 *>(pr1 + d0)[h];
+                    y0[h] = reinterpret_cast<const double2 *>(pc0 + d0)[h];
+                    y1[h] = reinterpret_cast<const double2 *>(pc1 + d0)[h];
+                }
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const double u0 = (h & 1) ? x0[h >> 1].y : x0[h >> 1].x, u1 = (h & 1) ? x1[h >> 1].y : x1[h >> 1].x;
+                    const double v0 = (h & 1) ? y0[h >> 1].y : y0[h >> 1].x, v1 = (h & 1) ? y1[h >> 1].y : y1[h >> 1].x;
+                    const double f[4] = {u0 - v0, u0 - v1, u1 - v0, u1 - v1};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        if (KIND == DGPAMD_SEXP) {
+                            corr_accum_sexp(f[w], sa[w]);
+                        } else {
+                            corr_accum_matern(f[w], pa[w], sa[w]);
+                            if (iso) cfa[w] += dcoef_v<KIND>(f[w]);
+                        }
                     }
                 }
             }
-        }
-        if (iso && KIND == DGPAMD_SEXP) {   // dcoef = 2 df^2
-            cf0 = 2.0 * s0;
-            cf1 = 2.0 * s1;
-        }
-        // exp_negated: the exponential from full-rate instructions only (the library's exp spends half of its issue cycles on three
-        // quarter-rate ones); the three modes of this kernel -- I-step sums, M-step sums + gradients, sparse-factor rows -- share it
-        double k0 = (KIND == DGPAMD_SEXP) ? exp_negated(s0) : p0 * exp_negated(SQRT5 * s0);
-        double k1 = (KIND == DGPAMD_SEXP) ? exp_negated(s1) : p1 * exp_negated(SQRT5 * s1);
-        if (c0 < pad) k0 = 0.0;   // pads come first
-        if (c1 < pad) k1 = 0.0;
-        A[e0 + r0] = k0;   // AT(r, c) = e + r
-        A[e1 + r1] = k1;
-        if (MODE == V_NLLIK) {   // kept for the derivative sums: dK itself with one shared lengthscale, else the correlation
-            Kp[e0] = iso ? cf0 * k0 : k0;
-            Kp[e1] = iso ? cf1 * k1 : k1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int r = (w & 2) ? r1 : r0, c = (w & 1) ? c1 : c0;
+                if (iso && KIND == DGPAMD_SEXP) cfa[w] = 2.0 * sa[w];   // dcoef = 2 df^2
+                // exp_negated: the exponential from full-rate instructions only (the library's exp spends half of its issue cycles on
+                // three quarter-rate ones); the three modes of this kernel -- I-step sums, M-step sums + gradients, sparse-factor rows
+                // -- share it
+                double kv = (KIND == DGPAMD_SEXP) ? exp_negated(sa[w]) : pa[w] * exp_negated(SQRT5 * sa[w]);
+                if (c < pad) kv = 0.0;   // pads come first
+                if (r < BS && c < r) {
+                    const int el = r * (r - 1) / 2 + c;
+                    A[el + r] = kv;   // AT(r, c) = r (r - 1) / 2 + c + r
+                    if (MODE == V_NLLIK) Kp[el] = iso ? cfa[w] * kv : kv;   // kept for the derivative sums: dK itself with one shared lengthscale, else the correlation
+                }
+            }
         }
     }
+    VR4_STAMP(3);
     __syncthreads();
+    VR4_STAMP(4);
 
     double ra[16], rb[NBB];   // rows t and 16 + t
     constexpr int LROWS = MODE == V_LMAT ? BS : BS + 1;   // (no right-hand-side row in the sparse-factor mode: nothing wrote it)
@@ -966,6 +973,7 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
     for (int c = 0; c < NBB; ++c) rb[c] = (c < BS && 16 + t < LROWS && c <= 16 + t) ? A[AT(16 + t, c < BS ? c : 0)] : 0.0;
 
     double sd_last = 1.0, w_last = 0.0;
+    VR4_STAMP(5);
     static_for<BS>([&](auto J) {
         constexpr int j = J;
         double d = j < 16 ? group_bcast<(j & 15)>(ra[j & 15]) : group_bcast<(j & 15)>(rb[j < NBB ? j : 0]);
@@ -999,6 +1007,7 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
         }
     });
     constexpr int WL = BS & 15;   // lane of the right-hand-side row BS (second row of the lane when BS >= 16)
+    VR4_STAMP(6);
 
     if (MODE == V_LLIK) {
         if (t == WL && live) {
@@ -1074,10 +1083,19 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
         out[1] = 2.0 * log(sd_last);
     }
     const double *u = V, *al = V + 32;
+    int gr0, gc0;   // the lane's first strictly-lower entry (r, c); advanced by sixteen entries per pass (see the pair loop)
+    tri_decode_small(t, gr0, gc0);
+    ++gr0;
     for (int k = 0; k < npl; ++k) {
         double tl = 0.0, sm = 0.0;
+        int gr = gr0, gc = gc0;
         for (int e = t; e < T2; e += 16) {
-            const int qe = g_tri.rc[e], r = qe & 255, c = qe >> 8;
+            const int r = gr, c = gc;
+            gc += 16;
+            while (gc >= gr) {
+                gc -= gr;
+                ++gr;
+            }
             const double dk = a.vp.nlen == 1 ? Kp[e] : dcoef_v<KIND>(xs[r * DP + k] - xs[c * DP + k]) * Kp[e];
             tl = fma(2.0 * dk, u[r] * u[c], tl);
             sm = fma(dk, al[r] * u[c] + al[c] * u[r], sm);
@@ -1137,6 +1155,7 @@ static int launch_vrow4_nb(dgpamd_ctx *ctx, VRowArgs &a, int batch) {
     // the cap applies to the launches a device-side queue may predicate away (ctx->pred set); the others keep one
     // workgroup per row block, which the hardware balances better (llik x6 688 vs 721 us, nllik 333 vs 380 us at n = 50 000)
     const int64_t cap = cap_env >= 0 ? (cap_env == 0 ? nrb : cap_env) : (a.pred ? VR4_GRID : nrb);
+    a.trace = ctx->trace;
     hipLaunchKernelGGL((vecchia_row4_kernel<KIND, MODE, BS>), dim3((unsigned)(nrb < cap ? nrb : cap), (unsigned)batch), dim3(64), shm,
                        ctx->stream, a);
     LAUNCH_CHECK(ctx);

@@ -134,7 +134,7 @@ class DrawStream:
                 except Exception:   # noqa: BLE001  (the host copy is still there)
                     self.__dict__.pop('_zdev', None)
         self._zbuf, self._zpos = None, 0
-        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread = threading.Thread(target=work)   # (not a daemon: the interpreter waits for it at exit -- killed inside a HIP call it took the process down with std::terminate)
         self._thread.start()
 
     def normals_device(self, engine, count):
