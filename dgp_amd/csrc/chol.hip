@@ -825,6 +825,13 @@ __device__ __forceinline__ void store_pt_sc1(const d4 (&P)[4], double *Pg, int64
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)Pg, 0, 0x7fffffff, 0x00020000);
     const int lm = lane & 15, lu = lane >> 4, odd = lu & 1;
     const int base = (int)(((int64_t)(16 * wave + lm) * ld + (lu & ~1) + 4 * odd) * 8);   // row 16w + lm, column (lu & ~1) + 4 odd
+    // All eight 16-byte values first, each in registers of its own, then the eight stores, then wait states before any of the
+    // registers may be rewritten.  (The first form built every value in the same four registers; the compiler rewrote them right
+    // behind each store -- with the store's offset in an SGPR it inserts no wait state, LLVM's rule for stores of more than 8
+    // bytes -- and with the memory pipeline under load from other processes the store had not read all of its data yet: the first
+    // double of the lanes read last held the NEXT pair's value.  Two ranks sharing one GPU: a few wrong factors per thousand
+    // launches, tools/gpu_mega_stress_shared.sh; never seen with the device to itself.)
+    u32x4 v[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -832,11 +839,23 @@ __device__ __forceinline__ void store_pt_sc1(const d4 (&P)[4], double *Pg, int64
             const double x = P[t][2 * rp], y = P[t][2 * rp + 1];
             const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
             const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
-            u32x4 v;
-            v.x = lo[0]; v.y = hi[0]; v.z = lo[1]; v.w = hi[1];
-            // (one per-lane base offset; the tile / register-pair part is a constant that folds into the instruction)
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, base, (16 * t + 8 * rp) * 8, 16);
+            v[2 * t + rp].x = lo[0]; v[2 * t + rp].y = hi[0]; v[2 * t + rp].z = lo[1]; v[2 * t + rp].w = hi[1];
         }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)   // (every value is complete, in registers of its own, before the first store is issued)
+        asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        // (one per-lane base offset; the tile / register-pair part is a constant that folds into the instruction)
+        __builtin_amdgcn_raw_buffer_store_b128(v[q], rs, base, (16 * (q >> 1) + 8 * (q & 1)) * 8, 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)   // (alive until here: four more stores have been issued behind each of these)
+        asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+    // (the last four values stay untouched for sixteen more wait states: the registers are operands of the statement that waits)
+    asm volatile("s_nop 7\n\ts_nop 7"
+                 : "+v"(v[4].x), "+v"(v[4].y), "+v"(v[4].z), "+v"(v[4].w), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[5].z), "+v"(v[5].w),
+                   "+v"(v[6].x), "+v"(v[6].y), "+v"(v[6].z), "+v"(v[6].w), "+v"(v[7].x), "+v"(v[7].y), "+v"(v[7].z), "+v"(v[7].w)
+                 :: "memory");
 }
 
 // ---- the per-wave parts of the chain's block step as static programs (W = wave: every role decision is a compile-time
@@ -954,7 +973,10 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
     load_cb_lower(D.v, A, ld, wave, lane0, scratch);
     DiagShadow shw;
     shw.hand = nullptr; shw.wout = nullptr;
-    if (tid == 0) sh.pcount = 0;   // (visible to the other waves behind the first factorisation's barriers)
+    if (tid == 0) {
+        sh.pcount = 0;   // (visible to the other waves behind the first factorisation's barriers)
+        sh.look = 0;
+    }
     double *pivots = g.piv + (int64_t)b * g.ld;   // every block's pivots: their logarithms are summed when the chain has ended
     int info = 0;
     vlds_double *hand = (vlds_double *)Ws;   // (Ws is idle between the solve and the next block's W_k)
@@ -1001,14 +1023,19 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
         // lane, handed to the others through LDS -- and the step goes on as if the poll had seen it.  No acquire here: every
         // load of these tiles below bypasses L1 (sc1), every store of them was write-through and drained ahead of the word,
         // and this CU holds the chain alone (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire, first row).
+        // (The bits go into a word of their own.  Written into sh.ready they raced with the other waves' read of it above: nothing
+        //  orders a slow wave's read before wave 0's update, the waves then disagreed about `ready != 3`, one side took a barrier
+        //  the other did not, and from there on every LDS hand-over of the step was off by one barrier.  With the chain alone on
+        //  its CU the four waves run in step and it never happened; with another process's waves on the same SIMDs -- two ranks
+        //  sharing a GPU -- it gave wrong factors a few times per thousand launches.)
         int ready2 = ready;
         if (ready != 3) {
             if (tid < 2 && !((ready >> tid) & 1)) {
                 const int got = __hip_atomic_load(ver + (k + 1) * g.nbk + k + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (got >= (tid == 0 ? need.x : need.y)) atomicOr(&sh.ready, 1 << tid);
+                if (got >= (tid == 0 ? need.x : need.y)) atomicOr(&sh.look, 1 << tid);
             }
             lds_barrier();
-            ready2 = g.nowait ? 3 : sh.ready;
+            ready2 = g.nowait ? 3 : (ready | sh.look);
         }
         bool published = false;
         if (!(ready2 & 1)) {
@@ -1042,6 +1069,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
             }
         }
         lds_barrier();
+        if (tid == 0) sh.look = 0;   // (every wave has read it: the next block's second look starts from zero, three barriers from here)
         if (tid == 0 && !published) __hip_atomic_store(wflag, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the panel tasks of this block can run
         if (tr) tr[16 * k + 2] = tr[16 * k + 3] = wall_clock64();
         if (!(ready2 & 2)) {

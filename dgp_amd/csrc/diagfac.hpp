@@ -53,6 +53,8 @@ struct DiagShared {
     int bad[4];             // per 16-block: 1 + index of its first non-positive pivot, or 0
     int ready;              // DiagPoll: bit i = the word lane i polled beside the last 16-block's elimination had reached its value
     int pcount;             // one-launch chain: waves whose stores of the panel tile have drained (a running count)
+    int look;               // one-launch chain: bits of `ready` a second look found set (a word of its own: `ready` itself must not
+                            // change between the factorisation's last barrier and the moment the SLOWEST wave has read it)
 };
 
 // Two version words (and the values they must reach) that wave 0 polls ONCE while wave 3 eliminates the last 16-block --

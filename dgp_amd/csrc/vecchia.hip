@@ -1058,6 +1058,7 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
                 if constexpr (MODE == V_NLLIK) acca[c] = fma(lrc, am, acca[c]);
             });
         });
+        VR4_STAMP(7);
         V[t] = u0;
         if (MODE == V_NLLIK) V[32 + t] = a0;
         if (16 + t < BS) {
@@ -1107,6 +1108,7 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
             out[2 + P + k] = tl;
         }
     }
+    VR4_STAMP(8);
     if (a.nugget_est) {   // dK/dlog eta = diag(nugget * nugget_diag)   vecchia.py:329-332
         double tl = 0.0, sm = 0.0;
 #pragma unroll

@@ -16,7 +16,8 @@ from . import _lib
 from ._lib import lib, KIND
 
 _NO_PINNED_UPLOAD = os.environ.get('DGPAMD_PINNED_UPLOAD') == '0'   # (comparison runs: pageable, blocking uploads)
-_POISON_ALL = os.environ.get('DGPAMD_POISON_LDS') == '2'   # (debugging: NaNs into every CU's LDS before every library call)
+_POISON_ALL = os.environ.get('DGPAMD_POISON_LDS') == '2'
+_POISON_HBM = os.environ.get('DGPAMD_POISON_HBM') == '1'   # (debugging: fresh device buffers are filled with 0xFF bytes -- NaNs as doubles)   # (debugging: NaNs into every CU's LDS before every library call)
 
 
 class DgpAmdError(RuntimeError):
@@ -145,7 +146,10 @@ class Engine:
         return pin.to(self.device, non_blocking=True)   # (the allocator keeps the block until the copy has run)
 
     def empty(self, *shape, dtype=torch.float64):
-        return torch.empty(*shape, dtype=dtype, device=self.device)
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        if _POISON_HBM and t.numel():   # (debugging: whatever is read before it is written shows up as NaN / -1)
+            t.view(torch.uint8).fill_(255)
+        return t
 
     def zeros(self, *shape, dtype=torch.float64):
         return torch.zeros(*shape, dtype=dtype, device=self.device)
@@ -155,6 +159,8 @@ class Engine:
         t = self._ws.get(key)
         if t is None or t.numel() < nbytes:
             t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            if _POISON_HBM:
+                t.fill_(255)
             self._ws[key] = t
         return t
 

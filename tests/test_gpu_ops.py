@@ -1126,3 +1126,22 @@ def test_mailboxes_deliver_results_without_draining_the_stream(eng):
     with pytest.raises(DgpAmdError):
         eng.post(ds, eng.MAILBOXES)
     assert np.array_equal(eng.fetch(ds), small) and np.array_equal(eng.fetch(dl), large)   # (fetch: the same two paths)
+
+
+def test_one_launch_factorisation_when_processes_share_the_gpu(eng):
+    """The one-launch factorisation with other processes' waves on its CUs (two ranks on one GPU; a busy neighbour): every result
+    must equal the first run of the same inputs, bit for bit.  Round 4's chain stored the panel tile with 16-byte stores whose four
+    data registers the compiler rewrote right behind each store (no wait state: the store's offset sits in an SGPR); with the memory
+    pipeline under load from the other processes the store had not read all of its data yet, and a few factors per thousand launches
+    came out wrong in the first double of the lanes read last -- never with the device to itself.  Three processes, small matrices
+    (the chain dominates), 2500 launches each."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SIZES='100,150,190,200,260,333', LAUNCHES='2500')
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'tools', 'gpu_mega_stress.py')], env=dict(env, SEED=str(11 + p)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for p in range(3)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and 'all results consistent' in o, o[-1500:]

@@ -13,7 +13,7 @@ shapes = {}
 t0 = time.perf_counter()
 nl = 0
 while nl < N:
-    n = int(rng.choice([64, 65, 130, 200, 333, 640, 1000, 1280, 1999, 2000, 2047, 2100]))
+    n = int(rng.choice([int(v) for v in os.environ['SIZES'].split(',')] if os.environ.get('SIZES') else [64, 65, 130, 200, 333, 640, 1000, 1280, 1999, 2000, 2047, 2100]))
     B = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 7, 8, 12, 16]))
     inv = bool(rng.integers(2))
     key = (n, B)

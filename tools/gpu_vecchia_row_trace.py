@@ -22,8 +22,10 @@ for name in ('sexp', 'matern2.5'):
             lib.dgpamd_debug_trace(eng.h, C.c_void_p(tr.data_ptr()))
             f(); torch.cuda.synchronize()
             lib.dgpamd_debug_trace(eng.h, None)
-            st = tr.cpu().numpy()[:64 * 16].reshape(64, 16)[8:, :7].astype(float)   # (row blocks 8..63: full conditioning sets)
+            full = tr.cpu().numpy()[:64 * 16].reshape(64, 16)[8:].astype(float)   # (row blocks 8..63: full conditioning sets)
+            st = full[:, :7]
             dt = np.diff(st, axis=1)
             med = np.median(dt, axis=0)
-            print('%-9s d=%2d %-5s cycles (median of 56 waves): gather+stage %6.0f | barrier %5.0f | pair loop %6.0f | barrier %5.0f | to registers %5.0f | factorisation %6.0f | total %6.0f'
-                  % (name, d, mode, med[0], med[1], med[2], med[3], med[4], med[5], np.median(st[:, 6] - st[:, 0])))
+            tail = '' if mode == 'llik' else ' | back-substitutions %6.0f | derivative sums %6.0f' % (np.median(full[:, 7] - full[:, 6]), np.median(full[:, 8] - full[:, 7]))
+            print('%-9s d=%2d %-5s cycles (median of 56 waves): gather+stage %6.0f | barrier %5.0f | pair loop %6.0f | barrier %5.0f | to registers %5.0f | factorisation %6.0f%s | total %6.0f'
+                  % (name, d, mode, med[0], med[1], med[2], med[3], med[4], med[5], tail, np.median(full[:, 8 if mode == 'nllik' else 6] - full[:, 0])))
