@@ -937,9 +937,20 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
                     for (int w = 0; w < 4; ++w) {
                         if (KIND == DGPAMD_SEXP) {
                             corr_accum_sexp(f[w], sa[w]);
-                        } else {
+                        } else if (!iso) {
                             corr_accum_matern(f[w], pa[w], sa[w]);
-                            if (iso) cfa[w] += dcoef_v<KIND>(f[w]);
+                        } else {
+                            // one shared lengthscale: dK/dlog(l) = K sum_d n_d / g_d with g_d = 1 + sqrt5 r + 5/3 r^2 the dimension's
+                            // factor of K and n_d = (5/3 r^2)(1 + sqrt5 r).  The sum is carried as a fraction over the running product
+                            // of the g_d -- which K needs anyway -- so that NO reciprocal is taken: N <- N g_d + n_d G, G <- G g_d, and
+                            // at the end dK = exp(-sqrt5 s) N  (K = G exp(-sqrt5 s), the G cancels).  A reciprocal per pair and
+                            // dimension (quarter-rate seed + two Newton rounds) was a third of this loop's issue cycles.
+                            const double r = fabs(f[w]);
+                            const double gk = fma(r, fma(r, 5.0 / 3.0, SQRT5), 1.0);   // (corr_accum_matern's factor: K holds the same bits in every mode)
+                            const double nd = ((5.0 / 3.0) * r * r) * fma(r, SQRT5, 1.0);
+                            cfa[w] = fma(nd, pa[w], cfa[w] * gk);
+                            pa[w] *= gk;
+                            sa[w] += r;
                         }
                     }
                 }
@@ -956,7 +967,10 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
                 if (r < BS && c < r) {
                     const int el = r * (r - 1) / 2 + c;
                     A[el + r] = kv;   // AT(r, c) = r (r - 1) / 2 + c + r
-                    if (MODE == V_NLLIK) Kp[el] = iso ? cfa[w] * kv : kv;   // kept for the derivative sums: dK itself with one shared lengthscale, else the correlation
+                    // kept for the derivative sums: dK itself with one shared lengthscale (Matern: the numerator of the fraction
+                    // above times the exponential), else the correlation
+                    if (MODE == V_NLLIK)
+                        Kp[el] = !iso ? kv : (KIND == DGPAMD_SEXP ? cfa[w] * kv : (c < pad ? 0.0 : cfa[w] * exp_negated(SQRT5 * sa[w])));
                 }
             }
         }
