@@ -206,6 +206,35 @@ __device__ __forceinline__ double exp_negated(double x) {
     return p * __hiloint2double((ki + 1023) << 20, 0);
 }
 
+// exp_negated with every Horner step pinned to ONE three-operand v_fma_f64 whose constant sits in an SGPR pair.  Left to itself the
+// compiler (inside vecchia_row4_kernel's pair loop) kept the nine polynomial constants in VGPRs and emitted each step as
+// v_mov_b64 tmp, C ; v_fmac_f64 tmp, p, r -- the two-address form needs the constant copied into its destination first -- nine moves
+// per exponential, 36 of the 290 VALU instructions of a pass.  The same operations in the same order: the same bits.
+#define EXPN_STEP(P, R, C) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(P) : "v"(P), "v"(R), "s"((double)(C)))
+__device__ __forceinline__ double exp_negated_v3(double x) {
+    const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+    const double kf = fma(x, -1.44269504088896338700e+00, MAGIC);
+    const double k = kf - MAGIC;
+    double r = fma(k, -6.93147180369123816490e-01, -x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;
+    EXPN_STEP(p, r, 2.50521083854417187751e-08);
+    EXPN_STEP(p, r, 2.75573192239858906526e-07);
+    EXPN_STEP(p, r, 2.75573192239858906526e-06);
+    EXPN_STEP(p, r, 2.48015873015873015873e-05);
+    EXPN_STEP(p, r, 1.98412698412698412698e-04);
+    EXPN_STEP(p, r, 1.38888888888888888889e-03);
+    EXPN_STEP(p, r, 8.33333333333333333333e-03);
+    EXPN_STEP(p, r, 4.16666666666666666667e-02);
+    EXPN_STEP(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int ki = __double2loint(kf);               // k as a two's-complement integer
+    ki = ki < -1022 ? -1022 : ki;
+    return p * __hiloint2double((ki + 1023) << 20, 0);
+}
+
 // The same with a 64-entry table tab[j] = 2^(j/64) (in LDS): exp(-x) = 2^e tab[j] exp(r), k = round(-64 x / ln 2) = 64 e + j,
 // |r| <= ln 2 / 128, so a degree-5 polynomial (truncation 3.5e-17) replaces the degree-12 one: 10 double-precision
 // instructions instead of 17, plus five integer ones and one LDS read that do not occupy the double-precision units.  For a

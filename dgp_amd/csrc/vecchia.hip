@@ -962,7 +962,10 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
                 // exp_negated: the exponential from full-rate instructions only (the library's exp spends half of its issue cycles on
                 // three quarter-rate ones); the three modes of this kernel -- I-step sums, M-step sums + gradients, sparse-factor rows
                 // -- share it
-                double kv = (KIND == DGPAMD_SEXP) ? exp_negated(sa[w]) : pa[w] * exp_negated(SQRT5 * sa[w]);
+                // (the squared-exponential instance gains 3-4 % from the pinned form; in the Matern instances it costs as much, SGPR pressure)
+                //  and the sparse-factor mode of the squared exponential loses 4 %)
+                const double ex = KIND == DGPAMD_SEXP ? (MODE == V_LMAT ? exp_negated(sa[w]) : exp_negated_v3(sa[w])) : exp_negated(SQRT5 * sa[w]);
+                double kv = (KIND == DGPAMD_SEXP) ? ex : pa[w] * ex;
                 if (c < pad) kv = 0.0;   // pads come first
                 if (r < BS && c < r) {
                     const int el = r * (r - 1) / 2 + c;
@@ -970,7 +973,7 @@ __device__ __forceinline__ void vrow4_body(const VRowArgs &a, double *lds, const
                     // kept for the derivative sums: dK itself with one shared lengthscale (Matern: the numerator of the fraction
                     // above times the exponential), else the correlation
                     if (MODE == V_NLLIK)
-                        Kp[el] = !iso ? kv : (KIND == DGPAMD_SEXP ? cfa[w] * kv : (c < pad ? 0.0 : cfa[w] * exp_negated(SQRT5 * sa[w])));
+                        Kp[el] = !iso ? kv : (KIND == DGPAMD_SEXP ? cfa[w] * kv : (c < pad ? 0.0 : cfa[w] * ex));
                 }
             }
         }
