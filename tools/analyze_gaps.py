@@ -19,6 +19,9 @@ for s, e, name in ev[1:]:
     if e > end:
         end, prev = e, name
 print('span %.1f ms, kernel busy (sum) %.1f ms, idle %.1f ms' % (span / 1e6, busy / 1e6, sum(g[0] for g in gaps.values()) / 1e6))
+nend = sum(1 for _, _, nm in ev if nm.startswith('ess_end_kernel'))
+if nend:   # one ess_end_kernel per queued I-step = per SI iteration: the device's own work per iteration, whatever the profiler does to the host
+    print('%d SI iterations in this window: %.1f ms of kernel time per iteration (the span per iteration under the profiler is %.1f ms; without it the iteration takes what the line above the table says)' % (nend, busy / 1e6 / nend, span / 1e6 / nend))
 for (a, b), (t, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:18]:
     print('%8.2f ms  %6d x %7.1f us   %s -> %s' % (t / 1e6, n, t / n / 1e3, a, b))
 if len(sys.argv) > 3:   # context of the gaps longer than argv[3] microseconds: the kernels either side, times relative to the gap's start
