@@ -61,6 +61,8 @@ SIGNATURES = {
     'dgpamd_set_linkgp_direct': (_i, [_p, _i]),
     'dgpamd_set_potrf_mode': (_i, [_p, _i]),
     'dgpamd_debug_trace': (_i, [_p, _p]),
+    'dgpamd_debug_tasklog': (_i, [_p, _p, C.c_longlong]),
+    'dgpamd_debug_mega_table': (_i, [_p, _l, _i, _i, _p, _l]),
     'dgpamd_prof_enable': (_i, [_p, _i]),
     'dgpamd_prof_event_overhead_us': (_i, [_p, C.POINTER(_d)]),
     'dgpamd_prof_collect': (_i, [_p, C.POINTER(_l), C.POINTER(_d), C.POINTER(_d)]),

@@ -222,7 +222,8 @@ __device__ __forceinline__ void store_acc(const d4 (&acc)[4], double *C, int64_t
 // the next half tile are in flight (registers) while the MFMAs of the current one run.  In the 64-block number
 // mask_kb (relative to the first) the columns >= klim of both operands read as zero.
 // SC1: every global load bypasses L1 (operands handed over inside a launch: the one-launch kernel).
-template <bool SC1 = false, bool AHEAD = false>
+// KEEP: acc is carried over from an earlier call (the panels of a visit applied in two runs, see the one-launch kernel's workers).
+template <bool SC1 = false, bool AHEAD = false, bool KEEP = false>
 __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const double *Lp, const double *Rp, int64_t ld,
                                             int nkb, double sign, int mask_kb, int klim, double *As, double *Bs, int tid,
                                             int wave, int lane) {
@@ -249,7 +250,8 @@ __device__ __forceinline__ void tile_update(d4 (&acc)[4], const double *C, const
         }
     };
     if (nh > 0) fetch(0);
-    if (C) {
+    if (KEEP) {
+    } else if (C) {
         if (SC1) load_acc_sc1(acc, C, ld, crow, ccol);
         else load_acc(acc, C, ld, crow, ccol);
     } else {
@@ -573,8 +575,10 @@ struct MegaArgs {
     double *logdet;
     int32_t *info;
     long long *trace;
+    long long *tlog;         // debug (dgpamd_debug_tasklog): every chain step's and every task's stamps, or null
     const int32_t *pred;     // null, or a device word: the launch does nothing when it is non-zero
     double *piv;             // [batch][ld]: the pivots (second chain form: their logarithms are summed at the end)
+    int split;               // 1 (default): a visit whose newest panel has not arrived applies the older ones first (DGPAMD_MEGA_SPLIT=0: off)
     int nowait;              // debug (DGPAMD_MEGA_NOWAIT=1, timing only, results invalid): the chain does not wait for the workers
     int ngroups;             // The matrices are dealt into this many groups (matrix b: group b % ngroups), the XCDs as well
                              // (XCD x: group x % ngroups; 1, 2, 4 or 8), and a worker takes the tasks of its own group's
@@ -641,6 +645,31 @@ __device__ __forceinline__ void wg_wait_flags(const int32_t *addr, int need, int
         }
     }
     __syncthreads();
+}
+
+// The same wait with OPTIONAL words (lanes with opt set): the wait ends when every other lane's word has reached its value; the
+// return value (the same in every thread, through LDS word `bcw`) says whether the optional ones had as well at that moment.
+__device__ __forceinline__ int wg_wait_flags_opt(const int32_t *addr, int need, bool opt, int code, int32_t *status, int tid, int32_t *bcw) {
+    if (tid < 64) {
+        bool ok = (addr == nullptr);
+        int spins = 0;
+        for (;;) {
+            if (!ok) ok = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+            if (__all(ok || opt)) break;
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+            if (spins > MEGA_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (tid == 0) atomicCAS(status, 0, code);
+                break;
+            }
+        }
+        const bool all_ok = __all(ok);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) *bcw = all_ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *bcw;
 }
 
 // acc (column-block layout) -= P P^T for the 32-column half of P staged MK in As
@@ -965,6 +994,8 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
     int32_t *ver = g.ver + (int64_t)b * VER_PLANES * g.nbk * g.nbk;   // buffer A's versions first
     int32_t *wflag = g.sync->wflag + b;
     long long *tr = (g.trace && b == 0 && tid == 0) ? g.trace : nullptr;
+    long long *tl = (g.tlog && tid == 0) ? g.tlog + 64 + 8 * (int64_t)b * g.nbk : nullptr;   // (full log: every matrix)
+    if (tl && b == 0) g.tlog[0] = wall_clock64();
     double *scratch = &sh.u[0][0][0];   // (wave-private 16 x 16 transposition areas; the factor writes sh.u only behind its first barrier)
     __builtin_amdgcn_s_setprio(3);
     if (tid == 0) __hip_atomic_store(&g.sync->cukey[b], cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -989,6 +1020,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
         asm volatile("" : "+v"(lane));
         const int lm = lane & 15, lu = lane >> 4;
         if (tr) tr[16 * k + 0] = wall_clock64();
+        if (tl) tl[8 * k + 0] = wall_clock64();
         const int64_t rem = g.n - (int64_t)k * 64;
         const int ncol = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
         double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)k * 4096;
@@ -1004,6 +1036,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
                                     &poll, &shw);
         const int ready = g.nowait ? 3 : sh.ready;
         if (tr) tr[16 * k + 1] = wall_clock64();
+        if (tl) tl[8 * k + 1] = wall_clock64();
         if (bad && !info) info = k * 64 + bad;
         if (wave == 3) __hip_atomic_store(pivots + 64 * k + lane, sh.piv[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         shw.hand = nullptr;
@@ -1072,6 +1105,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
         if (tid == 0) sh.look = 0;   // (every wave has read it: the next block's second look starts from zero, three barriers from here)
         if (tid == 0 && !published) __hip_atomic_store(wflag, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the panel tasks of this block can run
         if (tr) tr[16 * k + 2] = tr[16 * k + 3] = wall_clock64();
+        if (tl) { tl[8 * k + 2] = wall_clock64(); tl[8 * k + 6] = ready2; }
         if (!(ready2 & 2)) {
             wg_wait_flags<true>(tid == 0 ? ver + (k + 1) * g.nbk + k + 1 : nullptr, need.y, 200 + k, &g.sync->status, tid);
             if (__hip_atomic_load(&g.sync->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -1086,6 +1120,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
             default: chain_request_next<3>(nat, H, Cn, ld, lm, lu); break;
         }
         if (tr) tr[16 * k + 6] = wall_clock64();
+        if (tl) tl[8 * k + 3] = wall_clock64();
         // ---- P^T = W_k Q^T: tile t of wave w is P[16w.., 16t..]^T; W_k is LOWER triangular, so tile t sums the 16-blocks kb <= t ----
         d4 P[4];
 #pragma unroll
@@ -1114,6 +1149,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
             }
         }
         if (tr) tr[16 * k + 4] = wall_clock64();
+        if (tl) tl[8 * k + 4] = wall_clock64();
         lds_barrier();   // (Qs / Ws are no longer read: the exchange buffer lies over Qs)
         if (tr) tr[16 * k + 7] = wall_clock64();
 #pragma unroll
@@ -1133,6 +1169,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
         }
         D = Dn;
         if (tr) tr[16 * k + 5] = wall_clock64();
+        if (tl) tl[8 * k + 5] = wall_clock64();
     }
     // The log-determinant: per 64-block the logarithms of its pivots summed over the lanes (the same tree, then the same
     // running sum over the blocks as diag_logdet: the same bits).  Kept out of the block steps -- the double-precision
@@ -1237,6 +1274,9 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         const bool agg = g.trace != nullptr && tid == 0;
         long long a0 = 0, a1 = 0, a2 = 0;
         if (agg) a0 = wall_clock64();
+        // debug (dgpamd_debug_tasklog): pulled, inputs seen, arithmetic done, W_k seen, stored, published, workgroup
+        long long *tl = (g.tlog && tid == 0) ? g.tlog + 64 + 8 * ((int64_t)batch * g.nbk + (int64_t)b * g.ntask + slot) : nullptr;
+        if (tl) { tl[0] = wall_clock64(); tl[6] = blockIdx.x; }
         if (st) { st[0] = wall_clock64(); st[5] = (mt.a.x & 15) | ((mt.a.w >> 16) << 8) | ((long long)slot << 16); }
         const int4 tk = mt.a;
         const int post = tk.x & 15, first = (tk.x >> 4) & 1, plus = (tk.x >> 5) & 1, mask_last = (tk.x >> 6) & 1;
@@ -1260,6 +1300,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
             wg_publish(vflag, vvalue, tid);
             if (tid == 0) bc[1] = qn;
             if (st) st[4] = wall_clock64();
+            if (tl) tl[5] = wall_clock64();
             if (agg) {
                 const long long a4 = wall_clock64(), t00 = g.trace[5999];
                 long long bk = t00 > 0 ? (a0 - t00) / 10000 : 0;
@@ -1279,6 +1320,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
 
         if (post == T_TDIAG) {   // T[k][k] = W_k^T, rows of the carried right-hand sides zeroed
             wg_wait_flags<true>(tid == 0 ? wflag : nullptr, wk + 1, 2000 + wk, &g.sync->status, tid);
+            if (tl) tl[1] = tl[2] = tl[3] = wall_clock64();
             const int nrow = (wk == g.nbk - 1) ? ncol_last : 64;
             for (int idx = tid; idx < 4096; idx += 256)
                 tiles[(idx >> 6) * 65 + (idx & 63)] = __hip_atomic_load(Wk + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1292,26 +1334,47 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
             continue;
         }
         // ---- inputs: the output tile's earlier visits, the operand tiles final ----
+        // The NEWEST panel of a visit is usually the one that arrives last -- its operand tile was solved one block step ago, and
+        // along a row of tiles every solve waits for the previous column's (the recursion that bounds the whole launch when the
+        // engine is not saturated: 13-20 us per column with all of a visit's panels applied behind the last arrival).  So the
+        // newest panel's words are optional in the first wait: if they have not arrived, the older panels are applied first
+        // and only the last panel's products follow the arrival (the same products in the same order: the same bits).
+        int split = 0;
         {
             const int32_t *addr = nullptr;
             int nd = VER_FINAL;
             if (tid == 0) { addr = vC; nd = need_c; }
             else if (tid <= nkb) addr = ver + bufL * nb2 + li * g.nbk + kb0 + tid - 1;
             else if (tid <= 2 * nkb) addr = ver + bufR * nb2 + ri * g.nbk + kb0 + tid - 1 - nkb;
-            wg_wait_flags<true>(addr, nd, 1000 + slot % 1000, &g.sync->status, tid);
+            if (nkb >= 2 && g.split)
+                split = !wg_wait_flags_opt(addr, nd, tid == nkb || tid == 2 * nkb, 1000 + slot % 1000, &g.sync->status, tid, &bc[2]);
+            else
+                wg_wait_flags<true>(addr, nd, 1000 + slot % 1000, &g.sync->status, tid);
         }
         if (st) st[1] = wall_clock64();
         if (agg) a1 = wall_clock64();
+        if (tl) tl[1] = wall_clock64();
         Tile64 acc;
-        tile_update<true, true>(acc.v, first ? nullptr : C, g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64,
-                          g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64, ld, nkb, plus ? 1.0 : -1.0,
+        const double *Lp0 = g.buf[bufL] + mo + ((int64_t)li * 64) * ld + (int64_t)kb0 * 64;
+        const double *Rp0 = g.buf[bufR] + mo + ((int64_t)ri * 64) * ld + (int64_t)kb0 * 64;
+        tile_update<true, true>(acc.v, first ? nullptr : C, Lp0, Rp0, ld, split ? nkb - 1 : nkb, plus ? 1.0 : -1.0,
                           mask_last ? g.nbk - 1 - kb0 : -1, ncol_last, As, Bs, tid, wave, lane);
+        if (split) {
+            const int kl = kb0 + nkb - 1;
+            const int32_t *addr = tid == 0 ? ver + bufL * nb2 + li * g.nbk + kl : (tid == 1 ? ver + bufR * nb2 + ri * g.nbk + kl : nullptr);
+            wg_wait_flags<true>(addr, VER_FINAL, 6000 + slot % 1000, &g.sync->status, tid);
+            if (tl) tl[7] = wall_clock64();
+            tile_update<true, true, true>(acc.v, nullptr, Lp0 + (int64_t)(nkb - 1) * 64, Rp0 + (int64_t)(nkb - 1) * 64, ld, 1, plus ? 1.0 : -1.0,
+                                          mask_last ? g.nbk - 1 - kl : -1, ncol_last, As, Bs, tid, wave, lane);
+        }
         if (st) st[2] = wall_clock64();
         if (agg) a2 = wall_clock64();
+        if (tl) tl[2] = wall_clock64();
         if (post == T_STORE) {
             pull_next();
             store_acc_sc1(acc.v, C, ld, crow, ccol);
             if (st) st[3] = wall_clock64();
+            if (tl) tl[4] = wall_clock64();
             finish(vC, newver);
             continue;
         }
@@ -1326,6 +1389,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         }
         wg_wait_flags<true>(tid == 0 ? wflag : nullptr, wk + 1, 3000 + wk, &g.sync->status, tid);
         if (lk && post == T_LOOK) lk[2] = wall_clock64();
+        if (tl) tl[3] = wall_clock64();
         d4 out[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) out[t] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -1334,6 +1398,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
             pull_next();
             store_acc_sc1(out, C, ld, crow, ccol);
             if (st) st[3] = wall_clock64();
+            if (tl) tl[4] = wall_clock64();
             finish(vC, newver);
             continue;
         }
@@ -1355,6 +1420,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
                 if (lk) lk[3] = wall_clock64();
                 wg_wait_flags<true>(addr, nd, 4000 + wk, &g.sync->status, tid);
                 if (lk) lk[4] = wall_clock64();
+                if (tl) tl[7] = wall_clock64();
                 const double *Pg = Ab + ((int64_t)(ci - 1) * 64) * ld + (int64_t)cj * 64;
                 double *Qg = Ab + ((int64_t)ci * 64) * ld + (int64_t)(cj + 1) * 64;
                 const HalfTile p0 = fetch_mk_sc1(Pg, ld, tid, 0), p1 = fetch_mk_sc1(Pg, ld, tid, 1);
@@ -1374,12 +1440,14 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
                 pull_next();
                 store_acc_sc1(qt.v, Qg, ld, crow, ccol);
                 if (st) st[3] = wall_clock64();
+                if (tl) tl[4] = wall_clock64();
                 finish(vQ, need2 + 1);
                 if (lk) lk[5] = wall_clock64();
             } else {
                 int32_t *vD = vA + ci * g.nbk + ci;
                 // lane 0: the earlier visits of D; lane 1: T_LOOK has read the tile that S replaces
                 wg_wait_flags<true>(tid == 0 ? vD : (tid == 1 ? vX : nullptr), tid == 0 ? need2 : 1, 5000 + wk, &g.sync->status, tid);
+                if (tl) tl[7] = wall_clock64();
                 store_acc_sc1(out, C, ld, crow, ccol);   // the solved tile, final
                 double *Dg = Ab + ((int64_t)ci * 64) * ld + (int64_t)ci * 64;
                 Tile64 d;
@@ -1402,6 +1470,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
                 pull_next();
                 store_acc_sc1(d.v, Dg, ld, crow, ccol);
                 if (st) st[3] = wall_clock64();
+                if (tl) tl[4] = wall_clock64();
                 finish(vD, need2 + 1);
                 if (lk) lk[6] = wall_clock64();
             }
@@ -1768,6 +1837,17 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTab
     return DGPAMD_OK;
 }
 
+extern "C" int dgpamd_debug_mega_table(dgpamd_ctx *ctx, int64_t n, int inv, int batch, int32_t *host_out, int64_t cap_words) {
+    if (!ctx || !host_out || n <= 0 || batch <= 0) return -DGPAMD_BAD_ARG;
+    const int nbk = (int)(padded_dim(n) / 64);
+    MegaTable *mt = nullptr;
+    if (get_mega_tasks(ctx, nbk, inv != 0, batch, mt)) return -DGPAMD_BAD_ARG;
+    if ((int64_t)mt->ntask * 8 + 2 * nbk > cap_words) return -DGPAMD_BAD_ARG;
+    if (hipMemcpy(host_out, mt->dev, (size_t)mt->ntask * sizeof(MTask), hipMemcpyDeviceToHost) != hipSuccess) return -DGPAMD_HIP_ERROR;
+    if (hipMemcpy(host_out + (int64_t)mt->ntask * 8, mt->need_dev, (size_t)nbk * sizeof(int2), hipMemcpyDeviceToHost) != hipSuccess) return -DGPAMD_HIP_ERROR;
+    return mt->ntask;
+}
+
 static int mega_wgs_per_cu() {
     static int n = 0;
     if (!n) {
@@ -1798,9 +1878,12 @@ static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, d
     g.sync = reinterpret_cast<MegaSync *>(syncmem);
     g.ver = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(syncmem) + sizeof(MegaSync));
     g.logdet = logdet; g.info = info; g.trace = ctx->trace; g.pred = ctx->pred; g.piv = piv;
+    g.tlog = (ctx->tlog && 64 + 8 * ((int64_t)batch * nbk + (int64_t)batch * mt->ntask) <= ctx->tlog_words) ? ctx->tlog : nullptr;
     {
         static const int nowait = getenv("DGPAMD_MEGA_NOWAIT") ? atoi(getenv("DGPAMD_MEGA_NOWAIT")) : 0;
         g.nowait = nowait;
+        static const int split = getenv("DGPAMD_MEGA_SPLIT") ? atoi(getenv("DGPAMD_MEGA_SPLIT")) : 1;
+        g.split = split;
     }
     {
         const char *eg = getenv("DGPAMD_MEGA_GROUPS");

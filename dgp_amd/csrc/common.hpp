@@ -34,6 +34,8 @@ struct dgpamd_ctx {
     const int32_t *pred;                              // device word: kernels launched while it is set return at once when it is non-zero (dgpamd_ess_queue)
     int potrf_mode;                                   // 1: factorisation as one persistent dataflow launch; 0: one launch per block step
     long long *trace;                                 // device buffer for in-kernel timestamps (diagnostics), or null
+    long long *tlog = nullptr;                        // device buffer for the one-launch factorisation's full task log (dgpamd_debug_tasklog)
+    long long tlog_words = 0;
     double *pinned;                                   // small pinned staging buffer for result copies (lazy)
     int args_inflight;                                // 1 while a copy of `hostargs` may still be running (a call left early)
     unsigned long long host_seq;                      // sequence number of the last result a kernel published into `pinned`

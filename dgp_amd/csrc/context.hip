@@ -340,6 +340,13 @@ extern "C" int dgpamd_debug_trace(dgpamd_ctx *ctx, long long *device_buf) {
     return DGPAMD_OK;
 }
 
+extern "C" int dgpamd_debug_tasklog(dgpamd_ctx *ctx, long long *device_buf, long long words) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    ctx->tlog = words > 0 ? device_buf : nullptr;
+    ctx->tlog_words = device_buf ? words : 0;
+    return DGPAMD_OK;
+}
+
 extern "C" int dgpamd_set_linkgp_direct(dgpamd_ctx *ctx, int enable) {
     if (!ctx) return DGPAMD_BAD_ARG;
     ctx->linkgp_direct = enable ? 1 : 0;

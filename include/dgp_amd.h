@@ -358,6 +358,15 @@ int dgpamd_set_linkgp_direct(dgpamd_ctx *ctx, int enable);
  * wall_clock64() stamps of their phases into it (16 slots per launch; tools/gpu_potrf_trace.py decodes them).
  * NULL switches it off (the default). */
 int dgpamd_debug_trace(dgpamd_ctx *ctx, long long *device_buf);
+/* Diagnostics of the one-launch factorisation (tools/gpu_mega_tasklog.py): when device_buf (`words` int64 of device memory) is
+ * set, every chain step and every worker task of every matrix writes its wall_clock64() stamps into it -- chain step k of matrix b
+ * at 64 + 8 (b nbk + k): start, factored, panel tile staged, diagonal tile seen, solved, updated; task `slot` of matrix b at
+ * 64 + 8 batch nbk + 8 (b ntask + slot): pulled, inputs seen, arithmetic done, W_k seen, stored, published, workgroup.  A log that
+ * would not fit is not written.  dgpamd_debug_mega_table copies the task table those slots index (8 int32 per task as MTask, then
+ * 2 int32 per block: the visits of A[k+1][k] and A[k+1][k+1] the chain waits for) and returns the number of tasks, or a
+ * negative status.  NULL switches the log off (the default). */
+int dgpamd_debug_tasklog(dgpamd_ctx *ctx, long long *device_buf, long long words);
+int dgpamd_debug_mega_table(dgpamd_ctx *ctx, int64_t n, int inv, int batch, int32_t *host_out, int64_t cap_words);
 int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz,
                           const double *m, const double *v, const double *z,
                           const double *Wtr, const double *Wg, const double *length_h, int nlen,
