@@ -554,6 +554,7 @@ struct MegaSync {   // zeroed by a memset node ahead of every launch; the versio
     int32_t pad[6];
     int32_t wflag[DGPAMD_MAXB];     // per matrix: blocks factored (W_k is readable for k < wflag)
     int32_t cukey[DGPAMD_MAXB];     // per matrix: CU of its chain workgroup (cu_key())
+    int32_t uhead[8];               // head of each group's CRITICAL queue (ghead: the bulk queue's), see MegaArgs::nut
 };
 
 struct MTask {
@@ -569,6 +570,9 @@ struct MegaArgs {
     int nbk, batch, inv;
     const MTask *tasks;
     int ntask;               // per matrix
+    int nut;                 // the first nut entries of `tasks` form the CRITICAL queue (per block step the look-ahead pair, the first
+                             // solve and the catch-up updates: what the chain waits for next), the rest the bulk queue
+    int ncrit;               // workers per matrix that serve the critical queue first
     const int2 *chain_need;  // per block k: worker visits of A[k+1][k] and of A[k+1][k+1] the chain waits for
     MegaSync *sync;
     int32_t *ver;            // [batch][VER_PLANES][nbk * nbk]: versions of the tiles of A, T, S; auxiliary words (see T_LOOKD)
@@ -1197,6 +1201,23 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
     __syncthreads();   // (Qs becomes a worker's staging tile next)
 }
 
+// One ticket for a worker (called by thread 0 only): of the critical queue, of the bulk queue with bit 30 set, or -1 when both queues
+// of the group are empty.  role 0 asks the critical queue first, role 1 the bulk queue.  No look at the heads before the atomic:
+// the words are the hottest lines of the launch and a load of one costs as much as the atomic itself; a queue found empty once
+// is not asked again (qempty).  Not inlined: six call sites, and its state must not live in the worker loop's registers.
+__device__ __noinline__ int mega_pull(MegaSync *sync, int grp, int nbg, int nut, int ntask, int role, int32_t *qempty) {
+    const int ucap = nut * nbg, bcap = (ntask - nut) * nbg;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int eu = qempty[0], eb = qempty[1];
+        const int pick = (role == 0 ? !eu : eb) ? 0 : 1;   // 0: critical queue
+        if (pick == 0 ? eu : eb) break;
+        const int t = __hip_atomic_fetch_add(pick == 0 ? &sync->uhead[grp] : &sync->ghead[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < (pick == 0 ? ucap : bcap)) return pick == 0 ? t : (t | (1 << 30));
+        qempty[pick] = 1;
+    }
+    return -1;
+}
+
 #ifndef MEGA_V2
 #define MEGA_V2 1   // 0: the chain of rounds 2-3 (mega_chain), kept for same-box comparisons
 #endif
@@ -1249,25 +1270,43 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
     const int home = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) % G;   // HW_REG_XCC_ID
     int grp = home, tried = 0;
     auto group_size = [&](int gi) { return (batch - gi + G - 1) / G; };
-    // The pull of the NEXT task is issued when a task's arithmetic is done and lands while its tile is stored and
-    // published (an agent-scope atomic plus the descriptor read are several microseconds under load).
-    if (tid == 0) bc[1] = __hip_atomic_fetch_add(&g.sync->ghead[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Two queues per group of matrices.  CRITICAL: per block step the look-ahead pair, the first solve of the panel column and the
+    // catch-up updates behind it -- the lane that hands the chain its next inputs (six tasks per block step and matrix).  It is
+    // served by workers of its own (`ncrit` per matrix, taken from the group's XCDs), which pull it in order and wait inside
+    // their tasks.  With one queue these tasks sat behind what was left of the previous block step's bulk whenever the engine was
+    // busy (tools/analyze_tasklog.py: "pulled late", 12 us per look-ahead task at ten matrices, and the chain's loop -- factor,
+    // publish, look-ahead -- was 27 us per block step where the chain alone takes 12.6).  BULK: everything else, in the old order,
+    // for all other workers; each kind of worker helps with the other queue once its own is empty.  Both queues are topological
+    // orders of their own tasks and each has workers that take nothing else first, so the earliest unfinished task of the launch
+    // is always held, or about to be pulled, by a worker that can run it.
+    // The pull of the NEXT task is issued when a task's arithmetic is done and lands while its tile is stored and published.
+    const int widx = (int)blockIdx.x - batch;
+    const int crit_per_xcd = g.nut > 0 ? (g.ncrit * group_size(home) * G + 7) / 8 : 0;
+    const int role = (widx >= 0 && (widx >> 3) < crit_per_xcd) ? 0 : 1;   // 0: critical queue first, 1: bulk queue first
+    __shared__ int32_t qempty[2];   // (thread 0's notes: this group's critical / bulk queue has been found empty)
+    if (tid == 0) { qempty[0] = g.nut > 0 ? 0 : 1; qempty[1] = 0; }
+    auto pull_take = [&]() -> int { return mega_pull(g.sync, grp, group_size(grp), g.nut, g.ntask, role, qempty); };
+    if (tid == 0) bc[1] = pull_take();
     for (;;) {
         __syncthreads();
         int q = __builtin_amdgcn_readfirstlane(bc[1]);
         __syncthreads();
-        int nbg = group_size(grp);
-        while (q >= g.ntask * nbg) {   // this group's queue is empty: on to the next one (all empty: done)
+        while (q < 0) {   // this group's queues are empty: on to the next group (all empty: done)
             if (++tried >= G) break;
             grp = grp + 1 == G ? 0 : grp + 1;
-            nbg = group_size(grp);
-            if (tid == 0) bc[1] = __hip_atomic_fetch_add(&g.sync->ghead[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                qempty[0] = g.nut > 0 ? 0 : 1;
+                qempty[1] = 0;
+                bc[1] = pull_take();
+            }
             __syncthreads();
             q = __builtin_amdgcn_readfirstlane(bc[1]);
             __syncthreads();
         }
         if (tried >= G) break;
-        const int slot = q / nbg, b = grp + G * (q - slot * nbg);
+        const int nbg = group_size(grp);
+        const int qt = q & ~(1 << 30), qs = qt / nbg;
+        const int slot = (q >> 30) ? g.nut + qs : qs, b = grp + G * (qt - qs * nbg);
         const MTask mt = g.tasks[slot];
         long long *st = (wst && nst < 80) ? wst + 8 * nst++ : nullptr;
         // debug: every worker adds its waiting / arithmetic / remaining time to 100-us buckets of the launch (trace[6000..6095])
@@ -1283,7 +1322,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         const int bufC = (tk.x >> 8) & 3, bufL = (tk.x >> 10) & 3, bufR = (tk.x >> 12) & 3;
         const int ci = tk.y & 0xffff, cj = tk.y >> 16, li = tk.z & 0xffff, ri = tk.z >> 16;
         const int kb0 = tk.w & 0xffff, nkb = tk.w >> 16;
-        const int need_c = mt.b.x, fin = mt.b.y, wk = mt.b.z;
+        const int need_c = mt.b.x, fin = mt.b.y & 1, wk = mt.b.z;
         const int64_t mo = (int64_t)b * g.stride_a;
         const int nb2 = g.nbk * g.nbk;
         int32_t *ver = g.ver + (int64_t)b * VER_PLANES * nb2;
@@ -1294,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         const int newver = fin ? VER_FINAL : need_c + 1;
         int qn = 0;
         auto pull_next = [&]() {
-            if (tid == 0) qn = __hip_atomic_fetch_add(&g.sync->ghead[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) qn = pull_take();
         };
         auto finish = [&](int32_t *vflag, int vvalue) {   // drain (the tile's stores and the pull), publish, hand the next task to the loop's head
             wg_publish(vflag, vvalue, tid);
@@ -1659,13 +1698,16 @@ static int get_tasks(dgpamd_ctx *ctx, int nbk, bool inv, TaskTable *&out) {
 #define MEGA_SLAZY 8
 #define MEGA_NEAR 2
 struct MegaTable {
-    MTask *dev = nullptr;
+    MTask *dev = nullptr;        // urgent tasks first (nut of them), then the bulk tasks
     int2 *need_dev = nullptr;
-    int ntask = 0;
+    int ntask = 0, nut = 0;
 };
 
+// tag[i]: (block step << 1) | critical -- critical: the lane that hands the chain its next inputs (the look-ahead pair, the first solve
+// of the panel column and the catch-up updates behind it); everything else is bulk.
 static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::vector<int2> &need, int lazy, int slazy,
-                             int near = 0, int lag = 0, int xcatch = 0, int stail = 0, int look = 1) {
+                             int near, int lag, int xcatch, int stail, int look, std::vector<int> &tag, int slag = 0) {
+    int cur_step = 0, cur_urgent = 0;
     const int nb2 = nbk * nbk;
     std::vector<int> appliedA(nb2, 0), visitsA(nb2, 0), appliedT(nb2, 0), visitsT(nb2, 0), visitsS(nb2, 0), appliedS(nbk, 0);
     for (int q = 0; q < nbk; ++q) appliedS[q] = q;   // row q of K^-1 sums the panels kb >= q
@@ -1678,6 +1720,7 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
         t.a = a;
         t.b = make_int4(need_c, fin, wk, 0);
         out.push_back(t);
+        tag.push_back((cur_step << 1) | (cur_urgent ? 1 : 0));
     };
     // bring A[i][j] up to the panels < upto (plain update, stored)
     auto updA = [&](int i, int j, int upto) {
@@ -1713,37 +1756,45 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
         t.a = make_task(T_LOOK, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap);
         t.b = make_int4(visitsA[i * nbk + k], 0, k, visitsA[i * nbk + k + 1]);
         out.push_back(t);
+        tag.push_back((cur_step << 1) | 1);
         MTask d;
         d.a = make_task(T_LOOKD, 0, 0, 0, BUF_A, i, k, BUF_A, i, BUF_A, k, ap, k - ap);
         d.b = make_int4(visitsA[i * nbk + k]++, 1, k, visitsA[i * nbk + i]);
         out.push_back(d);
+        tag.push_back((cur_step << 1) | 1);
         ++visitsA[i * nbk + k + 1];
         ++visitsA[i * nbk + i];
         appliedA[i * nbk + k] = k;
         appliedA[i * nbk + k + 1] = appliedA[i * nbk + i] = k + 1;
         return true;
     };
-    const int nl = nbk + (inv ? 1 + lag : 0);   // (one more pass flushes what is left of K^-1)
+    const int nl = nbk + (inv ? 1 + lag + slag : 0);   // (one more pass flushes what is left of K^-1)
     for (int k = 0; k < nl; ++k) {
+        cur_step = k;
         if (k < nbk) {
             // LOOK-AHEAD: what the chain picks up after factoring block k+1 -- A[k+2][k+1] and A[k+2][k+2] with the panels
             // <= k -- needs only W_k and the chain's own panel tile A[k+1][k]: it comes first in the tasks of block k,
             // ahead of their bulk, so the chain's serial part (solve, update, factor: ~15 us) runs beside that bulk
             // instead of after it.
             if (k + 2 < nbk) {
+                cur_urgent = 1;
                 if (!lookA(k)) {
                     solveA(k + 2, k);
                     updA(k + 2, k + 2, k + 1);
                     updA(k + 2, k + 1, k + 1);
                 }
+                cur_urgent = 0;
                 need[k + 1] = make_int2(visitsA[(k + 2) * nbk + k + 1], visitsA[(k + 2) * nbk + k + 2]);
             }
             if (inv) emit(make_task(T_TDIAG, 1, 0, 0, BUF_T, k, k, BUF_A, 0, BUF_A, 0, 0, 0), visitsT[k * nbk + k]++, 1, k);
             // panel column k; behind its first tile the catch-up of the NEXT look-ahead's two tiles (panels <= k), so that
             // the visits the chain waits for apply one panel each
             for (int i = k + 3; i < nbk; ++i) {
+                cur_urgent = (i == k + 3);
                 solveA(i, k);
+                cur_urgent = 0;
                 if (i == k + 3) {
+                    cur_urgent = 1;
                     updA(k + 3, k + 3, k + 1);
                     updA(k + 3, k + 2, k + 1);
                     if (xcatch) updA(k + 3, k + 1, k + 1);   // (the next look-ahead solve then has no panel left to apply)
@@ -1752,6 +1803,7 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
                     // applied the three the lazy cadence leaves -- 5 us of arithmetic between the arrival of the last operand
                     // (the previous block's solved tile) and the solve, on the path to the tile the chain waits for.
                     else if (look) updA(k + 3, k + 1, k);
+                    cur_urgent = 0;
                 }
             }
             if (inv)
@@ -1780,7 +1832,7 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
             // with the block steps that are left, so that when the last chain has finished every K^-1 tile lacks one or two
             // panels, not eight: the tail after the chains is one round of short tasks behind the last column's solves
             // (potrf_inv of one matrix 0.57 -> 0.55 ms, of three 0.77 -> 0.75; with more matrices the extra shallow tasks cost more than the tail).
-            const int ks = k - lag;
+            const int ks = k - lag - slag;   // (slag: the K^-1 visits trail by that many block steps -- nothing waits for them)
             const int left = nbk - ks;   // block steps until the flush
             const int thr = ks >= nbk ? 1 : (stail && left < slazy ? (left > 1 ? left : 1) : slazy);
             for (int q = 0; q <= ks - 1 && q < nbk; ++q) {
@@ -1815,18 +1867,37 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTab
     const char *es = getenv("DGPAMD_MEGA_STAIL");
     // (a task waits on 1 + 2 nkb version words, one per lane of ONE wave: the overrides are clamped so that the deepest visit --
     //  lazy + 1 + near + lag panels -- stays within 64 flags, and build_mega_tasks' output is checked below)
-    const int near_raw = en ? atoi(en) : ((inv && deep) ? 3 : MEGA_NEAR), lag_raw = el ? atoi(el) : 0;
-    const int near = near_raw < 0 ? 0 : (near_raw > 3 ? 3 : near_raw), lag = lag_raw < 0 ? 0 : (lag_raw > 2 ? 2 : lag_raw), xcatch = (ex ? atoi(ex) : 0) + 2 * (es ? atoi(es) : (inv && batch <= 3 ? 1 : 0));
+    // Round 5 (profiles/r05_mega_table_sweeps.txt): with the newest panel of a visit applied on its own (kernel, `split`) the solves can
+    // leave more panels to themselves without lengthening the recursion along a row of tiles, and a column's last deep visit
+    // then lies four block steps ahead of its solves: three columns' distance (near = 3) at every batch size.
+    const int near_raw = en ? atoi(en) : 3, lag_raw = el ? atoi(el) : 0;
+    const int near = near_raw < 0 ? 0 : (near_raw > 6 ? 6 : near_raw), lag = lag_raw < 0 ? 0 : (lag_raw > 2 ? 2 : lag_raw), xcatch = (ex ? atoi(ex) : 0) + 2 * (es ? atoi(es) : (inv && batch <= 3 ? 1 : 0));
     const char *elk = getenv("DGPAMD_MEGA_LOOK");   // 0: the look-ahead as three tasks (rounds 2-3)
     const int look = elk ? (atoi(elk) != 0) : 1;
-    static std::map<std::pair<dgpamd_ctx *, std::array<int, 8>>, MegaTable> cache;
-    MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy, near, lag, xcatch, look}}];
+    const char *esl = getenv("DGPAMD_MEGA_SLAG");
+    const int slag = esl ? (atoi(esl) < 0 ? 0 : (atoi(esl) > 8 ? 8 : atoi(esl))) : 0;
+    const char *eq = getenv("DGPAMD_MEGA_QUEUES");   // 1: one queue per group of matrices (rounds 2-4)
+    const int queues = eq && atoi(eq) == 1 ? 1 : 2;
+    static std::map<std::pair<dgpamd_ctx *, std::array<int, 10>>, MegaTable> cache;
+    MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy, near, lag, xcatch, look, queues, slag}}];
     if (!mt.dev) {
-        std::vector<MTask> tasks;
+        std::vector<MTask> all, tasks;
         std::vector<int2> need;
-        build_mega_tasks(nbk, inv, tasks, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy, near, lag, xcatch & 1, xcatch >> 1, look);
-        for (const MTask &t : tasks)   // wg_wait_flags polls with the 64 lanes of one wave
+        std::vector<int> tag;
+        build_mega_tasks(nbk, inv, all, need, lazy > 24 ? 24 : lazy, slazy > 24 ? 24 : slazy, near, lag, xcatch & 1, xcatch >> 1, look, tag, slag);
+        for (const MTask &t : all)   // wg_wait_flags polls with the 64 lanes of one wave
             if (1 + 2 * (t.a.w >> 16) > 64) BAD_ARG(ctx, "task table: a visit applies more panels than one wave can wait for");
+        // urgent tasks first (their block step rides in b.y above the `final` bit), then the bulk tasks: two queues (see the kernel)
+        if (queues == 2)
+            for (size_t i = 0; i < all.size(); ++i)
+                if (tag[i] & 1) {
+                    MTask t = all[i];
+                    t.b.y |= (tag[i] >> 1) << 8;
+                    tasks.push_back(t);
+                }
+        mt.nut = (int)tasks.size();
+        for (size_t i = 0; i < all.size(); ++i)
+            if (queues != 2 || !(tag[i] & 1)) tasks.push_back(all[i]);
         mt.ntask = (int)tasks.size();
         HIP_TRY(ctx, hipMalloc((void **)&mt.dev, (tasks.size() + 1) * sizeof(MTask)));
         HIP_TRY(ctx, hipMemcpy(mt.dev, tasks.data(), tasks.size() * sizeof(MTask), hipMemcpyHostToDevice));
@@ -1875,6 +1946,12 @@ static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, d
     g.ws = ws; g.ld = Np; g.stride_a = stride_a; g.stride_ws = (int64_t)nbk * 4096; g.n = n; g.nbk = nbk; g.batch = batch;
     g.inv = T != nullptr;
     g.tasks = mt->dev; g.ntask = mt->ntask; g.chain_need = mt->need_dev;
+    g.nut = mt->nut;
+    {
+        // (workers of the critical queue per matrix: one per task of a block step, and a few more while the engine has room)
+        static const int ncrit_env = getenv("DGPAMD_MEGA_NCRIT") ? atoi(getenv("DGPAMD_MEGA_NCRIT")) : 0;
+        g.ncrit = ncrit_env > 0 ? ncrit_env : (batch <= 4 ? 12 : 8);
+    }
     g.sync = reinterpret_cast<MegaSync *>(syncmem);
     g.ver = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(syncmem) + sizeof(MegaSync));
     g.logdet = logdet; g.info = info; g.trace = ctx->trace; g.pred = ctx->pred; g.piv = piv;

@@ -27,7 +27,7 @@ def load(path):
     tab = d['table']
     T = dict(post=tab[:, 0] & 15, first=(tab[:, 0] >> 4) & 1, bufC=(tab[:, 0] >> 8) & 3, bufL=(tab[:, 0] >> 10) & 3, bufR=(tab[:, 0] >> 12) & 3,
              ci=tab[:, 1] & 0xffff, cj=tab[:, 1] >> 16, li=tab[:, 2] & 0xffff, ri=tab[:, 2] >> 16, kb0=tab[:, 3] & 0xffff, nkb=tab[:, 3] >> 16,
-             need_c=tab[:, 4], fin=tab[:, 5], wk=tab[:, 6], need2=tab[:, 7])
+             need_c=tab[:, 4], fin=tab[:, 5] & 1, step=tab[:, 5] >> 8, wk=tab[:, 6], need2=tab[:, 7])
     return d, B, nbk, ntask, ch, tk, wg, ready2, T
 
 
@@ -264,3 +264,21 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def look_table(path, mb):
+    """the look-ahead tasks of matrix mb, relative to the end of the chain's factorisation of their block"""
+    d, B, nbk, ntask, ch, tk, wg, ready2, T = load(path)
+    print('matrix %d look-ahead tasks, us after the chain factored block k: kind | pulled | own inputs seen | first run done | W_k seen | 2nd wait done | stored | published | worker' % mb)
+    for s in range(ntask):
+        p = int(T['post'][s])
+        if p not in (LOOK, LOOKD):
+            continue
+        k = int(T['wk'][s])
+        t0 = ch[mb, k, 1]
+        r = tk[mb, s]
+        print('%2d %-5s | %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f | wg %d' % (k, KIND[p], r[0] - t0, r[1] - t0, r[2] - t0, r[3] - t0, r[7] - t0, r[4] - t0, r[5] - t0, int(wg[mb, s])))
+
+
+if '--look' in sys.argv:
+    look_table(sys.argv[1], int(sys.argv[sys.argv.index('--matrix') + 1]) if '--matrix' in sys.argv else 0)
