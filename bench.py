@@ -26,6 +26,19 @@ F64_PEAK_TFLOPS = 78.6   # MI355X f64 matrix (= vector) peak, AMD datasheet; MI3
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_note(kernel, fallback):
+    """Counter evidence of this round for a kernel (profiles/r05_pmc_kernels.json, written by tools/pmc_summary.py from
+    rocprofv3 --pmc passes of this build), as a sentence for the result line; `fallback` while that file has no entry."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r05_pmc_kernels.json')) as f:
+            e = json.load(f).get(kernel)
+        if e and e.get('note'):
+            return e['note'] + ' (profiles/r05_pmc_kernels.json)'
+    except (OSError, ValueError):
+        pass
+    return fallback
+
+
 def synthetic(n, d, seed=2026):
     """X ~ U[0,1]^(n x d), standardised smooth non-stationary response."""
     rng = np.random.default_rng(seed)
@@ -113,6 +126,68 @@ def cpu_baseline(model, counts, ess_burn):
                 seconds_per_call=dict(fmvn=t_fmvn, log_likelihood_func=t_ll, llik_layer1=t_llik[0], llik_layer2=t_llik[1]))
 
 
+def _cpu_predict_points(job):
+    """One worker of cpu_baseline_predict (a spawned process, BLAS pinned to one thread: the reference's link_gp is a numba
+    prange over the test points, functions.py:396-430 -- one core per point)."""
+    import os
+    os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')
+    import time as _t
+    import numpy as _np
+    from oracle import dgp_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:   # noqa: BLE001
+        pass
+    x, l1, l2 = job
+    t0 = _t.perf_counter()
+    m = _np.empty((len(x), len(l1)))
+    v = _np.empty((len(x), len(l1)))
+    for k, nd in enumerate(l1):   # functions.gp (functions.py:379-394) of every first-layer node
+        m[:, k], v[:, k] = O.gp_predict(x[:, nd['cols']], nd['W'], nd['Rinv'], nd['Rinv_y'], nd['scale'], nd['length'], nd['nugget'], nd['name'])
+    mu, var = O.link_gp_predict(m, v, None, l2['W'], None, l2['Rinv'], l2['Rinv_y'], l2['scale'], l2['length'], l2['nugget'], l2['name'])
+    return _t.perf_counter() - t0, float(mu.sum()), float(var.sum())
+
+
+def cpu_baseline_predict(model, d, imputations, points_per_worker=1):
+    """The predict half of the metric on the host: the oracle's gp_predict (first layer) + link_gp_predict (Matern-2.5 IJ with the
+    reference's closed forms, functions.py:379-430,453-494) at n = 2000 for ONE imputation (the model's current latent state;
+    compute_stats = emulator.__init__ is not timed, as SURVEY 8(d) defines the metric) on a few test points per worker process,
+    one process per core up to 32 -- the reference parallelises link_gp over the test points -- scaled to `imputations`
+    imputations per point.  Reported beside the GPU number; never the thing measured."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    import psutil
+    from oracle import dgp_oracle as O
+    phys = psutil.cpu_count(logical=False) or 1
+    workers = max(1, min(32, phys))
+    l1 = []
+    for nd in model.all_layer[0]:
+        Xn = np.ascontiguousarray(nd._X())
+        st = O.compute_stats(Xn, nd.output[:, 0], nd.length, nd.nugget[0], nd.name, Xn.shape[1])
+        l1.append(dict(cols=np.r_[np.asarray(nd.input_dim), np.asarray(nd.connect if nd.connect is not None else [], dtype=int)] if nd.global_input is not None else np.asarray(nd.input_dim),
+                       W=Xn, Rinv=st['Rinv'], Rinv_y=st['Rinv_y'], scale=nd.scale, length=nd.length, nugget=nd.nugget, name=nd.name))
+    nd = model.all_layer[1][0]
+    W2 = np.ascontiguousarray(nd._X())
+    st = O.compute_stats(W2, nd.output[:, 0], nd.length, nd.nugget[0], nd.name, W2.shape[1])
+    l2 = dict(W=W2, Rinv=st['Rinv'], Rinv_y=st['Rinv_y'], scale=nd.scale, length=nd.length, nugget=nd.nugget, name=nd.name)
+    xt = np.random.default_rng(11).uniform(size=(workers * points_per_worker, d))
+    jobs = [(xt[w * points_per_worker:(w + 1) * points_per_worker], l1, l2) for w in range(workers)]
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn')) as ex:   # (spawn: this process holds a HIP context)
+        res = list(ex.map(_cpu_predict_points, jobs))
+    wall = time.perf_counter() - t0
+    busy = max(r[0] for r in res)            # the slowest worker's compute time (process start-up and pickling excluded)
+    pts = len(xt)
+    finite = bool(np.all(np.isfinite([r[1] for r in res])) and np.all(np.isfinite([r[2] for r in res])))
+    return dict(value=pts / busy / imputations, unit='pts/s', cores=workers, physical_cores=phys, kind='port', imputations=imputations,
+                seconds_per_point_imputation_one_core=float(np.mean([r[0] for r in res])) / points_per_worker, finite=finite,
+                sample=('%d worker processes x %d test points, one imputation each (gp_predict of the %d first-layer nodes + link_gp_predict of the '
+                        'Matern-2.5 output node at n=%d, one BLAS thread per process as the reference\'s prange over test points); slowest worker %.1f s, '
+                        '%.1f s wall with process start-up; scaled to %d imputations per point'
+                        % (workers, points_per_worker, len(l1), len(W2), busy, wall, imputations)))
+
+
 def potrf_table(eng, torch, n=2000):
     """The factorisation alone at the bench size, by batch (HIP events on the engine's stream, minimum of 5): ms and algorithmic
     TFLOP/s (n^3/3 per matrix, n^3 with the fused inverse) -- the headline roofline fraction averages over whatever batch sizes
@@ -121,13 +196,13 @@ def potrf_table(eng, torch, n=2000):
     rng = np.random.default_rng(1)
     out = {}
     ev0, ev1 = eng.event(), eng.event()
-    for B in (1, 6, 12):
+    for B in (1, 2, 3, 4, 6, 10, 12):
         X = eng.tensor(rng.uniform(size=(B, n, 5)))
         y = eng.tensor(rng.normal(size=n))
         A, T, S = eng.empty(B, Np, Np), eng.empty(B, Np, Np), eng.empty(B, Np, Np)
         work = eng.potrf_workspace(n, B)
         tf, tv = [], []
-        for rep in range(6):
+        for rep in range(5):
             eng.kmatrix('matern2.5', X, None, None, [1.0], 1e-6, out=A, full=False, Y=y, batch=B)
             eng.record(ev0); eng.potrf(n, A, batch=B, work=work); eng.record(ev1)
             torch.cuda.synchronize()
@@ -140,7 +215,8 @@ def potrf_table(eng, torch, n=2000):
         out['B=%d' % B] = dict(potrf_ms=f, potrf_tflops=B * n ** 3 / 3 / f / 1e9, potrf_frac=B * n ** 3 / 3 / f / 1e9 / F64_PEAK_TFLOPS,
                                potrf_inv_ms=v, potrf_inv_tflops=B * n ** 3 / v / 1e9, potrf_inv_frac=B * n ** 3 / v / 1e9 / F64_PEAK_TFLOPS)
         del A, T, S
-    out['note'] = 'n=%d; one call = one potrf_mega_kernel launch (+ its memset / copy-out); one matrix is bound by the 31-step pivot chain' % n
+    out['note'] = ('n=%d; one call = one potrf_mega_kernel launch (+ its memset / copy-out), minimum of 4; one matrix is bound by the 31-step '
+                   'pivot chain (12.6 us per step), an M-step round holds 1-5 matrices with the inverse, a speculative ESS batch 10 or 6 without' % n)
     return out
 
 
@@ -177,8 +253,8 @@ def vecchia_leg(eng, torch, n=50000, d=8, m=25, B=6):
                 llik_ms=t1, llik_rows_per_s=n / t1 * 1e3, llik_gather_GBs=gather / t1 / 1e6,
                 llik_batch=dict(candidates=B, ms=tb, rows_per_s=B * n / tb * 1e3, gather_GBs=B * gather / tb / 1e6),
                 nllik_ms=t2, nllik_rows_per_s=n / t2 * 1e3, lmatrix_ms=t3, lmatrix_rows_per_s=n / t3 * 1e3,
-                bound='f64 VALU issue (0.59 of peak, profiles/r02_cfg4_pmc_row_kernel.txt): the gather is %.1f MB per evaluation, '
-                      'a few per cent of the HBM roofline' % (gather / 1e6))
+                bound=pmc_note('vecchia_row4_kernel', 'f64 VALU issue (~0.79 of peak by in-kernel stamps, profiles/r04_vecchia_row_kernel_phases.txt)')
+                + ': the gather is %.1f MB per evaluation, a few per cent of the HBM roofline' % (gather / 1e6))
 
 
 def strong_leg_cfg3(dd, torch, local, dev, world, n=5000, d=10, q=3, S=16, M=2048):
@@ -245,6 +321,7 @@ def main():
                          'GPU legs have lasted this long in all, for an external sampler of device activity that needs a longer run')
     ap.add_argument('--no-strong-legs', action='store_true', help='N > 1: skip the strong-scaling legs (cfg3 prediction with the imputations sharded, cfg4 training with the Vecchia rows split)')
     ap.add_argument('--imputations', type=int, default=10)
+    ap.add_argument('--sustained-steps', type=int, default=100, help='iterations of the train(N) call behind the timed region (0: skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-predict', action='store_true')
     ap.add_argument('--no-split-leg', action='store_true', help='N > 1: skip the informational leg that trains one model with the M-step nodes split over the ranks')
@@ -355,6 +432,22 @@ def main():
                   llik_l1_per_iter=calls['l1'] / args.steps, llik_l2_per_iter=calls['l2'] / args.steps,
                   mstep_rounds_per_iter=rounds['n'] / args.steps)
 
+    # ---- the sustained figure: the reference's own entry point, train(N), over 100 iterations (the optimiser rounds per iteration range
+    #      6-45 along a training path, so a 20-step window reads +-10 %; SURVEY 8(d) defines the metric on train(N)) ----
+    sustained = None
+    if args.sustained_steps > 0:
+        r0 = rounds['n']
+        dd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.train(N=args.sustained_steps, ess_burn=args.ess_burn, disable=True)
+        torch.cuda.synchronize()
+        dd.barrier()
+        ts = dd.allreduce_max_scalar(time.perf_counter() - t0, dev if world > 1 else None)
+        sustained = dict(si_it_per_s=args.sustained_steps * world / ts, steps=args.sustained_steps, seconds=ts,
+                         mstep_rounds_per_iter=(rounds['n'] - r0) / args.sustained_steps,
+                         what='dgp.train(N=%d, ess_burn=%d) right after the timed region (same model, same chain)' % (args.sustained_steps, args.ess_burn))
+
     # ---- roofline of the dominant kernel: HIP events around each of its launches, same steps ----
     roof = None
     if rank == 0 and args.prof_kernel != 'none':
@@ -381,15 +474,13 @@ def main():
                 ach = tot_w / (tot_ms * 1e-3) / 1e12
                 roof = dict(bound='mfma', kernel={'syrk': 'potrf_mega_kernel (one launch = one batched factorisation, with or without the fused inverse)'}.get(args.prof_kernel, 'tile_gemm_kernel<%s>' % args.prof_kernel), achieved=ach,
                             peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None)
-            pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_bench_potrf_kernel.json')
-            if not os.path.exists(pmc):
-                pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_bench_potrf_kernel.json')
+            pmc = next((q for q in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_bench_potrf_kernel.json' % r) for r in (5, 4, 2)) if os.path.exists(q)), '')
             if args.prof_kernel == 'syrk' and os.path.exists(pmc):   # HBM bytes per launch, measured offline with rocprofv3 --pmc
                 with open(pmc) as f:
                     pj = json.load(f)
                 roof['traffic'] = pj['hbm_bytes_per_launch']
-                roof['traffic_source'] = ('profiles/' + os.path.basename(pmc) + ': FETCH_SIZE x2 + WRITE_SIZE per launch of the same '
-                                          'kernel in separate rocprofv3 --pmc passes of `%s` (an earlier run, not this one)' % pj.get('command', '?'))
+                roof['traffic_source'] = ('profiles/' + os.path.basename(pmc) + ': ' + pj.get('how', 'FETCH_SIZE x2 + WRITE_SIZE per launch of the same kernel')
+                                          + ' in separate rocprofv3 --pmc passes of `%s` (an earlier run of the same build, not this one)' % pj.get('command', '?'))
             roof.update(launches=tot_n, avg_launch_us=1e3 * tot_ms / tot_n, work_per_launch=tot_w / tot_n,
                         event_pair_overhead_us=ev_us, avg_launch_us_if_event_overhead_removed=1e3 * corrected_ms / tot_n,
                         note='algorithmic flops = n^3/3 per matrix (n^3 with the fused inverse), SURVEY 8(d); speculative batches '
@@ -406,9 +497,8 @@ def main():
             roof_k = dict(bound='hbm', kernel='kmatrix_kernel (lower tiles of the batched augmented buffers, as the training path assembles them)',
                           achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=None, launches=k_n,
                           avg_launch_us=1e3 * k_ms / k_n, bytes_per_launch=k_w / k_n,
-                          note='this kernel is f64-VALU-bound, not HBM-bound: 71 VALU instructions per Matern entry (22 of them the '
-                               'double-precision exp), 0.73 of the VALU issue peak (profiles/r02_pmc_valu_mfma_counters.txt); the HBM '
-                               'fraction is reported because the contract asks for it')
+                          note=pmc_note('kmatrix_kernel', 'this kernel is f64-VALU-bound, not HBM-bound (one entry per lane and ~70 VALU instructions '
+                                        'per Matern entry, 22 of them the double-precision exp); the HBM fraction is reported because the contract asks for it'))
     kernel_class.kernel._llik_finish = orig_finish
 
     # ---- K assembly alone against the HBM roofline, cache-defeating: full symmetric n = 5000, D = 10 (cfg3's node shape),
@@ -436,8 +526,22 @@ def main():
             roof_ks[name] = dict(bound='hbm', kernel='kmatrix_kernel<%s> (full symmetric, n=%d, D=%d, 3 x 200 MB outputs in turn)' % (name, nk, Dk),
                                  achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s', frac=nbytes / ms / 1e6 / HBM_PEAK_GBS,
                                  avg_launch_us=1e3 * ms, bytes_per_launch=nbytes, launches=k_n, traffic=None,
-                                 note='a write-only torch fill_ of the same 200 MB reaches 0.73 of 8 TB/s (profiles/r01_kmatrix_hbm_roofline.txt); '
-                                      'this kernel issues ~45 f64 VALU instructions per entry beside its stores')
+                                 note='the write-only ceiling of the same buffers is measured beside it (roofline_kmatrix_standalone.fill_)')
+        # a write-only fill_ of the same three buffers in turn, timed the same way (torch events on the engine's stream): the store
+        # ceiling this kernel is compared with, measured in this run
+        with eng.stream():
+            st = torch.cuda.current_stream()
+            for o in outs:
+                o.fill_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for r in range(30):
+                outs[r % 3].fill_(1.0)
+            e1.record(st)
+        torch.cuda.synchronize()
+        fill_ms = e0.elapsed_time(e1) / 30
+        roof_ks['fill_'] = dict(what='torch fill_ of the same 200-MB buffers in turn (write-only ceiling, this run)', avg_launch_us=1e3 * fill_ms,
+                                achieved=8.0 * nk * nk / fill_ms / 1e6, unit='GB/s', frac=8.0 * nk * nk / fill_ms / 1e6 / HBM_PEAK_GBS)
         del outs
 
     ptab = vleg = None
@@ -489,8 +593,14 @@ def main():
                 ach = p_w / (p_ms * 1e-3) / 1e12
                 pred['roofline_predict'] = dict(bound='mfma', kernel='linkgp_Jsep_kernel (Matern pair phase: record dot products on f64 MFMA)',
                                                 achieved=ach, peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None,
-                                                launches=p_n, avg_launch_us=1e3 * p_ms / p_n,
-                                                note='algorithmic flops = M n^2/2 x D x 30 x 2 per launch (DESIGN section 3)')
+                                                launches=p_n, avg_launch_us=1e3 * p_ms / p_n, flop_convention='executed',
+                                                J_elements_per_s=p_w / (args.d * 60.0) * 2.0 / (p_ms * 1e-3),
+                                                J_elements_executed_per_s=p_w / (args.d * 60.0) / (p_ms * 1e-3),
+                                                frac_of_f64_vector_peak=ach / F64_PEAK_TFLOPS,
+                                                note='EXECUTED flops = M n^2/2 x D x 30 x 2 per launch: the record dot products of the lower pairs '
+                                                     '(DESIGN section 3); SURVEY 8(d)\'s unit beside it: J elements per second, one element = one (i, j) of '
+                                                     'J for one test point as the reference evaluates them (all n^2; the kernel evaluates the n^2/2 lower ones '
+                                                     'and uses the symmetry), and the fraction of the f64 vector peak (= the matrix peak on gfx950)')
             # the first layer's predictor (functions.py:379-394: r^T R^-1 r on MFMA), a shorter pass of the same call
             xg = xt[:min(len(xt), 4096)]
             if rank == 0:
@@ -501,7 +611,7 @@ def main():
                 ach = g_w / (g_ms * 1e-3) / 1e12
                 pred['roofline_gp'] = dict(bound='mfma', kernel='gp_quad_kernel (r^T R^-1 r over the lower tiles of R^-1, f64 MFMA)', achieved=ach,
                                            peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None, launches=g_n,
-                                           avg_launch_us=1e3 * g_ms / g_n, points=len(xg),
+                                           avg_launch_us=1e3 * g_ms / g_n, points=len(xg), flop_convention='algorithmic / 2 = executed',
                                            note='algorithmic flops = 2 n^2 M per launch (R^-1 r, then the dot product, as the reference forms it); '
                                                 'the kernel uses the symmetry of R^-1 and executes half of them')
 
@@ -559,9 +669,14 @@ def main():
     torch.cuda.synchronize()
     gpu_leg_seconds = time.perf_counter() - t_gpu0
 
-    cpu = None
+    cpu = cpu_pred = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, counts, args.ess_burn)
+        if pred is not None:
+            try:
+                cpu_pred = cpu_baseline_predict(model, args.d, args.imputations)
+            except Exception as exc:   # noqa: BLE001  (informational: must not cost the run its result line)
+                cpu_pred = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
 
     dist_info = None
     if world > 1 or forced:   # RCCL's view of the job, in the record
@@ -579,12 +694,17 @@ def main():
             'ms_per_step': 1e3 * wall / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: 2-layer DGP, d=%d in / 1 out, n=%d, Matern-2.5, %d+1 GP nodes, '
-                                   'train(ess_burn=%d): one step = one SI iteration' % (args.d, args.n, args.d, args.ess_burn),
-                       'parallelism': 'replicas x%d (SI chain does not shard); predict: imputations sharded, 1 all-reduce' % world},
+                                   'train(ess_burn=%d): one step = imputer.sample() + the M-step = one iteration of dgp.train (dgp.py:1364-1412); '
+                                   'the same rate over a train(N=%d) call is in `sustained`' % (args.d, args.n, args.d, args.ess_burn, args.sustained_steps),
+                       'parallelism': ('replicas x%d (SI chain does not shard); predict: imputations sharded, 1 all-reduce' % world)
+                       + ('' if world == 1 else '; `value` is replicas x rate: linear in N by construction -- the scaling figure of this run is '
+                                                'strong_scaling.cfg3_predict_imputations_sharded.point_imputations_per_s (fixed total work)')},
+            'sustained': sustained, 'sustained_it_per_s': sustained['si_it_per_s'] if sustained else None,
             'predict': pred, 'counts': counts, 'roofline': roof, 'roofline_kmatrix': roof_k, 'roofline_kmatrix_standalone': roof_ks,
             'roofline_predict': (pred or {}).get('roofline_predict'), 'roofline_gp': (pred or {}).get('roofline_gp'),
-            'potrf_table': ptab, 'vecchia': vleg, 'cpu_baseline': cpu, 'mstep_nodes_split': split,
+            'potrf_table': ptab, 'vecchia': vleg, 'cpu_baseline': cpu, 'cpu_baseline_predict': cpu_pred, 'mstep_nodes_split': split,
             'speedup_vs_cpu_baseline': (value / world / cpu['value']) if cpu else None,
+            'predict_speedup_vs_cpu_baseline': (pred['pts_per_s'] / cpu_pred['value']) if (pred and cpu_pred and cpu_pred.get('value')) else None,
             'strong_scaling': strong, 'distributed': dist_info,
             'gpu_legs': dict(seconds=gpu_leg_seconds, untimed_extra_steps=extra_steps),
         }
