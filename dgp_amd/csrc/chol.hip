@@ -864,6 +864,27 @@ __device__ __forceinline__ void store_pt_sc1(const d4 (&P)[4], double *Pg, int64
     // bytes -- and with the memory pipeline under load from other processes the store had not read all of its data yet: the first
     // double of the lanes read last held the NEXT pair's value.  Two ranks sharing one GPU: a few wrong factors per thousand
     // launches, tools/gpu_mega_stress_shared.sh; never seen with the device to itself.)
+    // Round 5: the constant part of the address rides in the instruction's immediate offset field (voffset + constant) and the soffset
+    // operand is the literal 0 -- the form for which LLVM's hazard recogniser inserts the wait states itself (it skips a store whose
+    // soffset is a register: the constants above 64 used to be materialised in SGPRs).  The registers of their own and the
+    // wait states below stay; tests/test_isa_hazards.py reads the shipped code and fails when a data register of any 16-byte store
+    // of the kernel is rewritten too early, or when a store's soffset is a register again.
+    // (-DMEGA_DIAG_OLD_STORE=1: round 4's first form -- one set of data registers, offsets in SGPRs -- for the one-fix-at-a-time
+    //  stress of profiles/r05_hazard_one_fix_at_a_time.txt; never in a shipped build)
+#if defined(MEGA_DIAG_OLD_STORE) && MEGA_DIAG_OLD_STORE
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            const double x = P[t][2 * rp], y = P[t][2 * rp + 1];
+            const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+            u32x4 v1;
+            v1.x = lo[0]; v1.y = hi[0]; v1.z = lo[1]; v1.w = hi[1];
+            __builtin_amdgcn_raw_buffer_store_b128(v1, rs, base, (16 * t + 8 * rp) * 8, 16);
+        }
+    return;
+#endif
     u32x4 v[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -879,8 +900,8 @@ __device__ __forceinline__ void store_pt_sc1(const d4 (&P)[4], double *Pg, int64
         asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-        // (one per-lane base offset; the tile / register-pair part is a constant that folds into the instruction)
-        __builtin_amdgcn_raw_buffer_store_b128(v[q], rs, base, (16 * (q >> 1) + 8 * (q & 1)) * 8, 16);
+        // (one per-lane base offset; the tile / register-pair part is a constant that folds into the instruction's offset field)
+        __builtin_amdgcn_raw_buffer_store_b128(v[q], rs, base + (16 * (q >> 1) + 8 * (q & 1)) * 8, 0, 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q)   // (alive until here: four more stores have been issued behind each of these)
         asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
@@ -1069,10 +1090,17 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
         if (ready != 3) {
             if (tid < 2 && !((ready >> tid) & 1)) {
                 const int got = __hip_atomic_load(ver + (k + 1) * g.nbk + k + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(MEGA_DIAG_OLD_LOOK) && MEGA_DIAG_OLD_LOOK   // (round 4's first form, for the one-fix-at-a-time stress only)
+                if (got >= (tid == 0 ? need.x : need.y)) atomicOr(&sh.ready, 1 << tid);
+            }
+            lds_barrier();
+            ready2 = g.nowait ? 3 : sh.ready;
+#else
                 if (got >= (tid == 0 ? need.x : need.y)) atomicOr(&sh.look, 1 << tid);
             }
             lds_barrier();
             ready2 = g.nowait ? 3 : (ready | sh.look);
+#endif
         }
         bool published = false;
         if (!(ready2 & 1)) {

@@ -48,6 +48,7 @@ struct dgpamd_ctx {
         size_t cap = 0, bytes = 0;
         hipEvent_t ev = nullptr;
         const void *src = nullptr;
+        void *snap = nullptr;                         // device copy of a small result as it was at the post (mail_collect's fallback)
         unsigned long long seq = 0;
         int pending = 0, by_kernel = 0;
     } mail[DGPAMD_MAILBOXES + 1];                     // (the last one is dgpamd_fetch's own)

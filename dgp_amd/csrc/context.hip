@@ -1,5 +1,6 @@
 // Context, stream and timing entry points of libdgp_amd.
 #include "common.hpp"
+#include <sched.h>
 
 #include <new>
 #include <stdlib.h>
@@ -52,6 +53,7 @@ extern "C" int dgpamd_destroy(dgpamd_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &mb : ctx->mail) {
         if (mb.host) (void)hipHostFree(mb.host);
+        if (mb.snap) (void)hipFree(mb.snap);
         if (mb.ev) (void)hipEventDestroy(mb.ev);
     }
     if (ctx->devargs) (void)hipFree(ctx->devargs);
@@ -120,8 +122,14 @@ int ensure_devargs(dgpamd_ctx *ctx, size_t bytes) {
 // ---------------------------------------------------------------------------
 #define MAIL_KERNEL_MAX 16384   // bytes; above this the blit path is faster than one workgroup writing across the bus
 
-__global__ void mail_publish_kernel(const uint32_t *src, uint32_t *host, int words, unsigned long long *flag, unsigned long long seq) {
-    for (int i = threadIdx.x; i < words; i += blockDim.x) host[i] = src[i];
+// (`snap`: the same words once more in device memory -- what a collect falls back on when the host memory turns out not to be
+//  coherent: the state AT THE POST, whatever has been queued behind it since)
+__global__ void mail_publish_kernel(const uint32_t *src, uint32_t *host, uint32_t *snap, int words, unsigned long long *flag, unsigned long long seq) {
+    for (int i = threadIdx.x; i < words; i += blockDim.x) {
+        const uint32_t v = src[i];
+        host[i] = v;
+        snap[i] = v;
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -145,8 +153,9 @@ static int mail_post(dgpamd_ctx *ctx, dgpamd_ctx::Mailbox &mb, const void *src, 
     mb.seq = ++ctx->host_seq;
     mb.src = src; mb.bytes = bytes;
     if (mb.by_kernel) {
+        if (!mb.snap) HIP_TRY(ctx, hipMalloc((void **)&mb.snap, MAIL_KERNEL_MAX));
         __atomic_store_n(flag, 0ull, __ATOMIC_RELEASE);
-        hipLaunchKernelGGL(mail_publish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *)src, (uint32_t *)mb.host,
+        hipLaunchKernelGGL(mail_publish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *)src, (uint32_t *)mb.host, (uint32_t *)mb.snap,
                            (int)(bytes / 4), flag, mb.seq);
         LAUNCH_CHECK(ctx);
     } else
@@ -166,11 +175,14 @@ static int mail_collect(dgpamd_ctx *ctx, dgpamd_ctx::Mailbox &mb, void *host_dst
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == mb.seq) break;
             __builtin_ia32_pause();
             if ((it & 0xffff) != 0) continue;   // now and then: is the stream still alive? (a fault would leave the word unwritten)
+            if (it > (1ull << 22)) sched_yield();   // (a stalled stream must not burn a core flat out)
         }
         const hipError_t q = hipEventQuery(mb.ev);
         if (q == hipSuccess) {
-            if (mb.by_kernel && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != mb.seq)   // (this memory is not coherent: the slow way)
-                HIP_TRY(ctx, hipMemcpy(mb.host, mb.src, mb.bytes, hipMemcpyDeviceToHost));
+            // (this memory is not coherent: the slow way -- from the snapshot the publishing kernel left in device memory, which is
+            //  the state at the post; the event says that kernel has finished, so the blocking copy needs no further ordering)
+            if (mb.by_kernel && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != mb.seq)
+                HIP_TRY(ctx, hipMemcpy(mb.host, mb.snap, mb.bytes, hipMemcpyDeviceToHost));
             break;
         }
         if (q != hipErrorNotReady) HIP_TRY(ctx, q);

@@ -534,6 +534,8 @@ class dgp:
             try:
                 pgb = trange(1, N + 1, disable=disable)
                 for i in pgb:
+                    # (what an interrupted iteration may already have appended: every node's path length at the start)
+                    marks = [(nd, None if nd.para_path is None else len(nd.para_path)) for layer in self.all_layer for nd in layer if nd.type == 'gp']
                     for attempt in (0, 1):
                         try:
                             self._si_iteration(i, ess_burn)
@@ -544,7 +546,7 @@ class dgp:
                             # elliptical-slice transition is valid from wherever the interrupted I-step left the latents
                             if attempt or ddist.is_active():   # (ranks must not diverge: with a training split every rank raises)
                                 raise
-                            self._handoff_fallback(exc)
+                            self._handoff_fallback(exc, marks)
                     pgb.set_description('Iteration %i: Layer %i' % (i, self.n_layer))
                 self.N += N
                 return
@@ -603,8 +605,16 @@ class dgp:
                     return False
         return True
 
-    def _handoff_fallback(self, exc):
+    def _handoff_fallback(self, exc, marks=()):
+        """Undo what the interrupted iteration committed (nodes fitted before the failure have appended a row to their
+        para_path -- estimate()'s burn-in index and reinit_all_layer(row=...) count rows -- and the lock-step M-step may have
+        handed factors / log-likelihoods of its last evaluations to the imputer), then switch to the per-block-step kernel.
+        (A neighbour refresh of the interrupted attempt has drawn its permutation; the repeat draws another -- any ordering is
+        a valid one.)"""
         import warnings
+        for nd, rows in marks:
+            if rows is not None and nd.para_path is not None and len(nd.para_path) > rows:
+                nd.para_path = nd.para_path[:rows]
         warnings.warn('dgp_amd: %s -- this engine now factors with one launch per block step (set_potrf_mode(0)); the '
                       'iteration is repeated' % exc, RuntimeWarning)
         self.engine.sync()
@@ -612,7 +622,8 @@ class dgp:
         imp = getattr(self, 'imp', None)
         if imp is not None:   # nothing computed by the interrupted launches may be reused
             imp._ll_cache, imp._factor_cache = {}, {}
-            imp.__dict__.pop('_want_ll0', None)
+            for key in ('_want_ll0', '_adopt', '_adopt_ll'):
+                imp.__dict__.pop(key, None)
 
     def ptrain(self, N=500, ess_burn=10, disable=False, core_num=None):
         """dgp.py:1414-1472 optimised the nodes of a layer in a process pool; here they already run concurrently on the

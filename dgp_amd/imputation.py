@@ -325,7 +325,7 @@ class imputer:
             self._detach_pending = True
             # the latents start their way to the host NOW, ahead of whatever the caller queues next (the M-step's first
             # evaluations): finish_detach() waits for these copies only
-            self._F_posted = {l: self.engine.post(self.F[l], 2 + l) for l in range(L - 1)} if L - 1 <= self.engine.MAILBOXES - 2 else {}
+            self._F_posted = {l: self.engine.post(self.F[l], self.engine.DETACH_SLOT0 + l) for l in range(L - 1)} if L - 1 <= self.engine.MAILBOXES - self.engine.DETACH_SLOT0 else {}
             return
         self.__dict__.pop('_detach_pending', None)
         posted = self.__dict__.pop('_F_posted', {})

@@ -257,7 +257,9 @@ def maximise_lockstep_vecch(engine, nodes, after_first_launch=None):
         return collect(req, launch(req))
     evaluate.launch, evaluate.collect = launch, collect   # (the groups hold different nodes: a node's state is its own run's)
     evaluate.abandon = lambda token: engine.discard(token[1])
-    groups = int(os.environ.get('DGPAMD_MSTEP_GROUPS', '2')) if len(nodes) >= 4 else 1
+    # (one mailbox per group in flight, slots 0 .. groups-1: never more than the engine reserves for the M-step -- the deferred
+    #  detach of the I-step posts the latents to the slots behind them)
+    groups = max(1, min(int(os.environ.get('DGPAMD_MSTEP_GROUPS', '2')), engine.MSTEP_SLOTS)) if len(nodes) >= 4 else 1
 
     try:
         with engine.stream():

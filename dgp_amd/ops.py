@@ -384,6 +384,11 @@ class Engine:
         return out
 
     MAILBOXES = 8
+    # who uses which mailbox (the ranges must not overlap: a slot that still holds a result refuses the next post):
+    MSTEP_SLOTS = 2      # 0 .. MSTEP_SLOTS-1: the lock-step M-step's optimiser groups in flight (mstep.py); kernel.ord_nn's default is 0,
+                         # outside an M-step
+    DETACH_SLOT0 = 2     # DETACH_SLOT0 + l: the imputer's deferred detach posts hidden layer l's latents (imputation.py)
+    assert MSTEP_SLOTS <= DETACH_SLOT0 < MAILBOXES
 
     def use_dist_reduce(self):
         """Install dgp_amd.dist's all-reduce as the context's reduce hook (dgpamd_set_reduce_hook): the queued I-step of a model

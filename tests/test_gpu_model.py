@@ -307,6 +307,49 @@ def test_matern_2layer_train_predict_small(eng):
     assert len(mu_l) == 2 and mu_l[0].shape == (10, d) and np.allclose(mu_l[1], mu[:10], rtol=1e-9, atol=1e-12)
 
 
+def test_lost_handoff_retry_leaves_the_paths_as_one_iteration_does(eng):
+    """dgp.train repeats an iteration whose one-launch factorisation lost a hand-off (HandoffError) through the per-block-step
+    kernel.  What the interrupted attempt had already committed must not stay: nodes fitted before the failure have appended a
+    row to para_path (estimate()'s burn-in index and reinit_all_layer(row=...) count rows), and the M-step's hand-over to the
+    imputer (_adopt / _adopt_ll) belongs to the aborted state.  Injected: the first M-step of a run completes, then raises."""
+    import warnings
+    from dgp_amd import dgp, kernel, combine
+    from dgp_amd.ops import HandoffError
+    rng = np.random.default_rng(5)
+    n, d = 90, 2
+    X = rng.uniform(size=(n, d))
+    Y = (np.sin(5 * X[:, :1]) + X[:, 1:] ** 2)
+    Y = (Y - Y.mean()) / Y.std()
+    layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                     [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(d))])
+    model = dgp(X, Y, layers, seed=3)
+    nodes = [nd for layer in model.all_layer for nd in layer if nd.type == 'gp']
+    rows0 = [len(nd.para_path) for nd in nodes]
+    orig, calls = model._m_step, {'n': 0}
+
+    def failing(*a, **k):
+        calls['n'] += 1
+        r = orig(*a, **k)
+        if calls['n'] == 1:
+            raise HandoffError('injected: a bounded in-kernel spin ran out')
+        return r
+    model._m_step = failing
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            model.train(N=3, ess_burn=3, disable=True)
+        assert any('one launch per block step' in str(x.message) for x in w)
+        assert calls['n'] == 4                                   # iteration 1 twice, then 2 and 3
+        assert [len(nd.para_path) for nd in nodes] == [r + 3 for r in rows0]
+        assert '_adopt_ll' not in model.imp.__dict__ or model.imp.__dict__['_adopt_ll'] is not None   # (whatever is there is the LAST M-step's)
+        assert model.engine.potrf_mode() == 0 if hasattr(model.engine, 'potrf_mode') else True
+        est = model.estimate()
+        assert all(np.all(np.isfinite(nd.length)) for layer in est for nd in layer if nd.type == 'gp')
+    finally:
+        model._m_step = orig
+        model.engine.set_potrf_mode(1)
+
+
 def test_vecchia_train_predict_end_to_end(eng):
     """Vecchia mode through the public API: ordering + ordered NN on device, fmvn_sp prior draws,
     vecchia_llik ESS targets, vecchia_nllik M-step, NN refresh at iterations 2,4,.., Vecchia prediction."""

@@ -26,9 +26,10 @@ for (a, b), (t, n) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:18]:
     print('%8.2f ms  %6d x %7.1f us   %s -> %s' % (t / 1e6, n, t / n / 1e3, a, b))
 if len(sys.argv) > 3:   # context of the gaps longer than argv[3] microseconds: the kernels either side, times relative to the gap's start
     thr = float(sys.argv[3]) * 1e3
+    limit = int(sys.argv[4]) if len(sys.argv) > 4 else 6
     shown = 0
     for i in range(1, len(ev)):
-        if ev[i][0] - max(e for _, e, _ in ev[max(0, i - 8):i]) > thr and shown < int(sys.argv[4]) if len(sys.argv) > 4 else 6:
+        if ev[i][0] - max(e for _, e, _ in ev[max(0, i - 8):i]) > thr and shown < limit:
             t0 = max(e for _, e, _ in ev[max(0, i - 8):i])
             print('--- gap of %.0f us' % ((ev[i][0] - t0) / 1e3))
             for s, e, nm in ev[max(0, i - 4):i + 10]:
