@@ -509,8 +509,30 @@ def main():
         nk, Dk = 5000, 10
         Xk = eng.tensor(np.random.default_rng(3).uniform(size=(nk, Dk)))
         outs = [eng.empty(nk, nk) for _ in range(3)]
+        # ... and the same matrices as views of rows that start on 128-byte lines (5120 doubles per row): with n = ld = 5000 every second row
+        # starts in the middle of a line and every tile edge splits lines between two workgroups (profiles/r05_kmatrix_hbm_roofline.txt)
+        outs_al = [eng.empty(nk, 5120)[:, :nk] for _ in range(3)]
         lk = np.full(Dk, 0.9)
-        for name in ('sexp', 'matern2.5'):
+        for name, targets in (('sexp', outs), ('matern2.5', outs), ('sexp_rows_on_128B_lines', outs_al), ('matern2.5_rows_on_128B_lines', outs_al)):
+            kind = name.split('_')[0]
+            for o in targets:
+                eng.kmatrix(kind, Xk, None, None, lk, 1e-6, out=o, full=True)
+            torch.cuda.synchronize()
+            eng.prof_enable('kmatrix')       # HIP events around every launch (the host cannot issue 45-us kernels back to back)
+            reps = 30
+            for r in range(reps):
+                eng.kmatrix(kind, Xk, None, None, lk, 1e-6, out=targets[r % 3], full=True)
+            k_n, k_ms, k_w = eng.prof_collect()
+            if not k_n:
+                continue
+            ms = k_ms / k_n
+            nbytes = 8.0 * nk * nk + 8.0 * nk * Dk
+            roof_ks[name] = dict(bound='hbm', kernel='kmatrix_kernel<%s> (full symmetric, n=%d, D=%d, ld=%d, 3 x 200 MB outputs in turn)' % (kind, nk, Dk, targets[0].stride(0)),
+                                 achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s', frac=nbytes / ms / 1e6 / HBM_PEAK_GBS,
+                                 avg_launch_us=1e3 * ms, bytes_per_launch=nbytes, launches=k_n, traffic=None,
+                                 note='the write-only ceiling of the same buffers is measured beside it (roofline_kmatrix_standalone.fill_); tile-shaped stores '
+                                      'alone reach 0.66-0.72 of 8 TB/s at these sizes, 0.51-0.64 with rows off the 128-byte lines (profiles/r05_kmatrix_hbm_roofline.txt)')
+        for name in ():
             for o in outs:
                 eng.kmatrix(name, Xk, None, None, lk, 1e-6, out=o, full=True)
             torch.cuda.synchronize()
@@ -542,7 +564,7 @@ def main():
         fill_ms = e0.elapsed_time(e1) / 30
         roof_ks['fill_'] = dict(what='torch fill_ of the same 200-MB buffers in turn (write-only ceiling, this run)', avg_launch_us=1e3 * fill_ms,
                                 achieved=8.0 * nk * nk / fill_ms / 1e6, unit='GB/s', frac=8.0 * nk * nk / fill_ms / 1e6 / HBM_PEAK_GBS)
-        del outs
+        del outs, outs_al
 
     ptab = vleg = None
     if rank == 0 and args.prof_kernel != 'none':

@@ -14,13 +14,25 @@
 #include "common.hpp"
 #include <algorithm>
 
+#ifndef KM_WGS
+#define KM_WGS 8   // workgroups per CU the kernels are compiled for (registers <= 64)
+#endif
 
+
+// Round 5: the tile is computed and stored in TWO HALVES (rows ty, ty + 16, then rows ty + 32, ty + 48 of every thread): 8
+// entries per thread at a time instead of 16 halves the registers (108 -> <= 64: eight workgroups per CU instead of four), and a
+// workgroup's first stores are on their way while its second half is still being computed.  Why occupancy: a workgroup lives
+// ~12 us (inputs 2-5 us behind the CU's queued stores, arithmetic 2.5 us, its own stores' drain), so four per CU deliver a tile
+// per 3 us per CU -- exactly what the store stream takes (3.1 us per tile and CU at the 0.68 of HBM that tile-shaped stores reach,
+// profiles/r05_kmatrix_store_shapes.txt): any hiccup showed, and at n = 5000 (three rounds of workgroups that start together)
+// the arithmetic and the store phases of the whole launch did not overlap at all (26 us + 36 us = the 57 us measured).
 template <int KIND>
 __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     extern __shared__ double lds[];
     const int D = a.kp.Dl + a.kp.Dg;
     double *XiT = lds;            // [D][64]
     double *XjT = lds + D * 64;   // [D][64]
+    double *TT2 = lds + 2 * D * 64;   // [16][65]: the mirror's transposition buffer (symmetric mode)
     int bi, bj;
     {   // strictly-lower tiles first (row-major in the triangle), then the diagonal
         const int nb = a.nbk, nlow = nb * (nb - 1) / 2, t = blockIdx.x;
@@ -36,144 +48,149 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64;
     const double *Xl = a.Xloc + (int64_t)b * a.stride_loc;
 
-    for (int idx = tid; idx < 64 * D; idx += 256) {
-        int row = idx / D, d = idx - row * D;
-        int64_t gi = i0 + row, gj = j0 + row;
-        double vi = 0.0, vj = 0.0;
-        if (d < a.kp.Dl) {
-            int c = a.kp.colmap[d];
-            if (gi < a.n) vi = Xl[gi * a.ldloc + c];
-            if (gj < a.n) vj = Xl[gj * a.ldloc + c];
-        } else {
-            int c = d - a.kp.Dl;
-            if (gi < a.n) vi = a.Xglob[gi * a.kp.Dg + c];
-            if (gj < a.n) vj = a.Xglob[gj * a.kp.Dg + c];
+    {
+        const float invD = 1.0f / (float)D;
+        const bool small = 64 * D < (1 << 20);   // (idx / D through the float reciprocal: exact for these sizes)
+        for (int idx = tid; idx < 64 * D; idx += 256) {
+            int row = small ? (int)(((float)idx + 0.5f) * invD) : idx / D;
+            int d = idx - row * D;
+            int64_t gi = i0 + row, gj = j0 + row;
+            double vi = 0.0, vj = 0.0;
+            if (d < a.kp.Dl) {
+                int c = a.kp.colmap[d];
+                if (gi < a.n) vi = Xl[gi * a.ldloc + c];
+                if (gj < a.n) vj = Xl[gj * a.ldloc + c];
+            } else {
+                int c = d - a.kp.Dl;
+                if (gi < a.n) vi = a.Xglob[gi * a.kp.Dg + c];
+                if (gj < a.n) vj = a.Xglob[gj * a.kp.Dg + c];
+            }
+            double il = a.kp.inv_len[d];
+            XiT[d * 64 + row] = vi * il;
+            XjT[d * 64 + row] = vj * il;
         }
-        double il = a.kp.inv_len[d];
-        XiT[d * 64 + row] = vi * il;
-        XjT[d * 64 + row] = vj * il;
     }
     __syncthreads();
 
-    // micro-tile: rows ty + 16 p, columns col(q) = 32 (q >> 1) + 2 tx + (q & 1)
-    double s[4][4], pr[4][4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            s[p][q] = 0.0;
-            pr[p][q] = 1.0;
-        }
-    for (int d = 0; d < D; ++d) {
-        double xi[4], xj[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) xi[p] = XiT[d * 64 + ty + 16 * p];
-        {
-            const double2 lo = *reinterpret_cast<const double2 *>(XjT + d * 64 + 2 * tx);
-            const double2 hi = *reinterpret_cast<const double2 *>(XjT + d * 64 + 32 + 2 * tx);
-            xj[0] = lo.x; xj[1] = lo.y; xj[2] = hi.x; xj[3] = hi.y;
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double df = xi[p] - xj[q];
-                if (KIND == DGPAMD_SEXP)
-                    corr_accum_sexp(df, s[p][q]);
-                else
-                    corr_accum_matern(df, pr[p][q], s[p][q]);
-            }
-    }
-
     double *Kb = a.K + (int64_t)b * a.stride_k;
     const double *Yb = a.Y ? a.Y + (int64_t)b * a.stride_y : nullptr;
-    double v[4][4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            // (the library exp, as the gradient reductions that recompute these entries: csrc/train.hip -- the objective's K and the
-            //  gradient's dK then hold the same bits, and training paths are reproducible against the earlier rounds' runs; the
-            //  full-rate exp_negated of the pair kernels bought nothing here, the kernel's time is its stores)
-            v[p][q] = (KIND == DGPAMD_SEXP) ? exp(-s[p][q]) : pr[p][q] * exp(-SQRT5 * s[p][q]);
-    if (bi == bj) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (ty + 16 * p == 32 * (q >> 1) + 2 * tx + (q & 1)) {
-                    const int64_t gi = i0 + ty + 16 * p;
-                    v[p][q] = 1.0 + a.kp.nugget * (a.W ? a.W[gi < a.n ? gi : 0] : 1.0);
-                }
-    }
     const bool interior = i0 + 64 <= a.n;   // j0 <= i0: the whole tile lies inside the n x n correlation block
     const bool even_ld = (a.ldk & 1) == 0;  // (16-byte stores need 16-byte addresses: base pointers are, rows are when ldk is even)
-    if (interior && even_ld) {
+    const int pc = 2 * (tx & 7), pr0 = 2 * ty + (tx >> 3);   // mirror: column pair / row of this lane inside a 64 x 16 block (rows pr0, pr0 + 32)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            double *row = Kb + (i0 + ty + 16 * p) * a.ldk + j0 + 2 * tx;
-            *reinterpret_cast<double2 *>(row) = make_double2(v[p][0], v[p][1]);
-            *reinterpret_cast<double2 *>(row + 32) = make_double2(v[p][2], v[p][3]);
-        }
-    } else if (a.full) {
+    for (int h = 0; h < 2; ++h) {
+        // micro-tile of this half: rows ty + 16 (2 h + p), p = 0, 1; columns col(q) = 32 (q >> 1) + 2 tx + (q & 1)
+        double s[2][4], pr[2][4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int64_t gi = i0 + ty + 16 * p;
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int64_t gj = j0 + 32 * (q >> 1) + 2 * tx + (q & 1);
-                if (gi < a.n && gj < a.n) Kb[gi * a.ldk + gj] = v[p][q];
+                s[p][q] = 0.0;
+                pr[p][q] = 1.0;
             }
-        }
-    } else {
-        // augmented factorisation buffer: rows >= n carry right-hand sides, corner zero (ldk = padded dimension: even)
+        for (int d = 0; d < D; ++d) {
+            double xi[2], xj[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int64_t gi = i0 + ty + 16 * p;
-            double w[4];
+            for (int p = 0; p < 2; ++p) xi[p] = XiT[d * 64 + ty + 16 * (2 * h + p)];
+            {
+                const double2 lo = *reinterpret_cast<const double2 *>(XjT + d * 64 + 2 * tx);
+                const double2 hi = *reinterpret_cast<const double2 *>(XjT + d * 64 + 32 + 2 * tx);
+                xj[0] = lo.x; xj[1] = lo.y; xj[2] = hi.x; xj[3] = hi.y;
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t gj = j0 + 32 * (q >> 1) + 2 * tx + (q & 1);
-                double val = v[p][q];
-                if (gi >= a.n) {
-                    int64_t qy = gi - a.n;
-                    val = (gj < a.n && qy < a.r) ? Yb[qy * a.ldy + gj] : 0.0;
-                } else if (gj >= a.n) {
-                    val = 0.0;
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double df = xi[p] - xj[q];
+                    if (KIND == DGPAMD_SEXP)
+                        corr_accum_sexp(df, s[p][q]);
+                    else
+                        corr_accum_matern(df, pr[p][q], s[p][q]);
                 }
-                w[q] = val;
-            }
-            double *row = Kb + gi * a.ldk + j0 + 2 * tx;
-            *reinterpret_cast<double2 *>(row) = make_double2(w[0], w[1]);
-            *reinterpret_cast<double2 *>(row + 32) = make_double2(w[2], w[3]);
         }
-    }
-    if (a.full && bi != bj) {
-        // mirrored tile K[j][i]: transposed through LDS so that these stores are row-contiguous too (naive transposed
-        // stores write 32-byte fragments and cost 40% of the kernel's bandwidth).  In four passes of 16 rows through a
-        // 16 x 65 buffer that REUSES the input staging area (dead by now) -- a whole-tile buffer of its own (33 KB) held the
-        // kernel at three workgroups per CU, too few for the stores of one to hide behind the arithmetic of the others.
-        // Per pass the mirrored block is 64 rows x 16 columns: eight lanes cover a row's 128-byte line with 16-byte stores.
-        double *TT2 = lds;
-        const int pc = 2 * (tx & 7), pr0 = 2 * ty + (tx >> 3);   // column pair / row of this lane inside the block (rows pr0, pr0 + 32)
+        double v[2][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            __syncthreads();   // (pass c - 1 read / the staged inputs consumed)
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) TT2[ty * 65 + 32 * (q >> 1) + 2 * tx + (q & 1)] = v[c][q];   // rows i0 + 16 c + ty of the tile, all 64 columns
-            __syncthreads();
-            // mirrored block: rows j0 + r (r = 0..63), columns i0 + 16 c + cc (cc = 0..15)
+            for (int q = 0; q < 4; ++q)
+                // (the library exp, as the gradient reductions that recompute these entries: csrc/train.hip -- the objective's K and the
+                //  gradient's dK then hold the same bits, and training paths are reproducible against the earlier rounds' runs)
+                v[p][q] = (KIND == DGPAMD_SEXP) ? exp(-s[p][q]) : pr[p][q] * exp(-SQRT5 * s[p][q]);
+        if (bi == bj) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int r = pr0 + 32 * k;
-                const int64_t gc = i0 + 16 * c + pc;
-                const double m0 = TT2[pc * 65 + r], m1 = TT2[(pc + 1) * 65 + r];
-                double *dst = Kb + (j0 + r) * a.ldk + gc;
-                if (interior && even_ld) {
-                    *reinterpret_cast<double2 *>(dst) = make_double2(m0, m1);
-                } else {
-                    if (interior || gc < a.n) dst[0] = m0;
-                    if (interior || gc + 1 < a.n) dst[1] = m1;
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ty + 16 * (2 * h + p) == 32 * (q >> 1) + 2 * tx + (q & 1)) {
+                        const int64_t gi = i0 + ty + 16 * (2 * h + p);
+                        v[p][q] = 1.0 + a.kp.nugget * (a.W ? a.W[gi < a.n ? gi : 0] : 1.0);
+                    }
+        }
+        if (interior && even_ld) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                double *row = Kb + (i0 + ty + 16 * (2 * h + p)) * a.ldk + j0 + 2 * tx;
+                *reinterpret_cast<double2 *>(row) = make_double2(v[p][0], v[p][1]);
+                *reinterpret_cast<double2 *>(row + 32) = make_double2(v[p][2], v[p][3]);
+            }
+        } else if (a.full) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int64_t gi = i0 + ty + 16 * (2 * h + p);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t gj = j0 + 32 * (q >> 1) + 2 * tx + (q & 1);
+                    if (gi < a.n && gj < a.n) Kb[gi * a.ldk + gj] = v[p][q];
+                }
+            }
+        } else {
+            // augmented factorisation buffer: rows >= n carry right-hand sides, corner zero (ldk = padded dimension: even)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int64_t gi = i0 + ty + 16 * (2 * h + p);
+                double w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t gj = j0 + 32 * (q >> 1) + 2 * tx + (q & 1);
+                    double val = v[p][q];
+                    if (gi >= a.n) {
+                        int64_t qy = gi - a.n;
+                        val = (gj < a.n && qy < a.r) ? Yb[qy * a.ldy + gj] : 0.0;
+                    } else if (gj >= a.n) {
+                        val = 0.0;
+                    }
+                    w[q] = val;
+                }
+                double *row = Kb + gi * a.ldk + j0 + 2 * tx;
+                *reinterpret_cast<double2 *>(row) = make_double2(w[0], w[1]);
+                *reinterpret_cast<double2 *>(row + 32) = make_double2(w[2], w[3]);
+            }
+        }
+        if (a.full && bi != bj) {
+            // mirrored tile K[j][i]: transposed through LDS so that these stores are row-contiguous too (naive transposed
+            // stores write 32-byte fragments and cost 40% of the kernel's bandwidth), in passes of 16 rows through a 16 x 65
+            // buffer of its own (the staged inputs are still being read by the second half).  Per pass the mirrored block is
+            // 64 rows x 16 columns: eight lanes cover a row's 128-byte line with 16-byte stores.
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int c = 2 * h + p;
+                __syncthreads();   // (the previous pass has been read)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) TT2[ty * 65 + 32 * (q >> 1) + 2 * tx + (q & 1)] = v[p][q];   // rows i0 + 16 c + ty of the tile, all 64 columns
+                __syncthreads();
+                // mirrored block: rows j0 + r (r = 0..63), columns i0 + 16 c + cc (cc = 0..15)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int r = pr0 + 32 * k;
+                    const int64_t gc = i0 + 16 * c + pc;
+                    const double m0 = TT2[pc * 65 + r], m1 = TT2[(pc + 1) * 65 + r];
+                    double *dst = Kb + (j0 + r) * a.ldk + gc;
+                    if (interior && even_ld) {
+                        *reinterpret_cast<double2 *>(dst) = make_double2(m0, m1);
+                    } else {
+                        if (interior || gc < a.n) dst[0] = m0;
+                        if (interior || gc + 1 < a.n) dst[1] = m1;
+                    }
                 }
             }
         }
@@ -181,7 +198,7 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
+__global__ __launch_bounds__(256, KM_WGS) void kmatrix_kernel(KmatArgs a) {
     if (a.pred && *a.pred) return;   // (a speculative batch that an earlier one has made unnecessary: dgpamd_ess_queue)
     if (a.zero_ptr && blockIdx.z == 0)
         for (int i = blockIdx.x * 256 + threadIdx.x; i < a.zero_words; i += gridDim.x * 256) a.zero_ptr[i] = 0;
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(256) void kmatrix_kernel(KmatArgs a) {
 
 // Several nodes in one launch (grid.z = node): every node brings its own inputs, kernel family and hyper-parameters,
 // read from an argument array in device memory (uniform addresses: scalar loads).
-__global__ __launch_bounds__(256) void kmatrix_multi_kernel(const KmatArgs *args) {
+__global__ __launch_bounds__(256, 6) void kmatrix_multi_kernel(const KmatArgs *args) {   // (both kernel families inlined: 74 registers)
     const KmatArgs &a = args[blockIdx.z];
     if (a.zero_ptr)   // (set in one node's arguments only)
         for (int i = blockIdx.x * 256 + threadIdx.x; i < a.zero_words; i += gridDim.x * 256) a.zero_ptr[i] = 0;
@@ -208,7 +225,7 @@ int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatAr
     }
     int64_t rows = host_args[0].full ? host_args[0].n : padded_dim(host_args[0].n);
     int nbk = (int)((rows + 63) / 64);
-    size_t shm = std::max((size_t)2 * Dmax * 64, full ? (size_t)16 * 65 : (size_t)0) * sizeof(double);
+    size_t shm = ((size_t)2 * Dmax * 64 + (full ? (size_t)16 * 65 : (size_t)0)) * sizeof(double);
     hipLaunchKernelGGL(kmatrix_multi_kernel, dim3(nbk * (nbk + 1) / 2, 1, count), dim3(256), shm, ctx->stream, dev_args);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
@@ -221,7 +238,7 @@ int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a_, int batch) {
     int64_t rows = a.full ? a.n : padded_dim(a.n);
     int nbk = (int)((rows + 63) / 64);
     int ntiles = nbk * (nbk + 1) / 2;
-    size_t shm = std::max((size_t)2 * D * 64, a.full ? (size_t)16 * 65 : (size_t)0) * sizeof(double);
+    size_t shm = ((size_t)2 * D * 64 + (a.full ? (size_t)16 * 65 : (size_t)0)) * sizeof(double);
     a.nbk = nbk;
     dim3 grid(ntiles, 1, batch);
     // algorithmic bytes: the stored triangle(s) of K (8 n^2, or 4 n^2 for the lower tiles) + X once

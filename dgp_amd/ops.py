@@ -216,14 +216,17 @@ class Engine:
         length = _f64(length)
         stride_loc = n * ldloc if Xloc.dim() == 3 else 0
         if full:
-            ld = n
+            # (a caller's `out` may be a view of wider rows, e.g. buf[:, :n] of an (n, ld) buffer with 8 ld a multiple of 128 bytes:
+            #  rows that start on 128-byte lines let every tile store whole lines -- 0.55 -> 0.72 of HBM for the stores alone at
+            #  n = 5000, profiles/r05_kmatrix_store_shapes.txt)
+            ld = n if out is None else int(out.stride(-2))
             r = 0
         else:
             ld = self.padded_dim(n)
             r = 0 if Y is None else (1 if Y.dim() == 1 else Y.shape[-2])
         if out is None:
             out = self.empty((batch, ld, ld) if batch > 1 else (ld, ld))
-        stride_k = ld * ld if batch > 1 else 0
+        stride_k = (ld * ld if (out.dim() < 3 or not full) else int(out.stride(0))) if batch > 1 else 0
         stride_y = 0
         if Y is not None and Y.dim() == 3:
             stride_y = Y.shape[-2] * Y.shape[-1]
