@@ -367,3 +367,18 @@ def test_wellconditioned_fixture_at_1e10(golden):
                                    d['scale'], d['length'], d['nugget'], name)
         close(lm, d['link_m'], rtol=1e-10, atol=1e-12)
         close(lv, d['link_v'], rtol=1e-8, atol=1e-10 * d['scale'][0])   # (Jd-based Matern J: SURVEY 8(c) states 1e-8)
+
+
+def test_sexp_J_gemm_form_equals_the_direct_form():
+    """oracle.IJ_sexp_gemm (the pair exponent through one BLAS product: what lets the full-size GPU tests walk 64 test points at
+    n = 5000) against oracle.IJ, the restatement of the reference's IJ_sexp / IJ_nb (functions.py:432-451, vecchia.py:845-869)."""
+    rng = np.random.default_rng(3)
+    for n, d in ((40, 1), (90, 4), (130, 10)):
+        X = rng.normal(size=(n, d))
+        for length in (np.array([1.7]), rng.uniform(0.5, 3.0, size=d)):
+            zm, zv = rng.normal(size=d), rng.uniform(0.0, 0.6, size=d)
+            zv[0] = 0.0
+            I0, J0 = O.IJ(X, zm, zv, length, 'sexp')
+            I1, J1 = O.IJ_sexp_gemm(X, zm, zv, length)
+            np.testing.assert_allclose(I1, I0, rtol=1e-13, atol=1e-300)
+            np.testing.assert_allclose(J1, J0, rtol=2e-12, atol=1e-300)
