@@ -548,9 +548,259 @@ static int launch_nn_stream(dgpamd_ctx *ctx, int64_t nq, int64_t nx, int D, cons
     return DGPAMD_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Round 5, the QUERY form (vecchia.py:20-40) at prediction sizes -- 1e5 queries against 5e4 points, 50 neighbours: filter, then select.
+// The streaming kernel above keeps K = 51 sorted pairs per lane in registers: 256 VGPRs, ONE wave per SIMD, so every LDS read
+// and every dependent issue of its distance loop was exposed (one instruction per ~11 cycles; 43 ms at D = 16, a third of what its
+// own instruction count needs).  The top-k state does not have to ride along the scan:
+//   (A) nn_tau_kernel: per query the r-th smallest distance to a strided sample of S candidates (a small sorted list: r <= 32) -- an
+//       upper bound tau of its K-th nearest distance unless fewer than K of ALL candidates lie at or below it (r is chosen so that
+//       this has probability ~1e-8 per query, and it is CHECKED);
+//   (B) nn_collect_kernel: the scan itself -- 256 queries per workgroup share the staged candidates, a lane holds its query and tau
+//       (~60 VGPRs: five waves per SIMD) and notes every candidate with distance <= tau, through LDS, in a region of global memory of
+//       its own (per query and candidate chunk: no atomics);
+//   (C) nn_pick_kernel: per query the K nearest of its few hundred notes, by the same (distance, index) insertion as above.  A query
+//       whose notes are fewer than K, or overflowed their region, is scanned exactly by its lane (the rare slow path).
+// The distances are the same fma chains, the order the same (distance, index) order: identical neighbour arrays (tests).
+// ---------------------------------------------------------------------------
+#define NNF_R 32        // sample list length (r <= NNF_R)
+#define NNF_PEND 8      // notes a lane holds in LDS before the wave writes them out
+
+template <int DMAX>
+__global__ __launch_bounds__(64) void nn_tau_kernel(int64_t nq, int64_t nx, int D, const double *__restrict__ q, const double *__restrict__ x,
+                                                    int64_t S, int64_t stride, int r, double *__restrict__ tau) {
+    __shared__ __attribute__((aligned(16))) double tile[64 * DMAX];
+    const int lane = threadIdx.x;
+    const int64_t iq = (int64_t)blockIdx.x * 64 + lane;
+    const bool qlive = iq < nq;
+    double qv[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) qv[d] = (qlive && d < D) ? q[iq * D + d] : 0.0;
+    double ld[NNF_R];
+    int li[NNF_R];
+#pragma unroll
+    for (int t = 0; t < NNF_R; ++t) {
+        ld[t] = INFINITY;
+        li[t] = INT_MAX;
+    }
+    for (int64_t base = 0; base < S; base += 64) {
+        const int64_t js = (base + lane) * stride;   // the sample: every stride-th candidate
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) tile[lane * DMAX + d] = (base + lane < S && js < nx && d < D) ? x[js * D + d] : 0.0;
+        __syncthreads();
+        const int cnt_c = (int)(S - base < 64 ? S - base : 64);
+        for (int c = 0; c < cnt_c; ++c) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const double df = tile[c * DMAX + d] - qv[d];
+                sacc = fma(df, df, sacc);
+            }
+            if (__any(sacc < ld[NNF_R - 1])) topk_insert<NNF_R>(ld, li, sacc, (int)(base + c));
+        }
+    }
+    double t = ld[0];
+#pragma unroll
+    for (int u = 1; u < NNF_R; ++u) t = (u < r) ? ld[u] : t;   // the r-th smallest
+    if (qlive) tau[iq] = t;
+}
+
+// grid (query blocks of 256, candidate chunks); notes of query iq in chunk ch: nd / ni [(iq * nchunk + ch) * capc ...], count in ncnt
+template <int DMAX>
+__global__ __launch_bounds__(256) void nn_collect_kernel(int64_t nq, int64_t nx, int D, const double *__restrict__ q, const double *__restrict__ x,
+                                                         const double *__restrict__ tau, int64_t chunk, int nchunk, int capc,
+                                                         double *__restrict__ nd, int *__restrict__ ni, int *__restrict__ ncnt) {
+    __shared__ __attribute__((aligned(16))) double tile[64 * DMAX];
+    __shared__ double pend_d[4][NNF_PEND * 64];
+    __shared__ int pend_i[4][NNF_PEND * 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t iq = (int64_t)blockIdx.x * 256 + tid;
+    const bool qlive = iq < nq;
+    const int64_t lo = (int64_t)blockIdx.y * chunk, hi = lo + chunk < nx ? lo + chunk : nx;
+    double qv[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) qv[d] = (qlive && d < D) ? q[iq * D + d] : 0.0;
+    const double tq = qlive ? tau[iq] : -1.0;
+    double *mynd = nd + (iq * nchunk + blockIdx.y) * (int64_t)capc;
+    int *myni = ni + (iq * nchunk + blockIdx.y) * (int64_t)capc;
+    int cnt = 0, tot = 0;
+    auto flush = [&]() {
+        for (int p = 0; p < cnt; ++p)
+            if (tot + p < capc) {
+                mynd[tot + p] = pend_d[wave][p * 64 + lane];
+                myni[tot + p] = pend_i[wave][p * 64 + lane];
+            }
+        tot += cnt;   // (beyond capc: counted, not stored -- the pick kernel sees the overflow)
+        cnt = 0;
+    };
+    for (int64_t base = lo; base < hi; base += 64) {
+        __syncthreads();
+        {   // 64 candidates x DMAX doubles, staged by all 256 threads
+            const int c = tid >> 2, d0 = (tid & 3) * (DMAX / 4);
+            const int64_t jc = base + c;
+#pragma unroll
+            for (int d = 0; d < DMAX / 4; ++d) tile[c * DMAX + d0 + d] = (jc < hi && d0 + d < D) ? x[jc * D + d0 + d] : 0.0;
+        }
+        __syncthreads();
+        const int cnt_c = (int)(hi - base < 64 ? hi - base : 64);
+        for (int c = 0; c < cnt_c; c += 2) {   // two candidates per pass: independent chains
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const double d0 = tile[c * DMAX + d] - qv[d], d1 = tile[(c + 1) * DMAX + d] - qv[d];   // (c + 1 == cnt_c: a zero-padded row, never taken)
+                s0 = fma(d0, d0, s0);
+                s1 = fma(d1, d1, s1);
+            }
+            const bool t0 = s0 <= tq, t1 = c + 1 < cnt_c && s1 <= tq;
+            if (__any(t0 || t1)) {
+                if (t0) {
+                    pend_d[wave][cnt * 64 + lane] = s0;
+                    pend_i[wave][cnt * 64 + lane] = (int)(base + c);
+                    ++cnt;
+                }
+                if (__any(cnt == NNF_PEND)) flush();
+                if (t1) {
+                    pend_d[wave][cnt * 64 + lane] = s1;
+                    pend_i[wave][cnt * 64 + lane] = (int)(base + c + 1);
+                    ++cnt;
+                }
+                if (__any(cnt == NNF_PEND)) flush();
+            }
+        }
+    }
+    flush();
+    if (qlive) ncnt[iq * nchunk + blockIdx.y] = tot;
+}
+
+template <int DMAX, int K>
+__global__ __launch_bounds__(64) void nn_pick_kernel(int64_t nq, int64_t nx, int D, const double *__restrict__ q, const double *__restrict__ x,
+                                                     int nchunk, int capc, const double *__restrict__ nd, const int *__restrict__ ni,
+                                                     const int *__restrict__ ncnt, int m_out, int64_t *__restrict__ out, int *__restrict__ slow) {
+    const int lane = threadIdx.x;
+    const int64_t iq = (int64_t)blockIdx.x * 64 + lane;
+    const bool qlive = iq < nq;
+    double ld[K];
+    int li[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        ld[t] = INFINITY;
+        li[t] = INT_MAX;
+    }
+    int total = 0;
+    bool over = false;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int c0 = qlive ? ncnt[iq * nchunk + ch] : 0;
+        over |= c0 > capc;
+        const int cn = c0 < capc ? c0 : capc;
+        total += cn;
+        const double *mynd = nd + (iq * nchunk + ch) * (int64_t)capc;
+        const int *myni = ni + (iq * nchunk + ch) * (int64_t)capc;
+        int cmax = cn;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(cmax, off, 64);
+            cmax = o > cmax ? o : cmax;
+        }
+#pragma unroll 1
+        for (int p = 0; p < cmax; ++p) {
+            const bool have = p < cn;
+            const double cd = have ? mynd[p] : INFINITY;
+            const int ci = have ? myni[p] : INT_MAX;
+            if (__any(cd < ld[K - 1] || (cd == ld[K - 1] && ci < li[K - 1]))) topk_insert<K>(ld, li, cd, ci);
+        }
+    }
+    // the rare slow path: too few notes (the sampled bound was below the K-th nearest distance) or an overflowed region -- the lane
+    // scans every candidate itself (same chain, same order)
+    const int need = (int)(nx < m_out ? nx : m_out);
+    const bool bad = qlive && (over || total < need);
+    if (__any(bad)) {
+        if (bad) {
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                ld[t] = INFINITY;
+                li[t] = INT_MAX;
+            }
+            atomicAdd(slow, 1);
+        }
+        double qv[DMAX];
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) qv[d] = (qlive && d < D) ? q[iq * D + d] : 0.0;
+#pragma unroll 1
+        for (int64_t j = 0; j < nx; ++j) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const double df = (d < D ? x[j * D + d] : 0.0) - qv[d];
+                sacc = fma(df, df, sacc);
+            }
+            const bool take = bad && sacc < ld[K - 1];   // (equal distance: the earlier index stays)
+            if (__any(take)) topk_insert<K>(ld, li, take ? sacc : INFINITY, take ? (int)j : INT_MAX);
+        }
+    }
+    if (!qlive) return;
+    const int kk = (int)(nx < m_out ? nx : m_out);
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+        if (t < m_out) out[iq * m_out + t] = t < kk ? li[t] : -1;
+}
+
+// The filter pipeline's plan for (nq, nx, K): sample size, rank, chunking, region capacity; false when the shape does not suit it
+struct NnfPlan {
+    int64_t S, stride, chunk;
+    int r, nchunk, capc;
+};
+static bool nnf_plan(int64_t nq, int64_t nx, int K, NnfPlan &p) {
+    if (nq < 30000 || nx < 20000 || nx >= INT_MAX) return false;   // (measured: below ~25 000 queries the streaming kernel is as fast or faster)
+    p.S = nx / 16 < 2048 ? 2048 : (nx / 16 > 8192 ? 8192 : nx / 16);
+    p.stride = nx / p.S;
+    const double lam = (double)K * (double)p.S / (double)nx;             // sample points expected among the K nearest
+    const double rr = lam + 6.0 * sqrt(lam) + 6.0;                         // P(Poisson(lam) >= r) ~ 1e-8: the bound then holds K candidates
+    if (rr > NNF_R) return false;
+    p.r = (int)ceil(rr);
+    const double en = (double)p.r * (double)nx / (double)p.S;            // candidates expected at or below tau, +- en / sqrt(r)
+    // two chunks of candidates (the collect kernel is fast enough for 392 x 2 workgroups to fill the chip at 1e5 queries); more for few queries
+    p.nchunk = nq >= 60000 ? 2 : (nq >= 25000 ? 4 : 8);
+    p.chunk = ((nx + p.nchunk - 1) / p.nchunk + 63) / 64 * 64;
+    p.nchunk = (int)((nx + p.chunk - 1) / p.chunk);
+    const double per = en / p.nchunk * (1.0 + 5.0 / sqrt((double)p.r)) + 64.0;   // a region: its share at + 5 sigma of the rank's spread
+    p.capc = ((int)per + 63) / 64 * 64;
+    return (double)nq * p.nchunk * p.capc * 12.0 <= 1.5e9;                 // (scratch: <= 1.5 GB, else the streaming kernel)
+}
+
+template <int DMAX, int K>
+static int launch_nn_filter(dgpamd_ctx *ctx, int64_t nq, int64_t nx, int D, const double *q, const double *x, int m_out, int64_t *out,
+                            const NnfPlan &p) {
+    const size_t nreg = (size_t)nq * p.nchunk;
+    const size_t bytes = nreg * p.capc * 12 + nreg * 4 + (size_t)nq * 8 + 64;
+    void *both = nullptr;
+    int rc = ctx_scratch(ctx, 1, bytes, &both);
+    if (rc) return rc;
+    double *nd = reinterpret_cast<double *>(both);
+    double *tau = nd + nreg * p.capc;
+    int *ni = reinterpret_cast<int *>(tau + nq);
+    int *ncnt = ni + nreg * p.capc;
+    int *slow = ncnt + nreg;
+    HIP_TRY(ctx, hipMemsetAsync(slow, 0, 4, ctx->stream));
+    hipLaunchKernelGGL((nn_tau_kernel<DMAX>), dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, ctx->stream, nq, nx, D, q, x, p.S, p.stride, p.r, tau);
+    hipLaunchKernelGGL((nn_collect_kernel<DMAX>), dim3((unsigned)((nq + 255) / 256), (unsigned)p.nchunk), dim3(256), 0, ctx->stream, nq, nx, D, q, x,
+                       (const double *)tau, p.chunk, p.nchunk, p.capc, nd, ni, ncnt);
+    hipLaunchKernelGGL((nn_pick_kernel<DMAX, K>), dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, ctx->stream, nq, nx, D, q, x, p.nchunk, p.capc,
+                       (const double *)nd, (const int *)ni, (const int *)ncnt, m_out, out, slow);
+    return DGPAMD_OK;
+}
+
 template <int DMAX>
 static int launch_nn_stream_k(dgpamd_ctx *ctx, int64_t nq, int64_t nx, int D, const double *q, const double *x, int m_out,
                               int ordered, int64_t *out) {
+    // the query form at prediction sizes: filter, then select (DGPAMD_NN_FILTER=0: the streaming kernel, for comparisons)
+    const bool filter_on = !(getenv("DGPAMD_NN_FILTER") && getenv("DGPAMD_NN_FILTER")[0] == '0');   // (read per call: the tests flip it)
+    NnfPlan plan;
+    if (!ordered && filter_on && m_out > 26 && nnf_plan(nq, nx, m_out, plan)) {
+        if (m_out <= 32) return launch_nn_filter<DMAX, 32>(ctx, nq, nx, D, q, x, m_out, out, plan);
+        if (m_out <= 51) return launch_nn_filter<DMAX, 51>(ctx, nq, nx, D, q, x, m_out, out, plan);
+        return launch_nn_filter<DMAX, 64>(ctx, nq, nx, D, q, x, m_out, out, plan);
+    }
     if (m_out <= 16) return launch_nn_stream<DMAX, 16>(ctx, nq, nx, D, q, x, m_out, ordered, out);
     if (m_out <= 26) return launch_nn_stream<DMAX, 26>(ctx, nq, nx, D, q, x, m_out, ordered, out);
     if (m_out <= 32) return launch_nn_stream<DMAX, 32>(ctx, nq, nx, D, q, x, m_out, ordered, out);

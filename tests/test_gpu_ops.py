@@ -512,6 +512,36 @@ def test_nn_streaming_topk_equals_store_once_kernel(eng, monkeypatch):
         assert a.shape == (n, m + 1) and np.array_equal(a[:, 0], np.arange(n)) and np.all(a[:5, 6:] == -1)
 
 
+def test_nn_query_filter_then_select_equals_streaming_topk(eng, monkeypatch):
+    """From 30 000 queries against 20 000 points on the query search (vecchia.py:20-40) takes the filter-then-select kernels of round 5
+    (a sampled upper bound of every query's K-th nearest distance, a register-light scan that notes the candidates at or below it, the
+    K nearest of the notes; csrc/vecchia.hip nn_tau / nn_collect / nn_pick); DGPAMD_NN_FILTER=0 keeps the streaming top-k kernel.  Same
+    neighbour arrays element for element -- uniform points, a cluster the strided sample all but misses (wide bounds, the exact
+    slow path), exactly tied distances on a grid, all candidates equal, a query count that does not fill the last block -- and, on a
+    sample of queries, the brute-force (distance, index) order."""
+    rng = np.random.default_rng(23)
+    cases = [('uniform', rng.uniform(size=(30011, 6)), rng.uniform(size=(20050, 6)), 50),
+             ('uniform, 16 dims, 64 neighbours', rng.uniform(size=(30001, 16)), rng.uniform(size=(20000, 16)), 64)]
+    xc = np.concatenate([rng.normal(size=(300, 3)) * 1e-3, rng.uniform(size=(20700, 3)) * 30.0])
+    rng.shuffle(xc)
+    cases.append(('cluster', np.concatenate([rng.normal(size=(15000, 3)) * 1e-3, rng.uniform(size=(15040, 3)) * 30.0]), xc, 40))
+    g = np.stack(np.meshgrid(np.arange(150.), np.arange(140.)), -1).reshape(-1, 2)
+    cases.append(('grid', g[rng.integers(0, len(g), 30100)], g, 31))
+    cases.append(('equal', rng.uniform(size=(30000, 2)), np.ones((20000, 2)), 33))
+    for name, q, x, m in cases:
+        dq, dx = eng.tensor(q), eng.tensor(x)
+        got = {}
+        for flag in ('1', '0'):
+            monkeypatch.setenv('DGPAMD_NN_FILTER', flag)
+            got[flag] = npy(eng.nn_query(dq, dx, m))
+        np.testing.assert_array_equal(got['1'], got['0'], err_msg=name)
+        for i in rng.integers(0, len(q), 12):   # ... and both against brute force
+            dist = ((x - q[i]) ** 2).sum(1)
+            want = np.lexsort((np.arange(len(x)), dist))[:m]
+            # (numpy sums the squares in another order: compare the sets through their distances)
+            np.testing.assert_allclose(np.sort(dist[got['1'][i]]), np.sort(dist[want]), rtol=0, atol=1e-12 * max(1.0, dist.max()), err_msg=name)
+
+
 def test_vecchia_spsolve_long_chain(eng):
     """Rows span many 1024-row windows and deep in-window dependency chains."""
     from oracle import dgp_oracle as O
