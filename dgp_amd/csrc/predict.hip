@@ -918,13 +918,16 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
     // step, issued right after the step's barrier into the buffer the previous step read, landed by the next barrier.  No
     // registers, no LDS stores, no address arithmetic per element (the register-staged version spent a fifth of the kernel
     // on its 7 loads + 16 LDS stores per thread and step).
+    // (debug, timing only: no_order_classes & 2 makes every workgroup read the records of the first point block -- what the pair phase costs
+    //  when its records come from the XCD's L2 instead of the fabric)
+    const int64_t irec = (a.no_order_classes & 2) ? 0 : i0, jrec = (a.no_order_classes & 2) ? 0 : j0;
     auto stage = [&](int t, int k, double *P) {
         const double *base = a.recs + (((tbase - a.t0) + t) * Dw + k) * a.npad * REC;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int q = wave + 4 * u;   // KB number q of the 30-KB image: 0..14 the row block, 15..29 the column block
             if (q < 30) {
-                const double *src = base + (q >= 15 ? j0 * REC + (q - 15) * 128 : i0 * REC + q * 128) + lane * 2;
+                const double *src = base + (q >= 15 ? jrec * REC + (q - 15) * 128 : irec * REC + q * 128) + lane * 2;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(P + q * 128), 16, 0, 0);
             }
@@ -951,7 +954,7 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
             clo = x < clo ? x : clo;
             chi = x > chi ? x : chi;
         }
-        smode[idx] = a.no_order_classes ? 0 : (rhi <= clo ? 1 : (rlo > chi ? 2 : 0));
+        smode[idx] = (a.no_order_classes & 1) ? 0 : (rhi <= clo ? 1 : (rlo > chi ? 2 : 0));
     }
     __syncthreads();
     // The records of step (t, k) are double buffered in LDS: ONE barrier per step.
@@ -1214,7 +1217,7 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
                 hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_MATERN25, false>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else {
                 const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)TCH * Dz + TCH * 4 + 2 * 128 * PST) * sizeof(double) + (size_t)Dw * 4 * sizeof(int);
-                a.no_order_classes = getenv("DGPAMD_JSEP_NOCLASS") ? 1 : 0;
+                a.no_order_classes = (getenv("DGPAMD_JSEP_NOCLASS") ? 1 : 0) | (getenv("DGPAMD_JSEP_SAMEBLK") ? 2 : 0);
                 if (shm_sep > 48 * 1024)
                     HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_sep));
                 hipLaunchKernelGGL(matern_records_kernel, dim3((unsigned)((a.npad + 127) / 128), Dw, (unsigned)mc), dim3(256), 0, ctx->stream, a);
