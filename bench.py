@@ -145,7 +145,8 @@ def _cpu_predict_points(job):
     v = _np.empty((len(x), len(l1)))
     for k, nd in enumerate(l1):   # functions.gp (functions.py:379-394) of every first-layer node
         m[:, k], v[:, k] = O.gp_predict(x[:, nd['cols']], nd['W'], nd['Rinv'], nd['Rinv_y'], nd['scale'], nd['length'], nd['nugget'], nd['name'])
-    mu, var = O.link_gp_predict(m, v, None, l2['W'], None, l2['Rinv'], l2['Rinv_y'], l2['scale'], l2['length'], l2['nugget'], l2['name'])
+    z = None if l2['Wg'] is None else x[:, l2['gcols']]   # the output node's deterministic global inputs (connect)
+    mu, var = O.link_gp_predict(m, v, z, l2['W'], l2['Wg'], l2['Rinv'], l2['Rinv_y'], l2['scale'], l2['length'], l2['nugget'], l2['name'])
     return _t.perf_counter() - t0, float(mu.sum()), float(var.sum())
 
 
@@ -165,12 +166,15 @@ def cpu_baseline_predict(model, d, imputations, points_per_worker=1):
     for nd in model.all_layer[0]:
         Xn = np.ascontiguousarray(nd._X())
         st = O.compute_stats(Xn, nd.output[:, 0], nd.length, nd.nugget[0], nd.name, Xn.shape[1])
-        l1.append(dict(cols=np.r_[np.asarray(nd.input_dim), np.asarray(nd.connect if nd.connect is not None else [], dtype=int)] if nd.global_input is not None else np.asarray(nd.input_dim),
+        l1.append(dict(cols=np.asarray(nd.input_dim) if nd.input_dim is not None else np.arange(Xn.shape[1]),
                        W=Xn, Rinv=st['Rinv'], Rinv_y=st['Rinv_y'], scale=nd.scale, length=nd.length, nugget=nd.nugget, name=nd.name))
     nd = model.all_layer[1][0]
     W2 = np.ascontiguousarray(nd._X())
-    st = O.compute_stats(W2, nd.output[:, 0], nd.length, nd.nugget[0], nd.name, W2.shape[1])
-    l2 = dict(W=W2, Rinv=st['Rinv'], Rinv_y=st['Rinv_y'], scale=nd.scale, length=nd.length, nugget=nd.nugget, name=nd.name)
+    st = O.compute_stats(W2, nd.output[:, 0], nd.length, nd.nugget[0], nd.name, nd._input.shape[1])
+    nloc = nd._input.shape[1]
+    l2 = dict(W=np.ascontiguousarray(W2[:, :nloc]), Wg=None if nd._global_input is None else np.ascontiguousarray(W2[:, nloc:]),
+              gcols=None if nd.connect is None else np.asarray(nd.connect), Rinv=st['Rinv'], Rinv_y=st['Rinv_y'], scale=nd.scale, length=nd.length,
+              nugget=nd.nugget, name=nd.name)
     xt = np.random.default_rng(11).uniform(size=(workers * points_per_worker, d))
     jobs = [(xt[w * points_per_worker:(w + 1) * points_per_worker], l1, l2) for w in range(workers)]
     t0 = time.perf_counter()
