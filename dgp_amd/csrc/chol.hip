@@ -1123,6 +1123,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
             }
         }
         // the panel tile has landed -- and with it, vmcnt counting in order, this wave's older W_k stores have drained
+        if (tl) tl[8 * k + 7] = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         {
             const int c2 = (tid & 15) * 2;

@@ -181,8 +181,8 @@ def main():
             td, wd = arrival(mb, 0, k + 1, k + 1, int(need[k][1]))
             def nm(w):
                 return '-' if w is None else ('chain %d' % w[1] if w[0] == 'c' else describe(T, w[1]))
-            print('%2d | %5.1f | %5.1f | %5.1f | %5.1f | %5.1f || Q %+6.1f %-28s D %+6.1f %s' % (
-                k, c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4], tq - c[1], nm(wq), td - c[1], nm(wd)))
+            print('%2d | %5.1f | %5.1f (issue %4.1f, wait + stage %4.1f) | %5.1f | %5.1f | %5.1f || Q %+6.1f %-28s D %+6.1f %s' % (
+                k, c[1] - c[0], c[2] - c[1], c[7] - c[1], c[2] - c[7], c[3] - c[2], c[4] - c[3], c[5] - c[4], tq - c[1], nm(wq), td - c[1], nm(wd)))
 
     # ---- critical path, walked back from the last publication ----
     if '--path' in sys.argv:
