@@ -1310,7 +1310,10 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
     // is always held, or about to be pulled, by a worker that can run it.
     // The pull of the NEXT task is issued when a task's arithmetic is done and lands while its tile is stored and published.
     const int widx = (int)blockIdx.x - batch;
-    const int crit_per_xcd = g.nut > 0 ? (g.ncrit * group_size(home) * G + 7) / 8 : 0;
+    // (never more than a quarter of an XCD's ~64 workers: with 32-64 matrices `ncrit` per matrix would leave nobody who takes bulk work first,
+    //  and critical workers that run ahead wait inside their tasks for bulk results nobody computes)
+    const int crit_want = g.nut > 0 ? (g.ncrit * group_size(home) * G + 7) / 8 : 0;
+    const int crit_per_xcd = crit_want > 16 ? 16 : crit_want;
     const int role = (widx >= 0 && (widx >> 3) < crit_per_xcd) ? 0 : 1;   // 0: critical queue first, 1: bulk queue first
     __shared__ int32_t qempty[2];   // (thread 0's notes: this group's critical / bulk queue has been found empty)
     if (tid == 0) { qempty[0] = g.nut > 0 ? 0 : 1; qempty[1] = 0; }

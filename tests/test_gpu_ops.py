@@ -512,6 +512,35 @@ def test_nn_streaming_topk_equals_store_once_kernel(eng, monkeypatch):
         assert a.shape == (n, m + 1) and np.array_equal(a[:, 0], np.arange(n)) and np.all(a[:5, 6:] == -1)
 
 
+@pytest.mark.parametrize('B', [24, 32, 64])
+def test_one_launch_factorisation_with_many_matrices(eng, B):
+    """24-64 matrices per call (DGPAMD_MAXB = 64): the one-launch kernel's critical-lane workers are capped per XCD so that workers
+    which take bulk work first remain (uncapped, 12 x 64 of them would be every worker of the launch, each running ahead in the critical
+    queue and waiting for bulk results nobody computes).  Factors, inverses and log-determinants equal the per-block-step kernel's, bit for bit."""
+    import torch
+    n = 300
+    Np = eng.padded_dim(n)
+    r = np.random.default_rng(B)
+    X, G, y = eng.tensor(r.uniform(size=(B, n, 4))), eng.tensor(r.uniform(size=(n, 3))), eng.tensor(r.normal(size=n))
+    work = eng.potrf_workspace(n, B)
+    out = {}
+    try:
+        for mode in (0, 1):
+            eng.set_potrf_mode(mode)
+            A, T, S = eng.empty(B, Np, Np), eng.empty(B, Np, Np), eng.empty(B, Np, Np)
+            eng.kmatrix('matern2.5', X, None, G, [0.7], 1e-5, out=A, full=False, Y=y, batch=B)
+            ld, info = eng.potrf(n, A, batch=B, work=work)
+            L = torch.tril(A[:, :n + 1, :n]).clone()
+            eng.kmatrix('matern2.5', X, None, G, [0.7], 1e-5, out=A, full=False, Y=y, batch=B)
+            ld2, info2 = eng.potrf_inv(n, A, T, S, batch=B, work=work)
+            out[mode] = (L, torch.tril(S[:, :n + 1, :n]).clone(), ld.clone(), ld2.clone(), int(info.abs().sum()) + int(info2.abs().sum()))
+    finally:
+        eng.set_potrf_mode(1)
+    assert out[0][4] == 0 and out[1][4] == 0
+    for a, b in zip(out[0][:4], out[1][:4]):
+        assert torch.equal(a, b)
+
+
 def test_nn_query_filter_then_select_equals_streaming_topk(eng, monkeypatch):
     """From 30 000 queries against 20 000 points on the query search (vecchia.py:20-40) takes the filter-then-select kernels of round 5
     (a sampled upper bound of every query's K-th nearest distance, a register-light scan that notes the candidates at or below it, the
