@@ -316,7 +316,9 @@ class Hetero(TrackedInputs):
         """Log-likelihood of the data at the current latents (likelihood_class.py:108-113)."""
         mu, log_var = self.input[:, 0], self.input[:, 1]
         r2 = (np.asarray(self.output).flatten() - mu) ** 2
-        with np.errstate(divide='ignore'):
+        # (a proposal that drives the log-variance latent far down makes r^2 / var overflow: the log-likelihood is then -inf, which the
+        #  slice sampler rejects -- the reference's expression does the same; no warning for what is a legitimate value)
+        with np.errstate(divide='ignore', over='ignore'):
             return np.sum(-0.5 * (np.log(2 * np.pi) + log_var + np.exp(np.log(r2) - log_var)))
 
     @staticmethod
