@@ -224,7 +224,11 @@ struct LinkArgs {
     double *mean, *var;
     const int32_t *drop;   // leave-one-out: training point left out of the conditioning set of test point t (else null)
     int no_order_classes;  // linkgp_Jsep: treat every sub-tile as mixed (DGPAMD_JSEP_NOCLASS: the comparison run of the tools)
+    int tch;               // linkgp_Jsep: test points per workgroup
+    long long *dbg;        // linkgp_Jsep_kernel<2, true> (DGPAMD_JSEP_LOG=1 with dgpamd_debug_tasklog's buffer set): per-workgroup and per-step stamps, or null
 };
+#define JSEP_LOG_STEPS 48
+#define JSEP_LOG_WORDS (8 + JSEP_LOG_STEPS * 4 * 2)
 
 // mean_t = sum_i I_i(t) ry_i : one workgroup per test point (the training points strided over its 256 threads)
 template <int KIND>
@@ -803,6 +807,7 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
                  // column reads; the zero pads the 3-term erf-difference products to an MFMA k-step of 4)
 #define PST REC
 #define MC_SEP 256
+#define TCHS 32    // test points per workgroup of linkgp_Jsep_kernel
 
 __global__ __launch_bounds__(256) void matern_records_kernel(LinkArgs a) {
     // 128 points x (S role | T role) per workgroup; the 128 records are staged in LDS and leave as one contiguous
@@ -868,21 +873,23 @@ __global__ __launch_bounds__(256) void global_factor_kernel(LinkArgs a) {
     a.gfac[tt * a.npad + i] = pr * exp(-SQRT5 * sm);
 }
 
+template <int PIPE, bool LOG>
 __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
     extern __shared__ double lds[];
     const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
     double *WiT = lds;                    // [DT][64]
     double *WjT = WiT + DT * 64;          // [DT][64]
-    double *tz = WjT + DT * 64;           // [TCH][Dz]
-    double *red = tz + TCH * Dz;          // [TCH][4]
-    double *PT = red + TCH * 4;           // [2][128][PST]
+    const int tch = a.tch;
+    double *tz = WjT + DT * 64;           // [tch][Dz]
+    double *red = tz + tch * Dz;          // [tch][4]
+    double *PT = red + tch * 4;           // [2][128][PST]
     int *smode = reinterpret_cast<int *>(PT + 2 * 128 * PST);   // [Dw][4]: per (dimension, wave) the order class of its rows against the tile's columns
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
-    const int64_t tbase = a.t0 + (int64_t)blockIdx.y * TCH;
-    int nt = TCH;
+    const int64_t tbase = a.t0 + (int64_t)blockIdx.y * tch;
+    int nt = tch;
     if (tbase + nt > a.M) nt = (int)(a.M - tbase);
     if (tbase + nt > a.t0 + a.Mc) nt = (int)(a.t0 + a.Mc - tbase);
 
@@ -921,13 +928,20 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
     // (debug, timing only: no_order_classes & 2 makes every workgroup read the records of the first point block -- what the pair phase costs
     //  when its records come from the XCD's L2 instead of the fabric)
     const int64_t irec = (a.no_order_classes & 2) ? 0 : i0, jrec = (a.no_order_classes & 2) ? 0 : j0;
-    auto stage = [&](int t, int k, double *P) {
-        const double *base = a.recs + (((tbase - a.t0) + t) * Dw + k) * a.npad * REC;
+    // (addresses: the records of step s = t Dw + k of this chunk start at rec0 + s x npad x REC, so a step costs one scalar multiply-add; the wave number is made
+    //  uniform so that the KB numbers, the LDS destinations (M0) and the `q < 30` tests are scalar -- computed per lane they were 16 VALU instructions, four
+    //  readfirstlanes and four exec-masked branches per step, between the barrier and the first fragment read)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const double *rec0 = a.recs + (tbase - a.t0) * Dw * a.npad * REC + lane * 2;
+    const int64_t sstride = a.npad * REC;
+    const int qlim = (a.no_order_classes & 32) ? 15 : 30;
+    auto stage = [&](int s1, double *P, int u0 = 0, int u1 = 8) {
+        const double *base = rec0 + s1 * sstride;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int q = wave + 4 * u;   // KB number q of the 30-KB image: 0..14 the row block, 15..29 the column block
-            if (q < 30) {
-                const double *src = base + (q >= 15 ? jrec * REC + (q - 15) * 128 : irec * REC + q * 128) + lane * 2;
+        for (int u = u0; u < u1; ++u) {
+            const int q = wv + 4 * u;   // KB number q of the 30-KB image: 0..14 the row block, 15..29 the column block
+            if (q < qlim) {
+                const double *src = base + (q >= 15 ? jrec * REC + (q - 15) * 128 : irec * REC + q * 128);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(P + q * 128), 16, 0, 0);
             }
@@ -954,14 +968,31 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
             clo = x < clo ? x : clo;
             chi = x > chi ? x : chi;
         }
-        smode[idx] = (a.no_order_classes & 1) ? 0 : (rhi <= clo ? 1 : (rlo > chi ? 2 : 0));
+        smode[idx] = (a.no_order_classes & 4) ? 1 : ((a.no_order_classes & 1) ? 0 : (rhi <= clo ? 1 : (rlo > chi ? 2 : 0)));
     }
     __syncthreads();
     // The records of step (t, k) are double buffered in LDS: ONE barrier per step.
     double *PT1 = PT + 128 * PST;
     const int nstep = nt * Dw;
-    if (nstep > 0) stage(0, 0, PT);
+    if (nstep > 0) stage(0, PT);
     int step = 0;
+    int mw_next = __builtin_amdgcn_readfirstlane(smode[wave]);
+    // (diagnostics, LOG only: workgroup start / end on the 100-MHz clock and in shader cycles, where it ran, and for its first
+    //  JSEP_LOG_STEPS steps every wave's arrival at and departure from the step's barrier -- tools/gpu_pair_steplog.py)
+    long long *lg = nullptr;
+    long long *slog = reinterpret_cast<long long *>(smode + Dw * 4 + (Dw & 1) * 4);   // (LOG: JSEP_LOG_STEPS x 4 x 2 stamps behind the kernel's own LDS)
+    if (LOG && a.dbg) {
+        for (int e = tid; e < JSEP_LOG_STEPS * 8; e += 256) slog[e] = 0;
+        lg = a.dbg + 64 + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * JSEP_LOG_WORDS;
+        if (tid == 0) {
+            lg[0] = wall_clock64();
+            lg[2] = clock64();
+            lg[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            lg[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            lg[6] = ((long long)bi << 16) | bj;
+            lg[7] = nstep;
+        }
+    }
     for (int t = 0; t < nt; ++t) {
         d4 prod[4];
 #pragma unroll
@@ -969,11 +1000,13 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
 #pragma unroll 1
         for (int k = 0; k < Dw; ++k, ++step) {
             double *P = (step & 1) ? PT1 : PT;
+            if (LOG && lg && step < JSEP_LOG_STEPS && lane == 0) slog[(step * 4 + wave) * 2] = clock64();   // (kept in LDS: a global store here would be waited for by the barrier's vmcnt(0))
             __syncthreads();   // records of this step landed (the barrier's wait covers the LDS-DMA); every wave is done with the other buffer
-            {   // the next step's records into the other buffer.  Past the end the last step is staged again (harmless).
-                const int s1 = step + 1 < nstep ? step + 1 : nstep - 1;
-                stage(s1 / Dw, s1 % Dw, (step & 1) ? PT : PT1);
-            }
+            if (LOG && lg && step < JSEP_LOG_STEPS && lane == 0) slog[(step * 4 + wave) * 2 + 1] = clock64() | ((long long)mw_next << 60);
+            // the next step's records into the other buffer.  Past the end the last step is staged again (harmless).
+            const int s1 = step + 1 < nstep ? step + 1 : nstep - 1;
+            const bool nostage = (a.no_order_classes & 8) != 0;   // (timing only)
+            if (PIPE == 0 && !nostage) stage(s1, (step & 1) ? PT : PT1);   // (comparison build: all eight right behind the barrier)
             // volatile: keeps these fragment reads as ds_read_b64 (2 LDS cycles, 64 banks: conflict-free with PST = 30); merged
             // into ds_read2_b64 by the compiler they take 8 cycles and bank modulo 32 (2-way conflicts here)
             const vlds_double *Arow = (const vlds_double *)(P + (16 * wave + mi) * PST);   // this lane's row record as an MFMA A operand (i = lane&15)
@@ -983,7 +1016,8 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
                 f2r[r] = P[(mrow + 4 * r) * PST + 27];
                 xr[r] = P[(mrow + 4 * r) * PST + 28];
             }
-            const int mw = __builtin_amdgcn_readfirstlane(smode[k * 4 + wave]);
+            const int mw = mw_next;   // (read one step ahead: the LDS round trip + readfirstlane sat between the barrier and the first MFMA)
+            const int mraw = ((const volatile int *)smode)[(k + 1 < Dw ? k + 1 : 0) * 4 + wave];
             if (mw == 0) {   // mixed: both record products, selected per pair
                 // A fragments (rows): S[0..11] and T[0..11] in three k-steps each, the erf-difference pair in one (k=3 padded with 0)
                 double aS[3], aT[3];
@@ -997,42 +1031,51 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
                 // row groups of tile tt's (VALU) epilogue; the sched_barrier() fences pin that order (on its own the compiler
                 // issues all 32 MFMAs first and all epilogues afterwards).
                 d4 o1[2], o2[2], e1[2], e2[2];
-                double bf[8];
-                auto loadB = [&](int tt) {   // column records as MFMA B operands (j = lane&15)
+                // The column fragments are read TWO tiles ahead (two register sets) and a tile's f2 / x one tile ahead: the LDS round trip of a
+                // fragment read sat in front of every MFMA group otherwise (read, wait, MFMA), and with two waves per SIMD nobody hides it.
+                double bf[2][8], f2c[2], xc[2];
+                auto loadB = [&](int tt, int s) {   // column records as MFMA B operands (j = lane&15)
                     const vlds_double *Bcol = (const vlds_double *)(P + (64 + 16 * tt + mi) * PST);
 #pragma unroll
                     for (int ks = 0; ks < 3; ++ks) {
-                        bf[ks] = Bcol[12 + 4 * ks + kq];
-                        bf[3 + ks] = Bcol[4 * ks + kq];
+                        bf[s][ks] = Bcol[12 + 4 * ks + kq];
+                        bf[s][3 + ks] = Bcol[4 * ks + kq];
                     }
-                    bf[6] = Bcol[iTd];
-                    bf[7] = Bcol[iSd];
+                    bf[s][6] = Bcol[iTd];
+                    bf[s][7] = Bcol[iSd];
+                };
+                auto loadC = [&](int tt, int s) {
+                    const vlds_double *Ccol = (const vlds_double *)(P + (64 + 16 * tt + mcol) * PST);
+                    f2c[s] = Ccol[27];
+                    xc[s] = Ccol[28];
                 };
                 auto mm2 = [&](int c, int slot) {   // MFMA pair c of a tile: S_row . T_col and T_row . S_col, then the erf pair
                     const d4 z = {0.0, 0.0, 0.0, 0.0};
                     if (c < 3) {
-                        o1[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[c], bf[c], c ? o1[slot] : z, 0, 0, 0);
-                        o2[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[c], bf[3 + c], c ? o2[slot] : z, 0, 0, 0);
+                        o1[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[c], bf[slot][c], c ? o1[slot] : z, 0, 0, 0);
+                        o2[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[c], bf[slot][3 + c], c ? o2[slot] : z, 0, 0, 0);
                     } else {
-                        e1[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aSd, bf[6], z, 0, 0, 0);
-                        e2[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aTd, bf[7], z, 0, 0, 0);
+                        e1[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aSd, bf[slot][6], z, 0, 0, 0);
+                        e2[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aTd, bf[slot][7], z, 0, 0, 0);
                     }
                 };
-                loadB(0);
+                loadB(0, 0);
+                loadC(0, 0);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) mm2(c, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const int sl = tt & 1;
-                    const double f2c = P[(64 + 16 * tt + mcol) * PST + 27], xc = P[(64 + 16 * tt + mcol) * PST + 28];
-                    if (tt < 3) loadB(tt + 1);
+                    if (PIPE == 2 && !nostage) stage(s1, (step & 1) ? PT : PT1, 2 * tt, 2 * tt + 2);
+                    if (tt < 3) loadC(tt + 1, sl ^ 1);
+                    if (tt < 3) loadB(tt + 1, sl ^ 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (tt < 3) mm2(r, sl ^ 1);
-                        const double d = f2c - f2r[r];
+                        const double d = f2c[sl] - f2r[r];
                         const double j1 = fma(d, e1[sl][r], o1[sl][r]), j2 = fma(-d, e2[sl][r], o2[sl][r]);
-                        prod[tt][r] *= (xr[r] <= xc) ? j1 : j2;
+                        prod[tt][r] *= (xr[r] <= xc[sl]) ? j1 : j2;
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1047,39 +1090,46 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) g2r[r] = c1 ? f2r[r] : -f2r[r];
                 d4 oo[2], ee[2];
-                double bx[4];
-                auto loadBc = [&](int tt) {
+                double bx[2][4], g2c[2];
+                auto loadBc = [&](int tt, int s) {
                     const vlds_double *Bcol = (const vlds_double *)(P + (64 + 16 * tt + mi) * PST);
-                    bx[0] = Bcol[offB + kq];
-                    bx[1] = Bcol[offB + 4 + kq];
-                    bx[2] = Bcol[offB + 8 + kq];
-                    bx[3] = Bcol[iBd];
+                    bx[s][0] = Bcol[offB + kq];
+                    bx[s][1] = Bcol[offB + 4 + kq];
+                    bx[s][2] = Bcol[offB + 8 + kq];
+                    bx[s][3] = Bcol[iBd];
+                };
+                auto loadCc = [&](int tt, int s) {
+                    const vlds_double *Ccol = (const vlds_double *)(P + (64 + 16 * tt + mcol) * PST);
+                    g2c[s] = Ccol[27];
                 };
                 auto mmc = [&](int c, int slot) {
                     const d4 z = {0.0, 0.0, 0.0, 0.0};
-                    if (c == 0) oo[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aX0, bx[0], z, 0, 0, 0);
-                    else if (c == 1) ee[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aD, bx[3], z, 0, 0, 0);
-                    else if (c == 2) oo[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aX1, bx[1], oo[slot], 0, 0, 0);
-                    else oo[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aX2, bx[2], oo[slot], 0, 0, 0);
+                    if (c == 0) oo[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aX0, bx[slot][0], z, 0, 0, 0);
+                    else if (c == 1) ee[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aD, bx[slot][3], z, 0, 0, 0);
+                    else if (c == 2) oo[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aX1, bx[slot][1], oo[slot], 0, 0, 0);
+                    else oo[slot] = __builtin_amdgcn_mfma_f64_16x16x4f64(aX2, bx[slot][2], oo[slot], 0, 0, 0);
                 };
-                loadBc(0);
+                loadBc(0, 0);
+                loadCc(0, 0);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) mmc(c, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const int sl = tt & 1;
-                    const double f2c = P[(64 + 16 * tt + mcol) * PST + 27];
-                    const double g2c = c1 ? f2c : -f2c;
-                    if (tt < 3) loadBc(tt + 1);
+                    if (PIPE == 2 && !nostage) stage(s1, (step & 1) ? PT : PT1, 2 * tt, 2 * tt + 2);
+                    if (tt < 3) loadCc(tt + 1, sl ^ 1);
+                    if (tt < 3) loadBc(tt + 1, sl ^ 1);
+                    const double g2 = c1 ? g2c[sl] : -g2c[sl];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (tt < 3) mmc(r, sl ^ 1);
-                        prod[tt][r] *= fma(g2c - g2r[r], ee[sl][r], oo[sl][r]);
+                        prod[tt][r] *= fma(g2 - g2r[r], ee[sl][r], oo[sl][r]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
+            mw_next = __builtin_amdgcn_readfirstlane(mraw);
         }
         // deterministic global inputs: separable Matern factor (functions.py:413-420), precomputed per point
         double gr[4], gc[4];
@@ -1102,6 +1152,13 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
         if (lane == 0) red[t * 4 + wave] = acc;
     }
     __syncthreads();
+    if (LOG && lg) {
+        if (tid == 0) {
+            lg[1] = wall_clock64();
+            lg[3] = clock64();
+        }
+        for (int e = tid; e < JSEP_LOG_STEPS * 8; e += 256) lg[8 + e] = slog[e];
+    }
     if (tid < nt)
         a.partial[(int64_t)blockIdx.x * a.Mc + (tbase - a.t0) + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3];
 }
@@ -1125,11 +1182,37 @@ __global__ __launch_bounds__(256) void linkgp_finalize_kernel(LinkArgs a, int nt
     a.var[t] = fabs(s - mu * mu + a.scale * (1.0 + a.nugget));
 }
 
+// Test points per launch of the record-based pair kernels (Matern: linkgp_Jsep_kernel, `per_wg` = TCH; SExp: linkgp_Jsexp2_kernel,
+// TCH2).  A launch is ntiles x (points / per_wg) workgroups on the chip's 512 workgroup slots, and its last, ragged round leaves
+// slots idle: at n = 2000 with 256 points per launch that was 8.25 rounds and 10 % of the kernel's time (tools/gpu_pair_steplog.py:
+// slot occupancy 0.32 over the last tenth of the launch).  >= 32 rounds per launch bound that loss by 1-2 %; the records of a launch
+// (Matern: points x Dw x npad x 240 B) are kept under 4 GiB, and a launch never holds fewer than MC_SEP points.
+static int64_t pair_chunk(int64_t nb, int64_t Mc, int Dw, int per_wg) {
+    const int64_t ntiles = nb * (nb + 1) / 2;
+    int64_t want = ((32 * 512 + ntiles - 1) / ntiles) * per_wg;
+    const int64_t cap = (((int64_t)4 << 30) / ((int64_t)(Dw * REC + 1) * nb * 64 * (int64_t)sizeof(double))) / per_wg * per_wg;
+    if (want > cap) want = cap;
+    if (want < MC_SEP) want = MC_SEP;
+    return Mc < want ? Mc : want;
+}
+
+static int jsep_tch() {   // test points per workgroup of linkgp_Jsep_kernel (DGPAMD_JSEP_TCH: comparison runs)
+    if (getenv("DGPAMD_JSEP_TCH")) {
+        const int c = atoi(getenv("DGPAMD_JSEP_TCH"));
+        if (c >= 8 && c <= 256 && c % 8 == 0) return c;
+    }
+    return TCHS;
+}
+
 extern "C" size_t dgpamd_linkgp_workspace(int64_t n, int64_t M, int Dw) {
     int64_t nb = (n + 63) / 64;
     int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
     if (Mc > MC_MAX) Mc = MC_MAX;
-    int64_t Ms = Mc > MC_SEP ? MC_SEP : Mc;
+    int64_t Ms = pair_chunk(nb, Mc, Dw, jsep_tch());   // (the Matern records are the larger ones)
+    {
+        const int64_t m2 = pair_chunk(nb, Mc, Dw, TCH2);
+        if (m2 > Ms) Ms = m2;
+    }
     return (size_t)(nb * (nb + 1) / 2 * Mc + Ms * (int64_t)Dw * nb * 64 * REC + Ms * nb * 64) * sizeof(double);
 }
 
@@ -1152,6 +1235,8 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
     a.partial = (double *)work;
     a.drop = drop;
     a.no_order_classes = 0;
+    a.dbg = nullptr;
+    a.tch = jsep_tch();
     int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
     if (Mc > MC_MAX) Mc = MC_MAX;
     const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
@@ -1160,7 +1245,12 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
     a.recs = a.partial + (int64_t)ntiles * Mc;
     a.npad = (int64_t)nb * 64;
     const bool sx2 = (kind == DGPAMD_SEXP) && !direct && Dw + 2 <= 16;
-    if ((sep || sx2) && Mc > MC_SEP) Mc = MC_SEP;   // records of one chunk: Mc*Dw*npad*240 B (Matern), Mc*npad*(Dw+3..6)*8 B (SExp)
+    if (sep) Mc = pair_chunk(nb, Mc, Dw, a.tch);   // records of one chunk: Mc*Dw*npad*240 B (Matern), Mc*npad*(Dw+3..6)*8 B (SExp)
+    if (sx2) Mc = pair_chunk(nb, Mc, Dw, TCH2);
+    if (getenv("DGPAMD_PAIR_CHUNK") && (sep || sx2)) {   // (comparison runs: the fixed 256 points per launch of the earlier builds)
+        const int64_t c = atoll(getenv("DGPAMD_PAIR_CHUNK"));
+        if (c >= TCH && c < Mc) Mc = c / TCH * TCH;
+    }
     a.Mc = Mc;
     a.gfac = a.recs + Mc * (int64_t)Dw * a.npad * REC;
     const int DT = Dw + Dz;
@@ -1216,15 +1306,20 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
             } else if (direct) {
                 hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_MATERN25, false>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else {
-                const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)TCH * Dz + TCH * 4 + 2 * 128 * PST) * sizeof(double) + (size_t)Dw * 4 * sizeof(int);
-                a.no_order_classes = (getenv("DGPAMD_JSEP_NOCLASS") ? 1 : 0) | (getenv("DGPAMD_JSEP_SAMEBLK") ? 2 : 0);
+                const int pipe = getenv("DGPAMD_JSEP_PIPE") ? atoi(getenv("DGPAMD_JSEP_PIPE")) : 2;
+                const size_t shm_sep = ((size_t)2 * DT * 64 + (size_t)a.tch * Dz + a.tch * 4 + 2 * 128 * PST) * sizeof(double) + (size_t)Dw * 4 * sizeof(int) +
+                                       (getenv("DGPAMD_JSEP_LOG") ? 16 + JSEP_LOG_STEPS * 8 * sizeof(long long) : 0);
+                a.no_order_classes = (getenv("DGPAMD_JSEP_NOCLASS") ? 1 : 0) | (getenv("DGPAMD_JSEP_SAMEBLK") ? 2 : 0) | (getenv("DGPAMD_JSEP_DIAG") ? atoi(getenv("DGPAMD_JSEP_DIAG")) : 0);
+                const bool plog = ctx->tlog != nullptr && getenv("DGPAMD_JSEP_LOG") != nullptr;
+                auto jsep = plog ? linkgp_Jsep_kernel<2, true> : (pipe == 0 ? linkgp_Jsep_kernel<0, false> : linkgp_Jsep_kernel<2, false>);
+                a.dbg = (plog && ctx->tlog_words >= 64 + (long long)ntiles * ((mc + a.tch - 1) / a.tch) * JSEP_LOG_WORDS) ? ctx->tlog : nullptr;
                 if (shm_sep > 48 * 1024)
-                    HIP_TRY(ctx, hipFuncSetAttribute((const void *)linkgp_Jsep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_sep));
+                    HIP_TRY(ctx, hipFuncSetAttribute((const void *)jsep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_sep));
                 hipLaunchKernelGGL(matern_records_kernel, dim3((unsigned)((a.npad + 127) / 128), Dw, (unsigned)mc), dim3(256), 0, ctx->stream, a);
                 if (Dz)
                     hipLaunchKernelGGL(global_factor_kernel, dim3((unsigned)((a.npad + 255) / 256), (unsigned)mc), dim3(256), 0, ctx->stream, a);
                 PROF_BEGIN(ctx, PROF_LINKGP_J, (double)mc * (double)n * (double)n * 0.5 * Dw * 30.0 * 2.0);
-                hipLaunchKernelGGL(linkgp_Jsep_kernel, dim3(ntiles, tb), dim3(256), shm_sep, ctx->stream, a);
+                hipLaunchKernelGGL(jsep, dim3(ntiles, (unsigned)((mc + a.tch - 1) / a.tch)), dim3(256), shm_sep, ctx->stream, a);
                 PROF_END(ctx, PROF_LINKGP_J);
             }
             hipLaunchKernelGGL(linkgp_finalize_kernel<DGPAMD_MATERN25>, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, ctx->stream, a, ntiles);
