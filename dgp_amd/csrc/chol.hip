@@ -614,6 +614,11 @@ __device__ __forceinline__ void store_acc_sc1(const d4 (&acc)[4], double *C, int
             v.x = __double2loint(lo); v.y = __double2hiint(lo); v.z = __double2loint(hi); v.w = __double2hiint(hi);
             __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((int64_t)row * ld + col) * 8), 0, 16);
         }
+    // (eight 16-byte stores in a row: their data registers stay untouched for 16 wait states, as behind the chain's panel-tile stores --
+    //  tests/test_isa_hazards.py; the callers used to drain right behind them, now the next ticket is pulled first)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
 }
 // every storing wave drains its stores, then one lane publishes
 __device__ __forceinline__ void wg_publish(int32_t *flag, int value, int tid) {
@@ -1308,7 +1313,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
     // for all other workers; each kind of worker helps with the other queue once its own is empty.  Both queues are topological
     // orders of their own tasks and each has workers that take nothing else first, so the earliest unfinished task of the launch
     // is always held, or about to be pulled, by a worker that can run it.
-    // The pull of the NEXT task is issued when a task's arithmetic is done and lands while its tile is stored and published.
+    // The pull of the NEXT task is issued behind the stores of a task's tile and lands while they drain.
     const int widx = (int)blockIdx.x - batch;
     // (never more than a quarter of an XCD's ~64 workers: with 32-64 matrices `ncrit` per matrix would leave nobody who takes bulk work first,
     //  and critical workers that run ahead wait inside their tasks for bulk results nobody computes)
@@ -1442,8 +1447,8 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         if (agg) a2 = wall_clock64();
         if (tl) tl[2] = wall_clock64();
         if (post == T_STORE) {
-            pull_next();
             store_acc_sc1(acc.v, C, ld, crow, ccol);
+            pull_next();   // (behind the stores: the ticket's round trip delayed wave 0's stores, and with them the publication, by 1-2 us)
             if (st) st[3] = wall_clock64();
             if (tl) tl[4] = wall_clock64();
             finish(vC, newver);
@@ -1466,8 +1471,8 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         for (int t = 0; t < 4; ++t) out[t] = (d4){0.0, 0.0, 0.0, 0.0};
         mul_acc_bt<true>(out, acc.v, Wk, 64, As, Bs, tid, wave, lane);
         if (post == T_SOLVE) {
-            pull_next();
             store_acc_sc1(out, C, ld, crow, ccol);
+            pull_next();
             if (st) st[3] = wall_clock64();
             if (tl) tl[4] = wall_clock64();
             finish(vC, newver);
@@ -1508,8 +1513,8 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
                     __syncthreads();
                     mfma_tile_ahead<OP_MK, OP_MK>(As, Bs, qt.v, wave, lane, -1.0);
                 }
-                pull_next();
                 store_acc_sc1(qt.v, Qg, ld, crow, ccol);
+                pull_next();
                 if (st) st[3] = wall_clock64();
                 if (tl) tl[4] = wall_clock64();
                 finish(vQ, need2 + 1);
@@ -1538,8 +1543,8 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
                     __syncthreads();
                     mfma_tile_ahead<OP_MK, OP_MK>(As, As, d.v, wave, lane, -1.0);
                 }
-                pull_next();
                 store_acc_sc1(d.v, Dg, ld, crow, ccol);
+                pull_next();
                 if (st) st[3] = wall_clock64();
                 if (tl) tl[4] = wall_clock64();
                 finish(vD, need2 + 1);
