@@ -807,6 +807,43 @@ def test_linkgp_sexp_mfma_equals_direct_across_chunks(eng):
     close(npy(v2)[sl], lvr, rtol=1e-6, atol=1e-8)
 
 
+@pytest.mark.parametrize('kind,n,M,Dw,Dz', [('matern2.5', 130, 4500, 3, 1), ('matern2.5', 700, 1100, 5, 0), ('sexp', 130, 4500, 3, 1)])
+def test_linkgp_launch_geometry_does_not_change_a_bit(eng, monkeypatch, kind, n, M, Dw, Dz):
+    """Round 5: the record-based pair kernels take as many test points per launch as make >= 32 rounds of workgroups (csrc/predict.hip
+    pair_chunk; 256 before), the Matern kernel's records of a step are requested between its column tiles instead of behind the
+    step's barrier, with scalar addresses.  None of that touches a pair's arithmetic: the earlier geometry (DGPAMD_PAIR_CHUNK=256,
+    DGPAMD_JSEP_PIPE=0), other points per workgroup (DGPAMD_JSEP_TCH) and a chunk that is no multiple of the workgroup's points
+    give the same bits -- M spans several launches, the last one ragged -- and a slice equals the oracle (functions.py:453-494)."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(41)
+    X = rng.uniform(size=(n, Dw + Dz))
+    y = rng.normal(size=n)
+    length = rng.uniform(0.4, 1.2, size=Dw + Dz)
+    st = O.compute_stats(X, y, length, 1e-3, kind, Dw)
+    mm = rng.uniform(-0.2, 1.2, size=(M, Dw))
+    vv = 10.0 ** rng.uniform(-5, 0, size=(M, Dw))
+    vv[::19] = 0.0
+    z = rng.uniform(size=(M, Dz)) if Dz else None
+    args = (eng.tensor(mm), eng.tensor(vv), eng.tensor(z) if Dz else None, eng.tensor(X[:, :Dw]), eng.tensor(X[:, Dw:]) if Dz else None, length,
+            eng.tensor(st['Rinv']), n, eng.tensor(st['Rinv_y']), 1.4, 1e-3)
+    for v in ('DGPAMD_PAIR_CHUNK', 'DGPAMD_JSEP_PIPE', 'DGPAMD_JSEP_TCH'):
+        monkeypatch.delenv(v, raising=False)
+    m0, v0 = (npy(t) for t in eng.linkgp_predict(kind, *args))
+    for env in ({'DGPAMD_PAIR_CHUNK': '256', 'DGPAMD_JSEP_PIPE': '0'}, {'DGPAMD_JSEP_TCH': '16'}, {'DGPAMD_JSEP_TCH': '64', 'DGPAMD_PAIR_CHUNK': '416'},
+                {'DGPAMD_PAIR_CHUNK': '96', 'DGPAMD_JSEP_PIPE': '0', 'DGPAMD_JSEP_TCH': '8'}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        m1, v1 = (npy(t) for t in eng.linkgp_predict(kind, *args))
+        for k in env:
+            monkeypatch.delenv(k)
+        np.testing.assert_array_equal(m1, m0, err_msg=str(env))
+        np.testing.assert_array_equal(v1, v0, err_msg=str(env))
+    sl = slice(M - 12, M)
+    lmr, lvr = O.link_gp_predict(mm[sl], vv[sl], None if z is None else z[sl], X[:, :Dw], X[:, Dw:] if Dz else None, st['Rinv'], st['Rinv_y'], 1.4, length, 1e-3, kind)
+    close(m0[sl], lmr, rtol=1e-8, atol=1e-10)
+    close(v0[sl], lvr, rtol=1e-6, atol=1e-8)
+
+
 @pytest.mark.parametrize('name,n,Dz', [('sexp', 70, 1), ('matern2.5', 131, 2), ('matern2.5', 64, 0)])
 def test_linkgp_loo_equals_oracle_refit(eng, name, n, Dz):
     """dgpamd_linkgp_loo: test point t conditioned on all training points but drop[t] (arbitrary indices, as the
