@@ -547,15 +547,23 @@ __global__ __launch_bounds__(256, 2) void potrf_step_kernel(StepArgs g) {
 #define VER_PLANES 4   // version words per matrix: buffers A, T, S + one plane of auxiliary words
 #define MEGA_SPIN_LIMIT (1 << 20)   // polls of ~1 us: a lost hand-off gives up after about a second
 
+// One word on a 128-byte line of its own.  Round 5: the queue heads (one returning atomic per task pulled), the status word and the first sixteen matrices' W_k
+// counters used to share ONE line -- every publication of a W_k by a chain queued behind the workers' ticket atomics and the polls of everyone who waited for any
+// matrix's W (the "hot line" effects of profiles/r05_mega_table_sweeps.txt: one more read per solve of that line cost 15 %).
+struct alignas(128) MegaLine {
+    int32_t v;
+    int32_t fill[31];
+};
 struct MegaSync {   // zeroed by a memset node ahead of every launch; the version words follow it
     int32_t qhead;                  // (unused)
     int32_t status;                 // 0, or the code of the first spin that gave up
-    int32_t ghead[8];               // queue head of each group of matrices (see MegaArgs::ngroups)
-    int32_t pad[6];
-    int32_t wflag[DGPAMD_MAXB];     // per matrix: blocks factored (W_k is readable for k < wflag)
-    int32_t cukey[DGPAMD_MAXB];     // per matrix: CU of its chain workgroup (cu_key())
-    int32_t uhead[8];               // head of each group's CRITICAL queue (ghead: the bulk queue's), see MegaArgs::nut
+    int32_t pad[30];                // (pad[0]: the spare word of the deferred post-processing)
+    MegaLine ghead[8];              // queue head of each group of matrices (see MegaArgs::ngroups)
+    MegaLine uhead[8];              // head of each group's CRITICAL queue (ghead: the bulk queue's), see MegaArgs::nut
+    int32_t cukey[DGPAMD_MAXB];     // per matrix: CU of its chain workgroup (cu_key()); read once by every worker
+    MegaLine wflag[DGPAMD_MAXB];    // per matrix: blocks factored (W_k is readable for k < wflag)
 };
+static_assert(sizeof(MegaSync) % 128 == 0, "MegaSync is whole lines");
 
 struct MTask {
     int4 a;   // as the per-launch tables: what / where (make_task)
@@ -702,7 +710,7 @@ __device__ __forceinline__ void mega_chain(const MegaArgs &g, const int b, doubl
     const int64_t ld = g.ld;
     double *A = g.buf[BUF_A] + (int64_t)b * g.stride_a;
     int32_t *ver = g.ver + (int64_t)b * VER_PLANES * g.nbk * g.nbk;   // buffer A's versions first
-    int32_t *wflag = g.sync->wflag + b;
+    int32_t *wflag = &g.sync->wflag[b].v;
     long long *tr = (g.trace && b == 0 && tid == 0) ? g.trace : nullptr;
     __builtin_amdgcn_s_setprio(3);
     if (tid == 0) __hip_atomic_store(&g.sync->cukey[b], cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1022,7 +1030,7 @@ __device__ __forceinline__ void mega_chain2(const MegaArgs &g, const int b, doub
     const int64_t ld = g.ld;
     double *A = g.buf[BUF_A] + (int64_t)b * g.stride_a;
     int32_t *ver = g.ver + (int64_t)b * VER_PLANES * g.nbk * g.nbk;   // buffer A's versions first
-    int32_t *wflag = g.sync->wflag + b;
+    int32_t *wflag = &g.sync->wflag[b].v;
     long long *tr = (g.trace && b == 0 && tid == 0) ? g.trace : nullptr;
     long long *tl = (g.tlog && tid == 0) ? g.tlog + 64 + 8 * (int64_t)b * g.nbk : nullptr;   // (full log: every matrix)
     if (tl && b == 0) g.tlog[0] = wall_clock64();
@@ -1245,7 +1253,7 @@ __device__ __noinline__ int mega_pull(MegaSync *sync, int grp, int nbg, int nut,
         const int eu = qempty[0], eb = qempty[1];
         const int pick = (role == 0 ? !eu : eb) ? 0 : 1;   // 0: critical queue
         if (pick == 0 ? eu : eb) break;
-        const int t = __hip_atomic_fetch_add(pick == 0 ? &sync->uhead[grp] : &sync->ghead[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int t = __hip_atomic_fetch_add(pick == 0 ? &sync->uhead[grp].v : &sync->ghead[grp].v, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t < (pick == 0 ? ucap : bcap)) return pick == 0 ? t : (t | (1 << 30));
         qempty[pick] = 1;
     }
@@ -1366,7 +1374,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(MegaArgs g) {
         int32_t *vC = ver + bufC * nb2 + ci * g.nbk + cj;
         double *C = g.buf[bufC] + mo + ((int64_t)ci * 64) * ld + (int64_t)cj * 64;
         double *Wk = g.ws + (int64_t)b * g.stride_ws + (int64_t)wk * 4096;
-        int32_t *wflag = g.sync->wflag + b;
+        int32_t *wflag = &g.sync->wflag[b].v;
         const int newver = fin ? VER_FINAL : need_c + 1;
         int qn = 0;
         auto pull_next = [&]() {
@@ -1619,10 +1627,10 @@ size_t potrf_ws_doubles(int64_t n, int batch) {
 }
 
 static size_t mega_sync_bytes(int64_t nbk, int batch);
-// offset of the one-launch kernel's synchronisation block inside the workspace (16-byte aligned)
+// offset of the one-launch kernel's synchronisation block inside the workspace (on a 128-byte line: its hot words have lines of their own)
 static size_t mega_sync_offset(int64_t n, int batch) {
     const size_t b = potrf_ws_doubles(n, batch) * sizeof(double) + 3 * DGPAMD_MAXB * sizeof(int32_t);   // + info, step flags, chain CU keys
-    return (b + 15) / 16 * 16;
+    return (b + 127) / 128 * 128;
 }
 // offset of the one-launch kernel's pivot array (batch x Np doubles) behind the synchronisation block
 static size_t mega_piv_offset(int64_t n, int batch) {
