@@ -1921,8 +1921,11 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTab
     const int look = elk ? (atoi(elk) != 0) : 1;
     const char *esl = getenv("DGPAMD_MEGA_SLAG");
     const int slag = esl ? (atoi(esl) < 0 ? 0 : (atoi(esl) > 8 ? 8 : atoi(esl))) : 0;
-    const char *eq = getenv("DGPAMD_MEGA_QUEUES");   // 1: one queue per group of matrices (rounds 2-4)
-    const int queues = eq && atoi(eq) == 1 ? 1 : 2;
+    // Two queues (critical lane + bulk) up to three matrices, one from four on.  (Re-measured after the synchronisation block's words got lines of their own,
+    // profiles/r05_mega_table_sweeps.txt: most of what the critical queue had gained at four and more matrices was that ITS head did not share the line of the W
+    // counters -- with every word on its own line one queue is 1-5 % faster there, the two still 1.5-3 % at one to three.)
+    const char *eq = getenv("DGPAMD_MEGA_QUEUES");   // 1: one queue per group of matrices (rounds 2-4); 2: critical + bulk
+    const int queues = eq ? (atoi(eq) == 1 ? 1 : 2) : (batch <= 3 ? 2 : 1);
     static std::map<std::pair<dgpamd_ctx *, std::array<int, 10>>, MegaTable> cache;
     MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy, near, lag, xcatch, look, queues, slag}}];
     if (!mt.dev) {
@@ -2011,7 +2014,10 @@ static int potrf_mega_launch(dgpamd_ctx *ctx, int64_t n, double *A, double *T, d
         const char *eg = getenv("DGPAMD_MEGA_GROUPS");
         // (measured at n = 2000, tools/gpu_lazy_sweep.py: uneven groups are fine -- an XCD whose own queue has run out takes
         // from the others -- so odd batches use two groups as well: potrf_inv -10 % at 3 matrices, -7 % at 6, -12 % at 12)
-        int G = eg ? atoi(eg) : (batch % 8 == 0 ? 8 : batch % 4 == 0 ? 4 : batch >= 2 ? 2 : 1);
+        // (round 5, same sweeps: three matrices with the inverse, and odd batches without it, are 3-5 % faster as ONE group -- two groups of 2 + 1 or 3 + 2
+        //  matrices leave half the XCDs with the smaller share until their queue runs out)
+        const bool one_group = (batch & 1) && (batch == 3 || !g.inv);
+        int G = eg ? atoi(eg) : (one_group ? 1 : batch % 8 == 0 ? 8 : batch % 4 == 0 ? 4 : batch >= 2 ? 2 : 1);
         if (G != 1 && G != 2 && G != 4 && G != 8) G = 1;
         while (G > batch) G >>= 1;
         g.ngroups = G;
