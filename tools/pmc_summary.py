@@ -106,3 +106,13 @@ for nm in kst:
     e = entry('standalone ' + nm + ' n=8192 D=10 full', c, us, dict(duration_from='GRBM_GUI_ACTIVE / 8 at 2.4 GHz'))
     e['valu_per_entry'] = e['valu_per_wave'] / 16.0
 json.dump(res, open(out, 'w'), indent=1)
+# ... and the potrf entry in the form bench.py reads for roofline.traffic (profiles/rNN_pmc_bench_potrf_kernel.json)
+import os
+pe = res['potrf_mega_kernel']
+cmd = next((ln[1:].strip() for ln in open(d + '/pmc_bench_kernels.txt') if ln.startswith('#')), '')
+json.dump({'kernel': 'potrf_mega_kernel', 'launches': pe['launches'], 'fetch_size_kb_per_launch_raw': pe['counters']['FETCH_SIZE'],
+           'write_size_kb_per_launch': pe['counters']['WRITE_SIZE'], 'hbm_bytes_per_launch': pe['hbm_side_bytes_per_launch'],
+           'how': 'FETCH_SIZE x 2 + WRITE_SIZE per launch, the x 2 calibrated for each load form of the kernel (16-byte plain, 16-byte buffer sc1, 8-byte sc1 all report '
+                  'exactly 1/2: profiles/r05_pmc_fetch_calibration.txt); fabric-side traffic, Infinity-Cache hits included',
+           'command': cmd.split('(one pass per set')[0].strip().replace('<set>', 'FETCH_SIZE|WRITE_SIZE (separate passes)')},
+          open(os.path.join(os.path.dirname(out), 'r05_pmc_bench_potrf_kernel.json'), 'w'))
