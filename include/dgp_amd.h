@@ -364,7 +364,10 @@ int dgpamd_debug_trace(dgpamd_ctx *ctx, long long *device_buf);
  * 64 + 8 batch nbk + 8 (b ntask + slot): pulled, inputs seen, arithmetic done, W_k seen, stored, published, workgroup.  A log that
  * would not fit is not written.  dgpamd_debug_mega_table copies the task table those slots index (8 int32 per task as MTask, then
  * 2 int32 per block: the visits of A[k+1][k] and A[k+1][k+1] the chain waits for) and returns the number of tasks, or a
- * negative status.  NULL switches the log off (the default). */
+ * negative status.  NULL switches the log off (the default).  With DGPAMD_JSEP_LOG=1 in the environment the same buffer takes the
+ * step log of the next Matern pair-kernel launch of dgpamd_linkgp_predict instead (per workgroup 8 + 48 x 4 x 2 int64 from word 64:
+ * start / end on the 100-MHz clock and in shader cycles, HW_ID, XCC_ID, tile, steps; then per step and wave the cycle counts at the
+ * arrival at and the departure from the step's barrier, the order class in the top bits: tools/gpu_pair_steplog.py). */
 int dgpamd_debug_tasklog(dgpamd_ctx *ctx, long long *device_buf, long long words);
 int dgpamd_debug_mega_table(dgpamd_ctx *ctx, int64_t n, int inv, int batch, int32_t *host_out, int64_t cap_words);
 int dgpamd_linkgp_predict(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz,
