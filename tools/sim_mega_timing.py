@@ -123,9 +123,11 @@ class Sim:
     """One launch.  Model constants (us) from the task logs: a panel 2.8 alone .. 4.8 with every worker computing, the chain's factor 7.5 .. 8.7,
     stores 1.5 .. 2.5, a publication visible 1.0 .. 2.5 later."""
 
-    def __init__(self, tasks, need, B, nbk, inv, queues=2, ncrit=None, groups=None, split=True):
+    def __init__(self, tasks, need, B, nbk, inv, queues=2, ncrit=None, groups=None, split=True, window=0):
         self.tasks, self.need, self.B, self.nbk, self.inv = tasks, need, B, nbk, inv
         self.split = split
+        self.window = window   # > 0: a worker takes the first task among the next `window` of its queue whose first inputs have arrived (an idealised ready list)
+        self.taken = {}
         G = groups or (8 if B % 8 == 0 else 4 if B % 4 == 0 else 2 if B >= 2 else 1)
         while G > B:
             G //= 2
@@ -242,6 +244,27 @@ class Sim:
             for qi in order:
                 cap = len(self.q[qi]) * nbg
                 h = self.heads[grp][qi]
+                if self.window:
+                    tk_set = self.taken.setdefault((grp, qi), set())
+                    while h < cap and h in tk_set:
+                        h += 1
+                    self.heads[grp][qi] = h
+                    if h < cap:
+                        pick, seen = h, 0
+                        for c in range(h, cap):
+                            if c in tk_set:
+                                continue
+                            seen += 1
+                            if seen > self.window:
+                                break
+                            if self.ready_now(self.q[qi][c // nbg], grp + self.G * (c % nbg), t):
+                                pick = c
+                                break
+                        tk_set.add(pick)
+                        w['grp'] = grp
+                        self.run_task(w, self.q[qi][pick // nbg], grp + self.G * (pick % nbg), t)
+                        return
+                    continue
                 if h < cap:
                     self.heads[grp][qi] += 1
                     slot, b = h // nbg, grp + self.G * (h % nbg)
@@ -249,6 +272,23 @@ class Sim:
                     self.run_task(w, self.q[qi][slot], b, t)
                     return
         # nothing left anywhere
+
+    def has(self, b, buf, i, j, ver, t):
+        if ver <= 0:
+            return True
+        return any(v >= ver and tv <= t for v, tv in self.avail.get((b, buf, i, j), ()))
+
+    def ready_now(self, tk, b, t):
+        if tk['post'] == TDIAG:
+            return (b, tk['wk']) in self.wavail and self.wavail[(b, tk['wk'])] <= t
+        nkb, kb0 = tk['nkb'], tk['kb0']
+        n1 = nkb - 1 if (self.split and nkb >= 2) else nkb
+        if not self.has(b, tk['bufC'], tk['ci'], tk['cj'], tk['need_c'], t):
+            return False
+        for kb in range(kb0, kb0 + n1):
+            if not (self.has(b, tk['bufL'], tk['li'], kb, FINAL, t) and self.has(b, tk['bufR'], tk['ri'], kb, FINAL, t)):
+                return False
+        return True
 
     def run_task(self, w, tk, b, t):
         post, nkb, kb0 = tk['post'], tk['nkb'], tk['kb0']
@@ -365,7 +405,7 @@ class Sim:
 
 
 def model(B, inv, nbk=32, **kw):
-    simkw = {k: kw.pop(k) for k in list(kw) if k in ('queues', 'ncrit', 'groups', 'split')}
+    simkw = {k: kw.pop(k) for k in list(kw) if k in ('queues', 'ncrit', 'groups', 'split', 'window')}
     deep = B >= 6
     p = dict(lazy=(12 if inv else 10) if deep else (10 if inv else 8), slazy=(12 if inv else 10) if deep else (10 if inv else 8), near=3,
              stail=1 if (inv and B <= 3) else 0)
