@@ -220,7 +220,7 @@ def potrf_table(eng, torch, n=2000):
                                potrf_inv_ms=v, potrf_inv_tflops=B * n ** 3 / v / 1e9, potrf_inv_frac=B * n ** 3 / v / 1e9 / F64_PEAK_TFLOPS)
         del A, T, S
     out['note'] = ('n=%d; one call = one potrf_mega_kernel launch (+ its memset / copy-out), minimum of 4; one matrix is bound by the 31-step '
-                   'pivot chain (12.6 us per step alone, 13.9 with the inverse's tasks around it), an M-step round holds 1-5 matrices with the inverse, a speculative ESS batch 10 or 6 without' % n)
+                   'pivot chain (12.6 us per step alone, 13.9 with the tasks of the inverse around it), an M-step round holds 1-5 matrices with the inverse, a speculative ESS batch 10 or 6 without' % n)
     return out
 
 
