@@ -1187,14 +1187,17 @@ __global__ __launch_bounds__(256) void linkgp_finalize_kernel(LinkArgs a, int nt
 // slots idle: at n = 2000 with 256 points per launch that was 8.25 rounds and 10 % of the kernel's time (tools/gpu_pair_steplog.py:
 // slot occupancy 0.32 over the last tenth of the launch).  >= 32 rounds per launch bound that loss by 1-2 %; the records of a launch
 // (Matern: points x Dw x npad x 240 B) are kept under 4 GiB, and a launch never holds fewer than MC_SEP points.
-static int64_t pair_chunk(int64_t nb, int64_t Mc, int Dw, int per_wg) {
+static int64_t pair_chunk(int64_t nb, int64_t Mc, int Dw, int per_wg, int64_t rec_doubles_per_point) {
     const int64_t ntiles = nb * (nb + 1) / 2;
     int64_t want = ((32 * 512 + ntiles - 1) / ntiles) * per_wg;
-    const int64_t cap = (((int64_t)4 << 30) / ((int64_t)(Dw * REC + 1) * nb * 64 * (int64_t)sizeof(double))) / per_wg * per_wg;
+    const int64_t cap = (((int64_t)4 << 30) / (rec_doubles_per_point * (int64_t)sizeof(double))) / per_wg * per_wg;
     if (want > cap) want = cap;
     if (want < MC_SEP) want = MC_SEP;
     return Mc < want ? Mc : want;
 }
+// doubles of records per test point: Matern (Dw x npad records of REC + the global factor), SExp second form (npad x (KPA <= 16) + ss)
+static int64_t matern_rec_doubles(int64_t nb, int Dw) { return (int64_t)(Dw * REC + 1) * nb * 64; }
+static int64_t sexp_rec_doubles(int64_t nb, int Dw) { return (int64_t)(((Dw + 2 + 3) & ~3) + 1) * nb * 64; }
 
 static int jsep_tch() {   // test points per workgroup of linkgp_Jsep_kernel (DGPAMD_JSEP_TCH: comparison runs)
     if (getenv("DGPAMD_JSEP_TCH")) {
@@ -1208,12 +1211,13 @@ extern "C" size_t dgpamd_linkgp_workspace(int64_t n, int64_t M, int Dw) {
     int64_t nb = (n + 63) / 64;
     int64_t Mc = ((M + TCH - 1) / TCH) * TCH;
     if (Mc > MC_MAX) Mc = MC_MAX;
-    int64_t Ms = pair_chunk(nb, Mc, Dw, jsep_tch());   // (the Matern records are the larger ones)
+    // (the records of one launch: the larger of the Matern and the SExp form's -- the call's kind is not known here)
+    int64_t recs = pair_chunk(nb, Mc, Dw, jsep_tch(), matern_rec_doubles(nb, Dw)) * matern_rec_doubles(nb, Dw);
     {
-        const int64_t m2 = pair_chunk(nb, Mc, Dw, TCH2);
-        if (m2 > Ms) Ms = m2;
+        const int64_t r2 = pair_chunk(nb, Mc, Dw, TCH2, sexp_rec_doubles(nb, Dw)) * sexp_rec_doubles(nb, Dw);
+        if (r2 > recs) recs = r2;
     }
-    return (size_t)(nb * (nb + 1) / 2 * Mc + Ms * (int64_t)Dw * nb * 64 * REC + Ms * nb * 64) * sizeof(double);
+    return (size_t)(nb * (nb + 1) / 2 * Mc + recs) * sizeof(double);
 }
 
 static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, int Dz, const double *m, const double *v,
@@ -1245,14 +1249,15 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
     a.recs = a.partial + (int64_t)ntiles * Mc;
     a.npad = (int64_t)nb * 64;
     const bool sx2 = (kind == DGPAMD_SEXP) && !direct && Dw + 2 <= 16;
-    if (sep) Mc = pair_chunk(nb, Mc, Dw, a.tch);   // records of one chunk: Mc*Dw*npad*240 B (Matern), Mc*npad*(Dw+3..6)*8 B (SExp)
-    if (sx2) Mc = pair_chunk(nb, Mc, Dw, TCH2);
+    if (sep) Mc = pair_chunk(nb, Mc, Dw, a.tch, matern_rec_doubles(nb, Dw));   // records of one chunk: Mc*Dw*npad*240 B (Matern), Mc*npad*(Dw+3..6)*8 B (SExp)
+    if (sx2) Mc = pair_chunk(nb, Mc, Dw, TCH2, sexp_rec_doubles(nb, Dw));
     if (getenv("DGPAMD_PAIR_CHUNK") && (sep || sx2)) {   // (comparison runs: the fixed 256 points per launch of the earlier builds)
         const int64_t c = atoll(getenv("DGPAMD_PAIR_CHUNK"));
         if (c >= TCH && c < Mc) Mc = c / TCH * TCH;
     }
     a.Mc = Mc;
-    a.gfac = a.recs + Mc * (int64_t)Dw * a.npad * REC;
+    a.gfac = sx2 ? a.recs + Mc * a.npad * (int64_t)((Dw + 2 + 3) & ~3)   // (SExp second form: [Mc][npad][KPA] records, then the ss values)
+                 : a.recs + Mc * (int64_t)Dw * a.npad * REC;
     const int DT = Dw + Dz;
     size_t shm = ((size_t)2 * DT * 64 + (size_t)TCH * (2 * Dw + Dz) + TCH * 4) * sizeof(double);
     if (kind == DGPAMD_MATERN25) shm += 64 * 65 * sizeof(double);
