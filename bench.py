@@ -352,6 +352,9 @@ def main():
     if world_env != max(1, args.gpus):
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world_env, args.gpus))
 
+    # (the pool's host driver supports dmabuf IPC only: RCCL between processes fails with `hipIpcGetMemHandle: invalid argument` otherwise; the
+    #  launcher's environment carries it already -- set before the HIP runtime starts in case it does not)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
     from dgp_amd import dist as dd
     from dgp_amd import kernel_class
