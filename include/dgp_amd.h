@@ -129,8 +129,10 @@ int dgpamd_kmatrix(dgpamd_ctx *ctx, int kind, int64_t n,
  * functions.py:109,119 ; logdet_nb functions.py:220-222 ; cho_solve with y
  * kernel_class.py:423,487.
  * In place on `batch` augmented buffers (see top).  logdet[b] = 2 sum log L_ii;
- * info[b] as LAPACK.  work: dgpamd_potrf_workspace(n,batch) bytes; it keeps the
- * inverses of the 64x64 diagonal blocks for dgpamd_potri.                      */
+ * info[b] as LAPACK.  work: dgpamd_potrf_workspace(n,batch) bytes of device memory starting on a
+ * 128-byte line (any allocator's base address does; the one-launch kernel's synchronisation words
+ * sit on cache lines of their own inside it); it keeps the inverses of the 64x64 diagonal blocks
+ * for dgpamd_potri.                                                                            */
 size_t dgpamd_potrf_workspace(int64_t n, int batch);
 int dgpamd_potrf(dgpamd_ctx *ctx, int64_t n, double *A, int64_t stride_a, int batch,
                  double *logdet, int32_t *info, void *work);
