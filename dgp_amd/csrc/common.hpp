@@ -238,27 +238,50 @@ __device__ __forceinline__ double exp_negated_v3(double x) {
     return p * __hiloint2double((ki + 1023) << 20, 0);
 }
 
-// The same with a 64-entry table tab[j] = 2^(j/64) (in LDS): exp(-x) = 2^e tab[j] exp(r), k = round(-64 x / ln 2) = 64 e + j,
-// |r| <= ln 2 / 128, so a degree-5 polynomial (truncation 3.5e-17) replaces the degree-12 one: 10 double-precision
-// instructions instead of 17, plus five integer ones and one LDS read that do not occupy the double-precision units.  For a
+// The same with a table tab[j] = 2^(j/N) (in LDS): exp(-x) = 2^e tab[j] exp(r), k = round(-N x / ln 2) = N e + j,
+// |r| <= ln 2 / 2N, so a short polynomial replaces the degree-12 one (N = 64: degree 5, truncation 3.5e-17, 10 double-precision
+// instructions instead of 17; N = 256, since round 5: degree 4, nine), plus five integer ones and one LDS read that do not occupy the double-precision units.  For a
 // kernel whose inner loop leaves the LDS pipe idle (linkgp_Jsexp2_kernel; in one that feeds MFMA operands from LDS the table
 // reads cost more than they saved, round 2).
+#define EXPN_TAB 256   // entries of exp_negated_tab's table (tab[j] = 2^(j / EXPN_TAB))
 __device__ __forceinline__ double exp_negated_tab(double x, const double *tab) {
+    // (round 5: 256 entries instead of 64 -- |r| <= ln 2 / 512, a degree-4 polynomial (truncation r^5 / 120 <= 3.8e-17) instead of the degree-5 one:
+    //  nine double-precision instructions; the kernel that uses it is bound by exactly those)
     const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
-    const double kf = fma(x, -9.23324826168936567680e+01, MAGIC);   // 64 / ln 2
+    const double kf = fma(x, -3.69329930467574632284e+02, MAGIC);   // 256 / ln 2
     const double k = kf - MAGIC;
-    double r = fma(k, -6.93147180369123816490e-01 / 64.0, -x);
-    r = fma(k, -1.90821492927058770002e-10 / 64.0, r);
-    double p = 8.33333333333333333333e-03;
-    p = fma(p, r, 4.16666666666666666667e-02);
+    double r = fma(k, -6.93147180369123816490e-01 / 256.0, -x);
+    r = fma(k, -1.90821492927058770002e-10 / 256.0, r);
+    double p = 4.16666666666666666667e-02;
     p = fma(p, r, 1.66666666666666666667e-01);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     const int ki = __double2loint(kf);
-    int e = ki >> 6;
+    int e = ki >> 8;
     e = e < -1021 ? -1021 : e;
-    const double v = tab[ki & 63] * p;
+    const double v = tab[ki & 255] * p;
+    return __hiloint2double(__double2hiint(v) + (e << 20), __double2loint(v));
+}
+
+// exp_negated_tab in two halves, for a caller that issues the table read well ahead of its use (the LDS round trip sat in front of every
+// exponential of linkgp_Jsexp2_kernel otherwise: the scheduler sinks a load to its use): the same operations, the same bits.
+__device__ __forceinline__ void exp_negated_tab_begin(double x, const double *tab, double &kf, double &t) {
+    kf = fma(x, -3.69329930467574632284e+02, 6755399441055744.0);
+    t = tab[__double2loint(kf) & (EXPN_TAB - 1)];
+}
+__device__ __forceinline__ double exp_negated_tab_end(double x, double kf, double t) {
+    const double k = kf - 6755399441055744.0;
+    double r = fma(k, -6.93147180369123816490e-01 / 256.0, -x);
+    r = fma(k, -1.90821492927058770002e-10 / 256.0, r);
+    double p = 4.16666666666666666667e-02;
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int e = __double2loint(kf) >> 8;
+    e = e < -1021 ? -1021 : e;
+    const double v = t * p;
     return __hiloint2double(__double2hiint(v) + (e << 20), __double2loint(v));
 }
 

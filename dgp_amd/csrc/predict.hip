@@ -684,11 +684,11 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
     double *WiT = lds;                    // [Dw][64]
     double *WjT = WiT + Dw * 64;          // [Dw][64]
     double *red = WjT + Dw * 64;          // [TCH2][4]
-    double *etab = red + TCH2 * 4;        // [64]: 2^(j/64), exp_negated_tab's table
+    double *etab = red + TCH2 * 4;        // [EXPN_TAB]: 2^(j/EXPN_TAB), exp_negated_tab's table
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < 64) etab[tid] = exp2((double)tid * (1.0 / 64.0));
+    for (int j = tid; j < EXPN_TAB; j += 256) etab[j] = exp2((double)j * (1.0 / EXPN_TAB));
     const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
     const int64_t tbase = a.t0 + (int64_t)blockIdx.y * TCH2, tt0 = (int64_t)blockIdx.y * TCH2;
     int nt = TCH2;
@@ -749,14 +749,21 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
             en[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[ks], bv, ks == 0 ? base[tt] : en[tt], 0, 0, 0);
         }
     };
-    // exponentials of column tile g of `e`, weights Cr
-    auto group = [&](const d4 (&e)[4], int g, double &acc) {
+    // exponentials of column tile g of `e`, weights Cr.  TAB: the table reads of tile g + 1 are issued (begin) before tile g's arithmetic and pinned there,
+    // so that their LDS round trip runs under it (they sat, one by one, directly in front of their use).
+    double kfa[4], ta[4], kfb[4], tb[4];
+    auto begin = [&](const d4 (&e)[4], int g, double (&kf)[4], double (&t)[4]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = fma(Cr[g][r], TAB ? exp_negated_tab(e[g][r], etab) : exp_negated(e[g][r]), acc);
+        for (int r = 0; r < 4; ++r) exp_negated_tab_begin(e[g][r], etab, kf[r], t[r]);
+    };
+    auto group = [&](const d4 (&e)[4], int g, double &acc, const double (&kf)[4], const double (&t)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = fma(Cr[g][r], TAB ? exp_negated_tab_end(e[g][r], kf[r], t[r]) : exp_negated(e[g][r]), acc);
     };
     // test point t from `e`, while test point t + 1 (fragments f1) goes into `en`; f2 <- fragments of t + 2
     auto step = [&](int t, const d4 (&e)[4], d4 (&en)[4], const Frag &f1, Frag &f2) {
         f2 = fetch(t + 2);
+        if (TAB) begin(e, 0, kfa, ta);
         __builtin_amdgcn_sched_barrier(0);
         double acc = 0.0;
 #pragma unroll
@@ -767,13 +774,19 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
             // slower).  Measured: the f64 MFMA and the f64 VALU work do NOT overlap on gfx950 whatever the order -- the run time
             // is the sum of the two (41 ms = 29 without the products + 12; 78.6 TFLOP/s is the matrix AND the vector f64 peak:
             // one set of double-precision units) -- so the order only keeps the products' operands off the critical path.
+            if (TAB && g < 3) {
+                if (g & 1) begin(e, g + 1, kfa, ta);
+                else begin(e, g + 1, kfb, tb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (g < KS) kstep(f1, g, en);
-            group(e, g, acc);
+            if (g & 1) group(e, g, acc, kfb, tb);
+            else group(e, g, acc, kfa, ta);
             if (g < KS) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, TAB ? 19 : 21, 0);   // the VALU instructions of about one exponential
+                    __builtin_amdgcn_sched_group_barrier(0x002, TAB ? 16 : 21, 0);   // the VALU instructions of about one exponential
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1280,7 +1293,7 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
                 hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_SEXP, false>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else if (Dw + 2 <= 4 * SX_KS && !getenv("DGPAMD_SEXP_FORM1")) {
                 const int KPA = (Dw + 2 + 3) & ~3;
-                const size_t shm2 = ((size_t)2 * Dw * 64 + TCH2 * 4 + 64) * sizeof(double);
+                const size_t shm2 = ((size_t)2 * Dw * 64 + TCH2 * 4 + EXPN_TAB) * sizeof(double);
                 const bool poly = getenv("DGPAMD_SEXP_POLY") != nullptr;   // (comparison run: the table-free exponential)
                 const unsigned tb2 = (unsigned)((mc + TCH2 - 1) / TCH2);
                 hipLaunchKernelGGL(sexp_records_kernel, dim3((unsigned)((a.npad + 255) / 256), (unsigned)mc), dim3(256), 0, ctx->stream, a, KPA);
