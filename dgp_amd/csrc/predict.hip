@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void sexp_records_kernel(LinkArgs a, int KPA) 
 // KS = k-steps (compile time: no branches in the loop over test points).  The MFMAs of test point t + 1 are issued between
 // the four column-tile groups of test point t's exponentials.  The loop is unrolled by two so that the exponent tiles of
 // consecutive test points alternate between two register sets without copies.
-#define TCH2 128   // test points per workgroup of the second SExp form: the tile's weights and base exponents (a 32-KB tile of
+#define TCH2 128   // test points per workgroup of the second SExp form (256 where that still leaves >= 32 rounds of workgroups: sexp_tch2): the tile's weights and base exponents (a 32-KB tile of
                    // R^-1 read, 16 x Dw LDS reads per lane) are set up once per TCH2 test points -- at 32 that was 40 % of the run time
 template <int KS, bool TAB>
 __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
@@ -683,15 +683,16 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
     const int Dw = a.Dw;
     double *WiT = lds;                    // [Dw][64]
     double *WjT = WiT + Dw * 64;          // [Dw][64]
-    double *red = WjT + Dw * 64;          // [TCH2][4]
-    double *etab = red + TCH2 * 4;        // [EXPN_TAB]: 2^(j/EXPN_TAB), exp_negated_tab's table
+    const int tch2 = a.tch;               // (this kernel's test points per workgroup)
+    double *red = WjT + Dw * 64;          // [tch2][4]
+    double *etab = red + tch2 * 4;        // [EXPN_TAB]: 2^(j/EXPN_TAB), exp_negated_tab's table
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int j = tid; j < EXPN_TAB; j += 256) etab[j] = exp2((double)j * (1.0 / EXPN_TAB));
     const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64, n = a.n;
-    const int64_t tbase = a.t0 + (int64_t)blockIdx.y * TCH2, tt0 = (int64_t)blockIdx.y * TCH2;
-    int nt = TCH2;
+    const int64_t tbase = a.t0 + (int64_t)blockIdx.y * tch2, tt0 = (int64_t)blockIdx.y * tch2;
+    int nt = tch2;
     if (tbase + nt > a.M) nt = (int)(a.M - tbase);
     if (tbase + nt > a.t0 + a.Mc) nt = (int)(a.t0 + a.Mc - tbase);
     for (int idx = tid; idx < 64 * Dw; idx += 256) {
@@ -1212,6 +1213,16 @@ static int64_t pair_chunk(int64_t nb, int64_t Mc, int Dw, int per_wg, int64_t re
 static int64_t matern_rec_doubles(int64_t nb, int Dw) { return (int64_t)(Dw * REC + 1) * nb * 64; }
 static int64_t sexp_rec_doubles(int64_t nb, int Dw) { return (int64_t)(((Dw + 2 + 3) & ~3) + 1) * nb * 64; }
 
+// Test points per workgroup of linkgp_Jsexp2_kernel: a workgroup's set-up (the tile's weights and base exponents) is amortised over them -- 256 where a launch of
+// MC_MAX points still has 32 rounds of workgroups (n = 5000: 28.5 -> 27.4 ms per 2048 points), 128 below (n = 2000: 256 would leave 8 rounds and cost 6 %).
+static int sexp_tch2(int64_t nb) {
+    if (getenv("DGPAMD_JSEXP_TCH")) {
+        const int c = atoi(getenv("DGPAMD_JSEXP_TCH"));
+        if (c == 64 || c == 128 || c == 256) return c;
+    }
+    return nb * (nb + 1) / 2 * (MC_MAX / 256) >= 32 * 512 ? 256 : TCH2;
+}
+
 static int jsep_tch() {   // test points per workgroup of linkgp_Jsep_kernel (DGPAMD_JSEP_TCH: comparison runs)
     if (getenv("DGPAMD_JSEP_TCH")) {
         const int c = atoi(getenv("DGPAMD_JSEP_TCH"));
@@ -1227,7 +1238,7 @@ extern "C" size_t dgpamd_linkgp_workspace(int64_t n, int64_t M, int Dw) {
     // (the records of one launch: the larger of the Matern and the SExp form's -- the call's kind is not known here)
     int64_t recs = pair_chunk(nb, Mc, Dw, jsep_tch(), matern_rec_doubles(nb, Dw)) * matern_rec_doubles(nb, Dw);
     {
-        const int64_t r2 = pair_chunk(nb, Mc, Dw, TCH2, sexp_rec_doubles(nb, Dw)) * sexp_rec_doubles(nb, Dw);
+        const int64_t r2 = pair_chunk(nb, Mc, Dw, sexp_tch2(nb), sexp_rec_doubles(nb, Dw)) * sexp_rec_doubles(nb, Dw);
         if (r2 > recs) recs = r2;
     }
     return (size_t)(nb * (nb + 1) / 2 * Mc + recs) * sizeof(double);
@@ -1263,7 +1274,10 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
     a.npad = (int64_t)nb * 64;
     const bool sx2 = (kind == DGPAMD_SEXP) && !direct && Dw + 2 <= 16;
     if (sep) Mc = pair_chunk(nb, Mc, Dw, a.tch, matern_rec_doubles(nb, Dw));   // records of one chunk: Mc*Dw*npad*240 B (Matern), Mc*npad*(Dw+3..6)*8 B (SExp)
-    if (sx2) Mc = pair_chunk(nb, Mc, Dw, TCH2, sexp_rec_doubles(nb, Dw));
+    if (sx2) {
+        a.tch = sexp_tch2(nb);
+        Mc = pair_chunk(nb, Mc, Dw, a.tch, sexp_rec_doubles(nb, Dw));
+    }
     if (getenv("DGPAMD_PAIR_CHUNK") && (sep || sx2)) {   // (comparison runs: the fixed 256 points per launch of the earlier builds)
         const int64_t c = atoll(getenv("DGPAMD_PAIR_CHUNK"));
         if (c >= TCH && c < Mc) Mc = c / TCH * TCH;
@@ -1293,9 +1307,9 @@ static int linkgp_run(dgpamd_ctx *ctx, int kind, int64_t n, int64_t M, int Dw, i
                 hipLaunchKernelGGL((linkgp_J_kernel<DGPAMD_SEXP, false>), dim3(ntiles, tb), dim3(256), shm, ctx->stream, a);
             } else if (Dw + 2 <= 4 * SX_KS && !getenv("DGPAMD_SEXP_FORM1")) {
                 const int KPA = (Dw + 2 + 3) & ~3;
-                const size_t shm2 = ((size_t)2 * Dw * 64 + TCH2 * 4 + EXPN_TAB) * sizeof(double);
+                const size_t shm2 = ((size_t)2 * Dw * 64 + a.tch * 4 + EXPN_TAB) * sizeof(double);
                 const bool poly = getenv("DGPAMD_SEXP_POLY") != nullptr;   // (comparison run: the table-free exponential)
-                const unsigned tb2 = (unsigned)((mc + TCH2 - 1) / TCH2);
+                const unsigned tb2 = (unsigned)((mc + a.tch - 1) / a.tch);
                 hipLaunchKernelGGL(sexp_records_kernel, dim3((unsigned)((a.npad + 255) / 256), (unsigned)mc), dim3(256), 0, ctx->stream, a, KPA);
                 PROF_BEGIN(ctx, PROF_LINKGP_J, (double)mc * (double)n * (double)(n + 1) * 0.5);   // pair evaluations (one exponential each)
 #define JSEXP2(KS_) \

@@ -812,7 +812,7 @@ def test_linkgp_launch_geometry_does_not_change_a_bit(eng, monkeypatch, kind, n,
     """Round 5: the record-based pair kernels take as many test points per launch as make >= 32 rounds of workgroups (csrc/predict.hip
     pair_chunk; 256 before), the Matern kernel's records of a step are requested between its column tiles instead of behind the
     step's barrier, with scalar addresses.  None of that touches a pair's arithmetic: the earlier geometry (DGPAMD_PAIR_CHUNK=256,
-    DGPAMD_JSEP_PIPE=0), other points per workgroup (DGPAMD_JSEP_TCH) and a chunk that is no multiple of the workgroup's points
+    DGPAMD_JSEP_PIPE=0), other points per workgroup (DGPAMD_JSEP_TCH, DGPAMD_JSEXP_TCH) and a chunk that is no multiple of the workgroup's points
     give the same bits -- M spans several launches, the last one ragged -- and a slice equals the oracle (functions.py:453-494)."""
     from oracle import dgp_oracle as O
     rng = np.random.default_rng(41)
@@ -826,11 +826,11 @@ def test_linkgp_launch_geometry_does_not_change_a_bit(eng, monkeypatch, kind, n,
     z = rng.uniform(size=(M, Dz)) if Dz else None
     args = (eng.tensor(mm), eng.tensor(vv), eng.tensor(z) if Dz else None, eng.tensor(X[:, :Dw]), eng.tensor(X[:, Dw:]) if Dz else None, length,
             eng.tensor(st['Rinv']), n, eng.tensor(st['Rinv_y']), 1.4, 1e-3)
-    for v in ('DGPAMD_PAIR_CHUNK', 'DGPAMD_JSEP_PIPE', 'DGPAMD_JSEP_TCH'):
+    for v in ('DGPAMD_PAIR_CHUNK', 'DGPAMD_JSEP_PIPE', 'DGPAMD_JSEP_TCH', 'DGPAMD_JSEXP_TCH'):
         monkeypatch.delenv(v, raising=False)
     m0, v0 = (npy(t) for t in eng.linkgp_predict(kind, *args))
     for env in ({'DGPAMD_PAIR_CHUNK': '256', 'DGPAMD_JSEP_PIPE': '0'}, {'DGPAMD_JSEP_TCH': '16'}, {'DGPAMD_JSEP_TCH': '64', 'DGPAMD_PAIR_CHUNK': '416'},
-                {'DGPAMD_PAIR_CHUNK': '96', 'DGPAMD_JSEP_PIPE': '0', 'DGPAMD_JSEP_TCH': '8'}):
+                {'DGPAMD_PAIR_CHUNK': '96', 'DGPAMD_JSEP_PIPE': '0', 'DGPAMD_JSEP_TCH': '8'}, {'DGPAMD_JSEXP_TCH': '256'}, {'DGPAMD_JSEXP_TCH': '64', 'DGPAMD_PAIR_CHUNK': '160'}):
         for k, val in env.items():
             monkeypatch.setenv(k, val)
         m1, v1 = (npy(t) for t in eng.linkgp_predict(kind, *args))
