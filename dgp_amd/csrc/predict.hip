@@ -703,8 +703,8 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
     }
     __syncthreads();
     const int mrow = 16 * wave + (lane >> 4), mcol = lane & 15, kq = lane >> 4, mi = lane & 15;
-    const int ksS = (Dw + 1) >> 2, kqS = (Dw + 1) & 3;
-    const bool dyn = kq == kqS;   // this lane's B fragment of k-step ksS is the ss row
+    const int kqS = (Dw + 1) & 3;   // (the ss row: k = Dw + 1, in k-step (Dw + 1) >> 2 == KS - 1)
+    const bool dyn = kq == kqS;   // this lane holds the ss row in its B fragment of the last k-step
     const double wt = (bi == bj) ? 1.0 : 2.0;
     d4 Cr[4], base[4];
 #pragma unroll
@@ -739,14 +739,14 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) f.av[ks] = recA[t * strA + 4 * ks];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) f.bd[tt] = dyn ? recS[t * strS + 16 * tt] : 0.0;
+        for (int tt = 0; tt < 4; ++tt) f.bd[tt] = dyn ? recS[t * strS + 16 * tt] : bst[KS - 1][tt];   // (the ss row lies in the LAST k-step: (Dw + 1) >> 2 == KS - 1)
         return f;
     };
     // one k-step of test point f's exponent tiles into `en` (four independent MFMAs)
     auto kstep = [&](const Frag &f, int ks, d4 (&en)[4]) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const double bv = (ks == ksS && dyn) ? f.bd[tt] : bst[ks][tt];
+            const double bv = (ks == KS - 1) ? f.bd[tt] : bst[ks][tt];   // (selected once per test point, in fetch: three selects per k-step and tile here otherwise)
             en[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[ks], bv, ks == 0 ? base[tt] : en[tt], 0, 0, 0);
         }
     };
