@@ -890,6 +890,7 @@ __global__ __launch_bounds__(256) void global_factor_kernel(LinkArgs a) {
 template <int PIPE, bool LOG>
 __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
     extern __shared__ double lds[];
+    const long long t_entry = LOG ? wall_clock64() : 0;   // (step log: when the workgroup began, ahead of its set-up)
     const int Dw = a.Dw, Dz = a.Dz, DT = Dw + Dz;
     double *WiT = lds;                    // [DT][64]
     double *WjT = WiT + DT * 64;          // [DT][64]
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
             lg[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
             lg[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
             lg[6] = ((long long)bi << 16) | bj;
-            lg[7] = nstep;
+            lg[7] = t_entry;   // (the steps of a full chunk: a.tch x Dw)
         }
     }
     for (int t = 0; t < nt; ++t) {
@@ -1165,6 +1166,9 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
         acc = wave_sum_p(acc);
         if (lane == 0) red[t * 4 + wave] = acc;
     }
+    // (the compiler's barrier waits for LDS and scalar traffic only -- s_waitcnt lgkmcnt(0); s_barrier; s_endpgm in the emitted code: the last step's redundant
+    //  DMA, still in flight, would land in the LDS of whichever workgroup is given that space next)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (LOG && lg) {
         if (tid == 0) {

@@ -44,6 +44,21 @@ ncu = len(np.unique(cu))
 print('n=%d Dw=%d M=%d: %d workgroups on %d CUs, launch span %.0f us; sum of workgroup times / (span x 2 x CUs) = %.3f; clock %.0f MHz'
       % (n, Dw, M, len(L), ncu, span, busy / (span * 2 * ncu), np.median(cyc)))
 dur = (t1 - t0) / 100.0
+setup = (t0 - hd[:, 7]) / 100.0
+# per CU slot: the gap between one workgroup's end and the next one's entry
+gaps = []
+for c in np.unique(cu):
+    m = cu == c
+    ent, en = np.sort(hd[m, 7]), np.sort(t1[m])
+    # two slots per CU: pair every entry (but the first two) with the earliest end not yet used
+    ends = list(en)
+    for e in ent[2:]:
+        prev = [x for x in ends if x <= e]
+        if prev:
+            gaps.append((e - prev[0]) / 100.0)
+            ends.remove(prev[0])
+print('workgroup set-up (entry -> first step): median %.1f us, mean %.1f; slot idle between an end and the next entry on that CU: median %.1f us (mean %.1f, %d pairs)'
+      % (np.median(setup), setup.mean(), np.median(gaps) if gaps else float('nan'), np.mean(gaps) if gaps else float('nan'), len(gaps)))
 print('workgroup time: median %.0f us, 5%% %.0f, 95%% %.0f; last start at %.0f us of the span'
       % (np.median(dur), np.percentile(dur, 5), np.percentile(dur, 95), (t0.max() - t0.min()) / 100.0))
 # slots busy over time (10 bins)
@@ -53,7 +68,7 @@ print('slot occupancy by tenth of the span:', ' '.join('%.2f' % o for o in occ))
 S = L[:, 8:].reshape(len(L), 48, 4, 2)
 arr, lv = S[..., 0], S[..., 1] & ((1 << 60) - 1)
 cls = (S[..., 1] >> 60) & 3
-ok = (hd[:, 7] >= 48)
+ok = np.ones(len(L), dtype=bool)   # (every chunk of this run is full: 32 test points x Dw steps >= 48)
 arr, lv, cls = arr[ok], lv[ok], cls[ok]
 wait = lv - arr                       # cycles at the barrier (incl. the vmcnt wait in front of it)
 comp = arr[:, 1:] - lv[:, :-1]        # barrier departure -> next arrival: the wave's step
