@@ -110,3 +110,26 @@ def test_16_byte_stores_keep_their_data_registers(tmp_path):
             j += 1
         runs += in_run
     assert runs >= 8, 'the chain\'s eight-store run was not recognised: the test no longer watches what it was written for'
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason='llvm-objdump of the ROCm toolchain not found')
+def test_lds_dma_is_only_ever_waited_for_with_vmcnt_zero(tmp_path):
+    """The Matern pair kernel stages its records with LDS-DMA loads (global_load_lds_dwordx4).  Those do not retire in order with register
+    loads: a build that had register loads in flight together with them and waited with s_waitcnt vmcnt(N > 0) -- the compiler's way of waiting for
+    the OLDER of several loads -- gave wrong sums for most test points (round 5, profiles/r05_pair_kernel_staging.txt, block 11).  The shipped
+    kernel is right because every wait behind its first DMA load is a vmcnt(0); this test keeps it that way, in every variant the library holds, and
+    checks that the kernel drains its DMA ahead of s_endpgm."""
+    seen = 0
+    for sym in ('_Z18linkgp_Jsep_kernelILi2ELb0EEv8LinkArgs', '_Z18linkgp_Jsep_kernelILi0ELb0EEv8LinkArgs', '_Z18linkgp_Jsep_kernelILi2ELb1EEv8LinkArgs'):
+        isa = kernel_isa(tmp_path, sym)
+        assert isa and len(isa) > 1000, sym + ' not found in the library'
+        first = next(i for i, ins in enumerate(isa) if ins.startswith('global_load_lds'))
+        for i in range(first + 1, len(isa)):
+            m = re.search(r'vmcnt\((\d+)\)', isa[i]) if isa[i].startswith('s_waitcnt') else None
+            if m:
+                assert int(m.group(1)) == 0, '%s: %s (instruction %d) waits for part of the vector-memory operations with LDS-DMA loads possibly in flight' % (sym, isa[i], i)
+        end = max(i for i, ins in enumerate(isa) if ins.startswith('s_endpgm'))
+        last_dma = max(i for i, ins in enumerate(isa) if ins.startswith('global_load_lds'))
+        assert any(isa[i].startswith('s_waitcnt') and 'vmcnt(0)' in isa[i] for i in range(last_dma + 1, end)), sym + ': no vmcnt(0) between the last DMA load and s_endpgm'
+        seen += 1
+    assert seen == 3
