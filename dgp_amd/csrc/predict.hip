@@ -707,19 +707,47 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsexp2_kernel(LinkArgs a) {
     const bool dyn = kq == kqS;   // this lane holds the ss row in its B fragment of the last k-step
     const double wt = (bi == bj) ? 1.0 : 2.0;
     d4 Cr[4], base[4];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+    // The tile's weights: all 24 loads go out back to back, at clamped indices with the bound applied to the value, and land under the base exponents'
+    // arithmetic.  (Written as a conditional load inside the element loop every element was a branch with a load round trip of its own -- s_waitcnt
+    // vmcnt(1), vmcnt(0), sixteen times, ~15 us of a workgroup's 130-260.  No LDS-DMA in this kernel: register loads in flight together are safe.)
+    {
+        double ryr[4], ryc[4];
+        int64_t cir[4], cjc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t gi = i0 + mrow + 4 * r, gj = j0 + 16 * tt + mcol;
-            Cr[tt][r] = (gi < n && gj < n) ? wt * (a.ry[gi] * a.ry[gj] - a.scale * a.Rinv[gi * a.ldr + gj]) : 0.0;
-            double b = 0.0;   // t-independent part: sum_k (w_ik - w_jk)^2 / (2 l_k^2)
-            for (int k = 0; k < Dw; ++k) {
-                const double d = WiT[k * 64 + mrow + 4 * r] - WjT[k * 64 + 16 * tt + mcol];
-                b = fma(d * d, 1.0 / (2.0 * a.len[k] * a.len[k]), b);
-            }
-            base[tt][r] = b;
+            const int64_t gi = i0 + mrow + 4 * r;
+            cir[r] = gi < n ? gi : n - 1;
+            ryr[r] = a.ry[cir[r]];
         }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int64_t gj = j0 + 16 * tt + mcol;
+            cjc[tt] = gj < n ? gj : n - 1;
+            ryc[tt] = a.ry[cjc[tt]];
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cr[tt][r] = a.Rinv[cir[r] * a.ldr + cjc[tt]];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double b = 0.0;   // t-independent part: sum_k (w_ik - w_jk)^2 / (2 l_k^2)
+                for (int k = 0; k < Dw; ++k) {
+                    const double d = WiT[k * 64 + mrow + 4 * r] - WjT[k * 64 + 16 * tt + mcol];
+                    b = fma(d * d, 1.0 / (2.0 * a.len[k] * a.len[k]), b);
+                }
+                base[tt][r] = b;
+            }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = i0 + mrow + 4 * r < n && j0 + 16 * tt + mcol < n;
+                Cr[tt][r] = in ? wt * (ryr[r] * ryc[tt] - a.scale * Cr[tt][r]) : 0.0;
+            }
+    }
     // static B fragments: B[k][j], k = 4 ks + kq, j = 16 tt + mi (the ss row's lanes get theirs per test point)
     double bst[KS][4];
 #pragma unroll
