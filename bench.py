@@ -253,12 +253,65 @@ def vecchia_leg(eng, torch, n=50000, d=8, m=25, B=6):
     t2 = timed(lambda: eng.vecchia_nllik('matern2.5', dX, dy, NN, length, 1e-4, ones, True), 20)
     t3 = timed(lambda: eng.vecchia_lmatrix('matern2.5', dX, NN, length, 1e-4), 20)
     gather = n * (m + 1) * (d + 1) * 8.0   # bytes a likelihood evaluation gathers through the neighbour array (coordinates + output per neighbour)
-    return dict(shape='n=%d, d=%d, m=%d, Matern-2.5' % (n, d, m), ordered_nn_ms=t_nn,
+    # the query form at cfg4's prediction shape (vecchia.py:20-59: pred_m = 50 nearest training points of every test point)
+    Mq, pm = 100000, 50
+    xq = eng.tensor(rng.uniform(size=(Mq, d)) / length)
+    t_q = timed(lambda: eng.nn_query(xq, xs, pm), 3)
+    # brute force = 2 n^2 D flops (ordered: every point against all others; the kernels evaluate the n^2/2 earlier ones), queries 2 M n D;
+    # priced against the f64 vector peak (the distance chains are f64 fma)
+    nn_roof = dict(bound='f64 VALU', unit='TFLOP/s', peak=F64_PEAK_TFLOPS,
+                   ordered=dict(ms=t_nn, flops=2.0 * n * n * d, achieved=2.0 * n * n * d / t_nn / 1e9, frac=2.0 * n * n * d / t_nn / 1e9 / F64_PEAK_TFLOPS,
+                                executed_flops=1.0 * n * n * d, what='%d-NN among the earlier points of %d, D=%d (nn_scan_kernel + nn_merge_kernel)' % (m, n, d)),
+                   query=dict(ms=t_q, flops=2.0 * Mq * n * d, achieved=2.0 * Mq * n * d / t_q / 1e9, frac=2.0 * Mq * n * d / t_q / 1e9 / F64_PEAK_TFLOPS,
+                              what='%d nearest of %d points for %d queries, D=%d (nn_tau / nn_collect / nn_pick: filter, then select)' % (pm, n, Mq, d)),
+                   note='algorithmic flops as SURVEY 8(d) counts them (2 per dimension and pair: subtract, multiply-add); the ordered search needs only the pairs (i, j < i): '
+                        'executed = half of that.  Beside the distances the kernels keep K sorted (distance, index) pairs per query -- insertion work that the flop count does not see')
+    return dict(shape='n=%d, d=%d, m=%d, Matern-2.5' % (n, d, m), ordered_nn_ms=t_nn, nn_query_ms=t_q, roofline_nn=nn_roof,
                 llik_ms=t1, llik_rows_per_s=n / t1 * 1e3, llik_gather_GBs=gather / t1 / 1e6,
                 llik_batch=dict(candidates=B, ms=tb, rows_per_s=B * n / tb * 1e3, gather_GBs=B * gather / tb / 1e6),
                 nllik_ms=t2, nllik_rows_per_s=n / t2 * 1e3, lmatrix_ms=t3, lmatrix_rows_per_s=n / t3 * 1e3,
                 bound=pmc_note('vecchia_row4_kernel', 'f64 VALU issue (~0.79 of peak by in-kernel stamps, profiles/r04_vecchia_row_kernel_phases.txt)')
                 + ': the gather is %.1f MB per evaluation, a few per cent of the HBM roofline' % (gather / 1e6))
+
+
+def sexp_pair_leg(eng, torch, n=5000, Dw=10, Dz=10, M=2048):
+    """SURVEY 8(d), link_gp with the squared-exponential kernel at BASELINE configs[2]'s second-layer shape (functions.py:396-451: n = 5000, ten
+    uncertain local inputs + ten deterministic global ones, 2048 test points = one launch of the pair kernel): R^-1 from the device's own
+    factorisation of a synthetic node, then the predictor call with HIP events around the pair kernel (linkgp_Jsexp2_kernel)."""
+    rng = np.random.default_rng(5)
+    W, Wg = rng.normal(size=(n, Dw)), rng.uniform(size=(n, Dz))
+    y = np.sin(W[:, 0]) + Wg[:, 1] ** 2 + 0.1 * rng.normal(size=n)
+    length, scale, nugget = np.array([2.5]), 1.3, 1e-4
+    Np = eng.padded_dim(n)
+    A = eng.kmatrix('sexp', eng.tensor(np.concatenate((W, Wg), 1)), None, None, length, nugget, full=False, Y=eng.tensor(y))
+    _, info = eng.potrf(n, A)
+    Ainv = eng.empty(Np, Np)
+    eng.potri(n, A, Ainv, 1, eng.potrf_workspace(n, 1))
+    ry = (-Ainv[n, :n]).contiguous()
+    m, v, z = eng.tensor(rng.normal(size=(M, Dw))), eng.tensor(rng.uniform(0.01, 0.4, size=(M, Dw))), eng.tensor(rng.uniform(size=(M, Dz)))
+    Wd, Wgd = eng.tensor(W), eng.tensor(Wg)
+    call = lambda: eng.linkgp_predict('sexp', m, v, z, Wd, Wgd, length, Ainv, Np, ry, scale, nugget)   # noqa: E731
+    mu, var = call()
+    torch.cuda.synchronize()
+    ok = bool(int(info.cpu().numpy()[0]) == 0 and torch.isfinite(mu).all() and torch.isfinite(var).all())
+    eng.prof_enable('linkgp_j')
+    for _ in range(3):
+        call()
+    k, ms, pairs = eng.prof_collect()
+    if not k:
+        return dict(error='the pair kernel was not launched')
+    per = ms / k
+    # SURVEY 8(d): M n^2 (~8 D flops + 1 exp) for the reference's form; one exponential priced at 20 flops (a degree-12 polynomial evaluation, what
+    # the library exp costs; this kernel's table form takes 9 fma + 5 integer instructions)
+    flop_el = 8.0 * Dw + 20.0
+    el_s = 2.0 * (pairs / k) / (per * 1e-3)         # J elements per second as the reference evaluates them (all n^2; the kernel: the n(n+1)/2 lower pairs)
+    ach = el_s * flop_el / 1e12
+    return dict(bound='f64 VALU + MFMA (shared double-precision units)', kernel='linkgp_Jsexp2_kernel (SExp pair phase: exponent on f64 MFMA, one table exponential per pair)',
+                shape='n=%d, %d uncertain + %d deterministic inputs, %d test points' % (n, Dw, Dz, M), launches=k, avg_launch_us=1e3 * per,
+                ms_per_2048_points=per * 2048.0 / M, pair_evaluations_per_s=(pairs / k) / (per * 1e-3), J_elements_per_s=el_s,
+                achieved=ach, peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, flop_convention='algorithmic: %g flops per J element (8 D + 20 for the exponential), all n^2 elements' % flop_el,
+                executed_frac=ach / 2.0 / F64_PEAK_TFLOPS, traffic=None, finite=ok,
+                note=pmc_note('linkgp_Jsexp2_kernel', 'counters of this kernel: profiles/r05_pmc_kernels.txt'))
 
 
 def strong_leg_cfg3(dd, torch, local, dev, world, n=5000, d=10, q=3, S=16, M=2048):
@@ -402,15 +455,55 @@ def main():
     rounds = {'n': 0}
     orig_lock = mstep_mod.minimize_lockstep
 
-    def counted_lock(*a, **k):
-        r = orig_lock(*a, **k)
+    # ---- the step accounts for itself (host clock stamps at the phase boundaries and around every objective round of the lock-step M-step,
+    #      three pre-created HIP events per step on the engine's stream; ~10 us of stamps per 30-ms step, no profiler) ----
+    acct = dict(on=False, i_host=0.0, m_host=0.0, evaluate=0.0, turn=0.0, head=0.0, tail=0.0, rounds_by_batch={}, eval_by_batch={}, events=[], k=0)
+
+    def counted_lock(problems, evaluate, *a, **k):
+        if not acct['on'] or hasattr(evaluate, 'launch'):
+            r = orig_lock(problems, evaluate, *a, **k)
+            rounds['n'] += r
+            return r
+        st = dict(last=None, t0=time.perf_counter())
+
+        def timed_evaluate(req):
+            t = time.perf_counter()
+            if st['last'] is None:
+                acct['head'] += t - st['t0']          # the optimisers' first advance
+            else:
+                acct['turn'] += t - st['last']        # host turn-around between two rounds: results absorbed, optimisers advanced
+            out = evaluate(req)
+            t2 = time.perf_counter()
+            acct['evaluate'] += t2 - t                # one round: hyper-parameters in, K assembly + factorisation + inverse + reductions, results on the host
+            B = len(req)
+            acct['rounds_by_batch'][B] = acct['rounds_by_batch'].get(B, 0) + 1
+            acct['eval_by_batch'][B] = acct['eval_by_batch'].get(B, 0.0) + (t2 - t)
+            st['last'] = t2
+            return out
+        r = orig_lock(problems, timed_evaluate, *a, **k)
+        if st['last'] is not None:
+            acct['tail'] += time.perf_counter() - st['last']
         rounds['n'] += r
         return r
     mstep_mod.minimize_lockstep = counted_lock
 
     def step():
+        if not acct['on']:
+            model.imp.sample(burnin=args.ess_burn)
+            model._m_step()
+            return
+        e0, e1, e2 = acct['events'][acct['k']]
+        acct['k'] += 1
+        t0 = time.perf_counter()
+        eng.record(e0)
         model.imp.sample(burnin=args.ess_burn)
+        t1 = time.perf_counter()
+        eng.record(e1)
         model._m_step()
+        eng.record(e2)
+        t2 = time.perf_counter()
+        acct['i_host'] += t1 - t0
+        acct['m_host'] += t2 - t1
 
     t_gpu0 = time.perf_counter()
     for _ in range(args.warmup):
@@ -418,10 +511,12 @@ def main():
     calls['l1'] = calls['l2'] = 0
     rounds['n'] = 0
     st0 = dict(model.imp.stats)
+    acct['events'] = [(eng.event(), eng.event(), eng.event()) for _ in range(args.steps)]
     dd.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = eng.event(), eng.event()
     eng.record(ev0)
+    acct['on'] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -429,6 +524,7 @@ def main():
     torch.cuda.synchronize()
     dd.barrier()
     wall = time.perf_counter() - t0
+    acct['on'] = False
     wall = dd.allreduce_max_scalar(wall, dev if world > 1 else None)
     steps_total = args.steps * world
     value = steps_total / wall
@@ -438,6 +534,32 @@ def main():
                   batches_per_update=(st1['batches'] - st0['batches']) / upd,
                   llik_l1_per_iter=calls['l1'] / args.steps, llik_l2_per_iter=calls['l2'] / args.steps,
                   mstep_rounds_per_iter=rounds['n'] / args.steps)
+
+    # ---- step_split: where the timed region's wall time went (per step, ms) ----
+    step_split = None
+    if rank == 0:
+        K = float(args.steps)
+        gi = sum(eng.elapsed_ms(a, b) for a, b, _ in acct['events']) / K
+        gm = sum(eng.elapsed_ms(b, c) for _, b, c in acct['events']) / K
+        gap = sum(eng.elapsed_ms(acct['events'][i][2], acct['events'][i + 1][0]) for i in range(args.steps - 1)) / K
+        ms = lambda x: 1e3 * x / K   # noqa: E731
+        other_m = acct['m_host'] - acct['evaluate'] - acct['turn'] - acct['head'] - acct['tail']
+        parts = dict(istep_ms=ms(acct['i_host']), mstep_rounds_device_calls_ms=ms(acct['evaluate']), mstep_host_turnaround_between_rounds_ms=ms(acct['turn']),
+                     mstep_first_advance_ms=ms(acct['head']), mstep_after_last_round_ms=ms(acct['tail']), mstep_setup_and_diagnostics_ms=ms(other_m),
+                     outside_ms=1e3 * wall / K - ms(acct['i_host'] + acct['m_host']))
+        rb = {int(b): c / K for b, c in sorted(acct['rounds_by_batch'].items())}
+        eb = {int(b): 1e3 * acct['eval_by_batch'][b] / acct['rounds_by_batch'][b] for b in sorted(acct['rounds_by_batch'])}
+        step_split = dict(parts_ms_per_step=parts, sum_ms=sum(parts.values()), ms_per_step=1e3 * wall / K,
+                          mstep_rounds_per_step_by_matrices=rb, mstep_round_ms_by_matrices=eb,
+                          mstep_objective_evaluations_per_step=sum(b * c for b, c in rb.items()),
+                          gpu_timeline_ms_per_step=dict(istep_span=gi, mstep_span=gm, between_steps=gap, total=gi + gm + gap),
+                          istep=dict(sweeps=args.ess_burn + 1, updates_per_step=upd / K, proposals_per_step=counts['proposals_per_iter'],
+                                     speculative_batches_per_step=(st1['batches'] - st0['batches']) / K),
+                          how='host clock at the phase boundaries and around every objective round of the lock-step driver (one round = one dgpamd_llik_batch call: '
+                              'hyper-parameters in, K assembly + potrf_inv + gradient reductions of the round\'s matrices, results on the host), summed over the '
+                              'timed region; the parts are disjoint and cover the region, so sum_ms = ms_per_step up to clock reads.  gpu_timeline: HIP events recorded on the '
+                              'engine\'s stream at the same boundaries (when the DEVICE passed them).  Kernel-level times of the same build: roofline (potrf launches), '
+                              'potrf_table (by batch), profiles/r06_idle_gaps.txt (rocprofv3 trace of this command)')
 
     # ---- roofline of the dominant kernel: HIP events around each of its launches, same steps ----
     roof = None
@@ -539,23 +661,6 @@ def main():
                                  avg_launch_us=1e3 * ms, bytes_per_launch=nbytes, launches=k_n, traffic=None,
                                  note='the write-only ceiling of the same buffers is measured beside it (roofline_kmatrix_standalone.fill_); tile-shaped stores '
                                       'alone reach 0.66-0.72 of 8 TB/s at these sizes, 0.51-0.64 with rows off the 128-byte lines (profiles/r05_kmatrix_hbm_roofline.txt)')
-        for name in ():
-            for o in outs:
-                eng.kmatrix(name, Xk, None, None, lk, 1e-6, out=o, full=True)
-            torch.cuda.synchronize()
-            eng.prof_enable('kmatrix')       # HIP events around every launch (the host cannot issue 45-us kernels back to back)
-            reps = 30
-            for r in range(reps):
-                eng.kmatrix(name, Xk, None, None, lk, 1e-6, out=outs[r % 3], full=True)
-            k_n, k_ms, k_w = eng.prof_collect()
-            if not k_n:
-                continue
-            ms = k_ms / k_n
-            nbytes = 8.0 * nk * nk + 8.0 * nk * Dk
-            roof_ks[name] = dict(bound='hbm', kernel='kmatrix_kernel<%s> (full symmetric, n=%d, D=%d, 3 x 200 MB outputs in turn)' % (name, nk, Dk),
-                                 achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s', frac=nbytes / ms / 1e6 / HBM_PEAK_GBS,
-                                 avg_launch_us=1e3 * ms, bytes_per_launch=nbytes, launches=k_n, traffic=None,
-                                 note='the write-only ceiling of the same buffers is measured beside it (roofline_kmatrix_standalone.fill_)')
         # a write-only fill_ of the same three buffers in turn, timed the same way (torch events on the engine's stream): the store
         # ceiling this kernel is compared with, measured in this run
         with eng.stream():
@@ -573,7 +678,7 @@ def main():
                                 achieved=8.0 * nk * nk / fill_ms / 1e6, unit='GB/s', frac=8.0 * nk * nk / fill_ms / 1e6 / HBM_PEAK_GBS)
         del outs, outs_al
 
-    ptab = vleg = None
+    ptab = vleg = sxleg = None
     if rank == 0 and args.prof_kernel != 'none':
         try:
             ptab = potrf_table(eng, torch, args.n)
@@ -583,6 +688,10 @@ def main():
             vleg = vecchia_leg(eng, torch)
         except Exception as exc:   # noqa: BLE001
             vleg = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
+        try:
+            sxleg = sexp_pair_leg(eng, torch)
+        except Exception as exc:   # noqa: BLE001
+            sxleg = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
 
     # ---- prediction leg: emulator with the imputations sharded over the ranks --------------------
     pred = None
@@ -722,15 +831,23 @@ def main():
             'value': value, 'unit': 'SI it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * wall / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
+            'scaling_metric': None if world == 1 else dict(
+                columns=['predict.point_imputations_per_s', 'strong_scaling.cfg3_predict_imputations_sharded.point_imputations_per_s',
+                         'strong_scaling.cfg4_train_rows_split.si_it_per_s', 'mstep_nodes_split.si_it_per_s'],
+                note='`value` at N > 1 is N independent replica chains (the SI chain of one model does not shard): linear in N by construction and no evidence of '
+                     'scaling.  north_star\'s "imputation-sample throughput to 8 GPUs" is answered by predict.point_imputations_per_s (weak: every rank draws its '
+                     'imputations, one all-reduce of the moments) and by the strong_scaling legs (fixed total work over N ranks: the time should fall with N)'),
             'config': {'workload': 'configs[1]: 2-layer DGP, d=%d in / 1 out, n=%d, Matern-2.5, %d+1 GP nodes, '
                                    'train(ess_burn=%d): one step = imputer.sample() + the M-step = one iteration of dgp.train (dgp.py:1364-1412); '
                                    'the same rate over a train(N=%d) call is in `sustained`' % (args.d, args.n, args.d, args.ess_burn, args.sustained_steps),
                        'parallelism': ('replicas x%d (SI chain does not shard); predict: imputations sharded, 1 all-reduce' % world)
                        + ('' if world == 1 else '; `value` is replicas x rate: linear in N by construction -- the scaling figure of this run is '
                                                 'strong_scaling.cfg3_predict_imputations_sharded.point_imputations_per_s (fixed total work)')},
+            'step_split': step_split,
             'sustained': sustained, 'sustained_it_per_s': sustained['si_it_per_s'] if sustained else None,
             'predict': pred, 'counts': counts, 'roofline': roof, 'roofline_kmatrix': roof_k, 'roofline_kmatrix_standalone': roof_ks,
             'roofline_predict': (pred or {}).get('roofline_predict'), 'roofline_gp': (pred or {}).get('roofline_gp'),
+            'roofline_predict_sexp': sxleg, 'roofline_nn': (vleg or {}).get('roofline_nn'),
             'potrf_table': ptab, 'vecchia': vleg, 'cpu_baseline': cpu, 'cpu_baseline_predict': cpu_pred, 'mstep_nodes_split': split,
             'speedup_vs_cpu_baseline': (value / world / cpu['value']) if cpu else None,
             'predict_speedup_vs_cpu_baseline': (pred['pts_per_s'] / cpu_pred['value']) if (pred and cpu_pred and cpu_pred.get('value')) else None,

@@ -1893,6 +1893,7 @@ static void build_mega_tasks(int nbk, bool inv, std::vector<MTask> &out, std::ve
     }
 }
 
+static int mega_wgs_per_cu();
 static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTable *&out) {
     // Panels per visit: 8 (trailing and K^-1 tiles), 10 from six matrices on; the cadence starts three columns to the right
     // of the chain (near = 2).  Measured at n = 2000 (tools/gpu_lazy_sweep.py, profiles/r02_mega_table_sweeps.txt).
@@ -1925,7 +1926,18 @@ static int get_mega_tasks(dgpamd_ctx *ctx, int nbk, bool inv, int batch, MegaTab
     // profiles/r05_mega_table_sweeps.txt: most of what the critical queue had gained at four and more matrices was that ITS head did not share the line of the W
     // counters -- with every word on its own line one queue is 1-5 % faster there, the two still 1.5-3 % at one to three.)
     const char *eq = getenv("DGPAMD_MEGA_QUEUES");   // 1: one queue per group of matrices (rounds 2-4); 2: critical + bulk
-    const int queues = eq ? (atoi(eq) == 1 ? 1 : 2) : (batch <= 3 ? 2 : 1);
+    int queues = eq ? (atoi(eq) == 1 ? 1 : 2) : (batch <= 3 ? 2 : 1);
+    {
+        // The two-queue form needs workers of BOTH kinds: the kernel makes the first 8 x crit_per_xcd workers critical-first (crit_per_xcd =
+        // ceil(ncrit x matrices / 8), at most 16) and everybody else bulk-first.  On a small or CU-masked device every worker would be critical-first,
+        // run ahead into later block steps and wait there for bulk tiles that nobody pulls -- until the spin limit trips.  One queue then.
+        const int ncrit_env = getenv("DGPAMD_MEGA_NCRIT") ? atoi(getenv("DGPAMD_MEGA_NCRIT")) : 0;
+        const int ncrit = ncrit_env > 0 ? ncrit_env : (batch <= 4 ? 12 : 8);
+        int crit = (ncrit * batch + 7) / 8;
+        if (crit > 16) crit = 16;
+        const int64_t workers = (int64_t)mega_wgs_per_cu() * ctx->num_cu - batch;
+        if (workers < 2 * 8 * (int64_t)crit) queues = 1;
+    }
     static std::map<std::pair<dgpamd_ctx *, std::array<int, 10>>, MegaTable> cache;
     MegaTable &mt = cache[{ctx, {nbk, inv ? 1 : 0, lazy, slazy, near, lag, xcatch, look, queues, slag}}];
     if (!mt.dev) {

@@ -258,7 +258,9 @@ __device__ __forceinline__ double exp_negated_tab(double x, const double *tab) {
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     const int ki = __double2loint(kf);
-    int e = ki >> 8;
+    // k >> 8 from bits 8..39 of kf's mantissa (v_alignbit_b32: one instruction, as the 32-bit shift it replaces): the low word alone wraps
+    // from x = 2^31 ln 2 / 256 = 5.8e6 on and the clamp below was passed by; this form is right up to |k| < 2^39, x = 1.5e9
+    int e = (int)__builtin_amdgcn_alignbit((unsigned)__double2hiint(kf), (unsigned)ki, 8);
     e = e < -1021 ? -1021 : e;
     const double v = tab[ki & 255] * p;
     return __hiloint2double(__double2hiint(v) + (e << 20), __double2loint(v));
@@ -279,7 +281,7 @@ __device__ __forceinline__ double exp_negated_tab_end(double x, double kf, doubl
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    int e = __double2loint(kf) >> 8;
+    int e = (int)__builtin_amdgcn_alignbit((unsigned)__double2hiint(kf), (unsigned)__double2loint(kf), 8);   // (k >> 8 for |k| < 2^39: see exp_negated_tab)
     e = e < -1021 ? -1021 : e;
     const double v = t * p;
     return __hiloint2double(__double2hiint(v) + (e << 20), __double2loint(v));

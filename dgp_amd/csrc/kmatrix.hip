@@ -226,6 +226,9 @@ int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatAr
     int64_t rows = host_args[0].full ? host_args[0].n : padded_dim(host_args[0].n);
     int nbk = (int)((rows + 63) / 64);
     size_t shm = ((size_t)2 * Dmax * 64 + (full ? (size_t)16 * 65 : (size_t)0)) * sizeof(double);
+    // (D >= 44 in symmetric mode: more dynamic LDS than a launch gets by default; gfx950 has 160 KB per CU)
+    if (shm > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)kmatrix_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(kmatrix_multi_kernel, dim3(nbk * (nbk + 1) / 2, 1, count), dim3(256), shm, ctx->stream, dev_args);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;
@@ -241,6 +244,12 @@ int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a_, int batch) {
     size_t shm = ((size_t)2 * D * 64 + (a.full ? (size_t)16 * 65 : (size_t)0)) * sizeof(double);
     a.nbk = nbk;
     dim3 grid(ntiles, 1, batch);
+    if (shm > 48 * 1024) {   // (D up to DGPAMD_MAXD = 64: 65.5 KB + the mirror's 8.3 KB -- beyond a launch's default dynamic LDS)
+        if (a.kp.kind == DGPAMD_SEXP)
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)kmatrix_kernel<DGPAMD_SEXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        else
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)kmatrix_kernel<DGPAMD_MATERN25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    }
     // algorithmic bytes: the stored triangle(s) of K (8 n^2, or 4 n^2 for the lower tiles) + X once
     PROF_BEGIN(ctx, PROF_KMATRIX, (double)batch * ((a.full ? 8.0 : 4.0) * (double)rows * (double)rows + 8.0 * (double)a.n * D));
     if (a.kp.kind == DGPAMD_SEXP)

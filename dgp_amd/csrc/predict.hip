@@ -1044,7 +1044,11 @@ __global__ __launch_bounds__(256, 2) void linkgp_Jsep_kernel(LinkArgs a) {
         for (int k = 0; k < Dw; ++k, ++step) {
             double *P = (step & 1) ? PT1 : PT;
             if (LOG && lg && step < JSEP_LOG_STEPS && lane == 0) slog[(step * 4 + wave) * 2] = clock64();   // (kept in LDS: a global store here would be waited for by the barrier's vmcnt(0))
-            __syncthreads();   // records of this step landed (the barrier's wait covers the LDS-DMA); every wave is done with the other buffer
+            // records of this step landed; every wave is done with the other buffer.  The drain is explicit: a workgroup-scope fence orders LDS and scalar
+            // traffic only (lgkmcnt), and the other waves read this wave's DMA right behind the barrier -- the compiler happens to put its own vmcnt(0)
+            // here, nothing obliges it to (tests/test_isa_hazards.py checks the emitted code)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             if (LOG && lg && step < JSEP_LOG_STEPS && lane == 0) slog[(step * 4 + wave) * 2 + 1] = clock64() | ((long long)mw_next << 60);
             // the next step's records into the other buffer.  Past the end the last step is staged again (harmless).
             const int s1 = step + 1 < nstep ? step + 1 : nstep - 1;

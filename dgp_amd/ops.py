@@ -221,6 +221,11 @@ class Engine:
             #  n = 5000, profiles/r05_kmatrix_store_shapes.txt)
             ld = n if out is None else int(out.stride(-2))
             r = 0
+            if out is not None:   # (a transposed or narrow view would be written in a layout the caller does not expect)
+                if out.stride(-1) != 1 or ld < n or out.shape[-1] < n or out.shape[-2] < n:
+                    raise ValueError('kmatrix: `out` needs unit column stride and rows of at least n entries (strides %s, n = %d)' % (tuple(out.stride()), n))
+                if batch > 1 and (out.dim() != 3 or out.stride(0) < n * ld):
+                    raise ValueError('kmatrix: a batched `out` is (batch, n, ld) with matrices that do not overlap')
         else:
             ld = self.padded_dim(n)
             r = 0 if Y is None else (1 if Y.dim() == 1 else Y.shape[-2])

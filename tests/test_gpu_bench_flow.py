@@ -40,6 +40,10 @@ def test_bench_two_ranks_on_one_gpu():
     assert s3.get('finite') is True and _finite(s3['point_imputations_per_s']), s3
     assert _finite(s4['si_it_per_s']) and s4['si_it_per_s'] > 0, s4
     assert 'linear in N by construction' in d['config']['parallelism']
+    # the line itself names the columns that answer north_star's scaling question (the replica `value` does not)
+    assert 'predict.point_imputations_per_s' in d['scaling_metric']['columns'] and 'linear in N' in d['scaling_metric']['note']
+    ss = d['step_split']
+    assert abs(ss['sum_ms'] - ss['ms_per_step']) <= 0.03 * ss['ms_per_step'], ss
     assert _finite(d['sustained_it_per_s'])
     assert d['cpu_baseline'] is None   # (rank 0 at N = 1 only)
 
@@ -47,6 +51,6 @@ def test_bench_two_ranks_on_one_gpu():
 def test_bench_one_rank_through_rccl():
     d = _run(['--gpus', '1', '--backend', 'nccl', '--steps', '2', '--warmup', '1', '--predict-points', '256', '--predict-seconds', '0.1',
               '--sustained-steps', '2', '--prof-kernel', 'none', '--no-cpu-baseline'], env_extra={'DGPAMD_DIST_FORCE': '1'})
-    assert d['n_gpus'] == 1 and _finite(d['value'])
+    assert d['n_gpus'] == 1 and _finite(d['value']) and d['scaling_metric'] is None
     assert d['distributed']['world_size'] == 1 and d['distributed']['backend'] == 'nccl'
     assert d['predict']['finite']

@@ -247,6 +247,106 @@ def test_cfg3_sexp_link_gp_at_full_size_vs_oracle(eng):
     close(lv[pick], vo, rtol=1e-8, atol=1e-8 * scale)
 
 
+def test_cfg2_matern_link_gp_at_full_size_vs_oracle(eng):
+    """The kernel that is four fifths of the headline's prediction time, at the headline's own shape: the Matern-2.5 linked-GP
+    predictor (functions.py:396-430,453-494; vecchia.py:915-988 for the closed forms of Jd) of cfg2's output node -- n = 2000,
+    five uncertain local inputs, five deterministic global ones -- with the training points in the order the emulator hands
+    them over (Engine.linkgp_cells -> ops.cell_order, so the pair kernel's order classes are in play) and M = 2304 test
+    points: two 1024-point launches and a ragged 256-point one.  Both sides take the DEVICE's R^-1 and R^-1 y (downloaded),
+    so only the record / pair / finalize kernels are compared.  The oracle walks 32-36 points: both sides of every launch
+    boundary and of 32-point workgroup boundaries next to them, the first and last points, a point with one zero input
+    variance, one with all variances zero, one whose mean lies exactly on a training coordinate (in a v > 0 and in a v = 0
+    dimension), random others.  Means 1e-9, variances 1e-8 of the scale.  (~1.5 s of oracle per point.)"""
+    from oracle import dgp_oracle as O
+    n, Dw, Dz, M = 2000, 5, 5, 2304
+    rng = np.random.default_rng(2026)
+    W = rng.normal(size=(n, Dw))                    # a hidden layer's latents: standard-normal-ish columns
+    Wg = rng.uniform(size=(n, Dz))
+    y = np.sin(W[:, 0]) + 0.5 * W[:, 1] * Wg[:, 0] + Wg[:, 2] ** 2 + 0.05 * rng.normal(size=n)
+    y = (y - y.mean()) / y.std()
+    length, scale, nugget = np.array([1.7]), 1.3, 1e-4      # one shared lengthscale, as the bench's nodes (functions.py:402-410)
+    Xd = eng.tensor(np.concatenate((W, Wg), 1))
+    A = eng.kmatrix('matern2.5', Xd, None, None, length, nugget, full=False, Y=eng.tensor(y))
+    _, info = eng.potrf(n, A)
+    work = eng.potrf_workspace(n, 1)
+    Np = eng.padded_dim(n)
+    Ainv = eng.empty(Np, Np)
+    eng.potri(n, A, Ainv, 1, work)
+    assert int(npy(info)[0]) == 0
+    ry = (-Ainv[n, :n]).contiguous()
+    cells = eng.linkgp_cells('matern2.5', W, eng.tensor(Wg), Ainv, ry)
+    assert cells is not None
+    Wc, Wgc = npy(cells['W']), npy(cells['Wg'])
+    Ri, ryc = npy(cells['Rinv'])[:n, :n].copy(), npy(cells['ry'])
+    assert sorted(map(tuple, Wc)) == sorted(map(tuple, W))            # a permutation of the training points
+    m = rng.normal(size=(M, Dw))
+    v = 10.0 ** rng.uniform(-4, -0.5, size=(M, Dw))
+    z = rng.uniform(size=(M, Dz))
+    v[5, 2] = 0.0                       # one deterministic dimension among uncertain ones (the v = 0 branch of IJ_matern)
+    v[1029] = 0.0                       # all of them: J = outer product of the correlations
+    m[1023, 1] = Wc[777, 1]             # a mean exactly on a training coordinate, v > 0 (the x_i = x_j = mu corner of Jd / Jd0)
+    m[2050, 3], v[2050, 3] = Wc[13, 3], 0.0     # ... and in a v = 0 dimension
+    edge = [0, 1, 5, 31, 32, 1023, 1024, 1029, 1055, 1056, 2047, 2048, 2050, 2079, 2080, 2271, 2272, M - 2, M - 1]
+    pick = np.array(sorted(set(edge) | set(rng.choice(M, 17, replace=False).tolist())))
+    mo, vo = O.link_gp_predict(m[pick], v[pick], z[pick], Wc, Wgc, Ri, ryc, scale, length, nugget, 'matern2.5')
+    lm, lv = eng.linkgp_predict('matern2.5', eng.tensor(m), eng.tensor(v), eng.tensor(z), cells['W'], cells['Wg'], length,
+                                cells['Rinv'], Np, cells['ry'], scale, nugget)
+    lm, lv = npy(lm), npy(lv)
+    assert len(pick) >= 32 and np.all(np.isfinite(lm)) and np.all(np.isfinite(lv))
+    close(lm[pick], mo, rtol=1e-9, atol=1e-9)
+    close(lv[pick], vo, rtol=1e-8, atol=1e-8 * scale)
+    # the caller's order (no cells: every 16-row group takes the two-product path) gives the same predictions
+    um, uv = eng.linkgp_predict('matern2.5', eng.tensor(m), eng.tensor(v), eng.tensor(z), eng.tensor(W), eng.tensor(Wg), length,
+                                Ainv, Np, ry, scale, nugget)
+    close(npy(um)[pick], mo, rtol=1e-9, atol=1e-9)
+    close(npy(uv)[pick], vo, rtol=1e-8, atol=1e-8 * scale)
+
+
+def test_cfg2_emulator_predict_of_the_bench_model_vs_oracle_walk(eng):
+    """emulator.predict (emulation.py:701-779,846-847) of the MODEL bench.py times -- configs[1]: n = 2000, d = 5, five
+    Matern-2.5 nodes feeding one Matern-2.5 output node with the global connection, after two SI iterations -- on 1040 points
+    (one full 1024-point launch of the pair kernel and a ragged one) and two imputations, against the oracle's walk of the
+    same layers for 16 of the points: functions.gp at the inputs for every first-layer node, functions.link_gp through the
+    output node per imputation, the mixture's moments at the end.  The oracle is fed the device's own R^-1 / R^-1 y of every
+    node (the default nugget 1e-6 at n = 2000 leaves two factorisations ~1e-8 apart in R^-1 y, each in its own way), so the
+    comparison is of the prediction kernels and the layer walk."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import dgp_oracle as O
+    from dgp_amd import emulator
+    import bench
+    n, d, S, M = 2000, 5, 2, 1040
+    model, X, Y = bench.build_model(n, d, 100, 0)
+    model.train(N=2, ess_burn=10, disable=True)
+    emu = emulator(model.estimate(burnin=0), N=S, seed=7, device=0)
+    xt = np.random.default_rng(5).uniform(size=(M, d))
+    mu, var = emu.predict(xt)
+    mu_s, var_s = emu.predict(xt, aggregation=False)
+    assert mu.shape == (M, 1) and np.all(np.isfinite(mu)) and np.all(np.isfinite(var))
+    pick = np.array([0, 1, 2, 31, 32, 500, 777, 1000, 1022, 1023, 1024, 1025, 1030, 1037, 1038, 1039])
+    xp = xt[pick]
+    l1, out = emu.all_layer[0], emu.all_layer[1][0]
+    mus, vs = [], []
+    for s in range(S):
+        pm, pv = np.empty((len(pick), d)), np.empty((len(pick), d))
+        for k, nd in enumerate(l1):
+            st = emu._stats[(0, k)]
+            Ri = npy(st['Rinv'])[:n, :n]
+            pm[:, k], pv[:, k] = O.gp_predict(xp, npy(st['Wall']), Ri, npy(st['ry'][s]), nd.scale, nd.length, nd.nugget, nd.name)
+        st = emu._stats[(1, 0)]
+        ps = st['per'][s]
+        Wg = ps.get('Wg', st['Wg'])
+        mo, vo = O.link_gp_predict(pm[:, out.input_dim], pv[:, out.input_dim], xp[:, out.connect], npy(ps['W']), npy(Wg),
+                                   npy(ps['Rinv'])[:n, :n], npy(ps['ry']), out.scale, out.length, out.nugget, out.name)
+        close(np.asarray(mu_s[s])[pick, 0], mo, rtol=1e-8, atol=1e-8)
+        close(np.asarray(var_s[s])[pick, 0], vo, rtol=1e-7, atol=1e-8 * float(out.scale[0]))
+        mus.append(mo)
+        vs.append(vo)
+    mo, vo = O.aggregate_moments(mus, vs)
+    close(mu[pick, 0], mo, rtol=1e-8, atol=1e-8)
+    close(var[pick, 0], vo, rtol=1e-7, atol=1e-8 * float(out.scale[0]))
+
+
 def test_cfg5_chain_at_full_size_vs_oracle_walk(eng):
     """BASELINE configs[4] at its own size: GP -> DGP -> GP, n = 1000 each, Matern-2.5, through the public lgp.predict
     (linkgp.py:285-501) against the oracle's walk of the same chain -- gp at the inputs, then per imputation link_gp

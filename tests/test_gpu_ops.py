@@ -51,6 +51,66 @@ def test_kmatrix_golden(eng, golden, fixture):
         close(npy(K), d['K'], rtol=1e-12, atol=1e-15)
 
 
+@pytest.mark.parametrize('name', ['sexp', 'matern2.5'])
+@pytest.mark.parametrize('full', [True, False])
+def test_kmatrix_at_the_maximum_dimension(eng, name, full):
+    """D = DGPAMD_MAXD = 64 inputs (40 gathered local columns + 24 global ones): the symmetric form stages 2 x 64 x 64 inputs and
+    the mirror's transposition buffer in 73.9 KB of dynamic LDS -- more than a launch gets without asking -- and
+    the augmented form 65.5 KB; n = 150 (three row tiles, ragged edge), against the oracle (kernel_class.py:304-359)."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(64)
+    n, Dl, Dg = 150, 40, 24
+    X = rng.uniform(size=(n, 50))
+    cols = rng.permutation(50)[:Dl]
+    G = rng.uniform(size=(n, Dg))
+    length = rng.uniform(3.0, 6.0, size=Dl + Dg)
+    Kref = O.k_matrix(np.concatenate((X[:, cols], G), 1), length, 1e-5, name)
+    if full:
+        K = npy(eng.kmatrix(name, eng.tensor(X), cols, eng.tensor(G), length, 1e-5))
+        close(K, Kref, rtol=1e-12, atol=1e-15)
+    else:
+        y = rng.normal(size=n)
+        A = npy(eng.kmatrix(name, eng.tensor(X), cols, eng.tensor(G), length, 1e-5, full=False, Y=eng.tensor(y)))
+        close(np.tril(A[:n, :n]), np.tril(Kref), rtol=1e-12, atol=1e-15)
+        close(A[n, :n], y, rtol=0, atol=0)
+
+
+def test_kmatrix_rejects_views_it_would_write_wrongly(eng):
+    """Engine.kmatrix takes the row stride of a caller's `out` (rows on 128-byte lines: bench.py); a transposed or too narrow
+    view must be refused, not written in another layout."""
+    X = eng.tensor(np.random.default_rng(0).uniform(size=(70, 2)))
+    buf = eng.empty(70, 96)
+    K = eng.kmatrix('sexp', X, None, None, [1.0], 1e-6, out=buf[:, :70])
+    assert K.shape == (70, 70) and float(K[3, 3]) == 1.0 + 1e-6
+    with pytest.raises(ValueError):
+        eng.kmatrix('sexp', X, None, None, [1.0], 1e-6, out=eng.empty(70, 70).t())
+    with pytest.raises(ValueError):
+        eng.kmatrix('sexp', X, None, None, [1.0], 1e-6, out=eng.empty(70, 64))
+
+
+def test_sexp_link_gp_with_exponents_beyond_the_tables_old_range(eng):
+    """linkgp_Jsexp2_kernel's table exponential took k = round(-256 x / ln 2) from the low word of the magic-number sum: from
+    x = 5.8e6 on the word wrapped and the underflow clamp was passed by.  Lengthscales of 1e-3 against inputs of
+    order one put most pair exponents between 1e6 and 1e8: every such J entry is exactly zero in the reference's arithmetic
+    (functions.py:432-451) and must be here -- the prediction is then mean 0, variance scale (1 + nugget - sum_i Rinv_ii J_ii)."""
+    from oracle import dgp_oracle as O
+    rng = np.random.default_rng(8)
+    n, M, Dw = 200, 40, 3
+    W = rng.normal(size=(n, Dw)) * 2.0
+    y = rng.normal(size=n)
+    length, scale, nugget = np.array([1e-3]), 1.1, 1e-6
+    st = O.compute_stats(W, y, length, nugget, 'sexp', Dw)
+    m, v = rng.normal(size=(M, Dw)) * 2.0, rng.uniform(1e-8, 1e-6, size=(M, Dw))
+    m[:4] = W[:4] + 1e-4            # a few test points next to training points: non-trivial J_ii, everything else underflows
+    mo, vo = O.link_gp_predict(m, v, None, W, None, st['Rinv'], st['Rinv_y'], scale, length, nugget, 'sexp')
+    lm, lv = eng.linkgp_predict('sexp', eng.tensor(m), eng.tensor(v), None, eng.tensor(W), None, length, eng.tensor(st['Rinv']), n,
+                                eng.tensor(st['Rinv_y']), scale, nugget)
+    lm, lv = npy(lm), npy(lv)
+    assert np.all(np.isfinite(lm)) and np.all(np.isfinite(lv))
+    close(lm, mo, rtol=1e-9, atol=1e-12)
+    close(lv, vo, rtol=1e-9, atol=1e-12)
+
+
 def gpu_nll_grad(eng, d):
     """kernel.llik (kernel_class.py:403-449) assembled from the HIP pieces, host arithmetic as in dgp_amd.kernel."""
     from dgp_amd.kernel_class import kernel as K

@@ -128,6 +128,22 @@ def test_lds_dma_is_only_ever_waited_for_with_vmcnt_zero(tmp_path):
             m = re.search(r'vmcnt\((\d+)\)', isa[i]) if isa[i].startswith('s_waitcnt') else None
             if m:
                 assert int(m.group(1)) == 0, '%s: %s (instruction %d) waits for part of the vector-memory operations with LDS-DMA loads possibly in flight' % (sym, isa[i], i)
+        # every barrier behind the first DMA load has the issuing wave's vector-memory operations drained ahead of it: the other waves read the
+        # DMA's LDS destination right behind the barrier, and a workgroup-scope fence alone orders lgkmcnt traffic only (the in-loop
+        # barrier was right by the compiler's placement of its own wait, not by the source).  "Ahead" = a vmcnt(0) wait with no vector-memory
+        # instruction and no branch target between it and the s_barrier.
+        bars = [i for i in range(first + 1, len(isa)) if isa[i].startswith('s_barrier')]
+        assert len(bars) >= 2, sym + ': the in-loop and the exit barrier were expected behind the first DMA load'
+        for b in bars:
+            j = b - 1
+            while j > first and not (isa[j].startswith('s_waitcnt') and 'vmcnt(0)' in isa[j]):
+                assert not isa[j].startswith(('global_', 'buffer_', 'flat_', 'scratch_')), \
+                    '%s: %s (instruction %d) sits between the last vmcnt(0) and the barrier at %d' % (sym, isa[j], j, b)
+                assert not isa[j].startswith(('s_branch', 's_cbranch', 's_setpc', 's_endpgm')), \
+                    '%s: control flow (%s, instruction %d) between the last vmcnt(0) and the barrier at %d' % (sym, isa[j], j, b)
+                j -= 1
+            assert j > first, '%s: no vmcnt(0) ahead of the barrier at instruction %d' % (sym, b)
+            assert b - j <= 4, '%s: the vmcnt(0) nearest to the barrier at %d is %d instructions ahead of it' % (sym, b, b - j)
         end = max(i for i, ins in enumerate(isa) if ins.startswith('s_endpgm'))
         last_dma = max(i for i, ins in enumerate(isa) if ins.startswith('global_load_lds'))
         assert any(isa[i].startswith('s_waitcnt') and 'vmcnt(0)' in isa[i] for i in range(last_dma + 1, end)), sym + ': no vmcnt(0) between the last DMA load and s_endpgm'
