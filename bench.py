@@ -300,17 +300,21 @@ def sexp_pair_leg(eng, torch, n=5000, Dw=10, Dz=10, M=2048):
     k, ms, pairs = eng.prof_collect()
     if not k:
         return dict(error='the pair kernel was not launched')
-    per = ms / k
-    # M n^2 (~8 D flops + 1 exp) for the reference's form; one exponential priced at 20 flops (a degree-12 polynomial evaluation, what
-    # the library exp costs; this kernel's table form takes 9 fma + 5 integer instructions)
-    flop_el = 8.0 * Dw + 20.0
-    el_s = 2.0 * (pairs / k) / (per * 1e-3)         # J elements per second as the reference evaluates them (all n^2; the kernel: the n(n+1)/2 lower pairs)
-    ach = el_s * flop_el / 1e12
+    calls = 3
+    pair_s = pairs / (ms * 1e-3)                    # pair evaluations per second (one exponential each): what the kernel executes, the n (n + 1) / 2 lower pairs
+    el_s = 2.0 * pair_s                             # J elements per second as the reference evaluates them (all n^2: SURVEY 8(d)'s unit)
+    # Executed double-precision work per pair evaluation (ISA of the loop, profiles/r05_sexp_pair_kernel.txt: per test point and wave -- 16 x 64 pairs -- 12 MFMAs
+    # 16x16x4 for the (Dw + 2)-wide exponent and 166 f64 VALU instructions, the table exponential among them): 24 MFMA flops + 10.4 f64 VALU lane-instructions, an fma
+    # counted as 2 flops.  SURVEY 8(d)'s own model (M n^2 (8 D flops + 1 exp) for the reference's form) is reported beside it: the kernel evaluates half the
+    # elements (symmetry) and forms the exponent in 2 (Dw + 2) flops instead of 8 Dw, so that figure exceeds the peak and is no utilisation.
+    flop_pair = 24.0 + 2.0 * 166.0 * 64.0 / 1024.0
+    ach = pair_s * flop_pair / 1e12
     return dict(bound='f64 VALU + MFMA (shared double-precision units)', kernel='linkgp_Jsexp2_kernel (SExp pair phase: exponent on f64 MFMA, one table exponential per pair)',
-                shape='n=%d, %d uncertain + %d deterministic inputs, %d test points' % (n, Dw, Dz, M), launches=k, avg_launch_us=1e3 * per,
-                ms_per_2048_points=per * 2048.0 / M, pair_evaluations_per_s=(pairs / k) / (per * 1e-3), J_elements_per_s=el_s,
-                achieved=ach, peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, flop_convention='algorithmic: %g flops per J element (8 D + 20 for the exponential), all n^2 elements' % flop_el,
-                executed_frac=ach / 2.0 / F64_PEAK_TFLOPS, traffic=None, finite=ok,
+                shape='n=%d, %d uncertain + %d deterministic inputs, %d test points' % (n, Dw, Dz, M), launches=k, launches_per_call=k / calls, avg_launch_us=1e3 * ms / k,
+                ms_per_2048_points=(ms / calls) * 2048.0 / M, pair_evaluations_per_s=pair_s, J_elements_per_s=el_s,
+                achieved=ach, peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS,
+                flop_convention='executed: %.1f double-precision flops per pair evaluation (24 on MFMA + 10.4 f64 VALU instructions x 2)' % flop_pair,
+                survey_model_tflops=el_s * (8.0 * Dw + 20.0) / 1e12, traffic=None, finite=ok,
                 note=pmc_note('linkgp_Jsexp2_kernel', 'counters of this kernel: profiles/r05_pmc_kernels.txt'))
 
 

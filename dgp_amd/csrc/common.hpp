@@ -244,6 +244,9 @@ __device__ __forceinline__ double exp_negated_v3(double x) {
 // kernel whose inner loop leaves the LDS pipe idle (linkgp_Jsexp2_kernel; in one that feeds MFMA operands from LDS the table
 // reads cost more than they saved, round 2).
 #define EXPN_TAB 256   // entries of exp_negated_tab's table (tab[j] = 2^(j / EXPN_TAB))
+#ifndef KM_EXP_TAB
+#define KM_EXP_TAB 1   // K assembly and the gradient reductions take their exponential from the table form (0: the library's exp, rounds 1-5)
+#endif
 __device__ __forceinline__ double exp_negated_tab(double x, const double *tab) {
     // (round 5: 256 entries instead of 64 -- |r| <= ln 2 / 512, a degree-4 polynomial (truncation r^5 / 120 <= 3.8e-17) instead of the degree-5 one:
     //  nine double-precision instructions; the kernel that uses it is bound by exactly those)

@@ -33,6 +33,10 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
     double *XiT = lds;            // [D][64]
     double *XjT = lds + D * 64;   // [D][64]
     double *TT2 = lds + 2 * D * 64;   // [16][65]: the mirror's transposition buffer (symmetric mode)
+#if KM_EXP_TAB
+    double *etab = TT2 + (a.full ? 16 * 65 : 0);   // [EXPN_TAB]: 2^(j / EXPN_TAB), exp_negated_tab's table
+    for (int j = threadIdx.x; j < EXPN_TAB; j += 256) etab[j] = exp2((double)j * (1.0 / EXPN_TAB));   // (visible behind the staging barrier below)
+#endif
     int bi, bj;
     {   // strictly-lower tiles first (row-major in the triangle), then the diagonal
         const int nb = a.nbk, nlow = nb * (nb - 1) / 2, t = blockIdx.x;
@@ -113,9 +117,15 @@ __device__ __forceinline__ void kmatrix_body(const KmatArgs &a, const int b) {
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                // (the library exp, as the gradient reductions that recompute these entries: csrc/train.hip -- the objective's K and the
-                //  gradient's dK then hold the same bits, and training paths are reproducible against the earlier rounds' runs)
+                // Round 6: the table exponential of the pair kernels (common.hpp: nine f64 + five 32-bit instructions and an LDS read; <= 3.5e-16
+                // relative on [0, 700]) instead of the library's exp (22 instructions, a third of this kernel's arithmetic) -- the kernel is bound by its
+                // f64 VALU issue, not by its stores.  The gradient reductions that recompute these entries (csrc/train.hip) were
+                // switched in the same commit: the objective's K and the gradient's dK hold the same bits.  -DKM_EXP_TAB=0: rounds 1-5.
+#if KM_EXP_TAB
+                v[p][q] = (KIND == DGPAMD_SEXP) ? exp_negated_tab(s[p][q], etab) : pr[p][q] * exp_negated_tab(SQRT5 * s[p][q], etab);
+#else
                 v[p][q] = (KIND == DGPAMD_SEXP) ? exp(-s[p][q]) : pr[p][q] * exp(-SQRT5 * s[p][q]);
+#endif
         if (bi == bj) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
@@ -225,7 +235,7 @@ int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatAr
     }
     int64_t rows = host_args[0].full ? host_args[0].n : padded_dim(host_args[0].n);
     int nbk = (int)((rows + 63) / 64);
-    size_t shm = ((size_t)2 * Dmax * 64 + (full ? (size_t)16 * 65 : (size_t)0)) * sizeof(double);
+    size_t shm = ((size_t)2 * Dmax * 64 + (full ? (size_t)16 * 65 : (size_t)0) + KM_EXP_TAB * EXPN_TAB) * sizeof(double);
     // (D >= 44 in symmetric mode: more dynamic LDS than a launch gets by default; gfx950 has 160 KB per CU)
     if (shm > 48 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)kmatrix_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -241,7 +251,7 @@ int launch_kmatrix(dgpamd_ctx *ctx, const KmatArgs &a_, int batch) {
     int64_t rows = a.full ? a.n : padded_dim(a.n);
     int nbk = (int)((rows + 63) / 64);
     int ntiles = nbk * (nbk + 1) / 2;
-    size_t shm = ((size_t)2 * D * 64 + (a.full ? (size_t)16 * 65 : (size_t)0)) * sizeof(double);
+    size_t shm = ((size_t)2 * D * 64 + (a.full ? (size_t)16 * 65 : (size_t)0) + KM_EXP_TAB * EXPN_TAB) * sizeof(double);
     a.nbk = nbk;
     dim3 grid(ntiles, 1, batch);
     if (shm > 48 * 1024) {   // (D up to DGPAMD_MAXD = 64: 65.5 KB + the mirror's 8.3 KB -- beyond a launch's default dynamic LDS)

@@ -138,6 +138,10 @@ __device__ __forceinline__ void grad_reduce_body(const GradArgs &a) {
     const int D = a.kp.Dl + a.kp.Dg;
     double *XiT = lds, *XjT = lds + D * 64;
     double *red = lds + 2 * D * 64;   // [4 waves][2P]
+#if KM_EXP_TAB
+    double *etab = red + 4 * 2 * a.P;   // [EXPN_TAB]: exp_negated_tab's table, as kmatrix_body builds it (the same bits in K here and there)
+    for (int j = threadIdx.x; j < EXPN_TAB; j += 256) etab[j] = exp2((double)j * (1.0 / EXPN_TAB));
+#endif
     int bi, bj;
     tri_decode(blockIdx.x, bi, bj);
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, wave = tid >> 6, lane = tid & 63;
@@ -233,10 +237,17 @@ __device__ __forceinline__ void grad_reduce_body(const GradArgs &a) {
             const int64_t gj = j0 + tx + 16 * q;
             // K_ij -- or, with one shared lengthscale, directly c_ij K_ij (sexp: c = sum_d 2 df^2 = 2 s; Matern: num / prod)
             double kv;
+#if KM_EXP_TAB
+            if (KIND == DGPAMD_SEXP)
+                kv = (a.shared_len ? 2.0 * s[p][q] : 1.0) * exp_negated_tab(s[p][q], etab);
+            else
+                kv = (a.shared_len ? num[p][q] : pr[p][q]) * exp_negated_tab(SQRT5 * s[p][q], etab);
+#else
             if (KIND == DGPAMD_SEXP)
                 kv = (a.shared_len ? 2.0 * s[p][q] : 1.0) * exp(-s[p][q]);
             else
                 kv = (a.shared_len ? num[p][q] : pr[p][q]) * exp(-SQRT5 * s[p][q]);
+#endif
             const bool in = gi < n && gj < n;
             double kinv = in ? a.Ainv[gi * a.ld + gj] : 0.0;
             if (!in || gi == gj) kv = 0.0;
@@ -407,7 +418,7 @@ extern "C" int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n, const do
     a.partial = (double *)work;
     a.alpha_col = nullptr;
     const int nb = (int)((n + 63) / 64), ntiles = nb * (nb + 1) / 2;
-    size_t shm = ((size_t)2 * D * 64 + 4 * 2 * a.P) * sizeof(double);
+    size_t shm = ((size_t)2 * D * 64 + 4 * 2 * a.P + KM_EXP_TAB * EXPN_TAB) * sizeof(double);
     if (kind == DGPAMD_SEXP)
         hipLaunchKernelGGL(grad_reduce_kernel<DGPAMD_SEXP>, dim3(ntiles), dim3(256), shm, ctx->stream, a);
     else
@@ -544,7 +555,7 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
         hipLaunchKernelGGL(llik_pack_kernel, dim3(1), dim3(DGPAMD_MAXB), 0, ctx->stream, (const double *)logdet,
                            (const int32_t *)info, (const double *)A, Np, stride_a, n, dev_out, stride_out, batch);
     {
-        const size_t shm = ((size_t)2 * Dmax * 64 + 4 * 2 * Pmax) * sizeof(double);
+        const size_t shm = ((size_t)2 * Dmax * 64 + 4 * 2 * Pmax + KM_EXP_TAB * EXPN_TAB) * sizeof(double);
         hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(ntiles, 1, batch), dim3(256), shm, ctx->stream, gd);
         hipLaunchKernelGGL(grad_final_multi_kernel, dim3(2 * Pmax, batch), dim3(256), 0, ctx->stream, gd, ntiles, fin);
         LAUNCH_CHECK(ctx);
