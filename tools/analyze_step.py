@@ -26,29 +26,45 @@ def short(n):
     return 'ess_*' if 'ess_' in n else n[-28:]
 
 
-# ---- cut into iterations at ess_end_kernel (one per queued I-step)
-ends = [i for i, e in enumerate(ev) if 'ess_end_kernel' in e[2]]
-if len(ends) < 3:
-    sys.exit('fewer than three I-steps in the window')
+# ---- cut into iterations: an M-step is a maximal run of rounds (kmatrix_multi_kernel .. grad_final_multi_kernel) with no ess_* kernel inside; the I-step of an
+#      iteration is everything between the previous M-step's last kernel and this M-step's first round, ending with the LAST ess_end_kernel before it (an I-step whose
+#      device queue ran out of speculative batches is finished by the host and queued anew: several ess_end_kernel per I-step)
+mblocks, cur = [], None
+for j, e in enumerate(ev):
+    n = e[2]
+    if 'kmatrix_multi' in n and cur is None:
+        cur = [j, j]
+    if cur is not None:
+        if 'ess_' in n or 'trmv_lower' in n:
+            mblocks.append(cur); cur = None
+        elif 'grad_final_multi' in n:
+            cur[1] = j
+if cur is not None:
+    mblocks.append(cur)
 iters = []
-for a, b in zip(ends, ends[1:]):
-    # events (a, b]: M-step of iteration a, then the I-step that ends at b.  The I-step starts behind the LAST grad_final_multi_kernel of the window.
-    seg = ev[a + 1:b + 1]
-    last_gf = max((j for j, e in enumerate(seg) if 'grad_final_multi' in e[2]), default=None)
-    first_km = min((j for j, e in enumerate(seg) if 'kmatrix_multi' in e[2]), default=None)
-    if last_gf is None or first_km is None:
+for (a0, a1), (b0, b1) in zip(mblocks, mblocks[1:]):
+    between = ev[a1 + 1:b0]                       # the I-step of the iteration whose M-step is (b0, b1), with both boundaries
+    ends_ = [j for j, e in enumerate(between) if 'ess_end_kernel' in e[2]]
+    if not ends_:
         continue
-    iters.append(dict(t_prev_end=ev[a][1], pre=seg[:first_km], m=seg[first_km:last_gf + 1], i=seg[last_gf + 1:]))
+    last_end = ends_[-1]
+    while last_end + 1 < len(between) and 'mail_publish' in between[last_end + 1][2]:
+        last_end += 1
+    iters.append(dict(t_prev_end=between[last_end][1], pre=between[last_end + 1:], m=ev[b0:b1 + 1], i=between[:last_end + 1], t_m_prev_end=ev[a1][1],
+                      queues=len(ends_)))
+if len(iters) < 3:
+    sys.exit('fewer than three iterations in the window')
 print('%d iterations in the window (one ess_end_kernel each)' % len(iters))
 acc = collections.defaultdict(float)
 kern_i, kern_m = collections.defaultdict(lambda: [0.0, 0]), collections.defaultdict(lambda: [0.0, 0])
 rounds, round_span, turn = 0, 0.0, []
 for it in iters:
     m, i, pre = it['m'], it['i'], it['pre']
+    acc['boundary M->I (last round of the previous M-step .. first I-step kernel)'] += (i[0][0] - it['t_m_prev_end']) if i else 0.0
+    acc['I-step span (first kernel .. last ess_end_kernel)'] += (i[-1][1] - i[0][0]) if i else 0.0
     acc['boundary I->M (ess_end .. first M-step round: detach, diagnostics, set-up)'] += m[0][0] - it['t_prev_end']
     acc['M-step span (first round .. last round)'] += m[-1][1] - m[0][0]
-    acc['boundary M->I (last round .. first I-step kernel)'] += (i[0][0] - m[-1][1]) if i else 0.0
-    acc['I-step span (first kernel .. ess_end_kernel)'] += (i[-1][1] - i[0][0]) if i else 0.0
+    acc['I-steps whose device queue was re-queued (count per iteration)'] += 1e6 * (it['queues'] > 1)
     for s, e, n in m:
         k = kern_m[short(n)]; k[0] += e - s; k[1] += 1
     for s, e, n in i + pre:
@@ -74,7 +90,7 @@ for it in iters:
             last_end = e
     last_end = None
 N = float(len(iters))
-tot = sum(v for k, v in acc.items() if not k.startswith('idle'))
+tot = sum(v for k, v in acc.items() if not k.startswith('idle') and not k.startswith('I-steps whose'))
 print('per iteration (ms): sum of the four consecutive pieces = %.3f' % (tot / N / 1e6))
 for k, v in acc.items():
     print('  %8.3f  %s' % (v / N / 1e6, k))
