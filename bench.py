@@ -464,26 +464,45 @@ def main():
     acct = dict(on=False, i_host=0.0, m_host=0.0, evaluate=0.0, turn=0.0, head=0.0, tail=0.0, rounds_by_batch={}, eval_by_batch={}, events=[], k=0)
 
     def counted_lock(problems, evaluate, *a, **k):
-        if not acct['on'] or hasattr(evaluate, 'launch'):
+        if not acct['on'] or k.get('groups', 1) != 1:
             r = orig_lock(problems, evaluate, *a, **k)
             rounds['n'] += r
             return r
-        st = dict(last=None, t0=time.perf_counter())
+        st = dict(last=None, t0=time.perf_counter(), t=None)
 
-        def timed_evaluate(req):
+        def begin():
             t = time.perf_counter()
             if st['last'] is None:
                 acct['head'] += t - st['t0']          # the optimisers' first advance
             else:
                 acct['turn'] += t - st['last']        # host turn-around between two rounds: results absorbed, optimisers advanced
-            out = evaluate(req)
+            st['t'] = t
+
+        def end(req):
             t2 = time.perf_counter()
-            acct['evaluate'] += t2 - t                # one round: hyper-parameters in, K assembly + factorisation + inverse + reductions, results on the host
+            acct['evaluate'] += t2 - st['t']          # one round: hyper-parameters in, K assembly + factorisation + inverse + reductions, results on the host
             B = len(req)
             acct['rounds_by_batch'][B] = acct['rounds_by_batch'].get(B, 0) + 1
-            acct['eval_by_batch'][B] = acct['eval_by_batch'].get(B, 0.0) + (t2 - t)
+            acct['eval_by_batch'][B] = acct['eval_by_batch'].get(B, 0.0) + (t2 - st['t'])
             st['last'] = t2
+
+        def timed_evaluate(req):
+            begin()
+            out = evaluate(req)
+            end(req)
             return out
+        if hasattr(evaluate, 'launch'):   # (the first round in two halves: the caller's deferred host work runs between them, inside this round's time)
+            def t_launch(req, slot=0):
+                begin()
+                return evaluate.launch(req, slot)
+
+            def t_collect(req, token):
+                out = evaluate.collect(req, token)
+                end(req)
+                return out
+            timed_evaluate.launch, timed_evaluate.collect = t_launch, t_collect
+            if hasattr(evaluate, 'abandon'):
+                timed_evaluate.abandon = evaluate.abandon
         r = orig_lock(problems, timed_evaluate, *a, **k)
         if st['last'] is not None:
             acct['tail'] += time.perf_counter() - st['last']
@@ -491,23 +510,33 @@ def main():
         return r
     mstep_mod.minimize_lockstep = counted_lock
 
+    # one step = one iteration of dgp.train's own loop (dgp_amd.dgp._si_iteration <- dgp.py:1377-1398: imputer.sample, then the M-step; iteration numbers >= 2:
+    # the first iteration of a train() call initialises the scales).  The stamps at the I / M boundary ride on the two calls it makes.
+    it_no = {'i': 1}
+    imp_sample = model.imp.sample
+
+    def stamped_sample(*a, **k):
+        r = imp_sample(*a, **k)
+        if acct['on']:
+            acct['t1'] = time.perf_counter()
+            eng.record(acct['events'][acct['k']][1])
+        return r
+    model.imp.sample = stamped_sample
+
     def step():
+        it_no['i'] += 1
         if not acct['on']:
-            model.imp.sample(burnin=args.ess_burn)
-            model._m_step()
+            model._si_iteration(it_no['i'], args.ess_burn)
             return
         e0, e1, e2 = acct['events'][acct['k']]
-        acct['k'] += 1
         t0 = time.perf_counter()
         eng.record(e0)
-        model.imp.sample(burnin=args.ess_burn)
-        t1 = time.perf_counter()
-        eng.record(e1)
-        model._m_step()
+        model._si_iteration(it_no['i'], args.ess_burn)
         eng.record(e2)
         t2 = time.perf_counter()
-        acct['i_host'] += t1 - t0
-        acct['m_host'] += t2 - t1
+        acct['k'] += 1
+        acct['i_host'] += acct['t1'] - t0
+        acct['m_host'] += t2 - acct['t1']
 
     t_gpu0 = time.perf_counter()
     for _ in range(args.warmup):

@@ -86,6 +86,8 @@ SIGNATURES = {
     'dgpamd_ess_queue_vwork': (_z, [_l, _i, _i]),
     'dgpamd_ess_queue_note_info': (_i, [_p, _p, _p, _i]),
     'dgpamd_llik_batch': (_i, [_p, _l, _i, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l]),
+    'dgpamd_llik_batch_launch': (_i, [_p, _l, _i, _p, _p, _p, _p, _l, _p, _p, _p, _l]),
+    'dgpamd_llik_batch_wait': (_i, [_p, _p]),
     'dgpamd_potrf_inv': (_i, [_p, _l, _p, _p, _p, _l, _i, _p, _p, _p]),
     'dgpamd_gp_workspace': (_z, [_l, _l]),
     'dgpamd_gp_predict': (_i, [_p, _i, _l, _l, _i, _p, _p, _p, _i, _p, _l, _p, _i, _d, _d, _p, _p, _p]),

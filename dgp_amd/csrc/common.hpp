@@ -54,6 +54,12 @@ struct dgpamd_ctx {
     } mail[DGPAMD_MAILBOXES + 1];                     // (the last one is dgpamd_fetch's own)
     dgpamd_reduce_hook reduce_hook = nullptr;         // sum over ranks of a device vector, queued on the stream (dgpamd_set_reduce_hook)
     void *reduce_user = nullptr;
+    // dgpamd_llik_batch_launch / _wait: the evaluation in flight and its own pinned staging buffer
+    double *llik_pinned = nullptr;
+    size_t llik_pinned_bytes = 0, llik_bytes = 0;
+    int llik_pending = 0;
+    unsigned long long llik_seq = 0;
+    const double *llik_dev_out = nullptr;
     void *scratch[2] = {nullptr, nullptr};            // device scratch grown on demand (ctx_scratch): [0] per-row partial results of the
     size_t scratch_bytes[2] = {0, 0};                 // Vecchia row kernels, [1] per-chunk candidate lists of the neighbour searches
 };

@@ -51,6 +51,7 @@ extern "C" int dgpamd_destroy(dgpamd_ctx *ctx) {
     for (auto &kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->llik_pinned) (void)hipHostFree(ctx->llik_pinned);
     for (auto &mb : ctx->mail) {
         if (mb.host) (void)hipHostFree(mb.host);
         if (mb.snap) (void)hipFree(mb.snap);

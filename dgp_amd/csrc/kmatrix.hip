@@ -227,6 +227,22 @@ __global__ __launch_bounds__(256, 6) void kmatrix_multi_kernel(const KmatArgs *a
         kmatrix_body<DGPAMD_MATERN25>(a, 0);
 }
 
+// The same with the nodes' arguments BY VALUE (up to three nodes: 2.8 KB of kernel arguments): no argument array in device memory, no host-to-device
+// copy in front of the launch -- a blit kernel and its launch gap per round of the lock-step M-step, most of whose rounds hold one to three nodes.
+struct KmatArgs3 {
+    KmatArgs a[3];
+};
+static_assert(sizeof(KmatArgs3) <= 3800, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256, 6) void kmatrix_multi_val_kernel(KmatArgs3 v) {
+    const KmatArgs &a = v.a[blockIdx.z];
+    if (a.zero_ptr)   // (set in one node's arguments only)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.zero_words; i += gridDim.x * 256) a.zero_ptr[i] = 0;
+    if (a.kp.kind == DGPAMD_SEXP)
+        kmatrix_body<DGPAMD_SEXP>(a, 0);
+    else
+        kmatrix_body<DGPAMD_MATERN25>(a, 0);
+}
+
 int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatArgs *host_args, int count) {
     int Dmax = 0, full = 0;
     for (int c = 0; c < count; ++c) {
@@ -239,6 +255,16 @@ int launch_kmatrix_multi(dgpamd_ctx *ctx, const KmatArgs *dev_args, const KmatAr
     // (D >= 44 in symmetric mode: more dynamic LDS than a launch gets by default; gfx950 has 160 KB per CU)
     if (shm > 48 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)kmatrix_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    if (!dev_args) {   // by value (count <= 3)
+        if (count > 3) BAD_ARG(ctx, "by-value launch of more than three nodes");
+        KmatArgs3 v;
+        for (int c = 0; c < 3; ++c) v.a[c] = host_args[c < count ? c : 0];
+        if (shm > 48 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)kmatrix_multi_val_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(kmatrix_multi_val_kernel, dim3(nbk * (nbk + 1) / 2, 1, count), dim3(256), shm, ctx->stream, v);
+        LAUNCH_CHECK(ctx);
+        return DGPAMD_OK;
+    }
     hipLaunchKernelGGL(kmatrix_multi_kernel, dim3(nbk * (nbk + 1) / 2, 1, count), dim3(256), shm, ctx->stream, dev_args);
     LAUNCH_CHECK(ctx);
     return DGPAMD_OK;

@@ -11,11 +11,13 @@ struct ProposeArgs {
     const double *F, *NU;
     double *FP;
     int64_t count;   // n*M
-    double c[DGPAMD_MAXB], s[DGPAMD_MAXB];
+    double th[DGPAMD_MAXB];
 };
 __global__ __launch_bounds__(256) void ess_propose_kernel(ProposeArgs a) {
     const int b = blockIdx.y;
-    const double c = a.c[b], s = a.s[b];
+    // (cosine and sine on the device, as the device queue's ess_prepare takes them: the host loop and the queue then propose the same bits for the same
+    //  angle -- with the host's libm here an update that the host loop finished for the queue left latents one rounding away, profiles/r06_chain_fingerprint.txt)
+    const double c = cos(a.th[b]), s = sin(a.th[b]);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * 256)
         a.FP[(int64_t)b * a.count + i] = a.F[i] * c + a.NU[i] * s;
 }
@@ -27,10 +29,7 @@ extern "C" int dgpamd_ess_propose(dgpamd_ctx *ctx, int64_t n, int M, const doubl
     if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
     ProposeArgs a;
     a.F = F; a.NU = NU; a.FP = FP; a.count = n * M;
-    for (int b = 0; b < batch; ++b) {
-        a.c[b] = cos(theta_h[b]);
-        a.s[b] = sin(theta_h[b]);
-    }
+    for (int b = 0; b < batch; ++b) a.th[b] = theta_h[b];
     int64_t blocks = (a.count + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(ess_propose_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, ctx->stream, a);
@@ -330,6 +329,18 @@ __global__ __launch_bounds__(256) void grad_reduce_multi_kernel(const GradMulti 
     else
         grad_reduce_body<DGPAMD_MATERN25>(a);
 }
+// ... and with up to three nodes' arguments by value (see kmatrix_multi_val_kernel)
+struct GradMulti3 {
+    GradMulti g[3];
+};
+static_assert(sizeof(GradMulti3) <= 3600, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256) void grad_reduce_multi_val_kernel(GradMulti3 v) {
+    const GradArgs &a = v.g[blockIdx.z].a;
+    if (a.kp.kind == DGPAMD_SEXP)
+        grad_reduce_body<DGPAMD_SEXP>(a);
+    else
+        grad_reduce_body<DGPAMD_MATERN25>(a);
+}
 
 __global__ __launch_bounds__(256) void grad_final_kernel(const double *partial, int ntiles, int P2, double *out) {
     __shared__ double sm[4];
@@ -358,10 +369,16 @@ struct LlikFinish {
     double *host;
     unsigned long long *flag, seq;
 };
+__device__ __forceinline__ void grad_final_multi_body(const GradMulti &g, int ntiles, const LlikFinish &f);
 __global__ __launch_bounds__(256) void grad_final_multi_kernel(const GradMulti *args, int ntiles, LlikFinish f) {
+    grad_final_multi_body(args[blockIdx.y], ntiles, f);
+}
+__global__ __launch_bounds__(256) void grad_final_multi_val_kernel(GradMulti3 v, int ntiles, LlikFinish f) {
+    grad_final_multi_body(v.g[blockIdx.y], ntiles, f);
+}
+__device__ __forceinline__ void grad_final_multi_body(const GradMulti &g, int ntiles, const LlikFinish &f) {
     __shared__ double sm[4];
     __shared__ int last;
-    const GradMulti &g = args[blockIdx.y];
     const int idx = blockIdx.x, tid = threadIdx.x, P2 = 2 * g.a.P;
     if (idx < P2) {
         double v = 0.0;
@@ -472,11 +489,13 @@ __global__ void publish_host_kernel(const double *src, double *host, int nd, uns
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T,
-                                 double *Ainv, int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
-                                 int64_t stride_out) {
+// The two halves of dgpamd_llik_batch: everything queued (launch), then the wait for the results (wait).  Between the two the caller may do host work that
+// touches neither the evaluations' inputs nor this context's other blocking calls' staging (the results land in a pinned buffer of their own).
+extern "C" int dgpamd_llik_batch_launch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T,
+                                        double *Ainv, int64_t stride_a, void *work, void *grad_work, double *dev_out, int64_t stride_out) {
     if (!ctx) return DGPAMD_BAD_ARG;
-    if (n <= 0 || !nodes || !A || !T || !Ainv || !work || !grad_work || !dev_out || !host_out) BAD_ARG(ctx, "null pointer or n <= 0");
+    if (ctx->llik_pending) BAD_ARG(ctx, "an evaluation is still in flight: dgpamd_llik_batch_wait first");
+    if (n <= 0 || !nodes || !A || !T || !Ainv || !work || !grad_work || !dev_out) BAD_ARG(ctx, "null pointer or n <= 0");
     if (batch <= 0 || batch > DGPAMD_MAXB) BAD_ARG(ctx, "need 1 <= batch <= DGPAMD_MAXB");
     const int64_t Np = padded_dim(n);
     if (n + 1 > Np) BAD_ARG(ctx, "no room for the augmented row");
@@ -519,10 +538,17 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     const bool cleared = ka[0].zero_ptr != nullptr;   // = the factorisation will run as the one-launch kernel
     if (cleared)   // (its -alpha is read where it is, column n of L^-T: no copy into the inverse's row n)
         for (int b = 0; b < batch; ++b) ga[b].a.alpha_col = T + (int64_t)b * stride_a + n;
-    ctx->args_inflight = 1;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->devargs, ctx->hostargs, need, hipMemcpyHostToDevice, ctx->stream));
-    const KmatArgs *kd = reinterpret_cast<const KmatArgs *>(ctx->devargs);
-    const GradMulti *gd = reinterpret_cast<const GradMulti *>(ctx->devargs + (size_t)batch * sizeof(KmatArgs));
+    // one to three nodes (most rounds of an M-step): the arguments ride in the launches themselves, no copy into device memory (DGPAMD_LLIK_ARGS_COPY=1: always copy)
+    static const bool always_copy = getenv("DGPAMD_LLIK_ARGS_COPY") != nullptr && atoi(getenv("DGPAMD_LLIK_ARGS_COPY")) != 0;
+    const bool by_value = batch <= 3 && !always_copy;
+    const KmatArgs *kd = nullptr;
+    const GradMulti *gd = nullptr;
+    if (!by_value) {
+        ctx->args_inflight = 1;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->devargs, ctx->hostargs, need, hipMemcpyHostToDevice, ctx->stream));
+        kd = reinterpret_cast<const KmatArgs *>(ctx->devargs);
+        gd = reinterpret_cast<const GradMulti *>(ctx->devargs + (size_t)batch * sizeof(KmatArgs));
+    }
     rc = launch_kmatrix_multi(ctx, kd, ka, batch);
     if (rc) return rc;
     double *logdet = dev_out + (int64_t)batch * stride_out;
@@ -532,10 +558,16 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
     if (rc) return rc;
     const int nd = (int)(batch * stride_out);
     const size_t bytes = (size_t)nd * sizeof(double);
-    rc = ensure_pinned(ctx, bytes + 64);
-    if (rc) return rc;
-    unsigned long long *flag = reinterpret_cast<unsigned long long *>(ctx->pinned + (ctx->pinned_bytes / sizeof(double) - 1));
-    *flag = 0;   // (the stream is drained: nobody else touches the staging buffer now)
+    if (ctx->llik_pinned_bytes < bytes + 64) {   // (a staging buffer of this call's own: dgpamd_fetch and friends may run between launch and wait)
+        if (ctx->llik_pinned) (void)hipHostFree(ctx->llik_pinned);
+        ctx->llik_pinned = nullptr;
+        ctx->llik_pinned_bytes = 0;
+        const size_t want = ((bytes + 64 + 4095) / 4096) * 4096;
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->llik_pinned, want, hipHostMallocDefault));
+        ctx->llik_pinned_bytes = want;
+    }
+    unsigned long long *flag = reinterpret_cast<unsigned long long *>(ctx->llik_pinned + (ctx->llik_pinned_bytes / sizeof(double) - 1));
+    *flag = 0;   // (no evaluation is in flight: nobody else touches this buffer)
     const unsigned long long seq = ++ctx->host_seq;
     LlikFinish fin;
     memset(&fin, 0, sizeof(fin));
@@ -546,7 +578,7 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
         fin.ld_ws = post.ld_ws; fin.info_ws = post.info_ws; fin.status = post.status;
         fin.A = A; fin.ld = Np; fin.stride_a = stride_a; fin.n = n;
         fin.dev_out = dev_out; fin.stride_out = stride_out; fin.batch = batch;
-        fin.host = ctx->pinned; fin.flag = flag; fin.seq = seq;
+        fin.host = ctx->llik_pinned; fin.flag = flag; fin.seq = seq;
     } else if (post.pending)
         hipLaunchKernelGGL(llik_post_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, ctx->stream, (const double *)T,
                            Ainv, (const double *)A, Np, stride_a, n, post.ld_ws, post.info_ws, post.status, logdet, info, dev_out,
@@ -556,13 +588,36 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
                            (const int32_t *)info, (const double *)A, Np, stride_a, n, dev_out, stride_out, batch);
     {
         const size_t shm = ((size_t)2 * Dmax * 64 + 4 * 2 * Pmax + KM_EXP_TAB * EXPN_TAB) * sizeof(double);
-        hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(ntiles, 1, batch), dim3(256), shm, ctx->stream, gd);
-        hipLaunchKernelGGL(grad_final_multi_kernel, dim3(2 * Pmax, batch), dim3(256), 0, ctx->stream, gd, ntiles, fin);
+        if (by_value) {
+            GradMulti3 v;
+            for (int c = 0; c < 3; ++c) v.g[c] = ga[c < batch ? c : 0];
+            hipLaunchKernelGGL(grad_reduce_multi_val_kernel, dim3(ntiles, 1, batch), dim3(256), shm, ctx->stream, v);
+            hipLaunchKernelGGL(grad_final_multi_val_kernel, dim3(2 * Pmax, batch), dim3(256), 0, ctx->stream, v, ntiles, fin);
+        } else {
+            hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(ntiles, 1, batch), dim3(256), shm, ctx->stream, gd);
+            hipLaunchKernelGGL(grad_final_multi_kernel, dim3(2 * Pmax, batch), dim3(256), 0, ctx->stream, gd, ntiles, fin);
+        }
         LAUNCH_CHECK(ctx);
     }
     if (!fused)
-        hipLaunchKernelGGL(publish_host_kernel, dim3(1), dim3(128), 0, ctx->stream, (const double *)dev_out, ctx->pinned, nd, flag, seq);
+        hipLaunchKernelGGL(publish_host_kernel, dim3(1), dim3(128), 0, ctx->stream, (const double *)dev_out, ctx->llik_pinned, nd, flag, seq);
     LAUNCH_CHECK(ctx);
+    ctx->llik_pending = 1;
+    ctx->llik_seq = seq;
+    ctx->llik_bytes = bytes;
+    ctx->llik_dev_out = dev_out;
+    return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_llik_batch_wait(dgpamd_ctx *ctx, double *host_out) {
+    if (!ctx) return DGPAMD_BAD_ARG;
+    if (!ctx->llik_pending) BAD_ARG(ctx, "no evaluation in flight");
+    if (!host_out) BAD_ARG(ctx, "null pointer");
+    const unsigned long long seq = ctx->llik_seq;
+    const size_t bytes = ctx->llik_bytes;
+    const double *dev_out = ctx->llik_dev_out;
+    unsigned long long *flag = reinterpret_cast<unsigned long long *>(ctx->llik_pinned + (ctx->llik_pinned_bytes / sizeof(double) - 1));
+    ctx->llik_pending = 0;
     // spin on the sequence word; now and then make sure the stream is still alive (a fault would leave the word unwritten)
     for (unsigned long long it = 1;; ++it) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
@@ -572,15 +627,24 @@ extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dg
             if (q == hipSuccess) {   // everything ran: the word is there, or this memory is not coherent -- settle it the slow way
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
-                    HIP_TRY(ctx, hipMemcpy(ctx->pinned, dev_out, bytes, hipMemcpyDeviceToHost));
+                    HIP_TRY(ctx, hipMemcpy(ctx->llik_pinned, dev_out, bytes, hipMemcpyDeviceToHost));
                 break;
             }
             if (q != hipErrorNotReady) HIP_TRY(ctx, q);
         }
     }
     ctx->args_inflight = 0;
-    memcpy(host_out, ctx->pinned, bytes);
+    memcpy(host_out, ctx->llik_pinned, bytes);
     return DGPAMD_OK;
+}
+
+extern "C" int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T,
+                                 double *Ainv, int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
+                                 int64_t stride_out) {
+    if (ctx && !host_out) BAD_ARG(ctx, "null pointer or n <= 0");
+    const int rc = dgpamd_llik_batch_launch(ctx, n, batch, nodes, A, T, Ainv, stride_a, work, grad_work, dev_out, stride_out);
+    if (rc) return rc;
+    return dgpamd_llik_batch_wait(ctx, host_out);
 }
 
 
@@ -713,14 +777,14 @@ __device__ void ess_prepare(double *st, const double *u, int nuni, int B, EssScr
     if (st[ES_PENDING] != 0.0) {   // closing shrink of the previous, fully rejected batch
         if (cur >= nuni) { st[ES_STATUS] = 1.0; sc->done = 1; return; }
         if (theta < 0.0) lo = theta; else hi = theta;
-        theta = lo + (hi - lo) * u[cur++];
+        theta = __dadd_rn(lo, __dmul_rn(hi - lo, u[cur++]));   // numpy's uniform(lo, hi): a product and a sum, two roundings (no fma: the host loop's and the reference's bits)
         st[ES_THETA] = theta; st[ES_LO] = lo; st[ES_HI] = hi; st[ES_PENDING] = 0.0; st[ES_CURSOR] = cur;
     }
     int nb = 1;
     sc->th[0] = theta; sc->lo[0] = lo; sc->hi[0] = hi;
     while (nb < B && cur + nb - 1 < nuni) {
         if (theta < 0.0) lo = theta; else hi = theta;
-        theta = lo + (hi - lo) * u[cur + nb - 1];
+        theta = __dadd_rn(lo, __dmul_rn(hi - lo, u[cur + nb - 1]));
         sc->th[nb] = theta; sc->lo[nb] = lo; sc->hi[nb] = hi;
         ++nb;
     }

@@ -475,8 +475,17 @@ class dgp:
                     nd._vecch_prestaged = pre[id(nd)]
                 elif any(nd is d for d in dense):
                     nd._prestaged = pre[id(nd)]
+        if hook is not None:   # (run once, wherever the first round of evaluations is launched -- or at the end if there was none)
+            inner, called = hook, [False]
+
+            def hook():
+                if not called[0]:
+                    called[0] = True
+                    inner()
         if dense:
-            self.last_mstep = mstep.maximise_lockstep(eng, dense, self)
+            self.last_mstep = mstep.maximise_lockstep(eng, dense, self, after_first_launch=hook)
+            if hook is not None:
+                hook()
         else:
             self.last_mstep = None
         # Vecchia nodes whose optimiser needs no callback: lock-step as well (one synchronisation per round, not one per
@@ -588,15 +597,24 @@ class dgp:
 
     def _mstep_can_start_early(self):
         """True when the M-step's first objective evaluations can be queued on the device BEFORE the host has refreshed the
-        nodes' numpy attributes from the I-step's device state (imputer.sample(detach=False)): every GP node is a Vecchia
-        node fitted by the lock-step driver, from the imputer's own device views -- no reference prior (compute_cl reads the
+        nodes' numpy attributes from the I-step's device state (imputer.sample(detach=False)): every GP node is fitted by a
+        lock-step driver (all Vecchia or all dense), from the imputer's own device views -- no reference prior (compute_cl reads the
         numpy input), no replicates, one rank."""
         from . import mstep
-        if not (self.vecch and mstep._HAVE_CORE) or ddist.is_active() or os.environ.get('DGPAMD_MSTEP_EARLY', '1') == '0':
+        if not mstep._HAVE_CORE or ddist.is_active() or os.environ.get('DGPAMD_MSTEP_EARLY', '1') == '0':
             return False
         gps = [nd for layer in self.all_layer for nd in layer if nd.type == 'gp']
         if len(gps) < 2:
             return False
+        if not self.vecch:
+            # Dense models (round 6): every GP node is fitted by the dense lock-step driver from the imputer's device views; its first round is queued
+            # (dgpamd_llik_batch_launch) before the host refreshes the numpy attributes and runs the R2 diagnostics -- 0.6 ms of idle device per iteration
+            # at the bench shape (profiles/r06_idle_gaps.txt).  Only GP nodes without replicates or a reference prior, as below.
+            for layer in self.all_layer:
+                for nd in layer:
+                    if nd.type != 'gp' or nd.vecch or nd.rep is not None or not isinstance(nd, TrackedInputs) or nd.prior_name == 'ref':
+                        return False
+            return True
         for layer in self.all_layer:
             for nd in layer:
                 if nd.rep is not None or not isinstance(nd, TrackedInputs):

@@ -117,7 +117,15 @@ def minimize_lockstep(problems, evaluate, on_finish=None, after_first_launch=Non
                 return rounds
             if rounds == 0 and after_first_launch is not None and split:
                 token = evaluate.launch(req, 0)
-                after_first_launch()
+                try:
+                    after_first_launch()
+                except BaseException:   # (leave no evaluation in flight behind an exception of the caller's host work)
+                    if hasattr(evaluate, 'abandon'):
+                        try:
+                            evaluate.abandon(token)
+                        except Exception:   # noqa: BLE001
+                            pass
+                    raise
                 out = evaluate.collect(req, token)
             else:
                 if rounds == 0 and after_first_launch is not None:
@@ -154,10 +162,12 @@ def minimize_lockstep(problems, evaluate, on_finish=None, after_first_launch=Non
     return max(rounds)
 
 
-def maximise_lockstep(engine, nodes, cache):
+def maximise_lockstep(engine, nodes, cache, after_first_launch=None):
     """kernel.maximise() for several dense GP nodes at once (dgp.py:1391-1398 runs them one after another; given
     the imputed latents their objectives are independent): one L-BFGS-B state per node, every round's objective
-    evaluations batched on the device by ONE C call (dgpamd_llik_batch).  Returns (rounds, evaluations)."""
+    evaluations batched on the device by ONE C call (dgpamd_llik_batch).  after_first_launch(): host work of the caller that
+    touches nothing the evaluations read (dgp.train: the deferred refresh of the numpy attributes, the R2 diagnostics) -- run
+    between the two halves of the FIRST round's call, while the device works on it.  Returns (rounds, evaluations)."""
     setups = [nd._opt_setup() for nd in nodes]
     problems = [_Problem(x0, lb, ub, opts.get('maxiter', 15000), opts.get('maxfun', 15000)) for x0, lb, ub, opts in setups]
     evals = [0]
@@ -176,7 +186,7 @@ def maximise_lockstep(engine, nodes, cache):
             for pos, i in enumerate(idxs):
                 where[i] = (n, pos)
 
-    def evaluate(req):
+    def prepare(req):
         todo = {}
         for i, x in req:
             nd = nodes[i]
@@ -184,14 +194,31 @@ def maximise_lockstep(engine, nodes, cache):
             n, pos = where[i]
             plans[n].set(pos, nd.length, nd.nugget[0])
             todo.setdefault(n, []).append((pos, i))
+        return list(todo.items())
+
+    def finish(req, groups, first=None):
         host = {}
-        for n, lst in todo.items():   # (inside the engine's stream context entered once below, not once per round)
-            res = plans[n].run([pos for pos, _ in lst])
+        for g, (n, lst) in enumerate(groups):   # (inside the engine's stream context entered once below, not once per round)
+            res = plans[n].wait(first) if (g == 0 and first is not None) else plans[n].run([pos for pos, _ in lst])
             for r, (pos, i) in enumerate(lst):
                 host[i] = res[pos]
                 last[i] = (n, r, res[pos])   # where this node's factor is now: row r of the run's buffers
         evals[0] += len(req)
         return [nodes[i]._llik_finish(host[i]) for i, _ in req]
+
+    def evaluate(req):
+        return finish(req, prepare(req))
+
+    def launch(req, slot=0):   # the first group of sizes queued (one evaluation in flight per engine); the others follow in collect
+        groups = prepare(req)
+        n, lst = groups[0]
+        return groups, plans[n].launch([pos for pos, _ in lst])
+
+    def collect(req, token):
+        return finish(req, token[0], first=token[1])
+    if after_first_launch is not None:
+        evaluate.launch, evaluate.collect = launch, collect
+        evaluate.abandon = lambda token: plans[token[0][0][0]].wait(token[1])   # (wait for the queued evaluation, drop its results)
 
     last = {}
     imp = getattr(cache, 'imp', None)
@@ -206,7 +233,7 @@ def maximise_lockstep(engine, nodes, cache):
 
     try:
         with engine.stream():
-            rounds = minimize_lockstep(problems, evaluate, on_finish)
+            rounds = minimize_lockstep(problems, evaluate, on_finish, after_first_launch=after_first_launch)
     finally:
         for nd in nodes:
             nd._in_maximise = False

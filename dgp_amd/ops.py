@@ -726,6 +726,29 @@ class _LlikPlan:
         Np = self.e.padded_dim(self.n)
         return self.A[r * self.stride_a * 8:(r + 1) * self.stride_a * 8].view(torch.float64).view(Np, Np)
 
+    def launch(self, idx):
+        """First half of run(): everything queued on the device (dgpamd_llik_batch_launch); wait(token) returns the results."""
+        e = self.e
+        if len(idx) == self.B:
+            nodes, B = self.nodes, self.B
+        else:
+            B = len(idx)
+            nodes = (_lib.Node * B)(*[self.nodes[i] for i in idx])
+        e._chk(e._enter() or lib.dgpamd_llik_batch_launch(e.h, self.n, B, nodes, _dp(self.A), _dp(self.T), _dp(self.Ainv), self.stride_a, _dp(self.work),
+                                                          _dp(self.gwork), _dp(self.dev_out), self.stride_out))
+        return (list(idx), nodes)   # (the node array stays alive until the wait)
+
+    def wait(self, token):
+        idx = token[0]
+        e = self.e
+        host = self.host[:len(idx)]
+        e._chk(e._enter() or lib.dgpamd_llik_batch_wait(e.h, host.ctypes.data_as(C.c_void_p)))
+        out = {}
+        for r, i in enumerate(idx):
+            P = self.P[i]
+            out[i] = np.concatenate((host[r, :2], host[r, 3:3 + 2 * P], host[r, 2:3]))
+        return out
+
     def run(self, idx):
         """Evaluate the nodes listed in idx (positions in the plan); returns {position: host vector
         [logdet, y'K^-1y, tr.., quad.., info]} in kernel._llik_device's layout."""

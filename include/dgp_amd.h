@@ -327,6 +327,13 @@ int dgpamd_grad_reduce(dgpamd_ctx *ctx, int kind, int64_t n,
 int dgpamd_llik_batch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T, double *Ainv,
                       int64_t stride_a, void *work, void *grad_work, double *dev_out, double *host_out,
                       int64_t stride_out);
+/* The same call in two halves (round 6): _launch queues everything and returns, _wait returns when the results have landed in host_out (the layout above).
+ * Between the two the caller may do host work that does not touch the evaluations' inputs -- dgp.train's loop refreshes the nodes' numpy attributes from the I-step's
+ * device state and runs the R2 diagnostics (dgp.py:1391-1398 would do both BEFORE the first objective evaluation) while the device works on the M-step's first round.
+ * One evaluation in flight per context; every other entry point stays usable in between (the results have a pinned staging buffer of their own). */
+int dgpamd_llik_batch_launch(dgpamd_ctx *ctx, int64_t n, int batch, const dgpamd_node *nodes, double *A, double *T, double *Ainv,
+                             int64_t stride_a, void *work, void *grad_work, double *dev_out, int64_t stride_out);
+int dgpamd_llik_batch_wait(dgpamd_ctx *ctx, double *host_out);
 size_t dgpamd_grad_workspace(int64_t n, int nparam);
 
 /* ---- a11  GP prediction ------------------------------------------------------

@@ -781,16 +781,16 @@ def test_not_positive_definite_raises_and_train_restarts(eng):
     calls = {'n': 0}
     orig = model._m_step
 
-    def flaky():
+    def flaky(**kw):   # (dgp.train passes early=True where the first round may be queued ahead of the host's refresh: dense models since round 6)
         calls['n'] += 1
         if calls['n'] == 2:
             raise np.linalg.LinAlgError('injected')
-        return orig()
+        return orig(**kw)
     model._m_step = flaky
     model.train(N=3, ess_burn=2, disable=True)
     assert model.N == 5 and calls['n'] == 2 + 3           # one failed attempt (2 calls) + a full rerun
     assert all(nd.para_path.shape[0] == 6 for layer in model.all_layer for nd in layer)
-    model._m_step = lambda: (_ for _ in ()).throw(np.linalg.LinAlgError('always'))
+    model._m_step = lambda **kw: (_ for _ in ()).throw(np.linalg.LinAlgError('always'))
     with pytest.raises(RuntimeError):
         model.train(N=1, ess_burn=1, disable=True)
 
@@ -1495,6 +1495,45 @@ def test_vecchia_training_does_not_depend_on_the_host_overlaps(eng, monkeypatch)
             assert np.array_equal(na.ord, nb.ord) and np.array_equal(na.NNarray, nb.NNarray) and np.array_equal(na.rev_ord, np.argsort(na.ord))
             if getattr(na, 'R2', None) is not None:
                 assert np.array_equal(np.asarray(na.R2), np.asarray(nb.R2))
+
+
+def test_dense_training_does_not_depend_on_the_early_mstep_start(eng, monkeypatch):
+    """dgp.train on a dense model (round 6) queues the M-step's first round of objective evaluations from the imputer's device state
+    (dgpamd_llik_batch_launch) and refreshes the nodes' numpy attributes / runs the R2 diagnostics while the device works on it
+    (imputer.sample(detach=False), dgp._mstep_can_start_early, mstep.maximise_lockstep(after_first_launch=...)).  A schedule, not an
+    algorithm: hyper-parameters, paths, latents, node inputs and R2 after six iterations equal the plain order's, bit for bit --
+    dgp.py:1377-1398 in the reference's order.  Models the early start must refuse (a reference prior upstairs) take the plain order."""
+    from dgp_amd import dgp, kernel, combine
+    rng = np.random.default_rng(21)
+    n, d = 300, 3
+    X = rng.uniform(size=(n, d))
+    f = np.sin(4 * X[:, 0]) * np.cos(3 * X[:, 1]) + 0.5 * X[:, 2] ** 2
+    Y = ((f - f.mean()) / f.std())[:, None]
+
+    def run(early, prior='ga'):
+        monkeypatch.setenv('DGPAMD_MSTEP_EARLY', early)
+        np.random.seed(3)
+        layers = combine([kernel(length=np.array([1.0]), name='matern2.5') for _ in range(d)],
+                         [kernel(length=np.array([1.0]), name='matern2.5', scale_est=True, connect=np.arange(d), prior_name=prior)])
+        m = dgp(X, Y, layers, seed=8)
+        used = []
+        inner = m._mstep_can_start_early
+        m._mstep_can_start_early = lambda: used.append(inner()) or used[-1]
+        m.train(N=6, ess_burn=4, disable=True)
+        return m, used
+
+    a, ua = run('1')
+    b, ub = run('0')
+    assert ua == [True] * 6 and ub == [False] * 6
+    for la, lb in zip(a.all_layer, b.all_layer):
+        for na, nb in zip(la, lb):
+            assert np.array_equal(na.para_path, nb.para_path)
+            assert np.array_equal(na.length, nb.length) and np.array_equal(na.scale, nb.scale) and np.array_equal(na.nugget, nb.nugget)
+            assert np.array_equal(na.output, nb.output) and np.array_equal(na.input, nb.input)
+            if getattr(na, 'R2', None) is not None:
+                assert np.array_equal(np.asarray(na.R2), np.asarray(nb.R2))
+    c, uc = run('1', prior='ref')
+    assert uc == [False] * 6
 
 
 def test_one_si_iteration_at_bench_size_vs_oracle(eng):

@@ -339,6 +339,20 @@ def test_llik_batch_vs_oracle(eng):
             close(h[1], q, rtol=1e-8)
             close(h[2:2 + P], tr, rtol=1e-7, atol=1e-8 * np.abs(tr).max())
             close(h[2 + P:2 + 2 * P], qq, rtol=1e-7, atol=1e-8 * np.abs(qq).max())
+    # the same call in two halves (dgpamd_llik_batch_launch / _wait) with other blocking calls of the engine in between: the same bits
+    for b in (0, 1, 2):
+        plan.set(b, cfg[b]['length'], cfg[b]['nugget'])
+    whole = plan.run([0, 1, 2])
+    token = plan.launch([0, 1, 2])
+    probe = eng.tensor(np.arange(5000.0))
+    assert np.array_equal(eng.fetch(probe), np.arange(5000.0))       # (a fetch through the engine's own pinned staging buffer while the evaluation is in flight)
+    with pytest.raises(Exception):
+        plan.launch([0])                                             # one evaluation in flight per engine
+    halves = plan.wait(token)
+    for b in (0, 1, 2):
+        assert np.array_equal(whole[b], halves[b])
+    with pytest.raises(Exception):
+        plan.wait(token)                                             # nothing in flight any more
     # a non-positive-definite node is reported through its info word, the others are unaffected
     plan.set(0, cfg[0]['length'], -2.0)
     out = plan.run([0, 1])

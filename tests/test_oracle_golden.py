@@ -382,3 +382,22 @@ def test_sexp_J_gemm_form_equals_the_direct_form():
             I1, J1 = O.IJ_sexp_gemm(X, zm, zv, length)
             np.testing.assert_allclose(I1, I0, rtol=1e-13, atol=1e-300)
             np.testing.assert_allclose(J1, J0, rtol=2e-12, atol=1e-300)
+
+
+def test_oracle_pool_is_the_serial_oracle():
+    """tests/oracle_pool.py deals the test points of oracle.link_gp_predict to spawned host processes (the full-size GPU tests walk
+    16-64 points at ~1.5 s each): the same function on the same arguments -- the same bits, in order."""
+    import oracle_pool
+    rng = np.random.default_rng(0)
+    n, Dw, Dz, M = 120, 3, 2, 9
+    W, Wg = rng.normal(size=(n, Dw)), rng.uniform(size=(n, Dz))
+    y = rng.normal(size=n)
+    length = np.array([1.2])
+    st = O.compute_stats(np.concatenate((W, Wg), 1), y, length, 1e-3, 'matern2.5', Dw)
+    m, v, z = rng.normal(size=(M, Dw)), rng.uniform(0.01, 0.3, size=(M, Dw)), rng.uniform(size=(M, Dz))
+    a = O.link_gp_predict(m, v, z, W, Wg, st['Rinv'], st['Rinv_y'], 1.3, length, 1e-3, 'matern2.5')
+    b = oracle_pool.link_gp_predict(m, v, z, W, Wg, st['Rinv'], st['Rinv_y'], 1.3, length, 1e-3, 'matern2.5', workers=3)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    c = oracle_pool.link_gp_predict(m, v, None, W, None, st['Rinv'], st['Rinv_y'], 1.3, length, 1e-3, 'sexp', workers=2, gemm_form=True)
+    d = O.link_gp_predict(m, v, None, W, None, st['Rinv'], st['Rinv_y'], 1.3, length, 1e-3, 'sexp', gemm_form=True)
+    assert np.array_equal(c[0], d[0]) and np.array_equal(c[1], d[1])
