@@ -27,15 +27,16 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def pmc_note(kernel, fallback):
-    """Counter evidence of this round for a kernel (profiles/r05_pmc_kernels.json, written by tools/pmc_summary.py from
+    """Counter evidence for a kernel (profiles/r06_pmc_kernels.json, else round 5's; written by tools/pmc_summary.py from
     rocprofv3 --pmc passes of this build), as a sentence for the result line; `fallback` while that file has no entry."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r05_pmc_kernels.json')) as f:
-            e = json.load(f).get(kernel)
-        if e and e.get('note'):
-            return e['note'] + ' (profiles/r05_pmc_kernels.json)'
-    except (OSError, ValueError):
-        pass
+    for name in ('r06_pmc_kernels.json', 'r05_pmc_kernels.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                e = json.load(f).get(kernel)
+            if e and e.get('note'):
+                return e['note'] + ' (profiles/%s)' % name
+        except (OSError, ValueError):
+            pass
     return fallback
 
 
@@ -139,7 +140,13 @@ def _cpu_predict_points(job):
         threadpool_limits(limits=1)
     except Exception:   # noqa: BLE001
         pass
-    x, l1, l2 = job
+    x, path = job
+    import pickle as _pk
+    with open(os.path.join(path, 'meta.pkl'), 'rb') as f:
+        meta = _pk.load(f)
+    arr = lambda name: _np.load(os.path.join(path, name + '.npy'), mmap_mode='r')   # noqa: E731  (memory-mapped: ONE copy of the model's arrays for all workers)
+    l1 = [dict(nd, W=arr('l1_W_%d' % k), Rinv=arr('l1_Rinv_%d' % k), Rinv_y=arr('l1_ry_%d' % k)) for k, nd in enumerate(meta['l1'])]
+    l2 = dict(meta['l2'], W=arr('l2_W'), Wg=(arr('l2_Wg') if meta['l2_has_Wg'] else None), Rinv=arr('l2_Rinv'), Rinv_y=arr('l2_ry'))
     t0 = _t.perf_counter()
     m = _np.empty((len(x), len(l1)))
     v = _np.empty((len(x), len(l1)))
@@ -161,7 +168,11 @@ def cpu_baseline_predict(model, d, imputations, points_per_worker=1):
     import psutil
     from oracle import dgp_oracle as O
     phys = psutil.cpu_count(logical=False) or 1
-    workers = max(1, min(32, phys))
+    workers = max(1, phys)            # one process per physical core (32 at most before)
+    try:   # (a worker holds ~0.4 GB of n x n temporaries of the oracle's IJ at n = 2000: never more than a quarter of the free memory in all)
+        workers = max(1, min(workers, int(0.25 * psutil.virtual_memory().available / 0.4e9)))
+    except Exception:   # noqa: BLE001
+        workers = min(workers, 32)
     l1 = []
     for nd in model.all_layer[0]:
         Xn = np.ascontiguousarray(nd._X())
@@ -176,16 +187,36 @@ def cpu_baseline_predict(model, d, imputations, points_per_worker=1):
               gcols=None if nd.connect is None else np.asarray(nd.connect), Rinv=st['Rinv'], Rinv_y=st['Rinv_y'], scale=nd.scale, length=nd.length,
               nugget=nd.nugget, name=nd.name)
     xt = np.random.default_rng(11).uniform(size=(workers * points_per_worker, d))
-    jobs = [(xt[w * points_per_worker:(w + 1) * points_per_worker], l1, l2) for w in range(workers)]
-    t0 = time.perf_counter()
-    with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn')) as ex:   # (spawn: this process holds a HIP context)
-        res = list(ex.map(_cpu_predict_points, jobs))
-    wall = time.perf_counter() - t0
+    import pickle
+    import shutil
+    import tempfile
+    shm = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None
+    path = tempfile.mkdtemp(prefix='dgp_amd_cpu_baseline_', dir=shm)   # (~0.2 GB: the six nodes' R^-1; removed below)
+    try:
+        with open(os.path.join(path, 'meta.pkl'), 'wb') as f:
+            pickle.dump(dict(l1=[{k: v for k, v in nd.items() if k not in ('W', 'Rinv', 'Rinv_y')} for nd in l1],
+                             l2={k: v for k, v in l2.items() if k not in ('W', 'Wg', 'Rinv', 'Rinv_y')}, l2_has_Wg=l2['Wg'] is not None), f)
+        save = lambda name, a: np.save(os.path.join(path, name + '.npy'), np.ascontiguousarray(a))   # noqa: E731
+        save('l2_W', l2['W']); save('l2_Rinv', l2['Rinv']); save('l2_ry', l2['Rinv_y'])
+        if l2['Wg'] is not None:
+            save('l2_Wg', l2['Wg'])
+        for k, nd in enumerate(l1):
+            save('l1_W_%d' % k, nd['W']); save('l1_Rinv_%d' % k, nd['Rinv']); save('l1_ry_%d' % k, nd['Rinv_y'])
+        jobs = [(xt[w * points_per_worker:(w + 1) * points_per_worker], path) for w in range(workers)]
+        t0 = time.perf_counter()
+        with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context('spawn')) as ex:   # (spawn: this process holds a HIP context)
+            res = list(ex.map(_cpu_predict_points, jobs))
+        wall = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(path, ignore_errors=True)
     busy = max(r[0] for r in res)            # the slowest worker's compute time (process start-up and pickling excluded)
     pts = len(xt)
     finite = bool(np.all(np.isfinite([r[1] for r in res])) and np.all(np.isfinite([r[2] for r in res])))
     return dict(value=pts / busy / imputations, unit='pts/s', cores=workers, physical_cores=phys, kind='port', imputations=imputations,
                 seconds_per_point_imputation_one_core=float(np.mean([r[0] for r in res])) / points_per_worker, finite=finite,
+                note=('the reference evaluates link_gp in numba (functions.py:396-430, a prange over the test points); numba is absent from this image and cannot travel, so this is '
+                      'the oracle\'s numpy restatement of the same closed forms, one process per physical core -- one to two orders of magnitude slower per core than compiled code: a '
+                      'reported baseline, not a target'),
                 sample=('%d worker processes x %d test points, one imputation each (gp_predict of the %d first-layer nodes + link_gp_predict of the '
                         'Matern-2.5 output node at n=%d, one BLAS thread per process as the reference\'s prange over test points); slowest worker %.1f s, '
                         '%.1f s wall with process start-up; scaled to %d imputations per point'
@@ -620,7 +651,7 @@ def main():
                 ach = tot_w / (tot_ms * 1e-3) / 1e12
                 roof = dict(bound='mfma', kernel={'syrk': 'potrf_mega_kernel (one launch = one batched factorisation, with or without the fused inverse)'}.get(args.prof_kernel, 'tile_gemm_kernel<%s>' % args.prof_kernel), achieved=ach,
                             peak=F64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F64_PEAK_TFLOPS, traffic=None)
-            pmc = next((q for q in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_bench_potrf_kernel.json' % r) for r in (5, 4, 2)) if os.path.exists(q)), '')
+            pmc = next((q for q in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_bench_potrf_kernel.json' % r) for r in (6, 5, 4, 2)) if os.path.exists(q)), '')
             if args.prof_kernel == 'syrk' and os.path.exists(pmc):   # HBM bytes per launch, measured offline with rocprofv3 --pmc
                 with open(pmc) as f:
                     pj = json.load(f)

@@ -751,8 +751,14 @@ struct EssScratch {   // device scratch of one queue (dgpamd_ess_queue_scratch b
 __device__ void ess_prepare(double *st, const double *u, int nuni, int B, EssScratch *sc);
 // Opens update number `upd` of the queue: closes the previous one first (not accepted within its queued batches: status 3,
 // what ess_end_kernel does after the last update), draws the threshold and the first angle, and prepares the first batch.
-__global__ void ess_begin_kernel(double *st, const double *u, const double *logu, int nuni, EssScratch *sc, int upd, int B) {
+__global__ void ess_begin_kernel(double *st, const double *u, const double *logu, int nuni, EssScratch *sc, int upd, int B, int resume) {
     if (threadIdx.x) return;
+    if (resume && upd == 0) {   // the OPEN update of an earlier queue goes on: its threshold, angle and bracket are in the state (the closing shrink of its last, fully
+        sc->done = 0;           // rejected batch is taken by ess_prepare from the uniforms of THIS queue)
+        sc->halt = 0;
+        ess_prepare(st, u, nuni, B, sc);
+        return;
+    }
     if (upd > 0 && !sc->done && st[ES_STATUS] == 0.0) st[ES_STATUS] = 3.0;
     sc->acc = -1;
     sc->nb = 0;
@@ -1173,14 +1179,15 @@ extern "C" int dgpamd_ess_queue(dgpamd_ctx *ctx, int64_t n, int M, double *F, co
     if (blocks > 1024) blocks = 1024;
     int rc;
     HIP_TRY(ctx, hipMemsetAsync(sc, 0, sizeof(EssScratch), ctx->stream));
-    if (compute_ll0) {   // log-likelihood of the current state (imputation.py:70-78): the first threshold's base
+    const int resume = compute_ll0 == 2 ? 1 : 0;   // (2: the first update of this queue is the open update the previous queue of the I-step left)
+    if (compute_ll0 == 1) {   // log-likelihood of the current state (imputation.py:70-78): the first threshold's base
         rc = ess_queue_logliks(ctx, n, M, F, 0, 1, nodes, scales_h, nnodes, A, work, sc, nullptr, vwork, batch_first);
         if (rc) return rc;
         hipLaunchKernelGGL(ess_set_ll_kernel, dim3(1), dim3(64), 0, ctx->stream, state, (const EssScratch *)sc);
     }
     for (int u = 0; u < nupd; ++u) {
         const double *NUu = NU + (int64_t)u * count;
-        hipLaunchKernelGGL(ess_begin_kernel, dim3(1), dim3(64), 0, ctx->stream, state, uniforms, log_uniforms, nuni, sc, u, batch_first);
+        hipLaunchKernelGGL(ess_begin_kernel, dim3(1), dim3(64), 0, ctx->stream, state, uniforms, log_uniforms, nuni, sc, u, batch_first, resume);
         for (int j = 0; j < max_batches; ++j) {
             const int B = j == 0 ? batch_first : batch_next;
             if (j > 0) hipLaunchKernelGGL(ess_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, state, uniforms, nuni, B, sc);

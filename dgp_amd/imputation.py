@@ -542,14 +542,21 @@ class imputer:
         per = 2 + (b0 - 1) + (qmax - 1) * bn + 2
         scales = [float(nd.scale[0]) if nd.type == 'gp' else 1.0 for nd in upper]
         first = 0
+        begun = False
+        open_update = None   # the state of an update a queue left open (out of queued batches / of uploaded uniforms): the next queue goes on with it
         while first < sweeps:
             us = self.draws.uniform_peek((sweeps - first) * per)
             cur = self._ll_cache.get(0)
-            plan.queue(F, nu[first:], scales, us, 0, cur, cur is None, bn, qmax)
-            if first == 0:   # the next call's normals: generated by a background thread while this one waits in fetch()
+            if open_update is not None:
+                plan.resume_state(open_update)
+                plan.queue(F, nu[first:], scales, us, 0, None, 2, bn, qmax, fresh=False)
+                open_update = None
+            else:
+                plan.queue(F, nu[first:], scales, us, 0, cur, cur is None, bn, qmax)
+            if not begun:   # the next call's normals: generated by a background thread while this one waits in fetch()
                 self.draws.prefetch(sweeps * M * n, engine=e)   # (started only now: it would fight the launches above for the interpreter)
-            if first == 0:
                 self.queued_calls += 1
+                begun = True
             st = plan.fetch()   # the one synchronisation of the queue (of the whole I-step unless an update was left open)
             status, done = int(st['status']), int(st['updates'])
             self.draws.uniform_take(int(st['cursor']))
@@ -566,8 +573,15 @@ class imputer:
                 if not us:
                     raise RuntimeError('injected uniform stream exhausted')
                 continue
-            # the open update (out of queued batches, status 3, or of uploaded uniforms, status 1): the host loop finishes it,
-            # the remaining sweeps are queued anew
+            # the open update (out of queued batches, status 3, or of uploaded uniforms, status 1)
+            if status == 1 and not us:
+                raise RuntimeError('injected uniform stream exhausted')
+            if os.environ.get('DGPAMD_ESS_RESUME', '1') != '0':
+                # round 6: the next queue continues it on the device (dgpamd_ess_queue, compute_ll0 = 2) -- the host loop's finish cost an idle
+                # millisecond 0.4 times per iteration at the bench shape (profiles/r06_idle_gaps.txt)
+                open_update = st
+                continue
+            # (DGPAMD_ESS_RESUME=0, rounds 3-5: the host loop finishes it, the remaining sweeps are queued anew)
             self.one_sample_block(0, nu=nu[first], resume=dict(log_y=float(st['log_y']), theta=float(st['theta']), lo=float(st['lo']),
                                                                  hi=float(st['hi']), pending=bool(st['pending'])))
             first += 1

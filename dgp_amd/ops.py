@@ -897,8 +897,17 @@ class _EssQueue:
         e._chk(e._enter() or lib.dgpamd_ess_queue(e.h, self.n, self.M, _dp(F), _dp(NU), int(NU.shape[0]), C.cast(self.nodes, C.c_void_p),
                                     sc.ctypes.data_as(C.c_void_p), self.nnodes, _dp(self.state), _dp(ud), _dp(ud[nuni:]), nuni,
                                     self.batch, int(batch_next) if batch_next else self.batch, int(max_batches),
-                                    1 if compute_ll0 else 0, _dp(self.FP), _dp(self.A), _dp(self.work), _dp(self.scratch),
+                                    int(compute_ll0), _dp(self.FP), _dp(self.A), _dp(self.work), _dp(self.scratch),
                                     _dp(self.vwork)))
+
+    def resume_state(self, st, ll=None):
+        """The device state for a queue that CONTINUES the update an earlier one left open (status 3 / 1): angle, bracket, pending flag and threshold as
+        fetched (`st`: fetch()'s dict), status and counters zero, the cursor at the start of the uniforms the next queue() uploads."""
+        st0 = np.zeros(self.STATE)
+        st0[0], st0[1], st0[2], st0[3] = st['theta'], st['lo'], st['hi'], st['pending']
+        st0[7] = st['ll'] if ll is None else ll
+        st0[8] = st['log_y']
+        self.state.copy_(self.e.tensor(st0))
 
     def note_info(self, info):
         """A factorisation queued between two updates (a deeper layer's prior factors): non-zero info stops the queue."""

@@ -272,7 +272,9 @@ int dgpamd_ess_update(dgpamd_ctx *ctx, int64_t n, int M, double *F, const double
  * stream exactly as the sequential loop would; the launches of an update's later batches are predicated on its `done`
  * word.  `nupd` updates (prior draws NU: nupd x n x M) are queued on the context's stream and the call returns at once.
  *   state (device, DGPAMD_ESS_STATE doubles): {theta, lo, hi, pending, cursor, status, info, ll, log_y, proposals,
- *     batches, updates}; the caller zeroes it and sets cursor / ll as needed (compute_ll0 != 0: ll is computed from F first).
+ *     batches, updates}; the caller zeroes it and sets cursor / ll as needed (compute_ll0 = 1: ll is computed from F first; compute_ll0 = 2 (round 6): the FIRST
+ *     update of this call is the update an earlier queue left open -- out of queued batches (status 3) or of uploaded uniforms (1): the caller writes the state back with
+ *     status and counters zeroed and the cursor at the start of this call's uniforms, theta / lo / hi / pending / log_y / ll as fetched, and the update goes on where it stopped).
  *     status after the queue: 0 = every update accepted; 1 = uniforms used up; 2 = a proposal the sequential loop reaches
  *     is not positive definite (info); 3 = an update was not accepted within max_batches batches; 4 = uniforms used up
  *     before an update began (nothing of it is in the state).  After a non-zero status

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Round-5 counter summary: reads the per-kernel PMC averages and kernel durations tools/gpu_round5_pmc.sh left in a directory and writes
-profiles/r05_pmc_kernels.json (one entry per kernel: counters, derived fractions, a sentence for bench.py's notes) and a text table.
-usage: pmc_summary.py gpurun_out/r5pmc profiles/r05_pmc_kernels.json > profiles/r05_pmc_kernels.txt"""
+"""Counter summary of a round: reads the per-kernel PMC averages and kernel durations tools/gpu_round6_pmc.sh (round 5: gpu_round5_pmc.sh) left in a directory and writes
+profiles/rNN_pmc_kernels.json (one entry per kernel: counters, derived fractions, a sentence for bench.py's notes) and a text table.
+usage: pmc_summary.py gpurun_out/r6pmc profiles/r06_pmc_kernels.json [r06] > profiles/r06_pmc_kernels.txt"""
 import json, re, sys
 
 d, out = sys.argv[1], sys.argv[2]
+RND = sys.argv[3] if len(sys.argv) > 3 else 'r06'
 SIMDS, XCDS = 1024, 8
 
 
@@ -46,7 +47,7 @@ res = {'_calibration': {'what': 'FETCH_SIZE (KB) reported for 1 GiB streamed onc
                         'true_over_reported': factor,
                         'note': 'every load form the library uses -- 16-byte plain, 16-byte buffer sc1, 8-byte sc1 -- reads exactly 1/2: FETCH_SIZE x 2 is the '
                                 'correction for each of them, not a blanket guess'}}
-print('# Round 5 counter evidence (tools/gpu_round5_pmc.sh; rocprofv3 --kernel-trace --pmc, one counter set per pass, the program itself after "--").')
+print('# ' + RND + ' counter evidence (tools/gpu_round%s_pmc.sh;' % RND[-1] + ' rocprofv3 --kernel-trace --pmc, one counter set per pass, the program itself after "--").')
 print('# FETCH_SIZE calibration (1 GiB streamed once): true / reported = ' + ', '.join('%s %.3f' % (k, v) for k, v in factor.items()))
 print('# Derived columns: clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; VALU issue = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / elapsed cycles (an f64 wave-instruction')
 print('#   issues in 4 cycles; 32-bit ones in this count issue faster, so this is an upper bound of the f64 share); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / elapsed cycles;')
@@ -105,6 +106,23 @@ for nm in kst:
     us = cyc / 2.4e3   # (no duration table for this command: elapsed cycles at 2.4 GHz)
     e = entry('standalone ' + nm + ' n=8192 D=10 full', c, us, dict(duration_from='GRBM_GUI_ACTIVE / 8 at 2.4 GHz'))
     e['valu_per_entry'] = e['valu_per_wave'] / 16.0
+# round 6: the training form of K assembly (lower tiles, ten matrices, n = 5000) and the SExp pair kernel at cfg3's shape, if their passes were taken
+import os as _os
+if _os.path.exists(d + '/pmc_kmatrix_lower.txt'):
+    for nm, c in counters(d + '/pmc_kmatrix_lower.txt').items():
+        cyc = c['GRBM_GUI_ACTIVE'] / XCDS
+        e = entry('standalone ' + nm + ' n=5000 D=10 lower tiles, 10 matrices', c, cyc / 2.4e3, dict(duration_from='GRBM_GUI_ACTIVE / 8 at 2.4 GHz'))
+        e['valu_per_entry'] = e['valu_per_wave'] / 16.0
+        e['note'] = ('training form (lower tiles of ten n = 5000 matrices): %.0f VALU wave-instructions per matrix entry, VALU issue %.2f of the elapsed cycles (an f64 instruction '
+                     'issues in 4 cycles): the kernel is bound by its double-precision arithmetic, not by its stores' % (e['valu_per_entry'], e['valu_issue_frac']))
+if _os.path.exists(d + '/pmc_sexp_pair.txt'):
+    for nm, c in counters(d + '/pmc_sexp_pair.txt').items():
+        cyc = c['GRBM_GUI_ACTIVE'] / XCDS
+        e = entry(nm, c, cyc / 2.4e3, dict(duration_from='GRBM_GUI_ACTIVE / 8 at 2.4 GHz'))
+        issue = (c.get('SQ_INSTS_VALU', 0.0) * 4.0 + c.get('SQ_INSTS_MFMA', 0.0) * 64.0) / SIMDS / cyc
+        e['issue_cycles_frac'] = issue
+        e['note'] = ('SExp pair kernel at cfg3\'s shape: per launch %.1f M VALU wave-instructions (4 issue cycles each) + %.2f M f64 MFMAs (64 each) = %.2f of the SIMDs\' elapsed cycles: the kernel '
+                     'is bound by instruction issue (MFMA busy %.2f)' % (c.get('SQ_INSTS_VALU', 0.0) / 1e6, c.get('SQ_INSTS_MFMA', 0.0) / 1e6, issue, e.get('mfma_busy_frac', float('nan'))))
 json.dump(res, open(out, 'w'), indent=1)
 # ... and the potrf entry in the form bench.py reads for roofline.traffic (profiles/rNN_pmc_bench_potrf_kernel.json)
 import os
@@ -113,6 +131,6 @@ cmd = next((ln[1:].strip() for ln in open(d + '/pmc_bench_kernels.txt') if ln.st
 json.dump({'kernel': 'potrf_mega_kernel', 'launches': pe['launches'], 'fetch_size_kb_per_launch_raw': pe['counters']['FETCH_SIZE'],
            'write_size_kb_per_launch': pe['counters']['WRITE_SIZE'], 'hbm_bytes_per_launch': pe['hbm_side_bytes_per_launch'],
            'how': 'FETCH_SIZE x 2 + WRITE_SIZE per launch, the x 2 calibrated for each load form of the kernel (16-byte plain, 16-byte buffer sc1, 8-byte sc1 all report '
-                  'exactly 1/2: profiles/r05_pmc_fetch_calibration.txt); fabric-side traffic, Infinity-Cache hits included',
+                  'exactly 1/2: profiles/' + RND + '_pmc_fetch_calibration.txt); fabric-side traffic, Infinity-Cache hits included',
            'command': cmd.split('(one pass per set')[0].strip().replace('<set>', 'FETCH_SIZE|WRITE_SIZE (separate passes)')},
-          open(os.path.join(os.path.dirname(out), 'r05_pmc_bench_potrf_kernel.json'), 'w'))
+          open(os.path.join(os.path.dirname(out), RND + '_pmc_bench_potrf_kernel.json'), 'w'))
