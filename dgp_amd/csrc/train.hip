@@ -16,7 +16,7 @@ struct ProposeArgs {
 __global__ __launch_bounds__(256) void ess_propose_kernel(ProposeArgs a) {
     const int b = blockIdx.y;
     // (cosine and sine on the device, as the device queue's ess_prepare takes them: the host loop and the queue then propose the same bits for the same
-    //  angle -- with the host's libm here an update that the host loop finished for the queue left latents one rounding away, profiles/r06_chain_fingerprint.txt)
+    //  angle -- the host's libm here was one of the last-bit differences between the two paths, profiles/r06_mstep_host_edges.txt)
     const double c = cos(a.th[b]), s = sin(a.th[b]);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * 256)
         a.FP[(int64_t)b * a.count + i] = a.F[i] * c + a.NU[i] * s;
