@@ -1,5 +1,8 @@
-"""Size-independent properties of the HIP path at BASELINE.json's full sizes (the oracle is too slow there):
-cfg3's n = 5000 factorisation and inverse, cfg2's n = 2000 predictors, cfg4's n = 50 000 Vecchia kernels.
+"""The HIP path at BASELINE.json's full sizes: size-independent properties where the oracle is too slow (cfg3's n = 5000
+factorisation and inverse, cfg2's n = 2000 predictors, cfg4's n = 50 000 Vecchia kernels) and direct comparisons with the
+oracle where it finishes in seconds -- its per-test-point predictors dealt to host processes (tests/oracle_pool.py): the
+Matern link_gp of cfg2's output node at n = 2000 with 5 + 5 inputs and emulator.predict of the bench model against the
+oracle's layer walk (round 6), cfg3's SExp link_gp and block update at n = 5000, cfg5's chain at n = 1000.
 Needs an MI355X: -m gpu."""
 import numpy as np
 import pytest

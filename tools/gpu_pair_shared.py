@@ -36,7 +36,11 @@ def main():
         A, T, S = eng.empty(6, Np, Np), eng.empty(6, Np, Np), eng.empty(6, Np, Np)
         work = eng.potrf_workspace(n, 6)
         pr = problem(eng, 'matern2.5', 1000, 3, 2, 512, 99)
+        first = True
         while os.path.exists(os.environ['PAIR_SHARED_FLAG']):
+            if not first and not os.path.exists(os.environ['PAIR_SHARED_FLAG'] + '.ready.' + os.environ.get('SEED', '1')):
+                open(os.environ['PAIR_SHARED_FLAG'] + '.ready.' + os.environ.get('SEED', '1'), 'w').close()   # (looping: the checker may start)
+            first = False
             for B in (1, 3, 6):
                 eng.kmatrix('matern2.5', X[:B] if B > 1 else X[0], None, None, [1.0], 1e-6, out=A[:B] if B > 1 else A[0], full=False, Y=y, batch=B)
                 eng.potrf_inv(n, A, T, S, batch=B, work=work)
@@ -48,12 +52,21 @@ def main():
     alone = [[t.cpu().numpy().copy() for t in eng.linkgp_predict(*p)] for p in probs]
     again = [[t.cpu().numpy().copy() for t in eng.linkgp_predict(*p)] for p in probs]
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(alone, again)), 'not even alone'
+    t0 = time.perf_counter()
+    for p in probs:
+        [t.cpu().numpy() for t in eng.linkgp_predict(*p)]
+    t_alone = time.perf_counter() - t0
     flag = '/tmp/pair_shared_flag_%d' % os.getpid()
     open(flag, 'w').close()
     env = dict(os.environ, PAIR_SHARED_ROLE='load', PAIR_SHARED_FLAG=flag, DGPAMD_POTRF_MODE='0')   # (the load shares the device: per-block-step factorisation)
     loads = [subprocess.Popen([sys.executable, os.path.abspath(__file__)], env=dict(env, SEED=str(s))) for s in (1, 2)]
     try:
-        time.sleep(8.0)   # (the loads have built their problems and are looping)
+        for s_ in (1, 2):   # (wait until both loads have built their problems and are looping)
+            w0 = time.perf_counter()
+            while not os.path.exists(flag + '.ready.%d' % s_):
+                time.sleep(0.2)
+                if time.perf_counter() - w0 > 240 or any(p.poll() is not None for p in loads):
+                    raise RuntimeError('the load processes did not start')
         bad, t0 = 0, time.perf_counter()
         for r in range(reps):
             for k, p in enumerate(probs):
@@ -67,8 +80,11 @@ def main():
         os.unlink(flag)
         for p in loads:
             p.wait(timeout=120)
-    print('%d repetitions x %d problems under the load of two other processes (%d still running at the end): %d results differ from the ones computed alone; %.1f s'
-          % (reps, len(probs), alive, bad, dt))
+        for s_ in (1, 2):
+            if os.path.exists(flag + '.ready.%d' % s_):
+                os.unlink(flag + '.ready.%d' % s_)
+    print('%d repetitions x %d problems under the load of two other processes (%d still running at the end): %d results differ from the ones computed alone; '
+          '%.3f s per repetition under load against %.3f s alone' % (reps, len(probs), alive, bad, dt / reps, t_alone))
     sys.exit(1 if bad or alive != 2 else 0)
 
 
