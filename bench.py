@@ -168,11 +168,18 @@ def cpu_baseline_predict(model, d, imputations, points_per_worker=1):
     import psutil
     from oracle import dgp_oracle as O
     phys = psutil.cpu_count(logical=False) or 1
-    workers = max(1, phys)            # one process per physical core (32 at most before)
+    # One process per core up to 32.  One per PHYSICAL core was tried (profiles/r06_bench_default_cpu128.json): 128 processes of this numpy port take 177 s
+    # per point where 32 take 12 s -- 0.072 against 0.27 pts/s in aggregate (every process streams n x n temporaries: the host's memory system, not its cores, is what they
+    # share) -- and the leg alone then lasts three minutes.  So: the faster configuration, within the contract's 10-30 s of CPU work; `physical_cores` is reported beside it.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = phys
+    workers = max(1, min(32, phys, avail))
     try:   # (a worker holds ~0.4 GB of n x n temporaries of the oracle's IJ at n = 2000: never more than a quarter of the free memory in all)
         workers = max(1, min(workers, int(0.25 * psutil.virtual_memory().available / 0.4e9)))
     except Exception:   # noqa: BLE001
-        workers = min(workers, 32)
+        pass
     l1 = []
     for nd in model.all_layer[0]:
         Xn = np.ascontiguousarray(nd._X())
@@ -215,8 +222,8 @@ def cpu_baseline_predict(model, d, imputations, points_per_worker=1):
     return dict(value=pts / busy / imputations, unit='pts/s', cores=workers, physical_cores=phys, kind='port', imputations=imputations,
                 seconds_per_point_imputation_one_core=float(np.mean([r[0] for r in res])) / points_per_worker, finite=finite,
                 note=('the reference evaluates link_gp in numba (functions.py:396-430, a prange over the test points); numba is absent from this image and cannot travel, so this is '
-                      'the oracle\'s numpy restatement of the same closed forms, one process per physical core -- one to two orders of magnitude slower per core than compiled code: a '
-                      'reported baseline, not a target'),
+                      'the oracle\'s numpy restatement of the same closed forms, one process per core up to 32 (128 processes were slower in aggregate: profiles/'
+                      'r06_bench_default_cpu128.json) -- one to two orders of magnitude slower per core than compiled code: a reported baseline, not a target'),
                 sample=('%d worker processes x %d test points, one imputation each (gp_predict of the %d first-layer nodes + link_gp_predict of the '
                         'Matern-2.5 output node at n=%d, one BLAS thread per process as the reference\'s prange over test points); slowest worker %.1f s, '
                         '%.1f s wall with process start-up; scaled to %d imputations per point'
